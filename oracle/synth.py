@@ -1,0 +1,159 @@
+"""Deterministic synthetic weights and batches (TEST INFRASTRUCTURE ONLY).
+
+Both the golden-fixture generator (which feeds them to the reference) and the tests
+(which feed them to the oracle / the HIP path) draw weights and inputs from this module,
+so fixtures need to store outputs only.  Everything is NumPy default_rng -- reproducible
+on any machine without the reference.
+
+param_shapes() restates the reference's state_dict layout (transformer/tacotron.py:8-123,
+transformer/modules.py:23-106, transformer/attention.py:30-51); a CPU test checks it
+against the (name, shape) list captured from the reference.
+"""
+import numpy as np
+
+
+def param_shapes(cfg):
+    """Ordered [(name, shape, kind)] for every state_dict entry of Tacotron(cfg).
+
+    kind in {'embed','w','b','ln_w','ln_b','bn_w','bn_b','bn_rm','bn_rv','bn_nbt','scalar'}.
+    Order = the reference's nn.Module registration order.
+    """
+    out = []
+    De, Dh = cfg.embed_size, cfg.encoder_hidden
+    Dd = cfg.decoder_hidden
+    mem = Dh + (cfg.speaker_embedding_size if cfg.multi_speaker else 0) + \
+        (cfg.language_embedding_size if cfg.multi_lingual else 0)
+
+    def ln(prefix, n):
+        out.append((prefix + ".weight", (n,), "ln_w"))
+        out.append((prefix + ".bias", (n,), "ln_b"))
+
+    # Encoder (tacotron.py:9-19)
+    out.append(("encoder.embed.weight", (cfg.vocab_size, De), "embed"))
+    if cfg.multi_speaker:
+        out.append(("encoder.speaker_embed.weight", (cfg.max_num_speaker, cfg.speaker_embedding_size), "embed"))
+        out.append(("encoder.speaker_layer.weight", (cfg.speaker_embedding_size,) * 2, "w"))
+        out.append(("encoder.speaker_layer.bias", (cfg.speaker_embedding_size,), "b"))
+    if cfg.multi_lingual:
+        out.append(("encoder.language_embed.weight", (cfg.language_embedding_size, cfg.max_num_language), "w"))
+        out.append(("encoder.language_layer.weight", (cfg.language_embedding_size,) * 2, "w"))
+        out.append(("encoder.language_layer.bias", (cfg.language_embedding_size,), "b"))
+    # TransformerEncoder (modules.py:24-47): ModuleLists are registered list by list
+    p = "encoder.encoder."
+    out.append((p + "pe_scale", (), "scalar"))
+    for i in range(cfg.n_encoder_layer):
+        n = De if i == 0 else Dh
+        out.append((p + "self_attentions.%d.qkv_transform.weight" % i, (3 * n, n), "w"))
+        out.append((p + "self_attentions.%d.output_transform.weight" % i, (n, n), "w"))
+    for i in range(cfg.n_encoder_layer):
+        ln(p + "attn_layer_norms.%d" % i, De if i == 0 else Dh)
+    for i in range(cfg.n_encoder_layer):
+        out.append((p + "ffn_layers.%d.input_layer.weight" % i, (4 * Dh, Dh), "w"))
+        out.append((p + "ffn_layers.%d.output_layer.weight" % i, (Dh, 4 * Dh), "w"))
+    for i in range(cfg.n_encoder_layer):
+        ln(p + "ffn_layer_norms.%d" % i, Dh)
+    ln(p + "output_layer_norm", Dh)
+    # Decoder (tacotron.py:94-105)
+    out.append(("decoder.prenet.dense0.weight", (cfg.prenet_hidden, cfg.num_mels), "w"))
+    out.append(("decoder.prenet.dense0.bias", (cfg.prenet_hidden,), "b"))
+    out.append(("decoder.prenet.dense1.weight", (cfg.prenet_hidden, cfg.prenet_hidden), "w"))
+    out.append(("decoder.prenet.dense1.bias", (cfg.prenet_hidden,), "b"))
+    out.append(("decoder.prenet.dense_final.weight", (Dd, cfg.prenet_hidden), "w"))
+    p = "decoder.decoder."
+    out.append((p + "pe_scale", (), "scalar"))
+    for i in range(cfg.n_decoder_layer):
+        n = mem if i == 0 else Dd
+        out.append((p + "self_attentions.%d.qkv_transform.weight" % i, (3 * n, n), "w"))
+        out.append((p + "self_attentions.%d.output_transform.weight" % i, (n, n), "w"))
+    for i in range(cfg.n_decoder_layer):
+        ln(p + "attn_layer_norms.%d" % i, mem if i == 0 else Dd)
+    for i in range(cfg.n_decoder_layer):
+        out.append((p + "encdec_attentions.%d.q_transform.weight" % i, (Dd, Dd), "w"))
+        out.append((p + "encdec_attentions.%d.kv_transform.weight" % i, (2 * Dd, Dd), "w"))
+        out.append((p + "encdec_attentions.%d.output_transform.weight" % i, (Dd, Dd), "w"))
+    for i in range(cfg.n_decoder_layer):
+        ln(p + "encdec_layer_norms.%d" % i, mem if i == 0 else Dd)
+    for i in range(cfg.n_decoder_layer):
+        out.append((p + "ffn_layers.%d.input_layer.weight" % i, (4 * Dd, Dd), "w"))
+        out.append((p + "ffn_layers.%d.output_layer.weight" % i, (Dd, 4 * Dd), "w"))
+    for i in range(cfg.n_decoder_layer):
+        ln(p + "ffn_layer_norms.%d" % i, Dd)
+    ln(p + "output_layer_norm", Dd)
+    out.append(("decoder.mel_net.weight", (cfg.num_mels, Dd), "w"))
+    out.append(("decoder.stop_net.weight", (1, Dd), "w"))
+    out.append(("decoder.stop_net.bias", (1,), "b"))
+    # Postnet (tacotron.py:69-79)
+    for i in range(cfg.n_postnet_layer):
+        cin = cfg.num_mels if i == 0 else cfg.postnet_hidden
+        cout = cfg.num_mels if i == cfg.n_postnet_layer - 1 else cfg.postnet_hidden
+        out.append(("postnet.conv_layers.%d.weight" % i, (cout, cin, 5), "w"))
+    for i in range(cfg.n_postnet_layer):
+        cout = cfg.num_mels if i == cfg.n_postnet_layer - 1 else cfg.postnet_hidden
+        q = "postnet.batchnorm_layers.%d." % i
+        out.append((q + "weight", (cout,), "bn_w"))
+        out.append((q + "bias", (cout,), "bn_b"))
+        out.append((q + "running_mean", (cout,), "bn_rm"))
+        out.append((q + "running_var", (cout,), "bn_rv"))
+        out.append((q + "num_batches_tracked", (), "bn_nbt"))
+    return out
+
+
+def synthetic_state(cfg, seed=1234):
+    """{name: np.ndarray} with non-degenerate values for every state_dict entry."""
+    rng = np.random.default_rng(seed)
+    st = {}
+    for name, shape, kind in param_shapes(cfg):
+        if kind == "embed":
+            a = rng.standard_normal(shape) * 0.5
+        elif kind == "w":
+            fan_in = int(np.prod(shape[1:]))
+            a = rng.standard_normal(shape) * (1.0 / np.sqrt(fan_in))
+        elif kind in ("b", "ln_b", "bn_b"):
+            a = rng.standard_normal(shape) * 0.1
+        elif kind in ("ln_w", "bn_w"):
+            a = 1.0 + rng.standard_normal(shape) * 0.1
+        elif kind == "bn_rm":
+            a = rng.standard_normal(shape) * 0.1
+        elif kind == "bn_rv":
+            a = 0.5 + rng.random(shape)
+        elif kind == "bn_nbt":
+            st[name] = np.asarray(3, dtype=np.int64)
+            continue
+        elif kind == "scalar":
+            a = np.asarray(1.0 + 0.25 * rng.standard_normal())
+        else:
+            raise ValueError(kind)
+        st[name] = np.asarray(a, dtype=np.float32)
+    return st
+
+
+def synthetic_batch(cfg, B, S, T, seed=0, in_lens=None, tgt_lens=None, n_spk=None, n_lang=None):
+    """Batch dict in the dataloader's contract (dataloader.py:498-508), NumPy arrays.
+
+    inputs ~ U{3..255} with sos=2 first and eos=1 last (utils/text.py:3-19), zero padded;
+    mel_targets ~ N(0,1) clipped to [-4,4], zero beyond length.
+    """
+    rng = np.random.default_rng(seed)
+    if in_lens is None:
+        in_lens = np.round(np.linspace(S, max(2, 0.8 * S), B)).astype(np.int64)
+    if tgt_lens is None:
+        tgt_lens = np.round(np.linspace(T, max(1, 0.8 * T), B)).astype(np.int64)
+    in_lens = np.asarray(in_lens, dtype=np.int64)
+    tgt_lens = np.asarray(tgt_lens, dtype=np.int64)
+    hi = min(256, cfg.vocab_size)
+    inputs = rng.integers(3, hi, size=(B, S)).astype(np.int64)
+    mels = np.clip(rng.standard_normal((B, T, cfg.num_mels)), -4, 4).astype(np.float32)
+    for b in range(B):
+        inputs[b, 0] = 2
+        inputs[b, in_lens[b] - 1] = 1
+        inputs[b, in_lens[b]:] = 0
+        mels[b, tgt_lens[b]:] = 0
+    n_spk = n_spk or cfg.max_num_speaker
+    n_lang = n_lang or cfg.max_num_language
+    spk = rng.integers(0, n_spk, size=(B,)).astype(np.int64)
+    lang_ids = rng.integers(0, n_lang, size=(B,))
+    lang = np.zeros((B, cfg.max_num_language), dtype=np.float32)
+    lang[np.arange(B), lang_ids] = 1.0
+    return {"inputs": inputs, "input_lengths": in_lens, "mel_targets": mels,
+            "target_lengths": tgt_lens, "input_spk_ids": spk, "input_language_vecs": lang,
+            "names": ["utt%03d" % i for i in range(B)]}
