@@ -1,0 +1,342 @@
+"""Host glue between the nn.Module surface (transformer/tacotron.py) and libb2s_hip.so.
+
+HipEngine owns one b2s_model handle for a Tacotron module tree: it binds the device pointers of the
+module's parameters/buffers (re-binding when .to()/.cuda() replaced them, re-syncing the compute-dtype
+weight shadows when an optimizer changed them in place), owns the flat fp32 gradient buffer the HIP
+backward kernels accumulate into, and exposes each model segment as a torch.autograd.Function so
+`loss.backward()` / `optim.step()` in a train.py-style driver work unchanged.  PyTorch only provides
+device memory, streams and the autograd graph edges; no math runs in torch.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+DTYPES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+
+
+def config_from_hparams(hp):
+    cfg = L.Config()
+    for name, _ in L.Config._fields_:
+        if name in ("compute_dtype",):
+            continue
+        v = getattr(hp, name)
+        setattr(cfg, name, int(v) if isinstance(v, bool) else v)
+    cd = getattr(hp, "compute_dtype", "fp32")
+    if cd not in DTYPES:
+        raise ValueError("compute_dtype must be one of %s" % sorted(DTYPES))
+    cfg.compute_dtype = DTYPES[cd]
+    return cfg
+
+
+def _i32(t):
+    """lengths as contiguous int32 on the device (the batch dict holds int64, eval_batch int32)."""
+    if t.dtype != torch.int32:
+        t = t.to(torch.int32)
+    return t.contiguous()
+
+
+class _Ctx(object):
+    """Owns a b2s_ctx handle plus every tensor the HIP side still points into."""
+
+    def __init__(self, handle, keep):
+        self.handle = handle
+        self.keep = keep
+
+    def free(self):
+        if self.handle:
+            L.load().b2s_ctx_free(self.handle)
+            self.handle = None
+        self.keep = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HipEngine(object):
+    def __init__(self, root, hp):
+        self.lib = L.load()
+        self.root = root
+        self.hp = hp
+        self.cfg = config_from_hparams(hp)
+        self.dtype = self.cfg.compute_dtype
+        h = L.P()
+        L.check(self.lib.b2s_model_create(C.byref(self.cfg), C.byref(h)))
+        self.handle = h
+        n = self.lib.b2s_model_num_tensors(h)
+        self.names, self.shapes, self.kinds = [], [], []
+        buf = C.create_string_buffer(256)
+        shape = (C.c_int64 * 8)()
+        nd, kind = C.c_int(), C.c_int()
+        for i in range(n):
+            L.check(self.lib.b2s_model_tensor_info(h, i, buf, 256, shape, C.byref(nd), C.byref(kind)))
+            self.names.append(buf.value.decode())
+            self.shapes.append(tuple(shape[k] for k in range(nd.value)))
+            self.kinds.append(kind.value)
+        sd = root.state_dict()
+        mine = [(k, tuple(v.shape)) for k, v in sd.items()]
+        theirs = list(zip(self.names, self.shapes))
+        if mine != theirs:
+            raise L.B2SError("module state_dict layout differs from the HIP model layout")
+        self._sig = None
+        self._versions = None
+        self._gflat = None
+        self._gviews = {}
+        self._needs_zero = True
+        self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
+        self._calls = 0
+        self.index = {n_: i for i, n_ in enumerate(self.names)}
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.b2s_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ binding
+    def _tensors(self):
+        sd = dict(self.root.named_parameters())
+        sd.update(dict(self.root.named_buffers()))
+        return [sd[n] for n in self.names]
+
+    def ensure_bound(self):
+        ts = self._tensors()
+        dev = ts[0].device
+        if dev.type != "cuda":
+            raise L.B2SError("model parameters are on %s: the byte2speech hot path has no CPU fallback; "
+                             "move the model to a HIP device (model.cuda())" % dev)
+        sig = tuple(t.data_ptr() for t in ts)
+        if sig != self._sig:
+            for t, n, k in zip(ts, self.names, self.kinds):
+                want = torch.int64 if k == 2 else torch.float32
+                if t.dtype != want or not t.is_contiguous() or t.device != dev:
+                    raise L.B2SError("tensor %s must be contiguous %s on %s" % (n, want, dev))
+            total = sum(t.numel() for t, k in zip(ts, self.kinds) if k == 1)
+            if self._gflat is None or self._gflat.device != dev:
+                self._gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+            self._gviews = {}
+            data = (L.P * len(ts))(*[t.data_ptr() for t in ts])
+            grads = (L.P * len(ts))()
+            off = 0
+            for i, (t, k, n) in enumerate(zip(ts, self.kinds, self.names)):
+                if k == 1:
+                    v = self._gflat[off:off + t.numel()].view(t.shape)
+                    self._gviews[n] = v
+                    grads[i] = v.data_ptr()
+                    off += t.numel()
+                else:
+                    grads[i] = None
+            L.check(self.lib.b2s_model_bind(self.handle, data, grads, len(ts)))
+            self._sig = sig
+            self._versions = None
+        vers = tuple(t._version for t in ts)
+        if vers != self._versions:
+            L.check(self.lib.b2s_model_sync_weights(self.handle, L.stream()))
+            self._versions = vers
+        return dev
+
+    def next_seed(self):
+        self._calls += 1
+        return (self._seed * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def begin_backward(self):
+        if self._needs_zero:
+            L.check(self.lib.b2s_zero_grads(self.handle, L.stream()))
+            self._needs_zero = False
+
+    def grad_view(self, name):
+        return self._gviews[name]
+
+    # ------------------------------------------------------------------ segments (raw, no autograd)
+    def encoder_forward(self, inputs, lens32, spk, lang, train, seed, keep_ctx):
+        dev = self.ensure_bound()
+        B, S = inputs.shape
+        inputs = inputs.contiguous()
+        spk = spk.contiguous() if spk is not None else None
+        lang = lang.contiguous() if lang is not None else None
+        nbytes = self.lib.b2s_encoder_ws_bytes(self.handle, B, S)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        mem = torch.empty(B, S, self.cfg.decoder_hidden, dtype=torch.float32, device=dev)
+        h = L.P()
+        L.check(self.lib.b2s_encoder_forward(self.handle, L.ptr(inputs), L.ptr(lens32), L.ptr(spk), L.ptr(lang), B, S,
+                                             int(train), seed, L.ptr(ws), nbytes, L.ptr(mem), L.stream(),
+                                             C.byref(h) if keep_ctx else None))
+        self._needs_zero = True
+        return mem, (_Ctx(h, (ws, inputs, lens32, spk, lang)) if keep_ctx else None)
+
+    def encoder_backward(self, ctx, dmem):
+        self.begin_backward()
+        L.check(self.lib.b2s_encoder_backward(self.handle, ctx.handle, L.ptr(dmem.contiguous()), L.stream()))
+
+    def decoder_forward(self, memory, in32, targets, tgt32, train, seed, keep_ctx):
+        dev = self.ensure_bound()
+        B, T, NM = targets.shape
+        S = memory.shape[1]
+        memory = memory.contiguous()
+        targets = targets.contiguous()
+        nbytes = self.lib.b2s_decoder_ws_bytes(self.handle, B, S, T)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        mels = torch.empty(B, T, NM, dtype=torch.float32, device=dev)
+        stop = torch.empty(B, T, dtype=torch.float32, device=dev)
+        h = L.P()
+        L.check(self.lib.b2s_decoder_forward(self.handle, L.ptr(memory), L.ptr(in32), L.ptr(targets), L.ptr(tgt32), B, S, T,
+                                             int(train), seed, L.ptr(ws), nbytes, L.ptr(mels), L.ptr(stop), L.stream(),
+                                             C.byref(h)))
+        self._needs_zero = True
+        return mels, stop, _Ctx(h, (ws, memory, in32, targets, tgt32))
+
+    def decoder_backward(self, ctx, dmels, dstop, mem_shape):
+        self.begin_backward()
+        dmem = torch.empty(mem_shape, dtype=torch.float32, device=dmels.device)
+        L.check(self.lib.b2s_decoder_backward(self.handle, ctx.handle, L.ptr(dmels.contiguous()),
+                                              L.ptr(dstop.contiguous()) if dstop is not None else None, L.ptr(dmem),
+                                              L.stream()))
+        return dmem
+
+    def decoder_alignment(self, ctx, which, layer, B, H, Lk, Lq):
+        out = torch.empty(B, H, Lk, Lq, dtype=torch.float32, device=ctx.keep[0].device)
+        L.check(self.lib.b2s_decoder_alignment(self.handle, ctx.handle, which, layer, L.ptr(out), L.stream()))
+        return out
+
+    def postnet_forward(self, inputs, len32, add, train, seed, keep_ctx):
+        dev = self.ensure_bound()
+        B, T, NM = inputs.shape
+        inputs = inputs.contiguous()
+        nbytes = self.lib.b2s_postnet_ws_bytes(self.handle, B, T)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty(B, T, NM, dtype=torch.float32, device=dev)
+        h = L.P()
+        L.check(self.lib.b2s_postnet_forward(self.handle, L.ptr(inputs), L.ptr(len32), L.ptr(add), B, T, int(train), seed,
+                                             L.ptr(ws), nbytes, L.ptr(out), L.stream(), C.byref(h) if keep_ctx else None))
+        self._needs_zero = True
+        return out, (_Ctx(h, (ws, inputs, len32, add)) if keep_ctx else None)
+
+    def postnet_backward(self, ctx, dout):
+        self.begin_backward()
+        din = torch.empty_like(dout)
+        L.check(self.lib.b2s_postnet_backward(self.handle, ctx.handle, L.ptr(dout.contiguous()), L.ptr(din), L.stream()))
+        return din
+
+    def add(self, a, b):
+        out = torch.empty_like(a)
+        L.check(self.lib.b2s_add(L.ptr(a.contiguous()), L.ptr(b.contiguous()), L.ptr(out), a.numel(), L.stream()))
+        return out
+
+    def loss_forward(self, bef, aft, stop, tgt, len32):
+        dev = self.ensure_bound()
+        B, T, _ = tgt.shape
+        vals = torch.empty(7, dtype=torch.float32, device=dev)
+        per = torch.empty(B, dtype=torch.float32, device=dev)
+        scratch = torch.empty(8 + B, dtype=torch.float32, device=dev)
+        L.check(self.lib.b2s_loss_forward(self.handle, L.ptr(bef.contiguous()), L.ptr(aft.contiguous()),
+                                          L.ptr(stop.contiguous()), L.ptr(tgt.contiguous()), L.ptr(len32), B, T, L.ptr(vals),
+                                          L.ptr(per), L.ptr(scratch), L.stream()))
+        return vals, per
+
+    def loss_backward(self, bef, aft, stop, tgt, len32, w3):
+        B, T, _ = tgt.shape
+        dbef = torch.empty_like(bef)
+        daft = torch.empty_like(aft)
+        dstop = torch.empty_like(stop)
+        L.check(self.lib.b2s_loss_backward(self.handle, L.ptr(bef.contiguous()), L.ptr(aft.contiguous()),
+                                           L.ptr(stop.contiguous()), L.ptr(tgt.contiguous()), L.ptr(len32), B, T, L.ptr(w3),
+                                           L.ptr(dbef), L.ptr(daft), L.ptr(dstop), L.stream()))
+        return dbef, daft, dstop
+
+    def l2_backward(self, gscale):
+        self.begin_backward()
+        L.check(self.lib.b2s_l2_backward(self.handle, L.ptr(gscale), L.stream()))
+
+
+# ====================================================================================== autograd plumbing
+def _param_list(module):
+    return [(n, p) for n, p in module.named_parameters()]
+
+
+class EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, prefix, names, inputs, lens32, spk, lang, train, *params):
+        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        mem, c = eng.encoder_forward(inputs, lens32, spk, lang, train, eng.next_seed(), need)
+        ctx.eng, ctx.c, ctx.names, ctx.prefix = eng, c, names, prefix
+        ctx.req = [p.requires_grad for p in params]
+        return mem
+
+    @staticmethod
+    def backward(ctx, dmem):
+        eng = ctx.eng
+        eng.encoder_backward(ctx.c, dmem)
+        ctx.c.free()
+        grads = tuple(eng.grad_view(ctx.prefix + n) if r else None for n, r in zip(ctx.names, ctx.req))
+        return (None,) * 8 + grads
+
+
+class DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, prefix, names, memory, in32, targets, tgt32, train, holder, *params):
+        mels, stop, c = eng.decoder_forward(memory, in32, targets, tgt32, train, eng.next_seed(), True)
+        holder.append(c)
+        ctx.eng, ctx.c, ctx.names, ctx.prefix = eng, c, names, prefix
+        ctx.req = [p.requires_grad for p in params]
+        ctx.mem_shape = memory.shape
+        ctx.mem_req = memory.requires_grad
+        return mels, stop
+
+    @staticmethod
+    def backward(ctx, dmels, dstop):
+        eng = ctx.eng
+        if dmels is None:
+            dmels = torch.zeros(ctx.mem_shape[0], ctx.c.keep[3].shape[1], ctx.c.keep[3].shape[2], device=dstop.device)
+        dmem = eng.decoder_backward(ctx.c, dmels, dstop, ctx.mem_shape)
+        grads = tuple(eng.grad_view(ctx.prefix + n) if r else None for n, r in zip(ctx.names, ctx.req))
+        return (None, None, None, dmem if ctx.mem_req else None, None, None, None, None, None) + grads
+
+
+class PostnetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, prefix, names, inputs, len32, fuse_add, train, *params):
+        need = torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in params))
+        out, c = eng.postnet_forward(inputs, len32, inputs if fuse_add else None, train, eng.next_seed(), need)
+        ctx.eng, ctx.c, ctx.names, ctx.prefix, ctx.fuse = eng, c, names, prefix, fuse_add
+        ctx.req = [p.requires_grad for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.eng
+        din = eng.postnet_backward(ctx.c, dout)
+        if ctx.fuse:
+            din = eng.add(din, dout)
+        ctx.c.free()
+        grads = tuple(eng.grad_view(ctx.prefix + n) if r else None for n, r in zip(ctx.names, ctx.req))
+        return (None, None, None, din, None, None, None) + grads
+
+
+class LossFn(torch.autograd.Function):
+    """vals[7] = loss, bef, aft, mse, l2, stop, sum_len.  The L2 gradient is accumulated straight into the
+    engine's flat gradient buffer (returned to autograd by the segment functions)."""
+
+    @staticmethod
+    def forward(ctx, eng, bef, aft, stop, tgt, len32):
+        vals, per = eng.loss_forward(bef, aft, stop, tgt, len32)
+        ctx.eng = eng
+        ctx.save_for_backward(bef, aft, stop, tgt, len32)
+        ctx.mark_non_differentiable(per)
+        return vals, per
+
+    @staticmethod
+    def backward(ctx, g, _gper):
+        eng = ctx.eng
+        bef, aft, stop, tgt, len32 = ctx.saved_tensors
+        # d/d(bef_loss), d/d(aft_loss), d/d(stop_loss), d/d(l2) of the scalar being differentiated
+        w = torch.stack([g[0] + g[1] + 0.5 * g[3], g[0] + g[2] + 0.5 * g[3], g[0] + g[5], g[0] + g[4]]).contiguous()
+        eng.begin_backward()
+        dbef, daft, dstop = eng.loss_backward(bef, aft, stop, tgt, len32, w)
+        eng.l2_backward(w[3:])
+        return None, dbef, daft, dstop, None, None

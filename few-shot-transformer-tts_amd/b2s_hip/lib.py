@@ -1,0 +1,119 @@
+"""ctypes binding of libb2s_hip.so (C ABI in include/b2s_hip.h).
+
+The library is the product; there is NO CPU fallback: if it cannot be loaded, or a tensor is not on
+a HIP device, the calls raise.  PyTorch is used only for device memory, streams and autograd plumbing.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libb2s_hip.so")
+
+_lib = None
+
+
+class B2SError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "num_mels", "vocab_size", "embed_size", "encoder_hidden", "decoder_hidden",
+        "n_encoder_layer", "n_decoder_layer", "n_attention_head",
+        "prenet_hidden", "postnet_hidden", "n_postnet_layer",
+        "multi_speaker", "max_num_speaker", "speaker_embedding_size",
+        "multi_lingual", "max_num_language", "language_embedding_size")] + [
+        ("transformer_dropout_rate", C.c_float), ("decoder_dropout_rate", C.c_float),
+        ("reg_weight", C.c_float), ("compute_dtype", C.c_int32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "trans_a", "trans_b", "M", "N", "K", "lda", "ldb", "ldc", "c_fp32",
+                                         "batch", "batch_inner")] + \
+               [(n, C.c_int64) for n in ("a_bs_o", "a_bs_i", "b_bs_o", "b_bs_i", "c_bs_o", "c_bs_i")] + \
+               [("alpha", C.c_float), ("relu", C.c_int32), ("accumulate", C.c_int32), ("drop_p", C.c_float),
+                ("seed", C.c_uint64), ("conv_cin_a", C.c_int32), ("conv_T", C.c_int32), ("conv_dw_cin", C.c_int32),
+                ("rows_per_batch", C.c_int32)]
+
+
+P = C.c_void_p
+_PROTOS = {
+    "b2s_last_error": (C.c_char_p, []),
+    "b2s_version": (C.c_int, []),
+    "b2s_model_create": (C.c_int, [C.POINTER(Config), C.POINTER(P)]),
+    "b2s_model_destroy": (None, [P]),
+    "b2s_model_num_tensors": (C.c_int, [P]),
+    "b2s_model_tensor_info": (C.c_int, [P, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "b2s_model_bind": (C.c_int, [P, C.POINTER(P), C.POINTER(P), C.c_int]),
+    "b2s_model_sync_weights": (C.c_int, [P, P]),
+    "b2s_encoder_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int]),
+    "b2s_encoder_forward": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, C.POINTER(P)]),
+    "b2s_encoder_backward": (C.c_int, [P, P, P, P]),
+    "b2s_decoder_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int, C.c_int]),
+    "b2s_decoder_forward": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, P, C.POINTER(P)]),
+    "b2s_decoder_backward": (C.c_int, [P, P, P, P, P, P]),
+    "b2s_decoder_alignment": (C.c_int, [P, P, C.c_int, C.c_int, P, P]),
+    "b2s_postnet_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int]),
+    "b2s_postnet_forward": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, C.POINTER(P)]),
+    "b2s_postnet_backward": (C.c_int, [P, P, P, P, P]),
+    "b2s_ctx_free": (None, [P]),
+    "b2s_loss_forward": (C.c_int, [P, P, P, P, P, P, C.c_int, C.c_int, P, P, P, P]),
+    "b2s_loss_backward": (C.c_int, [P, P, P, P, P, P, C.c_int, C.c_int, P, P, P, P, P]),
+    "b2s_l2_backward": (C.c_int, [P, P, P]),
+    "b2s_adam_bind": (C.c_int, [P, C.POINTER(P), C.POINTER(P), C.c_int]),
+    "b2s_adam_step": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, P]),
+    "b2s_zero_grads": (C.c_int, [P, P]),
+    "b2s_gemm": (C.c_int, [C.POINTER(GemmDesc), P, P, P, P, P, P, P, P]),
+    "b2s_layernorm_forward": (C.c_int, [C.c_int, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, P]),
+    "b2s_layernorm_backward": (C.c_int, [C.c_int, P, P, P, P, P, P, P, P, C.c_int, C.c_int, P]),
+    "b2s_attention_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "b2s_attention_forward": (C.c_int, [C.c_int, P, C.c_int, P, C.c_int, P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, P, P, C.c_int64, C.c_int64, C.c_float, C.c_uint64, P, P, P, P]),
+    "b2s_attention_backward": (C.c_int, [C.c_int, P, C.c_int, P, C.c_int, P, C.c_int, P, C.c_int, P, P, P, C.c_int, P, C.c_int,
+                                         P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, P, P]),
+    "b2s_align_from_probs": (C.c_int, [C.c_int, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P]),
+    "b2s_add": (C.c_int, [P, P, P, C.c_int64, P]),
+    "b2s_cast": (C.c_int, [C.c_int, P, P, C.c_int64, P]),
+    "b2s_cast_back": (C.c_int, [C.c_int, P, P, C.c_int64, P]),
+    "b2s_dropout_mask": (C.c_int, [C.c_float, C.c_uint64, C.c_uint32, P, C.c_int64, P]),
+}
+EXPORTS = sorted(_PROTOS)
+
+
+def load():
+    """Load libb2s_hip.so (raises B2SError if it is missing -- there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise B2SError("libb2s_hip.so not found at %s -- build it with few-shot-transformer-tts_amd/csrc/build.sh "
+                       "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise B2SError(load().b2s_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses CPU tensors: the HIP path is the only path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise B2SError("tensor is on %s; the byte2speech hot path runs on a HIP device only" % t.device)
+    if not t.is_contiguous():
+        raise B2SError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,102 @@
+// Op-level C ABI: thin wrappers used by the standalone modules (MultiheadAttention, FFNLayer, ...) and by
+// the op parity tests.  See include/b2s_hip.h.
+#include "engine.h"
+
+namespace {
+inline hipStream_t S_(void* s) { return (hipStream_t)s; }
+inline int rup8(int x) { return (x + 7) & ~7; }
+__global__ void k_dropmask(DropCfg d, uint8_t* out, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = b2s_keep(d, (uint32_t)i) ? 1 : 0;
+}
+}  // namespace
+
+// defined in engine.hip
+int b2s_attn_core_fwd_export(int dtype, hipStream_t st, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                             void* ctx, int ldc, int B, int H, int Lq, int Lk, int dh, int mask_mode, const int* klen,
+                             const float* bias, long bias_sb, long bias_sq, DropCfg drop, float* S, void* P, void* Pd);
+int b2s_attn_core_bwd_export(int dtype, hipStream_t st, const void* dctx, int ldc, const void* q, int ldq, const void* k, int ldk,
+                             const void* v, int ldv, const void* P, const void* Pd, void* dq, int lddq, void* dk, int lddk,
+                             void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, DropCfg drop, float* dP, void* dS);
+
+extern "C" int b2s_gemm(const b2s_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
+                        const float* residual, const int32_t* row_len, const int32_t* conv_len, void* stream) {
+    B2S_CHECK(d && A && B && C, "null argument");
+    GemmArgs g;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.batch = d->batch > 0 ? d->batch : 1; g.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
+    g.A.p = A; g.A.ld = d->lda; g.A.bs_o = d->a_bs_o; g.A.bs_i = d->a_bs_i;
+    g.B.p = B; g.B.ld = d->ldb; g.B.bs_o = d->b_bs_o; g.B.bs_i = d->b_bs_i;
+    if (d->trans_a) { g.A.R = d->K; g.A.C = d->M; } else { g.A.R = d->M; g.A.C = d->K; }
+    if (d->trans_b) { g.B.R = d->K; g.B.C = d->N; } else { g.B.R = d->N; g.B.C = d->K; }
+    if (d->conv_cin_a > 0) {
+        B2S_CHECK(!d->trans_a, "conv gather is defined on the row-major A operand");
+        g.A.g_cin = d->conv_cin_a; g.A.g_T = d->conv_T; g.A.g_len = conv_len; g.A.R = d->M; g.A.C = d->K;
+    }
+    g.C = C; g.c_fp32 = d->c_fp32; g.ldc = d->ldc; g.cs_o = d->c_bs_o; g.cs_i = d->c_bs_i;
+    g.epi.alpha = d->alpha; g.epi.bias = bias; g.epi.relu = d->relu; g.epi.accumulate = d->accumulate;
+    g.epi.drop = make_drop(d->drop_p, d->seed, 7u);
+    g.epi.residual = residual; g.epi.ldr = d->ldc;
+    g.epi.row_len = row_len; g.epi.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
+    g.epi.conv_dw_cin = d->conv_dw_cin;
+    return b2s_gemm_launch(g, d->dtype, d->trans_a != 0, d->trans_b != 0, S_(stream));
+}
+extern "C" int b2s_layernorm_forward(int dtype, const float* x, const float* gamma, const float* beta, void* y, float* mean,
+                                     float* rstd, int M, int D, float eps, void* stream) {
+    B2S_CHECK(x && gamma && beta && y && mean && rstd, "null argument");
+    return ro_layernorm_fwd(dtype, x, gamma, beta, y, D, nullptr, 0, mean, rstd, M, D, eps, nullptr, 1, S_(stream));
+}
+extern "C" int b2s_layernorm_backward(int dtype, const void* dy, const float* x, const float* gamma, const float* mean,
+                                      const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int D, void* stream) {
+    B2S_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "null argument");
+    B2S_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * D, S_(stream)));
+    B2S_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * D, S_(stream)));
+    return ro_layernorm_bwd(dtype, dy, 0, D, x, gamma, mean, rstd, dx, 0, dgamma, dbeta, M, D, nullptr, 1, S_(stream));
+}
+extern "C" size_t b2s_attention_ws_bytes(int dtype, int B, int H, int Lq, int Lk) {
+    const size_t pn = (size_t)B * H * Lq * rup8(Lk);
+    return 2 * pn * 4 + pn * (dtype ? 2 : 4) + 1024;      // S / dP (fp32) + dS (T)
+}
+extern "C" int b2s_attention_forward(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* ctx,
+                                     int ldc, int B, int H, int Lq, int Lk, int dh, int mask_mode, const int32_t* klen,
+                                     const float* bias, int64_t bias_sb, int64_t bias_sq, float drop_p, uint64_t seed, void* ws,
+                                     void* P_out, void* Pd_out, void* stream) {
+    B2S_CHECK(q && k && v && ctx && ws && P_out, "null argument");
+    B2S_CHECK(drop_p <= 0.f || Pd_out, "Pd_out is required when dropout is on");
+    return b2s_attn_core_fwd_export(dtype, S_(stream), q, ldq, k, ldk, v, ldv, ctx, ldc, B, H, Lq, Lk, dh, mask_mode, klen, bias,
+                                    bias_sb, bias_sq, make_drop(drop_p, seed, 11u), (float*)ws, P_out, Pd_out);
+}
+extern "C" int b2s_attention_backward(int dtype, const void* dctx, int ldc, const void* q, int ldq, const void* k, int ldk,
+                                      const void* v, int ldv, const void* P, const void* Pd, void* dq, int lddq, void* dk, int lddk,
+                                      void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, float drop_p, uint64_t seed, void* ws,
+                                      void* stream) {
+    B2S_CHECK(dctx && q && k && v && P && dq && dk && dv && ws, "null argument");
+    const size_t pn = (size_t)B * H * Lq * rup8(Lk);
+    float* dP = (float*)ws + pn;
+    void* dS = (void*)((float*)ws + 2 * pn);
+    return b2s_attn_core_bwd_export(dtype, S_(stream), dctx, ldc, q, ldq, k, ldk, v, ldv, P, Pd, dq, lddq, dk, lddk, dv, lddv, B, H,
+                                    Lq, Lk, dh, make_drop(drop_p, seed, 11u), dP, dS);
+}
+extern "C" int b2s_align_from_probs(int dtype, const void* P, float* align, int B, int H, int Lq, int Lk, void* stream) {
+    B2S_CHECK(P && align, "null argument");
+    return ro_align_transpose(dtype, P, align, B * H, Lq, Lk, rup8(Lk), S_(stream));
+}
+extern "C" int b2s_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    B2S_CHECK(a && b && out, "null argument");
+    return ro_add(a, b, out, n, S_(stream));
+}
+extern "C" int b2s_cast(int dtype, const float* in, void* out, int64_t n, void* stream) {
+    B2S_CHECK(in && out, "null argument");
+    return ro_cast(dtype, in, out, n, S_(stream));
+}
+extern "C" int b2s_cast_back(int dtype, const void* in, float* out, int64_t n, void* stream) {
+    B2S_CHECK(in && out, "null argument");
+    return ro_cast_back(dtype, in, out, n, S_(stream));
+}
+extern "C" int b2s_dropout_mask(float p, uint64_t seed, uint32_t op_id, uint8_t* out, int64_t n, void* stream) {
+    B2S_CHECK(out && n >= 0, "bad argument");
+    DropCfg d = make_drop(p, seed, op_id);
+    if (p <= 0.f) { B2S_HIP(hipMemsetAsync(out, 1, n, S_(stream))); return 0; }
+    hipLaunchKernelGGL(k_dropmask, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), d, out, (long)n);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}

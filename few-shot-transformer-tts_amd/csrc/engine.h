@@ -1,0 +1,105 @@
+// Internal model / context structures of libb2s_hip (see engine.hip).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/b2s_hip.h"
+#include "b2s_common.h"
+#include "gemm.h"
+#include "rowops.h"
+
+struct TensorInfo {
+    std::string name;
+    std::vector<int64_t> shape;
+    int kind;      // 1 parameter, 0 fp32 buffer, 2 int64 buffer
+    long numel;
+    bool gemm_weight;   // gets a compute-dtype shadow
+    bool l2;            // member of the L2 set (tacotron.py:144-146)
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    bool overflow = false;
+    void* take(size_t bytes) {
+        size_t o = (off + 255) & ~(size_t)255;
+        off = o + bytes;
+        if (!base) return nullptr;                 // dry run: size only
+        if (off > cap) { overflow = true; return base; }
+        return base + o;
+    }
+    float* f32(long n) { return (float*)take((size_t)n * 4); }
+    void* T(long n, int esz) { return take((size_t)n * esz); }
+};
+
+struct AttnSave {            // one attention sub-layer
+    float* x_in = nullptr;   // residual input (fp32) = LayerNorm input
+    float *mean = nullptr, *rstd = nullptr;
+    void* h = nullptr;       // LN output (T)
+    void* qkv = nullptr;     // self: [M,3D] ; cross: q [M,D]
+    void* kv = nullptr;      // cross: [B*S,2D]
+    void *P = nullptr, *Pd = nullptr;   // softmax weights (T) [B,H,Lq,ldp] ; Pd == P when no dropout
+    void* ctx = nullptr;     // [M,D] (T)
+    int Lq = 0, Lk = 0, ldp = 0;
+    uint32_t op_attn = 0, op_res = 0;
+};
+struct FfnSave {
+    float* x_in = nullptr;
+    float *mean = nullptr, *rstd = nullptr;
+    void* h = nullptr;
+    void* f = nullptr;       // [M,4D] post relu+dropout (T)
+    uint32_t op_hid = 0, op_res = 0;
+};
+
+struct b2s_ctx {
+    int kind = 0;            // 1 encoder, 2 decoder, 3 postnet
+    int B = 0, S = 0, T = 0;
+    int train = 0;
+    uint64_t seed = 0;
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    Arena scratch;           // region after the saved activations (reused by backward)
+    // inputs (caller keeps them alive until backward)
+    const int64_t* ids = nullptr;
+    const int32_t *in_len = nullptr, *tgt_len = nullptr;
+    const int64_t* spk_ids = nullptr;
+    const float* lang_vecs = nullptr;
+    // encoder
+    std::vector<AttnSave> self_attn, cross_attn;
+    std::vector<FfnSave> ffn;
+    float* x_final = nullptr;           // input of the output LayerNorm
+    float *mean_f = nullptr, *rstd_f = nullptr;
+    float *spk_e = nullptr, *spk_h = nullptr, *lang_e = nullptr, *lang_h = nullptr;
+    // decoder
+    void* memT = nullptr;
+    void *tgtT = nullptr, *a1 = nullptr, *a2 = nullptr;
+    void* outT = nullptr;               // imputed decoder output (T)
+    // postnet
+    std::vector<void*> u;               // conv inputs (T), u[0] = cast(inputs)
+    std::vector<float*> y, bn_mean, bn_rstd;
+};
+
+struct b2s_model {
+    b2s_config cfg;
+    int dtype = 0, esz = 4;
+    int Dm = 0;                                     // memory width
+    std::vector<TensorInfo> tinfo;
+    std::map<std::string, int> index;
+    std::vector<void*> data, grad, shadow;          // per tensor
+    std::vector<void*> exp_avg, exp_avg_sq;
+    std::vector<void*> conv_wf, conv_wb;            // per postnet layer (T)
+    float *pe_enc = nullptr, *pe_dec = nullptr;
+    int pe_len = 0;
+    bool bound = false;
+    // multi-tensor chunk tables (device)
+    MtChunk *l2_chunks = nullptr, *adam_chunks = nullptr;
+    int n_l2_chunks = 0, n_adam_chunks = 0;
+    float* small = nullptr;                         // device scratch: [0..15] misc scalars
+    std::vector<void*> owned;                       // hipMalloc'ed buffers
+
+    int id(const std::string& n) const;
+    float* P(const std::string& n) const { return (float*)data[id(n)]; }
+    float* G(const std::string& n) const { return (float*)grad[id(n)]; }
+    void* W(const std::string& n) const { return shadow[id(n)]; }
+    long numel(const std::string& n) const { return tinfo[id(n)].numel; }
+};

@@ -1,0 +1,1006 @@
+// Model-level orchestration of the Transformer-TTS hot path on MI355X: encoder / decoder / postnet /
+// loss forward and hand-derived backward, built from the MFMA GEMM (gemm.hip) and the row kernels
+// (rowops.hip).  Reference: transformer/tacotron.py, transformer/modules.py, transformer/attention.py.
+//
+// Memory plan (HBM): every activation is token-major [B*L, C].  The residual stream, statistics,
+// parameter gradients and logits are fp32; GEMM operands ("T") are bf16 in performance mode and fp32
+// in parity mode.  One caller-provided workspace per forward call holds the saved activations and the
+// scratch of both passes (288 GB of HBM3E: nothing is recomputed, nothing is aliased).
+#include <cmath>
+#include <cstdarg>
+#include "engine.h"
+
+thread_local char g_b2s_err[512] = "";
+int b2s_fail(const char* file, int line, const char* fmt, ...) {
+    char msg[400];
+    va_list ap; va_start(ap, fmt); vsnprintf(msg, sizeof(msg), fmt, ap); va_end(ap);
+    const char* base = strrchr(file, '/');
+    snprintf(g_b2s_err, sizeof(g_b2s_err), "%s:%d: %s", base ? base + 1 : file, line, msg);
+    return 1;
+}
+
+int b2s_model::id(const std::string& n) const {
+    auto it = index.find(n);
+    return it == index.end() ? -1 : it->second;
+}
+
+namespace {
+
+inline int rup8(int x) { return (x + 7) & ~7; }
+inline hipStream_t S_(void* s) { return (hipStream_t)s; }
+inline uint32_t opid(int seg, int layer, int k) { return (uint32_t)(seg * 4096 + layer * 32 + k); }
+
+// ------------------------------------------------------------------------------------------------ layout
+void add_t(b2s_model* m, const std::string& name, std::vector<int64_t> shape, int kind, bool gw) {
+    TensorInfo t;
+    t.name = name; t.shape = shape; t.kind = kind; t.gemm_weight = gw;
+    t.numel = 1; for (auto d : shape) t.numel *= d;
+    t.l2 = kind == 1 && name.find("weight") != std::string::npos && name.find("layer_norm") == std::string::npos &&
+           name.find("batchnorm") == std::string::npos && name.find("encoder.speaker_embed") == std::string::npos &&
+           name.find("encoder.embed") == std::string::npos;                      // tacotron.py:144-146
+    m->index[name] = (int)m->tinfo.size();
+    m->tinfo.push_back(t);
+}
+std::string nm(const std::string& p, const char* list, int i, const char* leaf) {
+    return p + list + "." + std::to_string(i) + "." + leaf;
+}
+// state_dict layout of Tacotron(hp): registration order of the reference modules (tacotron.py:8-123,
+// modules.py:23-106, attention.py:30-51)
+void build_layout(b2s_model* m) {
+    const b2s_config& c = m->cfg;
+    const int De = c.embed_size, Dh = c.encoder_hidden, Dd = c.decoder_hidden;
+    const int Dm = m->Dm;
+    auto ln = [&](const std::string& p) { add_t(m, p + ".weight", {0}, 1, false); add_t(m, p + ".bias", {0}, 1, false); };
+    auto ln_n = [&](const std::string& p, int n) {
+        add_t(m, p + ".weight", {n}, 1, false); add_t(m, p + ".bias", {n}, 1, false);
+    };
+    (void)ln;
+    add_t(m, "encoder.embed.weight", {c.vocab_size, De}, 1, false);
+    if (c.multi_speaker) {
+        add_t(m, "encoder.speaker_embed.weight", {c.max_num_speaker, c.speaker_embedding_size}, 1, false);
+        add_t(m, "encoder.speaker_layer.weight", {c.speaker_embedding_size, c.speaker_embedding_size}, 1, false);
+        add_t(m, "encoder.speaker_layer.bias", {c.speaker_embedding_size}, 1, false);
+    }
+    if (c.multi_lingual) {
+        add_t(m, "encoder.language_embed.weight", {c.language_embedding_size, c.max_num_language}, 1, false);
+        add_t(m, "encoder.language_layer.weight", {c.language_embedding_size, c.language_embedding_size}, 1, false);
+        add_t(m, "encoder.language_layer.bias", {c.language_embedding_size}, 1, false);
+    }
+    std::string p = "encoder.encoder.";
+    add_t(m, p + "pe_scale", {}, 1, false);
+    for (int i = 0; i < c.n_encoder_layer; ++i) {
+        int n = i == 0 ? De : Dh;
+        add_t(m, nm(p, "self_attentions", i, "qkv_transform.weight"), {3 * n, n}, 1, true);
+        add_t(m, nm(p, "self_attentions", i, "output_transform.weight"), {n, n}, 1, true);
+    }
+    for (int i = 0; i < c.n_encoder_layer; ++i) ln_n(p + "attn_layer_norms." + std::to_string(i), i == 0 ? De : Dh);
+    for (int i = 0; i < c.n_encoder_layer; ++i) {
+        add_t(m, nm(p, "ffn_layers", i, "input_layer.weight"), {4 * Dh, Dh}, 1, true);
+        add_t(m, nm(p, "ffn_layers", i, "output_layer.weight"), {Dh, 4 * Dh}, 1, true);
+    }
+    for (int i = 0; i < c.n_encoder_layer; ++i) ln_n(p + "ffn_layer_norms." + std::to_string(i), Dh);
+    ln_n(p + "output_layer_norm", Dh);
+    add_t(m, "decoder.prenet.dense0.weight", {c.prenet_hidden, c.num_mels}, 1, true);
+    add_t(m, "decoder.prenet.dense0.bias", {c.prenet_hidden}, 1, false);
+    add_t(m, "decoder.prenet.dense1.weight", {c.prenet_hidden, c.prenet_hidden}, 1, true);
+    add_t(m, "decoder.prenet.dense1.bias", {c.prenet_hidden}, 1, false);
+    add_t(m, "decoder.prenet.dense_final.weight", {Dd, c.prenet_hidden}, 1, true);
+    p = "decoder.decoder.";
+    add_t(m, p + "pe_scale", {}, 1, false);
+    for (int i = 0; i < c.n_decoder_layer; ++i) {
+        int n = i == 0 ? Dm : Dd;
+        add_t(m, nm(p, "self_attentions", i, "qkv_transform.weight"), {3 * n, n}, 1, true);
+        add_t(m, nm(p, "self_attentions", i, "output_transform.weight"), {n, n}, 1, true);
+    }
+    for (int i = 0; i < c.n_decoder_layer; ++i) ln_n(p + "attn_layer_norms." + std::to_string(i), i == 0 ? Dm : Dd);
+    for (int i = 0; i < c.n_decoder_layer; ++i) {
+        add_t(m, nm(p, "encdec_attentions", i, "q_transform.weight"), {Dd, Dd}, 1, true);
+        add_t(m, nm(p, "encdec_attentions", i, "kv_transform.weight"), {2 * Dd, Dd}, 1, true);
+        add_t(m, nm(p, "encdec_attentions", i, "output_transform.weight"), {Dd, Dd}, 1, true);
+    }
+    for (int i = 0; i < c.n_decoder_layer; ++i) ln_n(p + "encdec_layer_norms." + std::to_string(i), i == 0 ? Dm : Dd);
+    for (int i = 0; i < c.n_decoder_layer; ++i) {
+        add_t(m, nm(p, "ffn_layers", i, "input_layer.weight"), {4 * Dd, Dd}, 1, true);
+        add_t(m, nm(p, "ffn_layers", i, "output_layer.weight"), {Dd, 4 * Dd}, 1, true);
+    }
+    for (int i = 0; i < c.n_decoder_layer; ++i) ln_n(p + "ffn_layer_norms." + std::to_string(i), Dd);
+    ln_n(p + "output_layer_norm", Dd);
+    add_t(m, "decoder.mel_net.weight", {c.num_mels, Dd}, 1, true);
+    add_t(m, "decoder.stop_net.weight", {1, Dd}, 1, false);
+    add_t(m, "decoder.stop_net.bias", {1}, 1, false);
+    for (int i = 0; i < c.n_postnet_layer; ++i) {
+        int cin = i == 0 ? c.num_mels : c.postnet_hidden;
+        int cout = i == c.n_postnet_layer - 1 ? c.num_mels : c.postnet_hidden;
+        add_t(m, "postnet.conv_layers." + std::to_string(i) + ".weight", {cout, cin, 5}, 1, false);
+    }
+    for (int i = 0; i < c.n_postnet_layer; ++i) {
+        int cout = i == c.n_postnet_layer - 1 ? c.num_mels : c.postnet_hidden;
+        std::string q = "postnet.batchnorm_layers." + std::to_string(i) + ".";
+        add_t(m, q + "weight", {cout}, 1, false);
+        add_t(m, q + "bias", {cout}, 1, false);
+        add_t(m, q + "running_mean", {cout}, 0, false);
+        add_t(m, q + "running_var", {cout}, 0, false);
+        add_t(m, q + "num_batches_tracked", {}, 2, false);
+    }
+}
+
+// sinusoid table, float64 then cast (common.py:4-29)
+void fill_pe(std::vector<float>& out, int length, int channels) {
+    const int nts = channels / 2;
+    const double inc = std::log(1.0e4 / 1.0) / (double)(nts - 1);
+    out.assign((size_t)length * channels, 0.f);
+    for (int i = 0; i < nts; ++i) {
+        const double inv = 1.0 * std::exp((double)i * -inc);
+        for (int pos = 0; pos < length; ++pos) {
+            const double st = (double)pos * inv;
+            out[(size_t)pos * channels + i] = (float)std::sin(st);
+            out[(size_t)pos * channels + nts + i] = (float)std::cos(st);
+        }
+    }
+}
+int ensure_pe(b2s_model* m, int len) {
+    if (len <= m->pe_len) return 0;
+    int n = 2048; while (n < len) n *= 2;
+    std::vector<float> h;
+    float *pe_e = nullptr, *pe_d = nullptr;
+    fill_pe(h, n, m->cfg.embed_size);
+    B2S_HIP(hipMalloc(&pe_e, h.size() * 4)); B2S_HIP(hipMemcpy(pe_e, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    fill_pe(h, n, m->cfg.decoder_hidden);
+    B2S_HIP(hipMalloc(&pe_d, h.size() * 4)); B2S_HIP(hipMemcpy(pe_d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    // old tables (if any) stay alive until the model is destroyed: earlier launches may still read them
+    m->owned.push_back(pe_e); m->owned.push_back(pe_d);
+    m->pe_enc = pe_e; m->pe_dec = pe_d; m->pe_len = n;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM helpers
+// Y[M,N] = X[M,K] * W[N,K]^T
+int linear(const b2s_model* m, hipStream_t st, const void* X, int ldx, const void* W, int M, int N, int K, void* out,
+           int out_fp32, int ldo, const GemmEpilogue& e) {
+    GemmArgs g;
+    g.A.p = X; g.A.ld = ldx; g.A.R = M; g.A.C = K;
+    g.B.p = W; g.B.ld = K; g.B.R = N; g.B.C = K;
+    g.M = M; g.N = N; g.K = K; g.C = out; g.c_fp32 = out_fp32; g.ldc = ldo; g.epi = e;
+    return b2s_gemm_launch(g, m->dtype, false, false, st);
+}
+// dX[M,Nin] = dY[M,Kout] * W[Kout,Nin]
+int linear_dx(const b2s_model* m, hipStream_t st, const void* dY, int lddy, const void* W, int M, int Nin, int Kout,
+              void* out, int out_fp32, int ldo, const GemmEpilogue& e) {
+    GemmArgs g;
+    g.A.p = dY; g.A.ld = lddy; g.A.R = M; g.A.C = Kout;
+    g.B.p = W; g.B.ld = Nin; g.B.R = Kout; g.B.C = Nin;
+    g.M = M; g.N = Nin; g.K = Kout; g.C = out; g.c_fp32 = out_fp32; g.ldc = ldo; g.epi = e;
+    return b2s_gemm_launch(g, m->dtype, false, true, st);
+}
+// dW[Nout,Kin] = dY[M,Nout]^T * X[M,Kin]
+int linear_dw(const b2s_model* m, hipStream_t st, const void* dY, int lddy, const void* X, int ldx, int M, int Nout,
+              int Kin, float* dW) {
+    GemmArgs g;
+    g.A.p = dY; g.A.ld = lddy; g.A.R = M; g.A.C = Nout;
+    g.B.p = X; g.B.ld = ldx; g.B.R = M; g.B.C = Kin;
+    g.M = Nout; g.N = Kin; g.K = M; g.C = dW; g.c_fp32 = 1; g.ldc = Kin;
+    g.epi.accumulate = 1;          // parameter gradients accumulate; the host zeroes them once per backward pass
+    return b2s_gemm_launch(g, m->dtype, true, true, st);
+}
+
+struct AttnScratch { float* S; float* dP; void* dS; };
+
+// softmax(scale * Q K^T + mask) V on head-interleaved rows (attention.py:72-92)
+int attn_core_fwd(int dtype, hipStream_t st, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                  void* ctx, int ldc, int B, int H, int Lq, int Lk, int dh, int mask_mode, const int* klen,
+                  const float* bias, long bias_sb, long bias_sq, DropCfg drop, float* S, void* P, void* Pd) {
+    const int ldp = rup8(Lk);
+    GemmArgs g;
+    g.A.p = q; g.A.ld = ldq; g.A.R = Lq; g.A.C = dh; g.A.bs_o = (long)Lq * ldq; g.A.bs_i = dh;
+    g.B.p = k; g.B.ld = ldk; g.B.R = Lk; g.B.C = dh; g.B.bs_o = (long)Lk * ldk; g.B.bs_i = dh;
+    g.M = Lq; g.N = Lk; g.K = dh; g.batch = B * H; g.batch_inner = H;
+    g.C = S; g.c_fp32 = 1; g.ldc = ldp; g.cs_o = (long)H * Lq * ldp; g.cs_i = (long)Lq * ldp;
+    B2S_TRY(b2s_gemm_launch(g, dtype, false, false, st));
+    const float scale = 1.f / sqrtf((float)dh);
+    B2S_TRY(ro_softmax_fwd(dtype, S, P, drop.thresh ? Pd : nullptr, B, H, Lq, Lk, ldp, scale, mask_mode, klen, bias,
+                           bias_sb, bias_sq, drop, st));
+    GemmArgs h;
+    h.A.p = drop.thresh ? Pd : P; h.A.ld = ldp; h.A.R = Lq; h.A.C = Lk; h.A.bs_o = (long)H * Lq * ldp; h.A.bs_i = (long)Lq * ldp;
+    h.B.p = v; h.B.ld = ldv; h.B.R = Lk; h.B.C = dh; h.B.bs_o = (long)Lk * ldv; h.B.bs_i = dh;
+    h.M = Lq; h.N = dh; h.K = Lk; h.batch = B * H; h.batch_inner = H;
+    h.C = ctx; h.c_fp32 = 0; h.ldc = ldc; h.cs_o = (long)Lq * ldc; h.cs_i = dh;
+    return b2s_gemm_launch(h, dtype, false, true, st);
+}
+int attn_core_bwd(int dtype, hipStream_t st, const void* dctx, int ldc, const void* q, int ldq, const void* k, int ldk,
+                  const void* v, int ldv, const void* P, const void* Pd, void* dq, int lddq, void* dk, int lddk,
+                  void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, DropCfg drop, float* dP, void* dS) {
+    const int ldp = rup8(Lk);
+    const long ps_o = (long)H * Lq * ldp, ps_i = (long)Lq * ldp;
+    const void* Pdrop = drop.thresh ? Pd : P;
+    {   // dPraw = dctx * V^T
+        GemmArgs g;
+        g.A.p = dctx; g.A.ld = ldc; g.A.R = Lq; g.A.C = dh; g.A.bs_o = (long)Lq * ldc; g.A.bs_i = dh;
+        g.B.p = v; g.B.ld = ldv; g.B.R = Lk; g.B.C = dh; g.B.bs_o = (long)Lk * ldv; g.B.bs_i = dh;
+        g.M = Lq; g.N = Lk; g.K = dh; g.batch = B * H; g.batch_inner = H;
+        g.C = dP; g.c_fp32 = 1; g.ldc = ldp; g.cs_o = ps_o; g.cs_i = ps_i;
+        B2S_TRY(b2s_gemm_launch(g, dtype, false, false, st));
+    }
+    {   // dV = Pdrop^T * dctx
+        GemmArgs g;
+        g.A.p = Pdrop; g.A.ld = ldp; g.A.R = Lq; g.A.C = Lk; g.A.bs_o = ps_o; g.A.bs_i = ps_i;
+        g.B.p = dctx; g.B.ld = ldc; g.B.R = Lq; g.B.C = dh; g.B.bs_o = (long)Lq * ldc; g.B.bs_i = dh;
+        g.M = Lk; g.N = dh; g.K = Lq; g.batch = B * H; g.batch_inner = H;
+        g.C = dv; g.c_fp32 = 0; g.ldc = lddv; g.cs_o = (long)Lk * lddv; g.cs_i = dh;
+        B2S_TRY(b2s_gemm_launch(g, dtype, true, true, st));
+    }
+    const float scale = 1.f / sqrtf((float)dh);
+    B2S_TRY(ro_softmax_bwd(dtype, P, dP, dS, B, H, Lq, Lk, ldp, scale, drop, st));
+    {   // dQ = dS * K
+        GemmArgs g;
+        g.A.p = dS; g.A.ld = ldp; g.A.R = Lq; g.A.C = Lk; g.A.bs_o = ps_o; g.A.bs_i = ps_i;
+        g.B.p = k; g.B.ld = ldk; g.B.R = Lk; g.B.C = dh; g.B.bs_o = (long)Lk * ldk; g.B.bs_i = dh;
+        g.M = Lq; g.N = dh; g.K = Lk; g.batch = B * H; g.batch_inner = H;
+        g.C = dq; g.c_fp32 = 0; g.ldc = lddq; g.cs_o = (long)Lq * lddq; g.cs_i = dh;
+        B2S_TRY(b2s_gemm_launch(g, dtype, false, true, st));
+    }
+    {   // dK = dS^T * Q
+        GemmArgs g;
+        g.A.p = dS; g.A.ld = ldp; g.A.R = Lq; g.A.C = Lk; g.A.bs_o = ps_o; g.A.bs_i = ps_i;
+        g.B.p = q; g.B.ld = ldq; g.B.R = Lq; g.B.C = dh; g.B.bs_o = (long)Lq * ldq; g.B.bs_i = dh;
+        g.M = Lk; g.N = dh; g.K = Lq; g.batch = B * H; g.batch_inner = H;
+        g.C = dk; g.c_fp32 = 0; g.ldc = lddk; g.cs_o = (long)Lk * lddk; g.cs_i = dh;
+        B2S_TRY(b2s_gemm_launch(g, dtype, true, true, st));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ planning
+struct Scratch {
+    float *S = nullptr, *dP = nullptr; void* dS = nullptr;
+    void *dyT = nullptr, *dz = nullptr, *dqkv = nullptr, *dctx = nullptr, *dh = nullptr, *dkv = nullptr;
+    float *dx = nullptr, *a3 = nullptr, *dmem = nullptr, *dstop_m = nullptr;
+    void *dmelT = nullptr, *doutT = nullptr, *da3 = nullptr, *dz1 = nullptr, *dz2 = nullptr;
+};
+
+void plan_attn(Arena& a, AttnSave& s, int esz, long M, int D, int B, int H, int Lq, int Lk, bool cross, long Mk,
+               bool dropout) {
+    s.Lq = Lq; s.Lk = Lk; s.ldp = rup8(Lk);
+    s.mean = a.f32(M); s.rstd = a.f32(M);
+    s.h = a.T(M * D, esz);
+    s.qkv = a.T(M * (cross ? D : 3 * D), esz);
+    if (cross) s.kv = a.T(Mk * 2 * D, esz);
+    const long pn = (long)B * H * Lq * s.ldp;
+    s.P = a.T(pn, esz);
+    s.Pd = dropout ? a.T(pn, esz) : s.P;
+    s.ctx = a.T(M * D, esz);
+}
+void plan_ffn(Arena& a, FfnSave& s, int esz, long M, int D) {
+    s.mean = a.f32(M); s.rstd = a.f32(M);
+    s.h = a.T(M * D, esz);
+    s.f = a.T(M * 4 * D, esz);
+}
+
+void plan_encoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::vector<float*>& xs) {
+    const b2s_config& cf = m->cfg;
+    const int B = c.B, S = c.S, D = cf.encoder_hidden, H = cf.n_attention_head, esz = m->esz;
+    const long M = (long)B * S;
+    const bool dr = c.train && cf.transformer_dropout_rate > 0.f;
+    c.self_attn.assign(cf.n_encoder_layer, AttnSave());
+    c.ffn.assign(cf.n_encoder_layer, FfnSave());
+    xs.clear();
+    xs.push_back(a.f32(M * D));
+    for (int l = 0; l < cf.n_encoder_layer; ++l) {
+        c.self_attn[l].x_in = xs.back();
+        plan_attn(a, c.self_attn[l], esz, M, D, B, H, S, S, false, 0, dr);
+        xs.push_back(a.f32(M * D));
+        c.ffn[l].x_in = xs.back();
+        plan_ffn(a, c.ffn[l], esz, M, D);
+        xs.push_back(a.f32(M * D));
+    }
+    c.x_final = xs.back();
+    c.mean_f = a.f32(M); c.rstd_f = a.f32(M);
+    c.memT = a.T(M * m->Dm, esz);
+    if (cf.multi_speaker) { c.spk_e = a.f32((long)B * cf.speaker_embedding_size); c.spk_h = a.f32((long)B * cf.speaker_embedding_size); }
+    if (cf.multi_lingual) { c.lang_e = a.f32((long)B * cf.language_embedding_size); c.lang_h = a.f32((long)B * cf.language_embedding_size); }
+    // scratch (forward + backward)
+    const long pn = (long)B * H * S * rup8(S);
+    sc.S = a.f32(pn); sc.dP = a.f32(pn); sc.dS = a.T(pn, esz);
+    sc.dyT = a.T(M * D, esz); sc.dz = a.T(M * 4 * D, esz); sc.dqkv = a.T(M * 3 * D, esz);
+    sc.dctx = a.T(M * D, esz); sc.dh = a.T(M * D, esz); sc.dx = a.f32(M * D);
+}
+
+void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::vector<float*>& xs) {
+    const b2s_config& cf = m->cfg;
+    const int B = c.B, S = c.S, T = c.T, D = cf.decoder_hidden, H = cf.n_attention_head, esz = m->esz;
+    const long M = (long)B * T, Mk = (long)B * S;
+    const bool dr = c.train && cf.transformer_dropout_rate > 0.f;
+    c.self_attn.assign(cf.n_decoder_layer, AttnSave());
+    c.cross_attn.assign(cf.n_decoder_layer, AttnSave());
+    c.ffn.assign(cf.n_decoder_layer, FfnSave());
+    c.memT = a.T(Mk * D, esz);
+    c.tgtT = a.T(M * cf.num_mels, esz);
+    c.a1 = a.T(M * cf.prenet_hidden, esz);
+    c.a2 = a.T(M * cf.prenet_hidden, esz);
+    xs.clear();
+    xs.push_back(a.f32(M * D));
+    for (int l = 0; l < cf.n_decoder_layer; ++l) {
+        c.self_attn[l].x_in = xs.back();
+        plan_attn(a, c.self_attn[l], esz, M, D, B, H, T, T, false, 0, dr);
+        xs.push_back(a.f32(M * D));
+        c.cross_attn[l].x_in = xs.back();
+        plan_attn(a, c.cross_attn[l], esz, M, D, B, H, T, S, true, Mk, dr);
+        xs.push_back(a.f32(M * D));
+        c.ffn[l].x_in = xs.back();
+        plan_ffn(a, c.ffn[l], esz, M, D);
+        xs.push_back(a.f32(M * D));
+    }
+    c.x_final = xs.back();
+    c.mean_f = a.f32(M); c.rstd_f = a.f32(M);
+    c.outT = a.T(M * D, esz);
+    const long pn = (long)B * H * T * rup8(std::max(T, S));
+    sc.S = a.f32(pn); sc.dP = a.f32(pn); sc.dS = a.T(pn, esz);
+    sc.a3 = a.f32(M * D);
+    sc.dyT = a.T(M * D, esz); sc.dz = a.T(M * 4 * D, esz); sc.dqkv = a.T(M * 3 * D, esz);
+    sc.dkv = a.T(Mk * 2 * D, esz);
+    sc.dctx = a.T(M * D, esz); sc.dh = a.T(M * D, esz); sc.dx = a.f32(M * D);
+    sc.dmelT = a.T(M * cf.num_mels, esz); sc.doutT = a.T(M * D, esz); sc.da3 = a.T(M * D, esz);
+    sc.dz1 = a.T(M * cf.prenet_hidden, esz); sc.dz2 = a.T(M * cf.prenet_hidden, esz);
+    sc.dstop_m = a.f32(M);
+}
+
+struct PostScratch { std::vector<void*> du; float* stat; };
+void plan_postnet(const b2s_model* m, b2s_ctx& c, Arena& a, PostScratch& ps) {
+    const b2s_config& cf = m->cfg;
+    const long M = (long)c.B * c.T;
+    const int n = cf.n_postnet_layer, esz = m->esz;
+    c.u.assign(n, nullptr); c.y.assign(n, nullptr); c.bn_mean.assign(n, nullptr); c.bn_rstd.assign(n, nullptr);
+    ps.du.assign(n + 1, nullptr);
+    for (int i = 0; i < n; ++i) {
+        int cin = i == 0 ? cf.num_mels : cf.postnet_hidden;
+        int cout = i == n - 1 ? cf.num_mels : cf.postnet_hidden;
+        c.u[i] = a.T(M * cin, esz);
+        c.y[i] = a.f32(M * cout);
+        c.bn_mean[i] = a.f32(cout); c.bn_rstd[i] = a.f32(cout);
+        ps.du[i] = a.T(M * cin, esz);                 // gradient w.r.t. u[i]
+        // dy (gradient w.r.t. conv output) reuses du slot i+1 sized below
+    }
+    int maxc = std::max(cf.num_mels, cf.postnet_hidden);
+    ps.du[n] = a.T(M * maxc, esz);                    // dy buffer (T), reused by every layer
+    ps.stat = a.f32(2 * maxc);
+}
+
+int check_bound(const b2s_model* m) {
+    B2S_CHECK(m && m->bound, "model parameters are not bound (call b2s_model_bind first)");
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI: model
+extern "C" const char* b2s_last_error(void) { return g_b2s_err; }
+extern "C" int b2s_version(void) { return 100; }
+
+extern "C" int b2s_model_create(const b2s_config* cfg, b2s_model** out) {
+    B2S_CHECK(cfg && out, "null argument");
+    const b2s_config& c = *cfg;
+    B2S_CHECK(c.compute_dtype == 0 || c.compute_dtype == 1, "compute_dtype must be 0 (fp32) or 1 (bf16)");
+    B2S_CHECK(c.embed_size == c.encoder_hidden, "embed_size (%d) must equal encoder_hidden (%d)", c.embed_size, c.encoder_hidden);
+    int Dm = c.encoder_hidden + (c.multi_speaker ? c.speaker_embedding_size : 0) + (c.multi_lingual ? c.language_embedding_size : 0);
+    B2S_CHECK(Dm == c.decoder_hidden, "decoder_hidden (%d) must equal encoder_hidden + speaker + language widths (%d) "
+              "(transformer/modules.py:86-96 builds decoder layer 0 at the memory width)", c.decoder_hidden, Dm);
+    B2S_CHECK(c.encoder_hidden % c.n_attention_head == 0 && c.decoder_hidden % c.n_attention_head == 0,
+              "hidden sizes must be divisible by n_attention_head");          // attention.py:40-41
+    B2S_CHECK((c.encoder_hidden / c.n_attention_head) % 8 == 0 && (c.decoder_hidden / c.n_attention_head) % 8 == 0,
+              "head size must be a multiple of 8");
+    B2S_CHECK(c.num_mels % 8 == 0 && c.prenet_hidden % 8 == 0 && c.postnet_hidden % 8 == 0 && c.encoder_hidden % 8 == 0,
+              "num_mels / prenet_hidden / postnet_hidden / hidden sizes must be multiples of 8");
+    B2S_CHECK(c.encoder_hidden <= 1024 && c.decoder_hidden <= 1024, "hidden sizes above 1024 are not supported");
+    b2s_model* m = new b2s_model();
+    m->cfg = c; m->dtype = c.compute_dtype; m->esz = c.compute_dtype ? 2 : 4; m->Dm = Dm;
+    build_layout(m);
+    const size_t n = m->tinfo.size();
+    m->data.assign(n, nullptr); m->grad.assign(n, nullptr); m->shadow.assign(n, nullptr);
+    m->exp_avg.assign(n, nullptr); m->exp_avg_sq.assign(n, nullptr);
+    m->conv_wf.assign(c.n_postnet_layer, nullptr); m->conv_wb.assign(c.n_postnet_layer, nullptr);
+    *out = m;
+    return 0;
+}
+extern "C" void b2s_model_destroy(b2s_model* m) {
+    if (!m) return;
+    for (void* p : m->owned) (void)hipFree(p);
+    delete m;
+}
+extern "C" int b2s_model_num_tensors(const b2s_model* m) { return m ? (int)m->tinfo.size() : -1; }
+extern "C" int b2s_model_tensor_info(const b2s_model* m, int i, char* name, int name_cap, int64_t* shape, int* ndim,
+                                     int* kind) {
+    B2S_CHECK(m && i >= 0 && i < (int)m->tinfo.size(), "tensor index out of range");
+    const TensorInfo& t = m->tinfo[i];
+    if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (ndim) *ndim = (int)t.shape.size();
+    if (shape) for (size_t k = 0; k < t.shape.size(); ++k) shape[k] = t.shape[k];
+    if (kind) *kind = t.kind;
+    return 0;
+}
+
+namespace {
+int build_chunks(b2s_model* m, bool l2only, bool with_state, MtChunk** out, int* nout) {
+    std::vector<MtChunk> h;
+    const int CH = 16384;
+    for (size_t i = 0; i < m->tinfo.size(); ++i) {
+        const TensorInfo& t = m->tinfo[i];
+        if (t.kind != 1 || (l2only && !t.l2)) continue;
+        if (!m->grad[i] && with_state) continue;
+        for (long o = 0; o < t.numel; o += CH) {
+            MtChunk c;
+            c.a = (float*)m->data[i] + o; c.b = m->grad[i] ? (float*)m->grad[i] + o : nullptr;
+            c.c = with_state ? (float*)m->exp_avg[i] + o : nullptr;
+            c.d = with_state ? (float*)m->exp_avg_sq[i] + o : nullptr;
+            c.n = (int)std::min<long>(CH, t.numel - o); c.pad = t.l2 ? 1 : 0;
+            h.push_back(c);
+        }
+    }
+    MtChunk* d = nullptr;
+    if (!h.empty()) {
+        B2S_HIP(hipMalloc(&d, h.size() * sizeof(MtChunk)));
+        B2S_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(MtChunk), hipMemcpyHostToDevice));
+        m->owned.push_back(d);
+    }
+    *out = d; *nout = (int)h.size();
+    return 0;
+}
+}  // namespace
+
+extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const* grad_host, int n) {
+    B2S_CHECK(m && data_host, "null argument");
+    B2S_CHECK(n == (int)m->tinfo.size(), "expected %d tensors, got %d", (int)m->tinfo.size(), n);
+    for (int i = 0; i < n; ++i) {
+        B2S_CHECK(data_host[i], "tensor %s has a null data pointer", m->tinfo[i].name.c_str());
+        m->data[i] = data_host[i];
+        m->grad[i] = grad_host ? grad_host[i] : nullptr;
+    }
+    // compute-dtype shadows
+    for (int i = 0; i < n; ++i) {
+        const TensorInfo& t = m->tinfo[i];
+        if (!t.gemm_weight) continue;
+        if (m->dtype == 0) { m->shadow[i] = m->data[i]; continue; }
+        if (!m->shadow[i] || m->shadow[i] == m->data[i]) {
+            void* p = nullptr;
+            B2S_HIP(hipMalloc(&p, (size_t)t.numel * 2));
+            m->owned.push_back(p); m->shadow[i] = p;
+        }
+    }
+    for (int l = 0; l < m->cfg.n_postnet_layer; ++l) {
+        if (m->conv_wf[l]) continue;
+        long ne = m->numel("postnet.conv_layers." + std::to_string(l) + ".weight");
+        void *a = nullptr, *b = nullptr;
+        B2S_HIP(hipMalloc(&a, (size_t)ne * m->esz)); B2S_HIP(hipMalloc(&b, (size_t)ne * m->esz));
+        m->owned.push_back(a); m->owned.push_back(b);
+        m->conv_wf[l] = a; m->conv_wb[l] = b;
+    }
+    if (!m->small) { B2S_HIP(hipMalloc(&m->small, 64 * sizeof(float))); m->owned.push_back(m->small); }
+    B2S_TRY(ensure_pe(m, 2048));
+    m->n_l2_chunks = 0; m->l2_chunks = nullptr;
+    B2S_TRY(build_chunks(m, true, false, &m->l2_chunks, &m->n_l2_chunks));
+    m->bound = true;
+    return 0;
+}
+
+extern "C" int b2s_model_sync_weights(b2s_model* m, void* stream) {
+    B2S_TRY(check_bound(m));
+    hipStream_t st = S_(stream);
+    if (m->dtype)
+        for (size_t i = 0; i < m->tinfo.size(); ++i)
+            if (m->tinfo[i].gemm_weight) B2S_TRY(ro_cast(1, (const float*)m->data[i], m->shadow[i], m->tinfo[i].numel, st));
+    for (int l = 0; l < m->cfg.n_postnet_layer; ++l) {
+        const TensorInfo& t = m->tinfo[m->id("postnet.conv_layers." + std::to_string(l) + ".weight")];
+        B2S_TRY(ro_conv_w_relayout(m->dtype, m->P(t.name), m->conv_wf[l], m->conv_wb[l], (int)t.shape[0], (int)t.shape[1], st));
+    }
+    return 0;
+}
+
+extern "C" void b2s_ctx_free(b2s_ctx* ctx) { delete ctx; }
+
+// ================================================================================================ encoder
+extern "C" size_t b2s_encoder_ws_bytes(const b2s_model* m, int B, int S) {
+    if (!m || B <= 0 || S <= 0) return 0;
+    b2s_ctx c; c.B = B; c.S = S; c.train = 1;
+    Arena a; Scratch sc; std::vector<float*> xs;
+    plan_encoder(m, c, a, sc, xs);
+    return a.off + 4096;
+}
+
+struct EncPlan { Scratch sc; std::vector<float*> xs; };
+
+extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const int32_t* input_lengths,
+                                   const int64_t* spk_ids, const float* language_vecs, int B, int S, int train,
+                                   uint64_t seed, void* ws, size_t ws_bytes, float* memory_out, void* stream,
+                                   b2s_ctx** ctx_out) {
+    B2S_TRY(check_bound(m));
+    const b2s_config& cf = m->cfg;
+    B2S_CHECK(inputs && input_lengths && memory_out && ws, "null argument");
+    B2S_CHECK(B > 0 && S > 0, "bad shape B=%d S=%d", B, S);
+    B2S_CHECK(!cf.multi_speaker || spk_ids, "input_spk_ids is required (tacotron.py:126-127)");
+    B2S_CHECK(!cf.multi_lingual || language_vecs, "input_language_vecs is required (tacotron.py:126-127)");
+    B2S_TRY(ensure_pe(m, S));
+    hipStream_t st = S_(stream);
+    b2s_ctx* c = new b2s_ctx();
+    c->kind = 1; c->B = B; c->S = S; c->train = train; c->seed = seed;
+    c->ids = inputs; c->in_len = input_lengths; c->spk_ids = spk_ids; c->lang_vecs = language_vecs;
+    c->ws = (char*)ws; c->ws_bytes = ws_bytes;
+    Arena a; a.base = (char*)ws; a.cap = ws_bytes;
+    Scratch sc; std::vector<float*> xs;
+    plan_encoder(m, *c, a, sc, xs);
+    if (a.overflow || a.off > ws_bytes) { delete c; return b2s_fail(__FILE__, __LINE__, "encoder workspace too small: need %zu bytes, got %zu", a.off, ws_bytes); }
+    const int D = cf.encoder_hidden, H = cf.n_attention_head, dh = D / H, dt = m->dtype;
+    const long M = (long)B * S;
+    const float pt = train ? cf.transformer_dropout_rate : 0.f;
+    const std::string p = "encoder.encoder.";
+    int rc = 0;
+    auto run = [&]() -> int {
+        B2S_TRY(ro_embed_prep_fwd((const long*)inputs, input_lengths, m->P("encoder.embed.weight"), m->pe_enc,
+                                  m->P(p + "pe_scale"), xs[0], B, S, D, make_drop(pt, seed, opid(1, 0, 1)), st));
+        for (int l = 0; l < cf.n_encoder_layer; ++l) {
+            AttnSave& s = c->self_attn[l];
+            FfnSave& f = c->ffn[l];
+            float* x0 = xs[2 * l]; float* x1 = xs[2 * l + 1]; float* x2 = xs[2 * l + 2];
+            const std::string lnp = p + "attn_layer_norms." + std::to_string(l);
+            B2S_TRY(ro_layernorm_fwd(dt, x0, m->P(lnp + ".weight"), m->P(lnp + ".bias"), s.h, D, nullptr, 0, s.mean, s.rstd,
+                                     (int)M, D, 1e-6f, nullptr, 1, st));
+            B2S_TRY(linear(m, st, s.h, D, m->W(nm(p, "self_attentions", l, "qkv_transform.weight")), (int)M, 3 * D, D, s.qkv,
+                           0, 3 * D, GemmEpilogue()));
+            s.op_attn = opid(1, l, 2); s.op_res = opid(1, l, 3);
+            const char* q = (const char*)s.qkv;
+            B2S_TRY(attn_core_fwd(dt, st, q, 3 * D, q + (size_t)D * m->esz, 3 * D, q + (size_t)2 * D * m->esz, 3 * D, s.ctx, D,
+                                  B, H, S, S, dh, 1, input_lengths, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd));
+            GemmEpilogue e; e.drop = make_drop(pt, seed, s.op_res); e.residual = x0; e.ldr = D;
+            B2S_TRY(linear(m, st, s.ctx, D, m->W(nm(p, "self_attentions", l, "output_transform.weight")), (int)M, D, D, x1, 1, D, e));
+            const std::string lnf = p + "ffn_layer_norms." + std::to_string(l);
+            B2S_TRY(ro_layernorm_fwd(dt, x1, m->P(lnf + ".weight"), m->P(lnf + ".bias"), f.h, D, nullptr, 0, f.mean, f.rstd,
+                                     (int)M, D, 1e-6f, nullptr, 1, st));
+            f.op_hid = opid(1, l, 4); f.op_res = opid(1, l, 5);
+            GemmEpilogue e1; e1.relu = 1; e1.drop = make_drop(pt, seed, f.op_hid);
+            B2S_TRY(linear(m, st, f.h, D, m->W(nm(p, "ffn_layers", l, "input_layer.weight")), (int)M, 4 * D, D, f.f, 0, 4 * D, e1));
+            GemmEpilogue e2; e2.drop = make_drop(pt, seed, f.op_res); e2.residual = x1; e2.ldr = D;
+            B2S_TRY(linear(m, st, f.f, 4 * D, m->W(nm(p, "ffn_layers", l, "output_layer.weight")), (int)M, D, 4 * D, x2, 1, D, e2));
+        }
+        const int Dm = m->Dm;
+        B2S_TRY(ro_layernorm_fwd(dt, c->x_final, m->P(p + "output_layer_norm.weight"), m->P(p + "output_layer_norm.bias"),
+                                 c->memT, Dm, memory_out, Dm, c->mean_f, c->rstd_f, (int)M, D, 1e-6f, nullptr, 1, st));
+        int col = D;
+        if (cf.multi_speaker) {
+            B2S_TRY(ro_spk_embed_fwd((const long*)spk_ids, m->P("encoder.speaker_embed.weight"), m->P("encoder.speaker_layer.weight"),
+                                     m->P("encoder.speaker_layer.bias"), c->spk_e, c->spk_h, memory_out, c->memT, dt, Dm, col, B, S,
+                                     cf.speaker_embedding_size, st));
+            col += cf.speaker_embedding_size;
+        }
+        if (cf.multi_lingual)
+            B2S_TRY(ro_lang_embed_fwd(language_vecs, cf.max_num_language, m->P("encoder.language_embed.weight"),
+                                      m->P("encoder.language_layer.weight"), m->P("encoder.language_layer.bias"), c->lang_e,
+                                      c->lang_h, memory_out, c->memT, dt, Dm, col, B, S, cf.language_embedding_size, st));
+        return 0;
+    };
+    rc = run();
+    if (rc || !ctx_out) { delete c; if (ctx_out) *ctx_out = nullptr; return rc; }
+    *ctx_out = c;
+    return 0;
+}
+
+namespace {
+// backward of  x_out = x_in + drop(FFN(LN(x_in)))  given dx (in place: dx becomes d x_in)
+int ffn_bwd(b2s_model* m, hipStream_t st, const FfnSave& f, Scratch& sc, long M, int D, float p, uint64_t seed,
+            const std::string& wp_in, const std::string& wp_out, const std::string& lnp) {
+    const int dt = m->dtype;
+    DropCfg dres = make_drop(p, seed, f.op_res), dhid = make_drop(p, seed, f.op_hid);
+    const void* dy = sc.dx;
+    if (dt || dres.thresh) { B2S_TRY(ro_cast_drop(dt, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); dy = sc.dyT; }
+    B2S_TRY(linear_dw(m, st, dy, D, f.f, 4 * D, (int)M, D, 4 * D, m->G(wp_out)));
+    GemmEpilogue e; e.relu_aux = f.f; e.ld_aux = 4 * D; e.aux_scale = dhid.scale;
+    B2S_TRY(linear_dx(m, st, dy, D, m->W(wp_out), (int)M, 4 * D, D, sc.dz, 0, 4 * D, e));
+    B2S_TRY(linear_dw(m, st, sc.dz, 4 * D, f.h, D, (int)M, 4 * D, D, m->G(wp_in)));
+    B2S_TRY(linear_dx(m, st, sc.dz, 4 * D, m->W(wp_in), (int)M, D, 4 * D, sc.dh, 0, D, GemmEpilogue()));
+    B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, f.x_in, m->P(lnp + ".weight"), f.mean, f.rstd, sc.dx, 1, m->G(lnp + ".weight"),
+                             m->G(lnp + ".bias"), (int)M, D, nullptr, 1, st));
+    return 0;
+}
+// backward of x_out = x_in + drop(SelfAttn(LN(x_in)))
+int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, long M, int D, int B, int H, int L,
+                  float p, uint64_t seed, const std::string& wq, const std::string& wo, const std::string& lnp) {
+    const int dt = m->dtype, dh = D / H, esz = m->esz;
+    DropCfg dres = make_drop(p, seed, s.op_res), datt = make_drop(p, seed, s.op_attn);
+    const void* dy = sc.dx;
+    if (dt || dres.thresh) { B2S_TRY(ro_cast_drop(dt, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); dy = sc.dyT; }
+    B2S_TRY(linear_dw(m, st, dy, D, s.ctx, D, (int)M, D, D, m->G(wo)));
+    B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, sc.dctx, 0, D, GemmEpilogue()));
+    const char* q = (const char*)s.qkv; char* dq = (char*)sc.dqkv;
+    B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, q, 3 * D, q + (size_t)D * esz, 3 * D, q + (size_t)2 * D * esz, 3 * D, s.P, s.Pd,
+                          dq, 3 * D, dq + (size_t)D * esz, 3 * D, dq + (size_t)2 * D * esz, 3 * D, B, H, L, L, dh, datt, sc.dP, sc.dS));
+    B2S_TRY(linear_dw(m, st, sc.dqkv, 3 * D, s.h, D, (int)M, 3 * D, D, m->G(wq)));
+    B2S_TRY(linear_dx(m, st, sc.dqkv, 3 * D, m->W(wq), (int)M, D, 3 * D, sc.dh, 0, D, GemmEpilogue()));
+    B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, s.x_in, m->P(lnp + ".weight"), s.mean, s.rstd, sc.dx, 1, m->G(lnp + ".weight"),
+                             m->G(lnp + ".bias"), (int)M, D, nullptr, 1, st));
+    return 0;
+}
+}  // namespace
+
+extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_memory, void* stream) {
+    B2S_TRY(check_bound(m));
+    B2S_CHECK(c && c->kind == 1 && d_memory, "bad encoder context");
+    const b2s_config& cf = m->cfg;
+    hipStream_t st = S_(stream);
+    const int B = c->B, S = c->S, D = cf.encoder_hidden, H = cf.n_attention_head, Dm = m->Dm, dt = m->dtype;
+    const long M = (long)B * S;
+    const float pt = c->train ? cf.transformer_dropout_rate : 0.f;
+    Arena a; a.base = c->ws; a.cap = c->ws_bytes;
+    b2s_ctx tmp; tmp.B = B; tmp.S = S; tmp.train = c->train;
+    Scratch sc; std::vector<float*> xs;
+    plan_encoder(m, tmp, a, sc, xs);
+    const std::string p = "encoder.encoder.";
+    int col = D;
+    if (cf.multi_speaker) {
+        B2S_TRY(ro_spk_embed_bwd(d_memory, Dm, col, (const long*)c->spk_ids, c->spk_e, c->spk_h, m->P("encoder.speaker_layer.weight"),
+                                 m->G("encoder.speaker_embed.weight"), m->G("encoder.speaker_layer.weight"),
+                                 m->G("encoder.speaker_layer.bias"), B, S, cf.speaker_embedding_size, st));
+        col += cf.speaker_embedding_size;
+    }
+    if (cf.multi_lingual) {
+        B2S_TRY(ro_lang_embed_bwd(d_memory, Dm, col, c->lang_vecs, cf.max_num_language, c->lang_e, c->lang_h,
+                                  m->P("encoder.language_embed.weight"), m->P("encoder.language_layer.weight"),
+                                  m->G("encoder.language_embed.weight"), m->G("encoder.language_layer.weight"),
+                                  m->G("encoder.language_layer.bias"), B, S, cf.language_embedding_size, st));
+    }
+    B2S_TRY(ro_layernorm_bwd(dt, d_memory, 1, Dm, c->x_final, m->P(p + "output_layer_norm.weight"), c->mean_f, c->rstd_f, sc.dx, 0,
+                             m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, nullptr, 1, st));
+    for (int l = cf.n_encoder_layer - 1; l >= 0; --l) {
+        const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lna = p + "attn_layer_norms." + std::to_string(l);
+        B2S_TRY(ffn_bwd(m, st, c->ffn[l], sc, M, D, pt, c->seed, nm(p, "ffn_layers", l, "input_layer.weight"),
+                        nm(p, "ffn_layers", l, "output_layer.weight"), lnf));
+        B2S_TRY(self_attn_bwd(m, st, c->self_attn[l], sc, M, D, B, H, S, pt, c->seed, nm(p, "self_attentions", l, "qkv_transform.weight"),
+                              nm(p, "self_attentions", l, "output_transform.weight"), lna));
+    }
+    B2S_TRY(ro_embed_prep_bwd(sc.dx, (const long*)c->ids, c->in_len, m->pe_enc, m->G("encoder.embed.weight"), m->G(p + "pe_scale"),
+                              B, S, D, make_drop(pt, c->seed, opid(1, 0, 1)), st));
+    return 0;
+}
+
+// ================================================================================================ decoder
+extern "C" size_t b2s_decoder_ws_bytes(const b2s_model* m, int B, int S, int T) {
+    if (!m || B <= 0 || S <= 0 || T <= 0) return 0;
+    b2s_ctx c; c.B = B; c.S = S; c.T = T; c.train = 1;
+    Arena a; Scratch sc; std::vector<float*> xs;
+    plan_decoder(m, c, a, sc, xs);
+    return a.off + 4096;
+}
+
+extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
+                                   const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
+                                   size_t ws_bytes, float* mels_out, float* stop_out, void* stream, b2s_ctx** ctx_out) {
+    B2S_TRY(check_bound(m));
+    const b2s_config& cf = m->cfg;
+    B2S_CHECK(memory && input_lengths && targets && target_lengths && mels_out && stop_out && ws, "null argument");
+    B2S_CHECK(B > 0 && S > 0 && T > 0, "bad shape B=%d S=%d T=%d", B, S, T);
+    B2S_TRY(ensure_pe(m, T));
+    hipStream_t st = S_(stream);
+    b2s_ctx* c = new b2s_ctx();
+    c->kind = 2; c->B = B; c->S = S; c->T = T; c->train = train; c->seed = seed;
+    c->in_len = input_lengths; c->tgt_len = target_lengths;
+    c->ws = (char*)ws; c->ws_bytes = ws_bytes;
+    Arena a; a.base = (char*)ws; a.cap = ws_bytes;
+    Scratch sc; std::vector<float*> xs;
+    plan_decoder(m, *c, a, sc, xs);
+    if (a.overflow || a.off > ws_bytes) { delete c; return b2s_fail(__FILE__, __LINE__, "decoder workspace too small: need %zu bytes, got %zu", a.off, ws_bytes); }
+    const int D = cf.decoder_hidden, H = cf.n_attention_head, dh = D / H, dt = m->dtype, esz = m->esz;
+    const int NM = cf.num_mels, HP = cf.prenet_hidden;
+    const long M = (long)B * T, Mk = (long)B * S;
+    const float pt = train ? cf.transformer_dropout_rate : 0.f, pd = train ? cf.decoder_dropout_rate : 0.f;
+    const std::string p = "decoder.decoder.";
+    auto run = [&]() -> int {
+        B2S_TRY(ro_cast(dt, memory, c->memT, Mk * D, st));
+        B2S_TRY(ro_cast(dt, targets, c->tgtT, M * NM, st));
+        // prenet (tacotron.py:55-65)
+        GemmEpilogue e0; e0.bias = m->P("decoder.prenet.dense0.bias"); e0.relu = 1; e0.drop = make_drop(pd, seed, opid(2, 0, 1));
+        B2S_TRY(linear(m, st, c->tgtT, NM, m->W("decoder.prenet.dense0.weight"), (int)M, HP, NM, c->a1, 0, HP, e0));
+        GemmEpilogue e1; e1.bias = m->P("decoder.prenet.dense1.bias"); e1.relu = 1; e1.drop = make_drop(pd, seed, opid(2, 0, 2));
+        B2S_TRY(linear(m, st, c->a1, HP, m->W("decoder.prenet.dense1.weight"), (int)M, HP, HP, c->a2, 0, HP, e1));
+        B2S_TRY(linear(m, st, c->a2, HP, m->W("decoder.prenet.dense_final.weight"), (int)M, D, HP, sc.a3, 1, D, GemmEpilogue()));
+        B2S_TRY(ro_shift_pe_fwd(sc.a3, target_lengths, m->pe_dec, m->P(p + "pe_scale"), xs[0], B, T, D,
+                                make_drop(pt, seed, opid(2, 0, 3)), st));
+        for (int l = 0; l < cf.n_decoder_layer; ++l) {
+            AttnSave& s = c->self_attn[l]; AttnSave& x = c->cross_attn[l]; FfnSave& f = c->ffn[l];
+            float* x0 = xs[3 * l]; float* x1 = xs[3 * l + 1]; float* x2 = xs[3 * l + 2]; float* x3 = xs[3 * l + 3];
+            // causal self-attention
+            const std::string lna = p + "attn_layer_norms." + std::to_string(l);
+            B2S_TRY(ro_layernorm_fwd(dt, x0, m->P(lna + ".weight"), m->P(lna + ".bias"), s.h, D, nullptr, 0, s.mean, s.rstd, (int)M, D,
+                                     1e-6f, nullptr, 1, st));
+            B2S_TRY(linear(m, st, s.h, D, m->W(nm(p, "self_attentions", l, "qkv_transform.weight")), (int)M, 3 * D, D, s.qkv, 0, 3 * D,
+                           GemmEpilogue()));
+            s.op_attn = opid(2, l, 4); s.op_res = opid(2, l, 5);
+            const char* q = (const char*)s.qkv;
+            B2S_TRY(attn_core_fwd(dt, st, q, 3 * D, q + (size_t)D * esz, 3 * D, q + (size_t)2 * D * esz, 3 * D, s.ctx, D, B, H, T, T, dh,
+                                  2, nullptr, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd));
+            GemmEpilogue ea; ea.drop = make_drop(pt, seed, s.op_res); ea.residual = x0; ea.ldr = D;
+            B2S_TRY(linear(m, st, s.ctx, D, m->W(nm(p, "self_attentions", l, "output_transform.weight")), (int)M, D, D, x1, 1, D, ea));
+            // encoder-decoder attention
+            const std::string lnx = p + "encdec_layer_norms." + std::to_string(l);
+            B2S_TRY(ro_layernorm_fwd(dt, x1, m->P(lnx + ".weight"), m->P(lnx + ".bias"), x.h, D, nullptr, 0, x.mean, x.rstd, (int)M, D,
+                                     1e-6f, nullptr, 1, st));
+            B2S_TRY(linear(m, st, x.h, D, m->W(nm(p, "encdec_attentions", l, "q_transform.weight")), (int)M, D, D, x.qkv, 0, D, GemmEpilogue()));
+            B2S_TRY(linear(m, st, c->memT, D, m->W(nm(p, "encdec_attentions", l, "kv_transform.weight")), (int)Mk, 2 * D, D, x.kv, 0, 2 * D,
+                           GemmEpilogue()));
+            x.op_attn = opid(2, l, 6); x.op_res = opid(2, l, 7);
+            const char* kv = (const char*)x.kv;
+            B2S_TRY(attn_core_fwd(dt, st, x.qkv, D, kv, 2 * D, kv + (size_t)D * esz, 2 * D, x.ctx, D, B, H, T, S, dh, 1, input_lengths,
+                                  nullptr, 0, 0, make_drop(pt, seed, x.op_attn), sc.S, x.P, x.Pd));
+            GemmEpilogue ex; ex.drop = make_drop(pt, seed, x.op_res); ex.residual = x1; ex.ldr = D;
+            B2S_TRY(linear(m, st, x.ctx, D, m->W(nm(p, "encdec_attentions", l, "output_transform.weight")), (int)M, D, D, x2, 1, D, ex));
+            // FFN
+            const std::string lnf = p + "ffn_layer_norms." + std::to_string(l);
+            B2S_TRY(ro_layernorm_fwd(dt, x2, m->P(lnf + ".weight"), m->P(lnf + ".bias"), f.h, D, nullptr, 0, f.mean, f.rstd, (int)M, D,
+                                     1e-6f, nullptr, 1, st));
+            f.op_hid = opid(2, l, 8); f.op_res = opid(2, l, 9);
+            GemmEpilogue f1; f1.relu = 1; f1.drop = make_drop(pt, seed, f.op_hid);
+            B2S_TRY(linear(m, st, f.h, D, m->W(nm(p, "ffn_layers", l, "input_layer.weight")), (int)M, 4 * D, D, f.f, 0, 4 * D, f1));
+            GemmEpilogue f2; f2.drop = make_drop(pt, seed, f.op_res); f2.residual = x2; f2.ldr = D;
+            B2S_TRY(linear(m, st, f.f, 4 * D, m->W(nm(p, "ffn_layers", l, "output_layer.weight")), (int)M, D, 4 * D, x3, 1, D, f2));
+        }
+        B2S_TRY(ro_layernorm_fwd(dt, c->x_final, m->P(p + "output_layer_norm.weight"), m->P(p + "output_layer_norm.bias"), c->outT, D,
+                                 nullptr, 0, c->mean_f, c->rstd_f, (int)M, D, 1e-6f, target_lengths, T, st));
+        GemmEpilogue em; em.row_len = target_lengths; em.rows_per_batch = T;
+        B2S_TRY(linear(m, st, c->outT, D, m->W("decoder.mel_net.weight"), (int)M, NM, D, mels_out, 1, NM, em));
+        B2S_TRY(ro_rowdot_fwd(dt, c->outT, D, m->P("decoder.stop_net.weight"), m->P("decoder.stop_net.bias"), stop_out, (int)M, D,
+                              target_lengths, T, st));
+        return 0;
+    };
+    int rc = run();
+    if (rc || !ctx_out) { delete c; if (ctx_out) *ctx_out = nullptr; return rc; }
+    *ctx_out = c;
+    return 0;
+}
+
+namespace {
+__global__ void k_rowmask_copy(const float* in, float* out, const int* lens, int T, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { int b = (int)(i / T), t = (int)(i - (long)b * T); out[i] = t < lens[b] ? in[i] : 0.f; }
+}
+}  // namespace
+
+extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mels, const float* d_stop, float* d_memory_out,
+                                    void* stream) {
+    B2S_TRY(check_bound(m));
+    B2S_CHECK(c && c->kind == 2 && d_mels && d_memory_out, "bad decoder context");
+    const b2s_config& cf = m->cfg;
+    hipStream_t st = S_(stream);
+    const int B = c->B, S = c->S, T = c->T, D = cf.decoder_hidden, H = cf.n_attention_head, dh = D / H, dt = m->dtype, esz = m->esz;
+    const int NM = cf.num_mels, HP = cf.prenet_hidden;
+    const long M = (long)B * T, Mk = (long)B * S;
+    const float pt = c->train ? cf.transformer_dropout_rate : 0.f, pd = c->train ? cf.decoder_dropout_rate : 0.f;
+    Arena a; a.base = c->ws; a.cap = c->ws_bytes;
+    b2s_ctx tmp; tmp.B = B; tmp.S = S; tmp.T = T; tmp.train = c->train;
+    Scratch sc; std::vector<float*> xs;
+    plan_decoder(m, tmp, a, sc, xs);
+    const std::string p = "decoder.decoder.";
+    // heads (tacotron.py:112-115)
+    B2S_TRY(ro_cast(dt, d_mels, sc.dmelT, M * NM, st));
+    B2S_TRY(linear_dw(m, st, sc.dmelT, NM, c->outT, D, (int)M, NM, D, m->G("decoder.mel_net.weight")));
+    GemmEpilogue eo; eo.row_len = c->tgt_len; eo.rows_per_batch = T;
+    B2S_TRY(linear_dx(m, st, sc.dmelT, NM, m->W("decoder.mel_net.weight"), (int)M, D, NM, sc.doutT, 0, D, eo));
+    if (d_stop) {
+        hipLaunchKernelGGL(k_rowmask_copy, dim3(cdiv(M, 256)), dim3(256), 0, st, d_stop, sc.dstop_m, c->tgt_len, T, M);
+        B2S_TRY(ro_colsum(dt, c->outT, 0, D, sc.dstop_m, m->G("decoder.stop_net.weight"), 1, (int)M, D, st));
+        B2S_TRY(ro_colsum(0, sc.dstop_m, 1, 1, nullptr, m->G("decoder.stop_net.bias"), 1, (int)M, 1, st));
+    }
+    B2S_TRY(ro_layernorm_bwd(dt, sc.doutT, 0, D, c->x_final, m->P(p + "output_layer_norm.weight"), c->mean_f, c->rstd_f, sc.dx, 0,
+                             m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, c->tgt_len, T, st));
+    bool first_mem = true;
+    for (int l = cf.n_decoder_layer - 1; l >= 0; --l) {
+        const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lnx = p + "encdec_layer_norms." + std::to_string(l),
+                          lna = p + "attn_layer_norms." + std::to_string(l);
+        B2S_TRY(ffn_bwd(m, st, c->ffn[l], sc, M, D, pt, c->seed, nm(p, "ffn_layers", l, "input_layer.weight"),
+                        nm(p, "ffn_layers", l, "output_layer.weight"), lnf));
+        {   // encoder-decoder attention backward
+            const AttnSave& x = c->cross_attn[l];
+            const std::string wq = nm(p, "encdec_attentions", l, "q_transform.weight"), wkv = nm(p, "encdec_attentions", l, "kv_transform.weight"),
+                              wo = nm(p, "encdec_attentions", l, "output_transform.weight");
+            DropCfg dres = make_drop(pt, c->seed, x.op_res), datt = make_drop(pt, c->seed, x.op_attn);
+            const void* dy = sc.dx;
+            if (dt || dres.thresh) { B2S_TRY(ro_cast_drop(dt, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); dy = sc.dyT; }
+            B2S_TRY(linear_dw(m, st, dy, D, x.ctx, D, (int)M, D, D, m->G(wo)));
+            B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, sc.dctx, 0, D, GemmEpilogue()));
+            const char* kv = (const char*)x.kv; char* dkv = (char*)sc.dkv;
+            B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, x.qkv, D, kv, 2 * D, kv + (size_t)D * esz, 2 * D, x.P, x.Pd, sc.dqkv, D, dkv, 2 * D,
+                                  dkv + (size_t)D * esz, 2 * D, B, H, T, S, dh, datt, sc.dP, sc.dS));
+            B2S_TRY(linear_dw(m, st, sc.dqkv, D, x.h, D, (int)M, D, D, m->G(wq)));
+            B2S_TRY(linear_dx(m, st, sc.dqkv, D, m->W(wq), (int)M, D, D, sc.dh, 0, D, GemmEpilogue()));
+            B2S_TRY(linear_dw(m, st, sc.dkv, 2 * D, c->memT, D, (int)Mk, 2 * D, D, m->G(wkv)));
+            GemmEpilogue em; em.accumulate = first_mem ? 0 : 1;
+            B2S_TRY(linear_dx(m, st, sc.dkv, 2 * D, m->W(wkv), (int)Mk, D, 2 * D, d_memory_out, 1, D, em));
+            first_mem = false;
+            B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, x.x_in, m->P(lnx + ".weight"), x.mean, x.rstd, sc.dx, 1, m->G(lnx + ".weight"),
+                                     m->G(lnx + ".bias"), (int)M, D, nullptr, 1, st));
+        }
+        B2S_TRY(self_attn_bwd(m, st, c->self_attn[l], sc, M, D, B, H, T, pt, c->seed, nm(p, "self_attentions", l, "qkv_transform.weight"),
+                              nm(p, "self_attentions", l, "output_transform.weight"), lna));
+    }
+    if (first_mem) B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
+    B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, opid(2, 0, 3)), st));
+    // prenet backward
+    DropCfg d1 = make_drop(pd, c->seed, opid(2, 0, 1)), d2 = make_drop(pd, c->seed, opid(2, 0, 2));
+    B2S_TRY(linear_dw(m, st, sc.da3, D, c->a2, HP, (int)M, D, HP, m->G("decoder.prenet.dense_final.weight")));
+    GemmEpilogue e2; e2.relu_aux = c->a2; e2.ld_aux = HP; e2.aux_scale = d2.scale;
+    B2S_TRY(linear_dx(m, st, sc.da3, D, m->W("decoder.prenet.dense_final.weight"), (int)M, HP, D, sc.dz2, 0, HP, e2));
+    B2S_TRY(ro_colsum(dt, sc.dz2, 0, HP, nullptr, m->G("decoder.prenet.dense1.bias"), 1, (int)M, HP, st));
+    B2S_TRY(linear_dw(m, st, sc.dz2, HP, c->a1, HP, (int)M, HP, HP, m->G("decoder.prenet.dense1.weight")));
+    GemmEpilogue e1; e1.relu_aux = c->a1; e1.ld_aux = HP; e1.aux_scale = d1.scale;
+    B2S_TRY(linear_dx(m, st, sc.dz2, HP, m->W("decoder.prenet.dense1.weight"), (int)M, HP, HP, sc.dz1, 0, HP, e1));
+    B2S_TRY(ro_colsum(dt, sc.dz1, 0, HP, nullptr, m->G("decoder.prenet.dense0.bias"), 1, (int)M, HP, st));
+    B2S_TRY(linear_dw(m, st, sc.dz1, HP, c->tgtT, NM, (int)M, HP, NM, m->G("decoder.prenet.dense0.weight")));
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int b2s_decoder_alignment(b2s_model* m, b2s_ctx* c, int which, int layer, float* out, void* stream) {
+    B2S_CHECK(m && c && c->kind == 2 && out, "bad decoder context");
+    B2S_CHECK(layer >= 0 && layer < m->cfg.n_decoder_layer && (which == 0 || which == 1), "bad alignment selector");
+    const AttnSave& s = which ? c->cross_attn[layer] : c->self_attn[layer];
+    return ro_align_transpose(m->dtype, s.P, out, c->B * m->cfg.n_attention_head, s.Lq, s.Lk, s.ldp, S_(stream));
+}
+
+// ================================================================================================ postnet
+extern "C" size_t b2s_postnet_ws_bytes(const b2s_model* m, int B, int T) {
+    if (!m || B <= 0 || T <= 0) return 0;
+    b2s_ctx c; c.B = B; c.T = T;
+    Arena a; PostScratch ps;
+    plan_postnet(m, c, a, ps);
+    return a.off + 4096;
+}
+
+extern "C" int b2s_postnet_forward(b2s_model* m, const float* inputs, const int32_t* lengths, const float* add, int B, int T,
+                                   int train, uint64_t seed, void* ws, size_t ws_bytes, float* out, void* stream,
+                                   b2s_ctx** ctx_out) {
+    B2S_TRY(check_bound(m));
+    const b2s_config& cf = m->cfg;
+    B2S_CHECK(inputs && lengths && out && ws && B > 0 && T > 0, "bad argument");
+    hipStream_t st = S_(stream);
+    b2s_ctx* c = new b2s_ctx();
+    c->kind = 3; c->B = B; c->T = T; c->train = train; c->seed = seed; c->tgt_len = lengths;
+    c->ws = (char*)ws; c->ws_bytes = ws_bytes;
+    Arena a; a.base = (char*)ws; a.cap = ws_bytes;
+    PostScratch ps;
+    plan_postnet(m, *c, a, ps);
+    if (a.overflow || a.off > ws_bytes) { delete c; return b2s_fail(__FILE__, __LINE__, "postnet workspace too small: need %zu bytes, got %zu", a.off, ws_bytes); }
+    const long M = (long)B * T;
+    const int n = cf.n_postnet_layer, dt = m->dtype;
+    const float pd = train ? cf.decoder_dropout_rate : 0.f;
+    auto run = [&]() -> int {
+        B2S_TRY(ro_cast(dt, inputs, c->u[0], M * cf.num_mels, st));
+        for (int i = 0; i < n; ++i) {
+            const int cin = i == 0 ? cf.num_mels : cf.postnet_hidden, cout = i == n - 1 ? cf.num_mels : cf.postnet_hidden;
+            const std::string q = "postnet.batchnorm_layers." + std::to_string(i) + ".";
+            GemmArgs g;       // y[m, co] = sum_{j,ci} x[m + j - 2, ci] * w[co, ci, j]   (impute + Conv1d k5 p2)
+            g.A.p = c->u[i]; g.A.ld = cin; g.A.R = (int)M; g.A.C = 5 * cin; g.A.g_cin = cin; g.A.g_T = T; g.A.g_len = lengths;
+            g.B.p = m->conv_wf[i]; g.B.ld = 5 * cin; g.B.R = cout; g.B.C = 5 * cin;
+            g.M = (int)M; g.N = cout; g.K = 5 * cin; g.C = c->y[i]; g.c_fp32 = 1; g.ldc = cout;
+            B2S_TRY(b2s_gemm_launch(g, dt, false, false, st));
+            if (train)
+                B2S_TRY(ro_bn_stats(c->y[i], (int)M, cout, c->bn_mean[i], c->bn_rstd[i], 1e-5f, m->P(q + "running_mean"),
+                                    m->P(q + "running_var"), (long*)m->data[m->id(q + "num_batches_tracked")], 0.1f, ps.stat, st));
+            else
+                B2S_TRY(ro_bn_eval_stats(m->P(q + "running_mean"), m->P(q + "running_var"), c->bn_mean[i], c->bn_rstd[i], 1e-5f, cout, st));
+            DropCfg d = make_drop(pd, seed, opid(3, i, 1));
+            if (i < n - 1)
+                B2S_TRY(ro_bn_apply(dt, c->y[i], c->bn_mean[i], c->bn_rstd[i], m->P(q + "weight"), m->P(q + "bias"), 1, c->u[i + 1],
+                                    nullptr, nullptr, (int)M, cout, d, st));
+            else
+                B2S_TRY(ro_bn_apply(dt, c->y[i], c->bn_mean[i], c->bn_rstd[i], m->P(q + "weight"), m->P(q + "bias"), 0, nullptr, out,
+                                    add, (int)M, cout, d, st));
+        }
+        return 0;
+    };
+    int rc = run();
+    if (rc || !ctx_out) { delete c; if (ctx_out) *ctx_out = nullptr; return rc; }
+    *ctx_out = c;
+    return 0;
+}
+
+extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out, float* d_inputs_out, void* stream) {
+    B2S_TRY(check_bound(m));
+    B2S_CHECK(c && c->kind == 3 && d_out && d_inputs_out, "bad postnet context");
+    B2S_CHECK(c->train, "postnet backward requires a train-mode forward (batch statistics)");
+    const b2s_config& cf = m->cfg;
+    hipStream_t st = S_(stream);
+    const int B = c->B, T = c->T, n = cf.n_postnet_layer, dt = m->dtype;
+    const long M = (long)B * T;
+    const float pd = cf.decoder_dropout_rate;
+    Arena a; a.base = c->ws; a.cap = c->ws_bytes;
+    b2s_ctx tmp; tmp.B = B; tmp.T = T;
+    PostScratch ps;
+    plan_postnet(m, tmp, a, ps);
+    void* dy = ps.du[n];
+    for (int i = n - 1; i >= 0; --i) {
+        const int cin = i == 0 ? cf.num_mels : cf.postnet_hidden, cout = i == n - 1 ? cf.num_mels : cf.postnet_hidden;
+        const std::string q = "postnet.batchnorm_layers." + std::to_string(i) + ".";
+        DropCfg d = make_drop(pd, c->seed, opid(3, i, 1));
+        const void* dout = i == n - 1 ? (const void*)d_out : ps.du[i + 1];
+        B2S_TRY(ro_bn_bwd(dt, dout, i == n - 1 ? 1 : 0, c->y[i], c->bn_mean[i], c->bn_rstd[i], m->P(q + "weight"), m->P(q + "bias"),
+                          i < n - 1 ? 1 : 0, m->G(q + "weight"), m->G(q + "bias"), dy, (int)M, cout, d, st));
+        {   // dW[co, ci, j] = sum_m dy[m, co] * xg[m, j*cin + ci]
+            GemmArgs g;
+            g.A.p = dy; g.A.ld = cout; g.A.R = (int)M; g.A.C = cout;
+            g.B.p = c->u[i]; g.B.ld = cin; g.B.R = (int)M; g.B.C = 5 * cin; g.B.g_cin = cin; g.B.g_T = T; g.B.g_len = c->tgt_len;
+            g.M = cout; g.N = 5 * cin; g.K = (int)M;
+            g.C = m->G("postnet.conv_layers." + std::to_string(i) + ".weight"); g.c_fp32 = 1; g.ldc = 5 * cin;
+            g.epi.conv_dw_cin = cin; g.epi.accumulate = 1;
+            B2S_TRY(b2s_gemm_launch(g, dt, true, true, st));
+        }
+        {   // dx[m, ci] = mask(m) * sum_{j', co} dy[m + j' - 2, co] * w[co, ci, 4 - j']
+            GemmArgs g;
+            g.A.p = dy; g.A.ld = cout; g.A.R = (int)M; g.A.C = 5 * cout; g.A.g_cin = cout; g.A.g_T = T; g.A.g_len = nullptr;
+            g.B.p = m->conv_wb[i]; g.B.ld = 5 * cout; g.B.R = cin; g.B.C = 5 * cout;
+            g.M = (int)M; g.N = cin; g.K = 5 * cout;
+            g.epi.row_len = c->tgt_len; g.epi.rows_per_batch = T;
+            if (i == 0) { g.C = d_inputs_out; g.c_fp32 = 1; } else { g.C = ps.du[i]; g.c_fp32 = 0; }
+            g.ldc = cin;
+            B2S_TRY(b2s_gemm_launch(g, dt, false, false, st));
+        }
+    }
+    return 0;
+}
+
+// ================================================================================================ loss / optimizer
+extern "C" int b2s_loss_forward(b2s_model* m, const float* mel_bef, const float* mel_aft, const float* stop_logits,
+                                const float* mel_targets, const int32_t* target_lengths, int B, int T, float* losses_out,
+                                float* aft_losses_out, float* scratch, void* stream) {
+    B2S_TRY(check_bound(m));
+    B2S_CHECK(mel_bef && mel_aft && stop_logits && mel_targets && target_lengths && losses_out && aft_losses_out && scratch, "null argument");
+    hipStream_t st = S_(stream);
+    float* l2 = scratch;                      // scratch[0] = l2, scratch[1..] partial sums
+    B2S_HIP(hipMemsetAsync(l2, 0, sizeof(float), st));
+    if (m->n_l2_chunks) B2S_TRY(ro_mt_sumsq(m->l2_chunks, m->n_l2_chunks, l2, 0.5f * m->cfg.reg_weight, st));
+    return ro_loss_fwd(mel_bef, mel_aft, stop_logits, mel_targets, target_lengths, l2, losses_out, aft_losses_out, B, T,
+                       m->cfg.num_mels, 5.0f, scratch + 1, st);
+}
+extern "C" int b2s_loss_backward(b2s_model* m, const float* mel_bef, const float* mel_aft, const float* stop_logits,
+                                 const float* mel_targets, const int32_t* target_lengths, int B, int T, const float* grad_scale,
+                                 float* d_bef, float* d_aft, float* d_stop, void* stream) {
+    B2S_CHECK(m && mel_bef && mel_aft && stop_logits && mel_targets && target_lengths && d_bef && d_aft && d_stop, "null argument");
+    return ro_loss_bwd(mel_bef, mel_aft, stop_logits, mel_targets, target_lengths, grad_scale, d_bef, d_aft, d_stop, B, T,
+                       m->cfg.num_mels, 5.0f, S_(stream));
+}
+extern "C" int b2s_l2_backward(b2s_model* m, const float* grad_scale, void* stream) {
+    B2S_TRY(check_bound(m));
+    for (size_t i = 0; i < m->tinfo.size(); ++i)
+        B2S_CHECK(!m->tinfo[i].l2 || m->grad[i], "gradient of %s is not bound", m->tinfo[i].name.c_str());
+    return ro_mt_axpy(m->l2_chunks, m->n_l2_chunks, m->cfg.reg_weight, grad_scale, S_(stream));
+}
+extern "C" int b2s_adam_bind(b2s_model* m, void* const* exp_avg_host, void* const* exp_avg_sq_host, int n) {
+    B2S_TRY(check_bound(m));
+    B2S_CHECK(n == (int)m->tinfo.size() && exp_avg_host && exp_avg_sq_host, "expected %d state pointers", (int)m->tinfo.size());
+    for (int i = 0; i < n; ++i) {
+        m->exp_avg[i] = exp_avg_host[i]; m->exp_avg_sq[i] = exp_avg_sq_host[i];
+        B2S_CHECK(m->tinfo[i].kind != 1 || !m->grad[i] || (m->exp_avg[i] && m->exp_avg_sq[i]), "missing Adam state for %s", m->tinfo[i].name.c_str());
+    }
+    return build_chunks(m, false, true, &m->adam_chunks, &m->n_adam_chunks);
+}
+extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
+                             void* stream) {
+    B2S_TRY(check_bound(m));
+    B2S_CHECK(m->adam_chunks && step >= 1, "Adam state not bound or bad step");
+    hipStream_t st = S_(stream);
+    float hp[3] = {lr, (float)(1.0 - std::pow((double)beta1, step)), (float)std::sqrt(1.0 - std::pow((double)beta2, step))};
+    float* dhp = m->small + 16 + (step % 8) * 4;         // rotate slots: earlier steps may still be in flight
+    B2S_HIP(hipMemcpyAsync(dhp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
+    // l2 is applied to the L2 member set only (chunk flag), i.e. g = grad*grad_scale + l2*p for members
+    return ro_mt_adam(m->adam_chunks, m->n_adam_chunks, dhp, beta1, beta2, eps, l2, grad_scale, st);
+}
+extern "C" int b2s_zero_grads(b2s_model* m, void* stream) {
+    B2S_TRY(check_bound(m));
+    for (size_t i = 0; i < m->tinfo.size(); ++i)
+        if (m->tinfo[i].kind == 1 && m->grad[i]) B2S_HIP(hipMemsetAsync(m->grad[i], 0, (size_t)m->tinfo[i].numel * 4, S_(stream)));
+    return 0;
+}
+
+// exported to capi_ops.hip
+int b2s_attn_core_fwd_export(int dtype, hipStream_t st, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                             void* ctx, int ldc, int B, int H, int Lq, int Lk, int dh, int mask_mode, const int* klen,
+                             const float* bias, long bias_sb, long bias_sq, DropCfg drop, float* S, void* P, void* Pd) {
+    return attn_core_fwd(dtype, st, q, ldq, k, ldk, v, ldv, ctx, ldc, B, H, Lq, Lk, dh, mask_mode, klen, bias, bias_sb, bias_sq, drop, S, P, Pd);
+}
+int b2s_attn_core_bwd_export(int dtype, hipStream_t st, const void* dctx, int ldc, const void* q, int ldq, const void* k, int ldk,
+                             const void* v, int ldv, const void* P, const void* Pd, void* dq, int lddq, void* dk, int lddk,
+                             void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, DropCfg drop, float* dP, void* dS) {
+    return attn_core_bwd(dtype, st, dctx, ldc, q, ldq, k, ldk, v, ldv, P, Pd, dq, lddq, dk, lddk, dv, lddv, B, H, Lq, Lk, dh, drop, dP, dS);
+}

@@ -1,0 +1,47 @@
+// GEMM descriptor shared by the engine and the C-ABI (see gemm.hip).
+#pragma once
+#include "b2s_common.h"
+
+// One operand of C = op(A) * op(B).  "Stored rows" R are the non-contiguous dimension, "stored
+// cols" C the contiguous one.  Non-transposed A is [M rows][K cols]; transposed A is [K rows][M cols].
+// Non-transposed B is [N rows][K cols] (i.e. the Linear weight layout); transposed B is [K rows][N cols].
+struct GemmOperand {
+    const void* p = nullptr;
+    long bs_o = 0, bs_i = 0;      // batch strides in elements (outer, inner batch index)
+    int ld = 0;                   // leading dimension in elements
+    int R = 0, C = 0;             // logical bounds of stored rows / cols
+    // conv gather: when g_cin > 0 the operand is the virtual matrix Xg[token m][j*cin + ci] =
+    // x[m + j - 2][ci] if 0 <= t+j-2 < min(len[b], T) else 0, with x stored [B*T][cin].
+    int g_cin = 0, g_T = 0;
+    const int* g_len = nullptr;
+};
+
+struct GemmEpilogue {
+    float alpha = 1.f;
+    const float* bias = nullptr;          // per output column
+    int relu = 0;
+    const void* relu_aux = nullptr;       // T*: out = aux > 0 ? v * aux_scale : 0   (ReLU+dropout backward)
+    int ld_aux = 0;
+    float aux_scale = 1.f;
+    DropCfg drop = {0, 0, 1.f};           // dropout on the result, element index (z*M + m)*N + n
+    const float* residual = nullptr;      // fp32, added after dropout
+    int ldr = 0;
+    const int* row_len = nullptr;         // zero rows with (m % rows_per_batch) >= row_len[m / rows_per_batch]
+    int rows_per_batch = 1;
+    int conv_dw_cin = 0;                  // >0: output column n = j*cin+ci is stored at ci*5 + j
+    int accumulate = 0;                   // fp32 output only: C += v
+};
+
+struct GemmArgs {
+    GemmOperand A, B;
+    int M = 0, N = 0, K = 0;
+    int batch = 1, batch_inner = 1;       // z -> (z / batch_inner, z % batch_inner)
+    void* C = nullptr;
+    int c_fp32 = 0;                       // 1: float*, 0: compute type T*
+    int ldc = 0;
+    long cs_o = 0, cs_i = 0;
+    GemmEpilogue epi;
+};
+
+// dtype: 0 = fp32 (mfma_f32_16x16x4f32), 1 = bf16 (mfma_f32_16x16x32_bf16, fp32 accumulate)
+int b2s_gemm_launch(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t stream);

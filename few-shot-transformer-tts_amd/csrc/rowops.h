@@ -1,0 +1,102 @@
+// Row-wise / element-wise HBM-bound kernels of the Transformer-TTS path (see rowops.hip).
+// dtype: 0 = fp32 compute tensors, 1 = bf16 compute tensors ("T" below).  Residual stream, statistics,
+// parameters and gradients of parameters are always fp32.
+#pragma once
+#include "b2s_common.h"
+
+// x[b,s,:] = embed[id]*(s<len[b]) + pe[s,:]*pe_scale ; dropout            (modules.py:49-56, tacotron.py:34)
+int ro_embed_prep_fwd(const long* ids, const int* lens, const float* embed, const float* pe, const float* pe_scale,
+                      float* x, int B, int S, int D, DropCfg drop, hipStream_t st);
+int ro_embed_prep_bwd(const float* dx, const long* ids, const int* lens, const float* pe, float* d_embed,
+                      float* d_pe_scale, int B, int S, int D, DropCfg drop, hipStream_t st);
+
+// y = LN(x) (eps), rows of width D; y (T) with leading dim ldy; optional fp32 copy y32 (ld ldy32);
+// optional row mask (rows t >= row_len[b] -> 0)                                    (modules.py:36-47,88-106)
+int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float* beta, void* y, int ldy, float* y32,
+                     int ldy32, float* mean, float* rstd, int M, int D, float eps, const int* row_len,
+                     int rows_per_batch, hipStream_t st);
+// dx (+)= LN'(dy); dgamma += ..., dbeta += ... (atomic; caller zeroes).  dy is T (dy_fp32=0) or fp32, ld lddy.
+int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const float* x, const float* gamma,
+                     const float* mean, const float* rstd, float* dx, int accumulate, float* dgamma, float* dbeta,
+                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st);
+
+// P = softmax(scale*S + mask) per row; rows [Z=B*H][Lq][ldp].  mask_mode bit0: keys >= klen[b] masked,
+// bit1: causal (key > query masked); bias: optional dense additive fp32 bias [bias_sb*b + bias_sq*q + k].
+// Writes P (T) and, if drop.thresh, Pd = dropout(P) (T); pad columns [Lk, ldp) are written as zeros.
+int ro_softmax_fwd(int dtype, const float* S, void* P, void* Pd, int B, int H, int Lq, int Lk, int ldp, float scale,
+                   int mask_mode, const int* klen, const float* bias, long bias_sb, long bias_sq, DropCfg drop,
+                   hipStream_t st);
+// dS = scale * P * (dPeff - sum_k P*dPeff), dPeff = dropmask(dPraw)                     (autograd of attention.py:83-91)
+int ro_softmax_bwd(int dtype, const void* P, const float* dPraw, void* dS, int B, int H, int Lq, int Lk, int ldp,
+                   float scale, DropCfg drop, hipStream_t st);
+// align[z][k][q] = P[z][q][k] (fp32)                                                   (attention.py:88)
+int ro_align_transpose(int dtype, const void* P, float* align, int Z, int Lq, int Lk, int ldp, hipStream_t st);
+
+// out(T)[i] = dropout(in[i]) ; n elements, 2-D index (row*ncols + col) with input ld
+int ro_cast_drop(int dtype, const float* in, int ldin, void* out, int ldo, int M, int N, DropCfg drop, hipStream_t st);
+// fp32 -> T cast of a flat array (weight shadows)
+int ro_cast(int dtype, const float* in, void* out, long n, hipStream_t st);
+int ro_cast_back(int dtype, const void* in, float* out, long n, hipStream_t st);
+
+// decoder input prep: x[b,t,:] = (t>0 && t-1<len[b] ? a[b,t-1,:] : 0) + pe[t,:]*pe_scale ; dropout  (modules.py:108-121)
+int ro_shift_pe_fwd(const float* a, const int* lens, const float* pe, const float* pe_scale, float* x, int B, int T,
+                    int D, DropCfg drop, hipStream_t st);
+int ro_shift_pe_bwd(int dtype, const float* dx, const int* lens, const float* pe, void* da, float* d_pe_scale, int B,
+                    int T, int D, DropCfg drop, hipStream_t st);
+
+// speaker / language embeddings (tacotron.py:21-31), written into memory[:, :, col0 : col0+E] for all S
+int ro_spk_embed_fwd(const long* spk_ids, const float* table, const float* W, const float* b, float* e_raw,
+                     float* h_pre, float* mem32, void* memT, int dtype, int ldm, int col0, int B, int S, int E,
+                     hipStream_t st);
+int ro_lang_embed_fwd(const float* vecs, int L, const float* Wl, const float* W, const float* b, float* e_raw,
+                      float* h_pre, float* mem32, void* memT, int dtype, int ldm, int col0, int B, int S, int E,
+                      hipStream_t st);
+// dmem32 [B*S, ldm] -> gradients of the tiny embedding nets (atomic adds; caller zeroes)
+int ro_spk_embed_bwd(const float* dmem, int ldm, int col0, const long* spk_ids, const float* e_raw, const float* h_pre,
+                     const float* W, float* d_table, float* dW, float* db, int B, int S, int E, hipStream_t st);
+int ro_lang_embed_bwd(const float* dmem, int ldm, int col0, const float* vecs, int L, const float* e_raw,
+                      const float* h_pre, const float* Wl, const float* W, float* dWl, float* dW, float* db, int B,
+                      int S, int E, hipStream_t st);
+
+// out[m] = (t<len ? x[m,:].w + b : 0)     (stop_net on the detached decoder output, tacotron.py:114-115)
+int ro_rowdot_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* out, int M, int D,
+                  const int* row_len, int rows_per_batch, hipStream_t st);
+// generic column reduction: out[c] (+)= sum_m wgt[m] * X[m,c]   (X is T or fp32)
+int ro_colsum(int dtype, const void* X, int x_fp32, int ldx, const float* wgt, float* out, int accumulate, int M,
+              int C, hipStream_t st);
+
+// BatchNorm1d over all M = B*T rows (tacotron.py:83-89)
+int ro_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float eps, float* running_mean,
+                float* running_var, long* num_batches_tracked, float momentum, float* scratch, hipStream_t st);
+int ro_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* rstd, float eps, int C,
+                     hipStream_t st);
+// u = dropout(act(gamma*(y-mean)*rstd+beta)); act = tanh if use_tanh.  out T (ldo) or, if out32, fp32 = add32 + u
+int ro_bn_apply(int dtype, const float* y, const float* mean, const float* rstd, const float* gamma,
+                const float* beta, int use_tanh, void* outT, float* out32, const float* add32, int M, int C,
+                DropCfg drop, hipStream_t st);
+// backward: dout (T or fp32) -> dgamma, dbeta (atomic, caller zeroes) then dy (T)
+int ro_bn_bwd(int dtype, const void* dout, int dout_fp32, const float* y, const float* mean, const float* rstd,
+              const float* gamma, const float* beta, int use_tanh, float* dgamma, float* dbeta, void* dyT, int M,
+              int C, DropCfg drop, hipStream_t st);
+
+// losses (tacotron.py:136-158).  out[0..6] = loss,bef,aft,mse,l2(unchanged),stop,sumlen ; aft_losses[B]
+// grads of (w0*bef_loss + w1*aft_loss + w2*stop_loss): d_bef[m,c], d_aft[m,c], d_stop[m]; gscale = device float[3] (null -> 1,1,1)
+int ro_loss_fwd(const float* bef, const float* aft, const float* stop, const float* tgt, const int* lens,
+                const float* l2, float* out, float* aft_losses, int B, int T, int C, float pos_weight, float* scratch,
+                hipStream_t st);
+int ro_loss_bwd(const float* bef, const float* aft, const float* stop, const float* tgt, const int* lens,
+                const float* gscale, float* d_bef, float* d_aft, float* d_stop, int B, int T, int C, float pos_weight,
+                hipStream_t st);
+
+// multi-tensor ops over a chunk table (device array of MtChunk)
+struct MtChunk { float* a; float* b; float* c; float* d; int n; int pad; };   // pad: 1 = member of the L2 set
+int ro_mt_sumsq(const MtChunk* chunks, int nchunks, float* out, float scale, hipStream_t st);         // out += scale*sum a^2
+int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gscale, hipStream_t st);  // b += alpha*gscale*a
+// Adam: a=param b=grad c=m d=v ; lr and step read from device (hp[0]=lr, hp[1]=bias_corr1, hp[2]=bias_corr2)
+int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1, float beta2, float eps, float l2,
+               float grad_scale, hipStream_t st);
+
+// conv weight relayouts (fp32 master [Cout][Cin][5] -> T):  fwd[co][j*Cin+ci] ; bwd[ci][j*Cout+co] = w[co][ci][4-j]
+int ro_conv_w_relayout(int dtype, const float* w, void* wf, void* wb, int Cout, int Cin, hipStream_t st);
+int ro_add(const float* a, const float* b, float* out, long n, hipStream_t st);
+int ro_fill(float* p, float v, long n, hipStream_t st);

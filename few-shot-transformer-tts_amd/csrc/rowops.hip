@@ -1,0 +1,831 @@
+// Row-wise / element-wise kernels (HBM-bound) for the Transformer-TTS path on gfx950.
+// Every kernel reads its rows with 16-byte (fp32x4) or 8/16-byte (bf16) coalesced accesses and reduces
+// with 64-lane wavefront shuffles; sequence masks come from the per-utterance lengths (no dense
+// bias tensors are built, unlike transformer/common.py:32-48).
+#include "rowops.h"
+
+namespace {
+
+#define RO_DISPATCH(dtype, CALL) do { if (dtype) { typedef bf16_t TY; CALL; } else { typedef float TY; CALL; } } while (0)
+
+__device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ inline float4 ld4(const bf16_t* p) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16));
+}
+__device__ inline void st4(bf16_t* p, float4 v) {
+    uint2 u;
+    u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ inline float4 drop4(float4 v, const DropCfg& d, uint32_t idx) {
+    if (!d.thresh) return v;
+    v.x = b2s_keep(d, idx) ? v.x * d.scale : 0.f;
+    v.y = b2s_keep(d, idx + 1) ? v.y * d.scale : 0.f;
+    v.z = b2s_keep(d, idx + 2) ? v.z * d.scale : 0.f;
+    v.w = b2s_keep(d, idx + 3) ? v.w * d.scale : 0.f;
+    return v;
+}
+__device__ inline float block_sum_256(float v, float* sh) {   // sh: >= 4 floats
+    v = wave_sum(v);
+    int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    return r;
+}
+
+// ---------------------------------------------------------------------------------- embedding prep
+__global__ void k_embed_prep_fwd(const long* ids, const int* lens, const float* embed, const float* pe,
+                                 const float* pe_scale, float* x, int S, int D, DropCfg drop) {
+    const int row = blockIdx.x, b = row / S, s = row - b * S;
+    const bool valid = s < lens[b];
+    const long id = ids[row];
+    const float sc = *pe_scale;
+    for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+        float4 e = valid ? ld4(embed + id * D + c) : make_float4(0, 0, 0, 0);
+        float4 p = ld4(pe + (long)s * D + c);
+        float4 v = make_float4(e.x + p.x * sc, e.y + p.y * sc, e.z + p.z * sc, e.w + p.w * sc);
+        st4(x + (long)row * D + c, drop4(v, drop, (uint32_t)((long)row * D + c)));
+    }
+}
+__global__ void k_embed_prep_bwd(const float* dx, const long* ids, const int* lens, const float* pe, float* d_embed,
+                                 float* d_pe_scale, int S, int D, DropCfg drop) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x, b = row / S, s = row - b * S;
+    const bool valid = s < lens[b];
+    const long id = ids[row];
+    float acc = 0.f;
+    for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+        float4 g = drop4(ld4(dx + (long)row * D + c), drop, (uint32_t)((long)row * D + c));
+        float4 p = ld4(pe + (long)s * D + c);
+        acc += g.x * p.x + g.y * p.y + g.z * p.z + g.w * p.w;
+        if (valid) {
+            float* de = d_embed + id * D + c;
+            atomicAdd(de, g.x); atomicAdd(de + 1, g.y); atomicAdd(de + 2, g.z); atomicAdd(de + 3, g.w);
+        }
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(d_pe_scale, acc);
+}
+
+// ---------------------------------------------------------------------------------- LayerNorm
+constexpr int LN_MAXC = 4;   // float4 chunks per lane -> D <= 1024
+template <typename T>
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* x, const float* gamma, const float* beta, T* y, int ldy,
+                                                float* y32, int ldy32, float* mean, float* rstd, int M, int D,
+                                                float eps, const int* row_len, int rpb) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = D >> 2;
+    float4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        int ci = lane + 64 * i;
+        if (ci < nch) { v[i] = ld4(x + (long)row * D + ci * 4); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        int ci = lane + 64 * i;
+        if (ci < nch) {
+            float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+            q += a * a + b * b + c * c + d * d;
+        }
+    }
+    const float rs = 1.f / sqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    bool zero = false;
+    if (row_len) { int b = row / rpb; zero = (row - b * rpb) >= row_len[b]; }
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        int ci = lane + 64 * i;
+        if (ci < nch) {
+            float4 g = ld4(gamma + ci * 4), be = ld4(beta + ci * 4), o;
+            o.x = (v[i].x - mu) * rs * g.x + be.x; o.y = (v[i].y - mu) * rs * g.y + be.y;
+            o.z = (v[i].z - mu) * rs * g.z + be.z; o.w = (v[i].w - mu) * rs * g.w + be.w;
+            if (zero) o = make_float4(0, 0, 0, 0);
+            if (y) st4(y + (long)row * ldy + ci * 4, o);
+            if (y32) st4(y32 + (long)row * ldy32 + ci * 4, o);
+        }
+    }
+}
+
+template <typename TD>
+__global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const float* x, const float* gamma,
+                                                const float* mean, const float* rstd, float* dx, int accumulate,
+                                                float* dgamma, float* dbeta, int M, int D, const int* row_len,
+                                                int rpb) {
+    __shared__ float sacc[2 * LN_MAXC * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = D >> 2;
+    for (int i = threadIdx.x; i < 2 * D; i += 256) sacc[i] = 0.f;
+    __syncthreads();
+    float4 pg[LN_MAXC], pb[LN_MAXC], gm[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        pg[i] = pb[i] = make_float4(0, 0, 0, 0);
+        int ci = lane + 64 * i;
+        gm[i] = ci < nch ? ld4(gamma + ci * 4) : make_float4(0, 0, 0, 0);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        bool zero = false;
+        if (row_len) { int b = row / rpb; zero = (row - b * rpb) >= row_len[b]; }
+        const float mu = mean[row], rs = rstd[row];
+        float4 g[LN_MAXC], xh[LN_MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            int ci = lane + 64 * i;
+            if (ci < nch) {
+                float4 d = zero ? make_float4(0, 0, 0, 0) : ld4(dy + (long)row * lddy + ci * 4);
+                float4 xv = ld4(x + (long)row * D + ci * 4);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                pb[i].x += d.x; pb[i].y += d.y; pb[i].z += d.z; pb[i].w += d.w;
+                pg[i].x += d.x * xh[i].x; pg[i].y += d.y * xh[i].y; pg[i].z += d.z * xh[i].z; pg[i].w += d.w * xh[i].w;
+                g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+                s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+                s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+            }
+        }
+        s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            int ci = lane + 64 * i;
+            if (ci < nch) {
+                float4 o;
+                o.x = rs * (g[i].x - s1 - xh[i].x * s2); o.y = rs * (g[i].y - s1 - xh[i].y * s2);
+                o.z = rs * (g[i].z - s1 - xh[i].z * s2); o.w = rs * (g[i].w - s1 - xh[i].w * s2);
+                float* p = dx + (long)row * D + ci * 4;
+                if (accumulate) { float4 a = ld4(p); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+                st4(p, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        int ci = lane + 64 * i;
+        if (ci < nch) {
+            float* a = sacc + ci * 4; float* b = sacc + D + ci * 4;
+            atomicAdd(a, pg[i].x); atomicAdd(a + 1, pg[i].y); atomicAdd(a + 2, pg[i].z); atomicAdd(a + 3, pg[i].w);
+            atomicAdd(b, pb[i].x); atomicAdd(b + 1, pb[i].y); atomicAdd(b + 2, pb[i].z); atomicAdd(b + 3, pb[i].w);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256) { atomicAdd(dgamma + i, sacc[i]); atomicAdd(dbeta + i, sacc[D + i]); }
+}
+
+// ---------------------------------------------------------------------------------- softmax
+template <typename T>
+__global__ __launch_bounds__(256) void k_softmax_fwd(const float* S, T* P, T* Pd, int H, int Lq, int Lk, int ldp,
+                                                     long rows, float scale, int mask_mode, const int* klen,
+                                                     const float* bias, long bias_sb, long bias_sq, DropCfg drop) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int q = (int)(r % Lq);
+    const int b = (int)(r / ((long)Lq * H));
+    int kend = Lk;
+    if (mask_mode & 1) kend = min(kend, klen[b]);
+    if (mask_mode & 2) kend = min(kend, q + 1);
+    const float* s = S + r * ldp;
+    const float* bi = bias ? bias + b * bias_sb + q * bias_sq : nullptr;
+    float mx = -INFINITY;
+    for (int k = lane; k < kend; k += 64) mx = fmaxf(mx, s[k] * scale + (bi ? bi[k] : 0.f));
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < kend; k += 64) sum += __expf(s[k] * scale + (bi ? bi[k] : 0.f) - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    T* p = P + r * ldp;
+    T* pd = Pd ? Pd + r * ldp : nullptr;
+    for (int k = lane; k < ldp; k += 64) {
+        float v = 0.f;
+        if (k < kend) v = __expf(s[k] * scale + (bi ? bi[k] : 0.f) - mx) * inv;
+        TT<T>::st(p + k, v);
+        if (pd) {
+            float w = v;
+            if (drop.thresh && k < kend) w = b2s_keep(drop, (uint32_t)(r * Lk + k)) ? v * drop.scale : 0.f;
+            TT<T>::st(pd + k, w);
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_softmax_bwd(const T* P, const float* dPraw, T* dS, int Lk, int ldp,
+                                                     long rows, float scale, DropCfg drop) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const T* p = P + r * ldp;
+    const float* dp = dPraw + r * ldp;
+    float acc = 0.f;
+    for (int k = lane; k < Lk; k += 64) {
+        float d = dp[k];
+        if (drop.thresh) d = b2s_keep(drop, (uint32_t)(r * Lk + k)) ? d * drop.scale : 0.f;
+        acc += TT<T>::ld(p + k) * d;
+    }
+    acc = wave_sum(acc);
+    T* o = dS + r * ldp;
+    for (int k = lane; k < ldp; k += 64) {
+        float v = 0.f;
+        if (k < Lk) {
+            float d = dp[k];
+            if (drop.thresh) d = b2s_keep(drop, (uint32_t)(r * Lk + k)) ? d * drop.scale : 0.f;
+            v = TT<T>::ld(p + k) * (d - acc) * scale;
+        }
+        TT<T>::st(o + k, v);
+    }
+}
+template <typename T>
+__global__ void k_align_transpose(const T* P, float* align, int Lq, int Lk, int ldp) {
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z, q0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 256 threads: ty 0..7
+    for (int j = ty; j < 32; j += 8) {
+        int q = q0 + j, k = k0 + tx;
+        tile[j][tx] = (q < Lq && k < Lk) ? TT<T>::ld(P + ((long)z * Lq + q) * ldp + k) : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int k = k0 + j, q = q0 + tx;
+        if (k < Lk && q < Lq) align[((long)z * Lk + k) * Lq + q] = tile[tx][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------- casts
+template <typename T>
+__global__ void k_cast_drop(const float* in, int ldin, T* out, int ldo, int M, int N, DropCfg drop) {
+    const int nq = N >> 2;
+    const long total = (long)M * nq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int m = (int)(i / nq), c = (int)(i - (long)m * nq) * 4;
+        float4 v = drop4(ld4(in + (long)m * ldin + c), drop, (uint32_t)((long)m * N + c));
+        st4(out + (long)m * ldo + c, v);
+    }
+}
+template <typename T>
+__global__ void k_cast(const float* in, T* out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        TT<T>::st(out + i, in[i]);
+}
+template <typename T>
+__global__ void k_cast_back(const T* in, float* out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = TT<T>::ld(in + i);
+}
+
+// ---------------------------------------------------------------------------------- decoder input prep
+__global__ void k_shift_pe_fwd(const float* a, const int* lens, const float* pe, const float* pe_scale, float* x,
+                               int T, int D, DropCfg drop) {
+    const int row = blockIdx.x, b = row / T, t = row - b * T;
+    const bool have = t > 0 && (t - 1) < lens[b];
+    const float sc = *pe_scale;
+    for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+        float4 e = have ? ld4(a + (long)(row - 1) * D + c) : make_float4(0, 0, 0, 0);
+        float4 p = ld4(pe + (long)t * D + c);
+        float4 v = make_float4(e.x + p.x * sc, e.y + p.y * sc, e.z + p.z * sc, e.w + p.w * sc);
+        st4(x + (long)row * D + c, drop4(v, drop, (uint32_t)((long)row * D + c)));
+    }
+}
+template <typename T_>
+__global__ void k_shift_pe_bwd(const float* dx, const int* lens, const float* pe, T_* da, float* d_pe_scale, int T,
+                               int D, DropCfg drop) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x, b = row / T, t = row - b * T;
+    // da[b,t] = g[b,t+1] if t+1 < T and t < len[b]
+    const bool have = (t + 1) < T && t < lens[b];
+    float acc = 0.f;
+    for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+        float4 g = drop4(ld4(dx + (long)row * D + c), drop, (uint32_t)((long)row * D + c));
+        float4 p = ld4(pe + (long)t * D + c);
+        acc += g.x * p.x + g.y * p.y + g.z * p.z + g.w * p.w;
+        float4 o = make_float4(0, 0, 0, 0);
+        if (have) o = drop4(ld4(dx + (long)(row + 1) * D + c), drop, (uint32_t)((long)(row + 1) * D + c));
+        st4(da + (long)row * D + c, o);
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(d_pe_scale, acc);
+}
+
+// ---------------------------------------------------------------------------------- speaker / language nets
+template <typename T>
+__global__ void k_embed_net_fwd(const long* ids, const float* table, const float* vecs, int L, const float* Wl,
+                                const float* W, const float* bias, float* e_raw, float* h_pre, float* mem32, T* memT,
+                                int ldm, int col0, int S, int E) {
+    extern __shared__ float sh[];        // E floats
+    const int b = blockIdx.x, n = threadIdx.x;
+    if (n < E) {
+        float e;
+        if (ids) e = table[ids[b] * E + n];
+        else { e = 0.f; for (int l = 0; l < L; ++l) e += Wl[n * L + l] * vecs[b * L + l]; }
+        sh[n] = e; e_raw[b * E + n] = e;
+    }
+    __syncthreads();
+    if (n < E) {
+        float h = bias[n];
+        for (int k = 0; k < E; ++k) h += W[n * E + k] * sh[k];
+        h_pre[b * E + n] = h;
+        float o = h / (1.f + fabsf(h));
+        for (int s = 0; s < S; ++s) {
+            long off = ((long)b * S + s) * ldm + col0 + n;
+            if (mem32) mem32[off] = o;
+            if (memT) TT<T>::st(memT + off, o);
+        }
+    }
+}
+__global__ void k_embed_net_bwd(const float* dmem, int ldm, int col0, const long* ids, const float* vecs, int L,
+                                const float* e_raw, const float* h_pre, const float* Wl, const float* W, float* d_table,
+                                float* dWl, float* dW, float* db, int S, int E) {
+    extern __shared__ float sh[];        // 2E floats: dh, de
+    const int b = blockIdx.x, n = threadIdx.x;
+    if (n < E) {
+        float d = 0.f;
+        for (int s = 0; s < S; ++s) d += dmem[((long)b * S + s) * ldm + col0 + n];
+        float h = h_pre[b * E + n], den = 1.f + fabsf(h);
+        float dh = d / (den * den);
+        sh[n] = dh;
+        atomicAdd(db + n, dh);
+    }
+    __syncthreads();
+    if (n < E) {
+        float dh = sh[n];
+        for (int k = 0; k < E; ++k) atomicAdd(dW + n * E + k, dh * e_raw[b * E + k]);
+        float de = 0.f;
+        for (int k = 0; k < E; ++k) de += W[k * E + n] * sh[k];      // de[n] = sum_k W[k][n] dh[k]
+        if (ids) atomicAdd(d_table + ids[b] * E + n, de);
+        else for (int l = 0; l < L; ++l) atomicAdd(dWl + n * L + l, de * vecs[b * L + l]);
+    }
+}
+
+// ---------------------------------------------------------------------------------- rowdot / colsum
+template <typename T>
+__global__ __launch_bounds__(256) void k_rowdot(const T* x, int ldx, const float* w, const float* b, float* out, int M,
+                                                int D, const int* row_len, int rpb) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float acc = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 v = ld4(x + (long)row * ldx + c), ww = ld4(w + c);
+        acc += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        bool zero = false;
+        if (row_len) { int bb = row / rpb; zero = (row - bb * rpb) >= row_len[bb]; }
+        out[row] = zero ? 0.f : acc + b[0];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_colsum(const T* X, int ldx, const float* wgt, float* out, int M, int C) {
+    __shared__ float sh[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float acc = 0.f;
+    if (c < C)
+        for (int m = blockIdx.y * 4 + ry; m < M; m += gridDim.y * 4)
+            acc += (wgt ? wgt[m] : 1.f) * TT<T>::ld(X + (long)m * ldx + c);
+    sh[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && c < C) atomicAdd(out + c, sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]);
+}
+
+// ---------------------------------------------------------------------------------- BatchNorm
+__global__ __launch_bounds__(256) void k_bn_colred(const float* y, int M, int C, const float* mu_sum, float* out) {
+    // mu_sum == nullptr: out[c] += sum_m y ; else out[c] += sum_m (y - mu_sum[c]/M)^2
+    __shared__ float sh[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float acc = 0.f;
+    if (c < C) {
+        const float mu = mu_sum ? mu_sum[c] / M : 0.f;
+        for (int m = blockIdx.y * 4 + ry; m < M; m += gridDim.y * 4) {
+            float v = y[(long)m * C + c];
+            if (mu_sum) { v -= mu; v *= v; }
+            acc += v;
+        }
+    }
+    sh[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && c < C) atomicAdd(out + c, sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]);
+}
+__global__ void k_bn_finalize(const float* scratch, int M, int C, float* mean, float* rstd, float eps, float* rm,
+                              float* rv, long* nbt, float mom) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        float mu = scratch[c] / M, var = scratch[C + c] / M;
+        mean[c] = mu; rstd[c] = 1.f / sqrtf(var + eps);
+        if (rm) {
+            rm[c] = (1.f - mom) * rm[c] + mom * mu;
+            rv[c] = (1.f - mom) * rv[c] + mom * var * ((float)M / (float)(M - 1));
+        }
+    }
+    if (c == 0 && nbt) *nbt += 1;
+}
+__global__ void k_bn_eval_stats(const float* rm, const float* rv, float* mean, float* rstd, float eps, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { mean[c] = rm[c]; rstd[c] = 1.f / sqrtf(rv[c] + eps); }
+}
+template <typename T>
+__global__ void k_bn_apply(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           int use_tanh, T* outT, float* out32, const float* add32, int M, int C, DropCfg drop) {
+    const int nq = C >> 2;
+    const long total = (long)M * nq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int m = (int)(i / nq), c = (int)(i - (long)m * nq) * 4;
+        float4 v = ld4(y + (long)m * C + c), mu = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), be = ld4(beta + c);
+        float4 o;
+        o.x = (v.x - mu.x) * rs.x * g.x + be.x; o.y = (v.y - mu.y) * rs.y * g.y + be.y;
+        o.z = (v.z - mu.z) * rs.z * g.z + be.z; o.w = (v.w - mu.w) * rs.w * g.w + be.w;
+        if (use_tanh) { o.x = tanhf(o.x); o.y = tanhf(o.y); o.z = tanhf(o.z); o.w = tanhf(o.w); }
+        o = drop4(o, drop, (uint32_t)((long)m * C + c));
+        if (outT) st4(outT + (long)m * C + c, o);
+        if (out32) {
+            if (add32) { float4 a = ld4(add32 + (long)m * C + c); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+            st4(out32 + (long)m * C + c, o);
+        }
+    }
+}
+template <typename TD>
+__device__ inline float bn_dz(const TD* dout, const float* y, long off, int c, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int use_tanh, const DropCfg& drop, float* xhat) {
+    float d = TT<TD>::ld(dout + off);
+    if (drop.thresh) d = b2s_keep(drop, (uint32_t)off) ? d * drop.scale : 0.f;
+    float xh = (y[off] - mean[c]) * rstd[c];
+    *xhat = xh;
+    if (use_tanh) { float a = tanhf(gamma[c] * xh + beta[c]); d *= (1.f - a * a); }
+    return d;
+}
+template <typename TD>
+__global__ __launch_bounds__(256) void k_bn_bwd_red(const TD* dout, const float* y, const float* mean,
+                                                    const float* rstd, const float* gamma, const float* beta,
+                                                    int use_tanh, float* dgamma, float* dbeta, int M, int C,
+                                                    DropCfg drop) {
+    __shared__ float sh[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C)
+        for (int m = blockIdx.y * 4 + ry; m < M; m += gridDim.y * 4) {
+            float xh;
+            float dz = bn_dz<TD>(dout, y, (long)m * C + c, c, mean, rstd, gamma, beta, use_tanh, drop, &xh);
+            a1 += dz; a2 += dz * xh;
+        }
+    sh[0][ry][cx] = a1; sh[1][ry][cx] = a2;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        atomicAdd(dbeta + c, sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx]);
+        atomicAdd(dgamma + c, sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx]);
+    }
+}
+template <typename TD, typename T>
+__global__ void k_bn_bwd_apply(const TD* dout, const float* y, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, int use_tanh, const float* dgamma,
+                               const float* dbeta, T* dy, int M, int C, DropCfg drop) {
+    const long total = (long)M * C;
+    const float invM = 1.f / M;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        float xh;
+        float dz = bn_dz<TD>(dout, y, i, c, mean, rstd, gamma, beta, use_tanh, drop, &xh);
+        TT<T>::st(dy + i, gamma[c] * rstd[c] * (dz - dbeta[c] * invM - xh * dgamma[c] * invM));
+    }
+}
+
+// ---------------------------------------------------------------------------------- loss
+__device__ inline float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
+__global__ __launch_bounds__(256) void k_loss_partial(const float* bef, const float* aft, const float* stop,
+                                                      const float* tgt, const int* lens, float* scratch, int B, int T,
+                                                      int C, float pw) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * T) return;
+    const int b = row / T, t = row - b * T, len = lens[b];
+    if (t >= len) return;
+    float sb = 0.f, sa = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float y = tgt[(long)row * C + c];
+        float d1 = bef[(long)row * C + c] - y, d2 = aft[(long)row * C + c] - y;
+        sb += d1 * d1; sa += d2 * d2;
+    }
+    sb = wave_sum(sb) / C; sa = wave_sum(sa) / C;
+    if (lane == 0) {
+        float x = stop[row];
+        float ce = (t == len - 1) ? pw * softplusf(-x) : softplusf(x);
+        atomicAdd(scratch + 0, sb); atomicAdd(scratch + 1, sa); atomicAdd(scratch + 2, ce);
+        atomicAdd(scratch + 3 + b, sa);
+    }
+}
+__global__ void k_loss_finalize(const float* scratch, const int* lens, const float* l2, float* out, float* aft_losses,
+                                int B) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float sl = 0.f;
+        for (int b = 0; b < B; ++b) sl += (float)lens[b];
+        float bef = scratch[0] / sl, aft = scratch[1] / sl, ce = scratch[2] / sl, l = l2 ? *l2 : 0.f;
+        out[0] = bef + aft + l + ce; out[1] = bef; out[2] = aft; out[3] = (bef + aft) * 0.5f; out[4] = l; out[5] = ce;
+        out[6] = sl;
+        for (int b = 0; b < B; ++b) aft_losses[b] = scratch[3 + b] / (float)lens[b];
+    }
+}
+__global__ __launch_bounds__(256) void k_loss_bwd(const float* bef, const float* aft, const float* stop,
+                                                  const float* tgt, const int* lens, const float* gscale, float* d_bef,
+                                                  float* d_aft, float* d_stop, int B, int T, int C, float pw) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * T) return;
+    const int b = row / T, t = row - b * T, len = lens[b];
+    float sl = 0.f;
+    for (int i = 0; i < B; ++i) sl += (float)lens[i];
+    const float wb = (gscale ? gscale[0] : 1.f) / sl, wa = (gscale ? gscale[1] : 1.f) / sl, ws = (gscale ? gscale[2] : 1.f) / sl;
+    const bool valid = t < len;
+    const float k = valid ? 2.f / C : 0.f;
+    for (int c = lane; c < C; c += 64) {
+        long o = (long)row * C + c;
+        float y = tgt[o];
+        d_bef[o] = k * wb * (bef[o] - y);
+        d_aft[o] = k * wa * (aft[o] - y);
+    }
+    if (lane == 0) {
+        float g = 0.f;
+        if (valid) {
+            float x = stop[row], sg = 1.f / (1.f + __expf(-x));
+            g = (t == len - 1) ? -pw * (1.f - sg) : sg;
+            g *= ws;
+        }
+        d_stop[row] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------- multi-tensor
+__global__ __launch_bounds__(256) void k_mt_sumsq(const MtChunk* ch, float* out, float scale) {
+    __shared__ float sh[4];
+    const MtChunk c = ch[blockIdx.x];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < c.n; i += 256) { float v = c.a[i]; acc += v * v; }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(out, acc * scale);
+}
+__global__ __launch_bounds__(256) void k_mt_axpy(const MtChunk* ch, float alpha, const float* gscale) {
+    const MtChunk c = ch[blockIdx.x];
+    const float a = alpha * (gscale ? *gscale : 1.f);
+    for (int i = threadIdx.x; i < c.n; i += 256) c.b[i] += a * c.a[i];
+}
+__global__ __launch_bounds__(256) void k_mt_adam(const MtChunk* ch, const float* hp, float b1, float b2, float eps,
+                                                 float l2, float gs) {
+    const MtChunk c = ch[blockIdx.x];
+    const float lr = hp[0], bc1 = hp[1], sbc2 = hp[2];     // sbc2 = sqrt(1 - beta2^t)
+    for (int i = threadIdx.x; i < c.n; i += 256) {
+        float p = c.a[i], g = c.b[i] * gs + (c.pad ? l2 : 0.f) * p, m = c.c[i], v = c.d[i];
+        m = b1 * m + (1.f - b1) * g;
+        v = b2 * v + (1.f - b2) * g * g;
+        c.c[i] = m; c.d[i] = v;
+        c.a[i] = p - (lr / bc1) * m / (sqrtf(v) / sbc2 + eps);
+    }
+}
+
+template <typename T>
+__global__ void k_conv_w_relayout(const float* w, T* wf, T* wb, int Cout, int Cin) {
+    const long total = (long)Cout * Cin * 5;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int j = (int)(i % 5); long r = i / 5; int ci = (int)(r % Cin), co = (int)(r / Cin);
+        float v = w[i];
+        TT<T>::st(wf + (long)co * 5 * Cin + (long)j * Cin + ci, v);
+        TT<T>::st(wb + (long)ci * 5 * Cout + (long)(4 - j) * Cout + co, v);
+    }
+}
+__global__ void k_add(const float* a, const float* b, float* o, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) o[i] = a[i] + b[i];
+}
+__global__ void k_fill(float* p, float v, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+inline int ew_grid(long n, int per = 256) { long g = (n + per - 1) / per; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+
+}  // namespace
+
+// ====================================================================================== host wrappers
+int ro_embed_prep_fwd(const long* ids, const int* lens, const float* embed, const float* pe, const float* pe_scale,
+                      float* x, int B, int S, int D, DropCfg drop, hipStream_t st) {
+    B2S_CHECK(D % 4 == 0, "embed_prep: D=%d must be a multiple of 4", D);
+    hipLaunchKernelGGL(k_embed_prep_fwd, dim3(B * S), dim3(128), 0, st, ids, lens, embed, pe, pe_scale, x, S, D, drop);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_embed_prep_bwd(const float* dx, const long* ids, const int* lens, const float* pe, float* d_embed,
+                      float* d_pe_scale, int B, int S, int D, DropCfg drop, hipStream_t st) {
+    hipLaunchKernelGGL(k_embed_prep_bwd, dim3(B * S), dim3(128), 0, st, dx, ids, lens, pe, d_embed, d_pe_scale, S, D, drop);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float* beta, void* y, int ldy, float* y32,
+                     int ldy32, float* mean, float* rstd, int M, int D, float eps, const int* row_len,
+                     int rows_per_batch, hipStream_t st) {
+    B2S_CHECK(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_ln_fwd<TY>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, (TY*)y, ldy,
+                                          y32, ldy32, mean, rstd, M, D, eps, row_len, rows_per_batch));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const float* x, const float* gamma,
+                     const float* mean, const float* rstd, float* dx, int accumulate, float* dgamma, float* dbeta,
+                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st) {
+    B2S_CHECK(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
+    int grid = cdiv(M, 4); if (grid > 512) grid = 512;
+    if (dy_fp32 || !dtype)
+        hipLaunchKernelGGL((k_ln_bwd<float>), dim3(grid), dim3(256), 0, st, (const float*)dy, lddy, x, gamma, mean, rstd,
+                           dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch);
+    else
+        hipLaunchKernelGGL((k_ln_bwd<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, lddy, x, gamma, mean,
+                           rstd, dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_softmax_fwd(int dtype, const float* S, void* P, void* Pd, int B, int H, int Lq, int Lk, int ldp, float scale,
+                   int mask_mode, const int* klen, const float* bias, long bias_sb, long bias_sq, DropCfg drop,
+                   hipStream_t st) {
+    const long rows = (long)B * H * Lq;
+    B2S_CHECK(!(mask_mode & 1) || klen, "softmax: key-length mask needs klen");
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_softmax_fwd<TY>), dim3(cdiv(rows, 4)), dim3(256), 0, st, S, (TY*)P, (TY*)Pd, H,
+                                          Lq, Lk, ldp, rows, scale, mask_mode, klen, bias, bias_sb, bias_sq, drop));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_softmax_bwd(int dtype, const void* P, const float* dPraw, void* dS, int B, int H, int Lq, int Lk, int ldp,
+                   float scale, DropCfg drop, hipStream_t st) {
+    const long rows = (long)B * H * Lq;
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_softmax_bwd<TY>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const TY*)P, dPraw,
+                                          (TY*)dS, Lk, ldp, rows, scale, drop));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_align_transpose(int dtype, const void* P, float* align, int Z, int Lq, int Lk, int ldp, hipStream_t st) {
+    dim3 grid(cdiv(Lk, 32), cdiv(Lq, 32), Z);
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_align_transpose<TY>), grid, dim3(256), 0, st, (const TY*)P, align, Lq, Lk, ldp));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_cast_drop(int dtype, const float* in, int ldin, void* out, int ldo, int M, int N, DropCfg drop, hipStream_t st) {
+    B2S_CHECK(N % 4 == 0, "cast_drop: N=%d must be a multiple of 4", N);
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_cast_drop<TY>), dim3(ew_grid((long)M * N / 4)), dim3(256), 0, st, in, ldin,
+                                          (TY*)out, ldo, M, N, drop));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_cast(int dtype, const float* in, void* out, long n, hipStream_t st) {
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_cast<TY>), dim3(ew_grid(n)), dim3(256), 0, st, in, (TY*)out, n));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_cast_back(int dtype, const void* in, float* out, long n, hipStream_t st) {
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_cast_back<TY>), dim3(ew_grid(n)), dim3(256), 0, st, (const TY*)in, out, n));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_shift_pe_fwd(const float* a, const int* lens, const float* pe, const float* pe_scale, float* x, int B, int T,
+                    int D, DropCfg drop, hipStream_t st) {
+    B2S_CHECK(D % 4 == 0, "shift_pe: D=%d must be a multiple of 4", D);
+    hipLaunchKernelGGL(k_shift_pe_fwd, dim3(B * T), dim3(128), 0, st, a, lens, pe, pe_scale, x, T, D, drop);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_shift_pe_bwd(int dtype, const float* dx, const int* lens, const float* pe, void* da, float* d_pe_scale, int B,
+                    int T, int D, DropCfg drop, hipStream_t st) {
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_shift_pe_bwd<TY>), dim3(B * T), dim3(128), 0, st, dx, lens, pe, (TY*)da,
+                                          d_pe_scale, T, D, drop));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_spk_embed_fwd(const long* spk_ids, const float* table, const float* W, const float* b, float* e_raw,
+                     float* h_pre, float* mem32, void* memT, int dtype, int ldm, int col0, int B, int S, int E,
+                     hipStream_t st) {
+    B2S_CHECK(E <= 1024, "embedding size %d too large", E);
+    int th = ((E + 63) / 64) * 64;
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_embed_net_fwd<TY>), dim3(B), dim3(th), E * sizeof(float), st, spk_ids, table,
+                                          (const float*)nullptr, 0, (const float*)nullptr, W, b, e_raw, h_pre, mem32,
+                                          (TY*)memT, ldm, col0, S, E));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_lang_embed_fwd(const float* vecs, int L, const float* Wl, const float* W, const float* b, float* e_raw,
+                      float* h_pre, float* mem32, void* memT, int dtype, int ldm, int col0, int B, int S, int E,
+                      hipStream_t st) {
+    B2S_CHECK(E <= 1024, "embedding size %d too large", E);
+    int th = ((E + 63) / 64) * 64;
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_embed_net_fwd<TY>), dim3(B), dim3(th), E * sizeof(float), st,
+                                          (const long*)nullptr, (const float*)nullptr, vecs, L, Wl, W, b, e_raw, h_pre,
+                                          mem32, (TY*)memT, ldm, col0, S, E));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_spk_embed_bwd(const float* dmem, int ldm, int col0, const long* spk_ids, const float* e_raw, const float* h_pre,
+                     const float* W, float* d_table, float* dW, float* db, int B, int S, int E, hipStream_t st) {
+    int th = ((E + 63) / 64) * 64;
+    hipLaunchKernelGGL(k_embed_net_bwd, dim3(B), dim3(th), 2 * E * sizeof(float), st, dmem, ldm, col0, spk_ids,
+                       (const float*)nullptr, 0, e_raw, h_pre, (const float*)nullptr, W, d_table, (float*)nullptr, dW, db,
+                       S, E);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_lang_embed_bwd(const float* dmem, int ldm, int col0, const float* vecs, int L, const float* e_raw,
+                      const float* h_pre, const float* Wl, const float* W, float* dWl, float* dW, float* db, int B,
+                      int S, int E, hipStream_t st) {
+    int th = ((E + 63) / 64) * 64;
+    hipLaunchKernelGGL(k_embed_net_bwd, dim3(B), dim3(th), 2 * E * sizeof(float), st, dmem, ldm, col0,
+                       (const long*)nullptr, vecs, L, e_raw, h_pre, Wl, W, (float*)nullptr, dWl, dW, db, S, E);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_rowdot_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* out, int M, int D,
+                  const int* row_len, int rows_per_batch, hipStream_t st) {
+    B2S_CHECK(D % 4 == 0, "rowdot: D=%d must be a multiple of 4", D);
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_rowdot<TY>), dim3(cdiv(M, 4)), dim3(256), 0, st, (const TY*)x, ldx, w, b, out,
+                                          M, D, row_len, rows_per_batch));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_colsum(int dtype, const void* X, int x_fp32, int ldx, const float* wgt, float* out, int accumulate, int M,
+              int C, hipStream_t st) {
+    if (!accumulate) B2S_HIP(hipMemsetAsync(out, 0, sizeof(float) * C, st));
+    int gy = cdiv(M, 4 * 16); if (gy > 128) gy = 128; if (gy < 1) gy = 1;
+    dim3 grid(cdiv(C, 64), gy);
+    if (x_fp32 || !dtype)
+        hipLaunchKernelGGL((k_colsum<float>), grid, dim3(256), 0, st, (const float*)X, ldx, wgt, out, M, C);
+    else
+        hipLaunchKernelGGL((k_colsum<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)X, ldx, wgt, out, M, C);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float eps, float* running_mean,
+                float* running_var, long* num_batches_tracked, float momentum, float* scratch, hipStream_t st) {
+    B2S_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * 2 * C, st));
+    int gy = cdiv(M, 4 * 16); if (gy > 128) gy = 128; if (gy < 1) gy = 1;
+    dim3 grid(cdiv(C, 64), gy);
+    hipLaunchKernelGGL(k_bn_colred, grid, dim3(256), 0, st, y, M, C, (const float*)nullptr, scratch);
+    hipLaunchKernelGGL(k_bn_colred, grid, dim3(256), 0, st, y, M, C, (const float*)scratch, scratch + C);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)scratch, M, C, mean, rstd, eps,
+                       running_mean, running_var, num_batches_tracked, momentum);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* rstd, float eps, int C,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_eval_stats, dim3(cdiv(C, 256)), dim3(256), 0, st, running_mean, running_var, mean, rstd, eps, C);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_bn_apply(int dtype, const float* y, const float* mean, const float* rstd, const float* gamma,
+                const float* beta, int use_tanh, void* outT, float* out32, const float* add32, int M, int C,
+                DropCfg drop, hipStream_t st) {
+    B2S_CHECK(C % 4 == 0, "bn_apply: C=%d must be a multiple of 4", C);
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<TY>), dim3(ew_grid((long)M * C / 4)), dim3(256), 0, st, y, mean, rstd,
+                                          gamma, beta, use_tanh, (TY*)outT, out32, add32, M, C, drop));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_bn_bwd(int dtype, const void* dout, int dout_fp32, const float* y, const float* mean, const float* rstd,
+              const float* gamma, const float* beta, int use_tanh, float* dgamma, float* dbeta, void* dyT, int M,
+              int C, DropCfg drop, hipStream_t st) {
+    int gy = cdiv(M, 4 * 16); if (gy > 128) gy = 128; if (gy < 1) gy = 1;
+    dim3 grid(cdiv(C, 64), gy);
+    const int g2 = ew_grid((long)M * C);
+    if (dout_fp32 || !dtype) {
+        hipLaunchKernelGGL((k_bn_bwd_red<float>), grid, dim3(256), 0, st, (const float*)dout, y, mean, rstd, gamma, beta,
+                           use_tanh, dgamma, dbeta, M, C, drop);
+        RO_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_bwd_apply<float, TY>), dim3(g2), dim3(256), 0, st, (const float*)dout,
+                                              y, mean, rstd, gamma, beta, use_tanh, (const float*)dgamma,
+                                              (const float*)dbeta, (TY*)dyT, M, C, drop));
+    } else {
+        hipLaunchKernelGGL((k_bn_bwd_red<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dout, y, mean, rstd, gamma,
+                           beta, use_tanh, dgamma, dbeta, M, C, drop);
+        hipLaunchKernelGGL((k_bn_bwd_apply<bf16_t, bf16_t>), dim3(g2), dim3(256), 0, st, (const bf16_t*)dout, y, mean,
+                           rstd, gamma, beta, use_tanh, (const float*)dgamma, (const float*)dbeta, (bf16_t*)dyT, M, C,
+                           drop);
+    }
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_loss_fwd(const float* bef, const float* aft, const float* stop, const float* tgt, const int* lens,
+                const float* l2, float* out, float* aft_losses, int B, int T, int C, float pos_weight, float* scratch,
+                hipStream_t st) {
+    B2S_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * (3 + B), st));
+    hipLaunchKernelGGL(k_loss_partial, dim3(cdiv((long)B * T, 4)), dim3(256), 0, st, bef, aft, stop, tgt, lens, scratch, B,
+                       T, C, pos_weight);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, (const float*)scratch, lens, l2, out, aft_losses, B);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_loss_bwd(const float* bef, const float* aft, const float* stop, const float* tgt, const int* lens,
+                const float* gscale, float* d_bef, float* d_aft, float* d_stop, int B, int T, int C, float pos_weight,
+                hipStream_t st) {
+    hipLaunchKernelGGL(k_loss_bwd, dim3(cdiv((long)B * T, 4)), dim3(256), 0, st, bef, aft, stop, tgt, lens, gscale, d_bef,
+                       d_aft, d_stop, B, T, C, pos_weight);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_mt_sumsq(const MtChunk* chunks, int nchunks, float* out, float scale, hipStream_t st) {
+    if (nchunks > 0) hipLaunchKernelGGL(k_mt_sumsq, dim3(nchunks), dim3(256), 0, st, chunks, out, scale);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gscale, hipStream_t st) {
+    if (nchunks > 0) hipLaunchKernelGGL(k_mt_axpy, dim3(nchunks), dim3(256), 0, st, chunks, alpha, gscale);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1, float beta2, float eps, float l2,
+               float grad_scale, hipStream_t st) {
+    if (nchunks > 0)
+        hipLaunchKernelGGL(k_mt_adam, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_conv_w_relayout(int dtype, const float* w, void* wf, void* wb, int Cout, int Cin, hipStream_t st) {
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_conv_w_relayout<TY>), dim3(ew_grid((long)Cout * Cin * 5)), dim3(256), 0, st, w,
+                                          (TY*)wf, (TY*)wb, Cout, Cin));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_add(const float* a, const float* b, float* out, long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_add, dim3(ew_grid(n)), dim3(256), 0, st, a, b, out, n);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_fill(float* p, float v, long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_fill, dim3(ew_grid(n)), dim3(256), 0, st, p, v, n);
+    B2S_LAUNCH_CHECK(); return 0;
+}

@@ -1,0 +1,224 @@
+"""Tacotron wrapper (encoder / decoder / postnet), loss, init and LR schedule with the reference's API
+(transformer/tacotron.py:1-179).  forward/backward of every segment run in libb2s_hip (hand-written HIP for
+gfx950); this file only holds parameters under the reference's state_dict names and wires autograd."""
+import weakref
+
+import torch
+from torch import nn
+
+from b2s_hip.engine import HipEngine, EncoderFn, DecoderFn, PostnetFn, LossFn, _i32, DTYPES
+from b2s_hip import ops
+from transformer.attention import HipLinear
+from transformer.modules import TransformerEncoder, TransformerDecoder
+from transformer.common import impute, mask_reduce, truncated_normal, variance_scaling_initializer  # noqa: F401
+
+
+class _Segment(nn.Module):
+    """A model segment executed by the engine of the Tacotron that owns it."""
+    _prefix = ""
+
+    def _engine(self):
+        root = self.__dict__.get("_root_ref")
+        root = root() if root is not None else None
+        if root is None:
+            raise RuntimeError("%s must be part of a Tacotron model (it executes inside libb2s_hip)" % type(self).__name__)
+        return root.engine()
+
+    def _params(self):
+        names, params = [], []
+        for n, p in self.named_parameters():
+            names.append(n)
+            params.append(p)
+        return names, params
+
+
+class Encoder(_Segment):
+    _prefix = "encoder."
+
+    def __init__(self, hparams):
+        super(Encoder, self).__init__()
+        self.hparams = hparams
+        self.embed = nn.Embedding(hparams.vocab_size, hparams.embed_size)       # parameter holder (gather runs in HIP)
+        if hparams.multi_speaker:
+            self.speaker_embed = nn.Embedding(hparams.max_num_speaker, hparams.speaker_embedding_size)
+            self.speaker_layer = HipLinear(hparams.speaker_embedding_size, hparams.speaker_embedding_size)
+        if hparams.multi_lingual:
+            self.language_embed = HipLinear(hparams.max_num_language, hparams.language_embedding_size, bias=False)
+            self.language_layer = HipLinear(hparams.language_embedding_size, hparams.language_embedding_size)
+        self.encoder = TransformerEncoder(hparams.embed_size, hparams)
+
+    def forward(self, inputs, input_lengths, input_spk_ids=None, input_language_vecs=None):
+        """-> [B, S, encoder_hidden (+speaker) (+language)]  (tacotron.py:33-44)."""
+        eng = self._engine()
+        names, params = self._params()
+        return EncoderFn.apply(eng, self._prefix, names, inputs, _i32(input_lengths), input_spk_ids, input_language_vecs,
+                               self.training, *params)
+
+
+class DecoderPrenet(nn.Module):
+    def __init__(self, in_size, hidden_size, out_size, dropout_rate, compute_dtype="fp32"):
+        super(DecoderPrenet, self).__init__()
+        self.dense0 = HipLinear(in_size, hidden_size)
+        self.dense1 = HipLinear(hidden_size, hidden_size)
+        self.dense_final = HipLinear(hidden_size, out_size, bias=False)
+        self.dropout = nn.Dropout(dropout_rate)
+        self.compute_dtype = compute_dtype
+
+    def forward(self, x):
+        """Stand-alone prenet (tacotron.py:55-65); dropout-on use goes through Decoder (in-kernel RNG)."""
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("stand-alone DecoderPrenet with dropout: run it inside Tacotron (engine path)")
+        for m in (self.dense0, self.dense1, self.dense_final):
+            m.compute_dtype = self.compute_dtype
+        return self.dense_final(self.dense1(self.dense0(x, relu=True), relu=True))
+
+
+class Postnet(_Segment):
+    _prefix = "postnet."
+
+    def __init__(self, hparams):
+        super(Postnet, self).__init__()
+        self.conv_layers = nn.ModuleList()
+        self.batchnorm_layers = nn.ModuleList()
+        self.dropout = nn.Dropout(hparams.decoder_dropout_rate)
+        hidden = hparams.postnet_hidden
+        for i in range(hparams.n_postnet_layer):
+            in_size = hparams.num_mels if i == 0 else hidden
+            out_size = hparams.num_mels if i == hparams.n_postnet_layer - 1 else hidden
+            self.conv_layers.append(nn.Conv1d(in_size, out_size, 5, stride=1, padding=2, bias=False))   # holders
+            self.batchnorm_layers.append(nn.BatchNorm1d(out_size))
+
+    def forward(self, inputs, input_lengths, _fuse_add=False):
+        """[B,T,M] -> residual [B,T,M] (tacotron.py:81-90): 5x {mask, conv k5 (implicit GEMM), BatchNorm, tanh, dropout}."""
+        eng = self._engine()
+        names, params = self._params()
+        return PostnetFn.apply(eng, self._prefix, names, inputs, _i32(input_lengths), _fuse_add, self.training, *params)
+
+
+class LazyAlignments(dict):
+    """{'self': [L tensors], 'encdec': [L tensors]} of shape [B,H,Lk,Lq] (modules.py:145), materialised from the
+    softmax weights held by the decoder context only when a key is read (training never reads them)."""
+
+    def __init__(self, eng, ctx, n_layers, B, H, T, S):
+        super(LazyAlignments, self).__init__()
+        self._a = (eng, ctx, n_layers, B, H, T, S)
+
+    def _fill(self, key):
+        if not dict.__contains__(self, key):
+            eng, ctx, n, B, H, T, S = self._a
+            which, lk = (0, T) if key == "self" else (1, S)
+            dict.__setitem__(self, key, [eng.decoder_alignment(ctx, which, i, B, H, lk, T) for i in range(n)])
+
+    def __getitem__(self, key):
+        if key in ("self", "encdec"):
+            self._fill(key)
+        return dict.__getitem__(self, key)
+
+    def __contains__(self, key):
+        return key in ("self", "encdec")
+
+    def keys(self):
+        return ["self", "encdec"]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return 2
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
+class Decoder(_Segment):
+    _prefix = "decoder."
+
+    def __init__(self, hparams):
+        super(Decoder, self).__init__()
+        in_size = hparams.encoder_hidden
+        if hparams.multi_speaker:
+            in_size += hparams.speaker_embedding_size
+        if hparams.multi_lingual:
+            in_size += hparams.language_embedding_size
+        cd = getattr(hparams, "compute_dtype", "fp32")
+        self.prenet = DecoderPrenet(hparams.num_mels, hparams.prenet_hidden, hparams.decoder_hidden,
+                                    hparams.decoder_dropout_rate, cd)
+        self.decoder = TransformerDecoder(in_size, hparams)
+        self.mel_net = HipLinear(hparams.decoder_hidden, hparams.num_mels, bias=False)
+        self.stop_net = HipLinear(hparams.decoder_hidden, 1)
+        self._n_layers = hparams.n_decoder_layer
+        self._heads = hparams.n_attention_head
+
+    def forward(self, encoder_outputs, input_lengths, targets, target_lengths, leave_one=False):
+        """-> (mels [B,T,M], stop_logits [B,T], {'self','encdec'} alignments)  (tacotron.py:107-116).
+        leave_one zeroes the last prenet row, which the shift-right then drops (modules.py:115-116): a no-op."""
+        eng = self._engine()
+        names, params = self._params()
+        holder = []
+        mels, stop = DecoderFn.apply(eng, self._prefix, names, encoder_outputs, _i32(input_lengths), targets,
+                                     _i32(target_lengths), self.training, holder, *params)
+        B, T = targets.shape[0], targets.shape[1]
+        align = LazyAlignments(eng, holder[0], self._n_layers, B, self._heads, T, encoder_outputs.shape[1])
+        return mels, stop, align
+
+
+class Tacotron(nn.Module):
+    def __init__(self, hparams):
+        super(Tacotron, self).__init__()
+        self.encoder = Encoder(hparams)
+        self.decoder = Decoder(hparams)
+        self.postnet = Postnet(hparams)
+        self.__dict__["_hp"] = hparams
+        self.__dict__["_engine"] = None
+        for seg in (self.encoder, self.decoder, self.postnet):
+            seg.__dict__["_root_ref"] = weakref.ref(self)
+
+    def engine(self):
+        """The HIP engine bound to this module tree (created on first use; raises if libb2s_hip.so is missing)."""
+        if self.__dict__["_engine"] is None:
+            self.__dict__["_engine"] = HipEngine(self, self.__dict__["_hp"])
+        return self.__dict__["_engine"]
+
+    def forward(self, inputs, input_lengths, mel_targets, target_lengths, input_spk_ids, input_language_vecs, **kwargs):
+        """tacotron.py:126-133: kwargs are the dataloader batch dict (unknown keys such as `names` are ignored)."""
+        enc_outputs = self.encoder(inputs, input_lengths, input_spk_ids, input_language_vecs)
+        mel_bef, stop_logits, alignments = self.decoder(enc_outputs, input_lengths, mel_targets, target_lengths)
+        mel_aft = self.postnet(mel_bef, target_lengths, _fuse_add=True)          # mel_bef + postnet(mel_bef), fused
+        return {'mel_bef': mel_bef, 'mel_aft': mel_aft, 'stop_logits': stop_logits, 'alignments': alignments}
+
+
+def compute_loss(model, mel_targets, target_lengths, outputs, hparams):
+    """tacotron.py:136-158: masked MSE before/after the postnet, stop-token BCE (pos_weight 5), L2 over the
+    name-filtered weights; one fused HIP reduction + fused gradient kernels."""
+    root = model.module if hasattr(model, "module") else model
+    eng = root.engine()
+    vals, per = LossFn.apply(eng, outputs['mel_bef'], outputs['mel_aft'], outputs['stop_logits'], mel_targets,
+                             _i32(target_lengths))
+    return {'loss': vals[0], 'bef_loss': vals[1], 'aft_loss': vals[2], 'aft_losses': per,
+            'mse_loss': vals[3], 'l2': vals[4], 'stop_loss': vals[5]}
+
+
+def initialize_variables(model):
+    """TF-style init (tacotron.py:161-173); host-side, once."""
+    state_dict = model.state_dict()
+    updates = {}
+    for name, tensor in state_dict.items():
+        if name == 'encoder.embed.weight':
+            updates[name] = torch.normal(mean=0, std=1, size=tensor.shape).to(tensor.device)
+        elif name in ['encoder.speaker_embed.weight', 'encoder.language_embed.weight']:
+            updates[name] = truncated_normal(tensor, mean=0, std=0.5).to(tensor.device)
+        elif ('weight' in name) and ('layer_norm' not in name and 'batchnorm' not in name):
+            updates[name] = variance_scaling_initializer(tensor).to(tensor.device)
+        elif 'bias' in name:
+            updates[name] = torch.zeros_like(tensor)
+    model.load_state_dict(updates, strict=False)
+
+
+def learning_rate_schedule(global_step, hp):
+    """tacotron.py:176-179."""
+    step = max(global_step - hp.warmup_steps, 0)
+    lr_rate = hp.lr_decay_rate ** (step / hp.lr_decay_step)
+    return max(hp.min_lr / hp.max_lr, lr_rate)

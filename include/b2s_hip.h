@@ -1,0 +1,161 @@
+/*
+ * b2s_hip.h -- C ABI of libb2s_hip.so: the MI355X (gfx950) implementation of the Transformer-TTS
+ * ("byte2speech") hot path of mutiann/few-shot-transformer-tts.
+ *
+ * The reference has no FFI: its hot path is Python calling PyTorch aten ops.  This header is the
+ * boundary a maintainer binds instead (ctypes stub in INTEGRATION.md); each entry point names the
+ * reference code it replaces.  Conventions:
+ *   - plain C, no torch types; every pointer is DEVICE memory unless the name ends in _host;
+ *   - tensors are contiguous row-major fp32 unless stated; lengths are int32, token ids int64;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued
+ *     asynchronously on it, nothing synchronises;
+ *   - functions return 0 on success, non-zero on error (message via b2s_last_error()); they never
+ *     abort the process (reference convention: Python exceptions);
+ *   - no hidden global state: all state lives in the b2s_model / b2s_ctx handles; one model handle
+ *     is used from one host thread at a time (the reference calls the model from the main thread only).
+ */
+#ifndef B2S_HIP_H
+#define B2S_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define B2S_DTYPE_FP32 0 /* parity mode: exact fp32 MFMA (v_mfma_f32_16x16x4_f32)            */
+#define B2S_DTYPE_BF16 1 /* performance mode: bf16 MFMA operands, fp32 accumulate / residual */
+
+const char* b2s_last_error(void);
+int b2s_version(void);
+
+/* ---- hyper-parameters that shape the model (hyperparams.py:4,24-35,54-61) ------------------------ */
+typedef struct b2s_config {
+    int32_t num_mels, vocab_size, embed_size, encoder_hidden, decoder_hidden;
+    int32_t n_encoder_layer, n_decoder_layer, n_attention_head;
+    int32_t prenet_hidden, postnet_hidden, n_postnet_layer;
+    int32_t multi_speaker, max_num_speaker, speaker_embedding_size;
+    int32_t multi_lingual, max_num_language, language_embedding_size;
+    float transformer_dropout_rate, decoder_dropout_rate;
+    float reg_weight;
+    int32_t compute_dtype; /* B2S_DTYPE_* */
+} b2s_config;
+
+typedef struct b2s_model b2s_model; /* replaces transformer.tacotron.Tacotron (tacotron.py:119-133)  */
+typedef struct b2s_ctx b2s_ctx;     /* activations saved by one forward call, consumed by backward   */
+
+/* Tacotron.__init__ (tacotron.py:119-124).  The model owns only compute-dtype weight shadows and
+ * sinusoid tables; parameters stay caller-owned (state_dict names/shapes/order of the reference). */
+int b2s_model_create(const b2s_config* cfg, b2s_model** out);
+void b2s_model_destroy(b2s_model* m);
+/* state_dict layout: number of entries, then name / shape / kind of entry i
+ * (kind: 1 = parameter, 0 = fp32 buffer, 2 = int64 buffer num_batches_tracked). */
+int b2s_model_num_tensors(const b2s_model* m);
+int b2s_model_tensor_info(const b2s_model* m, int i, char* name, int name_cap, int64_t* shape, int* ndim, int* kind);
+/* Bind device pointers of every state_dict entry (data) and of the gradient of every parameter
+ * (grad[i] may be NULL for buffers).  Arrays are host arrays of device pointers. */
+int b2s_model_bind(b2s_model* m, void* const* data_host, void* const* grad_host, int n);
+/* Refresh the compute-dtype weight shadows (bf16 copies, conv re-layouts) after parameters changed. */
+int b2s_model_sync_weights(b2s_model* m, void* stream);
+
+/* ---- Encoder.forward (tacotron.py:33-44; modules.py:49-69) ---------------------------------------
+ * memory_out: [B, S, encoder_hidden (+spk) (+lang)].  train != 0 enables dropout (seeded by `seed`).
+ * need_grad != 0 keeps activations in `ws` and returns a ctx for b2s_encoder_backward. */
+size_t b2s_encoder_ws_bytes(const b2s_model* m, int B, int S);
+int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const int32_t* input_lengths, const int64_t* spk_ids,
+                        const float* language_vecs, int B, int S, int train, uint64_t seed, void* ws, size_t ws_bytes,
+                        float* memory_out, void* stream, b2s_ctx** ctx_out);
+int b2s_encoder_backward(b2s_model* m, b2s_ctx* ctx, const float* d_memory, void* stream);
+
+/* ---- Decoder.forward (tacotron.py:107-116; modules.py:108-145) -----------------------------------
+ * memory [B,S,Dm], targets [B,T,num_mels] -> mels [B,T,num_mels], stop_logits [B,T]. */
+size_t b2s_decoder_ws_bytes(const b2s_model* m, int B, int S, int T);
+int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
+                        const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
+                        size_t ws_bytes, float* mels_out, float* stop_out, void* stream, b2s_ctx** ctx_out);
+/* d_memory_out [B,S,Dm] is overwritten. */
+int b2s_decoder_backward(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, float* d_memory_out,
+                         void* stream);
+/* Alignments of the last forward held in ctx (attention.py:88): which = 0 decoder self, 1 encoder-decoder;
+ * out [B, H, Lk, Lq] fp32. */
+int b2s_decoder_alignment(b2s_model* m, b2s_ctx* ctx, int which, int layer, float* out, void* stream);
+
+/* ---- Postnet.forward (tacotron.py:81-90).  out = (add ? add : 0) + postnet(inputs) ----------------
+ * train != 0: batch statistics + running-stat update + dropout; else running statistics. */
+size_t b2s_postnet_ws_bytes(const b2s_model* m, int B, int T);
+int b2s_postnet_forward(b2s_model* m, const float* inputs, const int32_t* lengths, const float* add, int B, int T,
+                        int train, uint64_t seed, void* ws, size_t ws_bytes, float* out, void* stream,
+                        b2s_ctx** ctx_out);
+/* d_inputs_out [B,T,num_mels] = gradient through the conv stack only (caller adds the skip path). */
+int b2s_postnet_backward(b2s_model* m, b2s_ctx* ctx, const float* d_out, float* d_inputs_out, void* stream);
+
+void b2s_ctx_free(b2s_ctx* ctx);
+
+/* ---- compute_loss (tacotron.py:136-158) ------------------------------------------------------------
+ * losses_out[7] = loss, bef_loss, aft_loss, mse_loss, l2, stop_loss, sum(lengths); aft_losses_out[B].
+ * scratch: >= (4 + B) floats. */
+int b2s_loss_forward(b2s_model* m, const float* mel_bef, const float* mel_aft, const float* stop_logits,
+                     const float* mel_targets, const int32_t* target_lengths, int B, int T, float* losses_out,
+                     float* aft_losses_out, float* scratch, void* stream);
+/* Gradients of w[0]*bef_loss + w[1]*aft_loss + w[2]*stop_loss w.r.t. mel_bef / mel_aft / stop_logits;
+ * w = device float[3] (NULL -> 1,1,1, i.e. the gradient of `loss` without the L2 term). */
+int b2s_loss_backward(b2s_model* m, const float* mel_bef, const float* mel_aft, const float* stop_logits,
+                      const float* mel_targets, const int32_t* target_lengths, int B, int T, const float* w,
+                      float* d_bef, float* d_aft, float* d_stop, void* stream);
+/* grad[p] += reg_weight * (*grad_scale) * p for the L2 member set (tacotron.py:144-146). */
+int b2s_l2_backward(b2s_model* m, const float* grad_scale, void* stream);
+
+/* ---- optimizer (train.py:130-131,188-189): Adam(lr, eps) with bias correction, over all bound
+ * parameters; m/v are caller-owned flat fp32 state laid out like the bound grads.  step is 1-based.
+ * l2 > 0 folds the L2 gradient (l2 * p) in; grad_scale multiplies the bound gradient first (1/world). */
+int b2s_adam_bind(b2s_model* m, void* const* exp_avg_host, void* const* exp_avg_sq_host, int n);
+int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
+                  void* stream);
+/* Zero every bound parameter gradient.  Every *_backward entry point ACCUMULATES into the bound gradient
+ * buffers (several use atomics), so the host calls this once at the start of each backward pass. */
+int b2s_zero_grads(b2s_model* m, void* stream);
+
+/* ---- op level (used by the standalone modules and the op parity tests) --------------------------- */
+/* C[M,N] = A * B^T style GEMM family; see csrc/gemm.h.  dtype operands are fp32 or raw bf16. */
+typedef struct b2s_gemm_desc {
+    int32_t dtype, trans_a, trans_b, M, N, K, lda, ldb, ldc, c_fp32;
+    int32_t batch, batch_inner;
+    int64_t a_bs_o, a_bs_i, b_bs_o, b_bs_i, c_bs_o, c_bs_i;
+    float alpha;
+    int32_t relu, accumulate;
+    float drop_p;
+    uint64_t seed;
+    int32_t conv_cin_a, conv_T, conv_dw_cin; /* conv gather on A (token rows) */
+    int32_t rows_per_batch;
+} b2s_gemm_desc;
+int b2s_gemm(const b2s_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, const float* residual,
+             const int32_t* row_len, const int32_t* conv_len, void* stream);
+int b2s_layernorm_forward(int dtype, const float* x, const float* gamma, const float* beta, void* y, float* mean,
+                          float* rstd, int M, int D, float eps, void* stream);
+int b2s_layernorm_backward(int dtype, const void* dy, const float* x, const float* gamma, const float* mean,
+                           const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int D, void* stream);
+/* MultiheadAttention core (attention.py:72-92) on head-interleaved rows: q [B,Lq,H*dh] (ld ldq) etc.
+ * mask_mode bit0 = key-length mask (klen), bit1 = causal; bias = optional dense additive fp32 bias
+ * broadcast as bias[b*bias_sb + q*bias_sq + k].  ws: scratch of b2s_attention_ws_bytes().  P_out (optional)
+ * receives softmax weights [B,H,Lq,ldp] in compute dtype, ldp = round_up(Lk, 8). */
+size_t b2s_attention_ws_bytes(int dtype, int B, int H, int Lq, int Lk);
+int b2s_attention_forward(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* ctx,
+                          int ldc, int B, int H, int Lq, int Lk, int dh, int mask_mode, const int32_t* klen,
+                          const float* bias, int64_t bias_sb, int64_t bias_sq, float drop_p, uint64_t seed, void* ws,
+                          void* P_out, void* Pd_out, void* stream);
+int b2s_attention_backward(int dtype, const void* dctx, int ldc, const void* q, int ldq, const void* k, int ldk,
+                           const void* v, int ldv, const void* P, const void* Pd, void* dq, int lddq, void* dk,
+                           int lddk, void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, float drop_p,
+                           uint64_t seed, void* ws, void* stream);
+int b2s_align_from_probs(int dtype, const void* P, float* align, int B, int H, int Lq, int Lk, void* stream);
+/* out = a + b (fp32, n elements) */
+int b2s_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+int b2s_cast(int dtype, const float* in, void* out, int64_t n, void* stream);      /* fp32 -> compute dtype */
+int b2s_cast_back(int dtype, const void* in, float* out, int64_t n, void* stream); /* compute dtype -> fp32 */
+/* keep-mask of the dropout RNG for element indices [0,n): out[i] = 1 or 0 (statistical tests) */
+int b2s_dropout_mask(float p, uint64_t seed, uint32_t op_id, uint8_t* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* B2S_HIP_H */

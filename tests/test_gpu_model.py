@@ -1,0 +1,256 @@
+"""Model-level parity on the GPU: HIP path (through the C ABI) vs the CPU oracle and the golden fixtures.
+
+Tolerances (north_star): fp32 mode mel <= 1e-3 abs, integer outputs exact.  We hold the fp32 path to the
+tighter 2e-4 on activations and 2e-3 relative on gradient norms.  bf16 mode: drift is recorded, gated loosely.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import b2s_oracle as O                     # checker only
+from oracle import synth, make_config, TINY, TINY96
+from gpu_util import DEV, relerr, report
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name + ".npz")))
+
+
+def build(over, seed=1234, compute_dtype="fp32", state_edit=None):
+    from hyperparams import hparams as hp
+    from transformer.tacotron import Tacotron
+    defaults = getattr(build, "_defaults", None)
+    if defaults is None:
+        defaults = build._defaults = dict(hp.values())
+    hp.override_from_dict(defaults)
+    if over:
+        hp.parse(over)
+    hp.parse("compute_dtype=%s" % compute_dtype)
+    cfg = make_config(over)
+    m = Tacotron(hp)
+    st = synth.synthetic_state(cfg, seed)
+    if state_edit:
+        state_edit(st)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()}, strict=True)
+    return m.to(DEV), cfg, st, hp
+
+
+def dev_batch(nb):
+    return {k: (torch.from_numpy(np.asarray(v)).to(DEV) if not isinstance(v, list) else v) for k, v in nb.items()}
+
+
+@pytest.mark.parametrize("tag,over", [("tiny", TINY), ("tiny96", TINY96)])
+def test_forward_loss_grads_fp32(tag, over):
+    from transformer.tacotron import compute_loss
+    g = load("g2_model_" + tag)
+    m, cfg, st, hp = build(over)
+    nb = synth.synthetic_batch(cfg, B=3, S=11, T=23, seed=7, in_lens=[11, 7, 4], tgt_lens=[23, 15, 9])
+    b = dev_batch(nb)
+    # eval mode (BatchNorm running statistics)
+    m.eval()
+    with torch.no_grad():
+        o = m(**b)
+    for k, gk in (("mel_bef", "eval_mel_bef"), ("mel_aft", "eval_mel_aft"), ("stop_logits", "eval_stop")):
+        d = np.abs(o[k].cpu().numpy() - g[gk]).max()
+        assert d < 2e-4, (k, d)
+    # train mode: forward, losses, every gradient
+    m.train()
+    o = m(**b)
+    losses = compute_loss(m, b["mel_targets"], b["target_lengths"], o, hp)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    for k, gk in (("mel_bef", "mel_bef"), ("mel_aft", "mel_aft"), ("stop_logits", "stop")):
+        d = np.abs(o[k].detach().cpu().numpy() - g[gk]).max()
+        assert d < 2e-4, (k, d)
+    for i in range(cfg.n_decoder_layer):
+        for kind in ("self", "encdec"):
+            a = o["alignments"][kind][i].cpu().numpy()
+            ref = g["align_%s_%d" % (kind, i)]
+            assert a.shape == ref.shape
+            assert np.abs(a - ref).max() < 1e-5, (kind, i)
+            assert (a.argmax(2) == ref.argmax(2)).all()
+    for k in ("loss", "bef_loss", "aft_loss", "mse_loss", "l2", "stop_loss"):
+        assert abs(float(losses[k]) - float(g["loss_" + k])) < 1e-5 + 1e-4 * abs(float(g["loss_" + k])), k
+    assert np.abs(losses["aft_losses"].cpu().numpy() - g["loss_aft_losses"]).max() < 1e-4
+    bad = []
+    for n, p in m.named_parameters():
+        ref_norm = float(g["gnorm/" + n])
+        gr = p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(p).cpu()
+        if "grad/" + n in g:
+            err = float((gr - torch.from_numpy(g["grad/" + n])).abs().max())
+            if err > 2e-4 * max(1.0, ref_norm):
+                bad.append((n, err, ref_norm))
+        elif abs(float(gr.double().norm()) - ref_norm) > 2e-3 * ref_norm + 1e-6:
+            bad.append((n, float(gr.double().norm()), ref_norm))
+    assert not bad, bad[:8]
+    # BatchNorm running statistics were updated by the train-mode forward (momentum 0.1, unbiased variance)
+    P = O.to_torch_state(st); bn = {}
+    with torch.no_grad():
+        O.tacotron_forward(P, cfg, O.to_torch_batch(nb), train=True, bn_state=bn)
+    sd = m.state_dict()
+    for k, v in bn.items():
+        assert np.abs(sd[k].cpu().numpy() - v.numpy()).max() < 1e-4, k
+
+
+def test_forward_bf16_drift_recorded():
+    """bf16 performance mode on the tiny model: drift vs the fp32 oracle is measured and loosely gated."""
+    from transformer.tacotron import compute_loss
+    g = load("g2_model_tiny96")
+    m, cfg, st, hp = build(TINY96, compute_dtype="bf16")
+    nb = synth.synthetic_batch(cfg, B=3, S=11, T=23, seed=7, in_lens=[11, 7, 4], tgt_lens=[23, 15, 9])
+    b = dev_batch(nb)
+    m.train()
+    o = m(**b)
+    losses = compute_loss(m, b["mel_targets"], b["target_lengths"], o, hp)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    drift = float(np.abs(o["mel_bef"].detach().cpu().numpy() - g["mel_bef"]).max())
+    print("bf16 mel_bef max abs drift vs fp32 reference: %.4f" % drift)
+    assert drift < 0.15
+    assert abs(float(losses["loss"]) - float(g["loss_loss"])) < 0.05 * abs(float(g["loss_loss"]))
+    worst = 0.0
+    for n, p in m.named_parameters():
+        ref = float(g["gnorm/" + n])
+        if ref > 1e-3:
+            worst = max(worst, abs(float(p.grad.double().norm()) - ref) / ref)
+    print("bf16 worst relative gradient-norm error: %.4f" % worst)
+    assert worst < 0.2
+
+
+def test_adam_training_steps_match_oracle():
+    """Three steps of the drop-in loop (torch.optim.Adam + LambdaLR over the HIP model) track the oracle's loss."""
+    from transformer.tacotron import compute_loss, learning_rate_schedule
+    from functools import partial
+    g = load("g2_model_tiny")
+    m, cfg, st, hp = build(TINY)
+    b = dev_batch(synth.synthetic_batch(cfg, B=3, S=11, T=23, seed=7, in_lens=[11, 7, 4], tgt_lens=[23, 15, 9]))
+    m.train()
+    optim = torch.optim.Adam(m.parameters(), lr=hp.max_lr, eps=hp.adam_eps)
+    sched = torch.optim.lr_scheduler.LambdaLR(optim, lr_lambda=partial(learning_rate_schedule, hp=hp))
+    for step in range(3):
+        o = m(**b)
+        losses = compute_loss(m, b["mel_targets"], b["target_lengths"], o, hp)
+        optim.zero_grad()
+        losses["loss"].backward()
+        optim.step(); sched.step()
+        if step in (0, 2):
+            assert abs(float(losses["loss"]) - float(g["after%d_loss" % (step + 1)])) < 2e-3
+            sd = m.state_dict()
+            for n, v in sd.items():
+                rn = float(g["after%d_norm/%s" % (step + 1, n)])
+                assert abs(float(v.double().norm()) - rn) <= 2e-3 * rn + 1e-4, (step, n)
+
+
+def test_modules_standalone():
+    """MultiheadAttention / FFNLayer / DecoderPrenet / segments called on their own (G3)."""
+    from transformer.attention import MultiheadAttention
+    from transformer.modules import FFNLayer
+    from transformer.common import attention_bias
+    g = load("g3_modules")
+    for kind, C in (("self", 64), ("cross", 128)):
+        mha = MultiheadAttention(C, C, kind == "self", 2, dropout_rate=0.0).to(DEV)
+        mha.load_state_dict({k.split("/w/")[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("mha_%s/w/" % kind)})
+        q = torch.from_numpy(g["mha_%s/q" % kind]).to(DEV).requires_grad_(True)
+        lens = torch.from_numpy(g["mha_%s/lens" % kind])
+        if kind == "self":
+            mem, bias = None, attention_bias(q.shape[1], "causal")
+        else:
+            mem = torch.from_numpy(g["mha_cross/mem"]).to(DEV).requires_grad_(True)
+            bias = attention_bias(torch.arange(mem.shape[1])[None, :] < lens[:, None], "masking")
+        out = mha(q, mem, bias)
+        out["outputs"].backward(torch.from_numpy(g["mha_%s/go" % kind]).to(DEV))
+        torch.cuda.synchronize()
+        assert np.abs(out["outputs"].detach().cpu().numpy() - g["mha_%s/out" % kind]).max() < 1e-4
+        assert np.abs(out["align"].cpu().numpy() - g["mha_%s/align" % kind]).max() < 1e-5
+        assert np.abs(q.grad.cpu().numpy() - g["mha_%s/dq" % kind]).max() < 2e-4
+        if mem is not None:
+            assert np.abs(mem.grad.cpu().numpy() - g["mha_cross/dmem"]).max() < 2e-4
+        for n, p in mha.named_parameters():
+            assert np.abs(p.grad.cpu().numpy() - g["mha_%s/dw/%s" % (kind, n)]).max() < 5e-4, n
+    f = FFNLayer(64, 256, 64, dropout_rate=0.0).to(DEV)
+    f.load_state_dict({k.split("/w/")[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("ffn/w/")})
+    assert np.abs(f(torch.from_numpy(g["ffn/x"]).to(DEV)).detach().cpu().numpy() - g["ffn/out"]).max() < 1e-4
+
+    m, cfg, st, hp = build(TINY)
+    m.eval()
+    b = dev_batch(synth.synthetic_batch(cfg, B=2, S=9, T=14, seed=3, in_lens=[9, 5], tgt_lens=[14, 8]))
+    with torch.no_grad():
+        assert np.abs(m.decoder.prenet(b["mel_targets"]).cpu().numpy() - g["prenet/out"]).max() < 1e-4
+        enc = m.encoder(b["inputs"], b["input_lengths"], b["input_spk_ids"], b["input_language_vecs"])
+        assert np.abs(enc.cpu().numpy() - g["encoder/out"]).max() < 1e-4
+        for lo in (0, 1):
+            mels, stop, al = m.decoder(enc, b["input_lengths"], b["mel_targets"], b["target_lengths"], leave_one=bool(lo))
+            assert np.abs(mels.cpu().numpy() - g["decoder_lo%d/mels" % lo]).max() < 2e-4
+            assert np.abs(stop.cpu().numpy() - g["decoder_lo%d/stop" % lo]).max() < 2e-4
+            assert np.abs(al["encdec"][1].cpu().numpy() - g["decoder_lo%d/align_encdec_1" % lo]).max() < 1e-5
+        assert np.abs(m.postnet(b["mel_targets"], b["target_lengths"]).cpu().numpy() - g["postnet_eval/out"]).max() < 2e-4
+        m.postnet.train()
+        assert np.abs(m.postnet(b["mel_targets"], b["target_lengths"]).cpu().numpy() - g["postnet_train/out"]).max() < 2e-4
+        for i in range(cfg.n_postnet_layer):
+            bn = m.postnet.batchnorm_layers[i]
+            assert np.abs(bn.running_mean.cpu().numpy() - g["postnet_train/running_mean_%d" % i]).max() < 1e-5
+            assert np.abs(bn.running_var.cpu().numpy() - g["postnet_train/running_var_%d" % i]).max() < 1e-5
+
+
+@pytest.mark.parametrize("tag,over", [("tiny", TINY), ("tiny96", TINY96)])
+@pytest.mark.parametrize("case", ["never", "mixed", "first"])
+def test_decode_eval_batch(tag, over, case):
+    """eval_batch: mels <= 1e-3, generated_lengths and alignment arg-max bit-exact (G4)."""
+    import synthesize
+    g = load("g4_decode")
+    bias = {"never": -100.0, "first": 100.0}.get(case)
+    if bias is None:
+        bias = float(g["%s_%s/stop_bias" % (tag, case)])
+
+    def edit(st):
+        st["decoder.stop_net.bias"] = np.full((1,), bias, dtype=np.float32)
+    m, cfg, st, hp = build(over + ",max_generation_frames=40", state_edit=edit)
+    m.eval()
+    nb = synth.synthetic_batch(cfg, B=3, S=10, T=4, seed=11, in_lens=[10, 6, 8])
+    nb.pop("mel_targets"); nb.pop("target_lengths")
+    r = synthesize.eval_batch(m, dev_batch(nb), use_bar=False, bar_interval=-1)
+    pre = "%s_%s/" % (tag, case)
+    assert [int(x) for x in r["generated_lengths"]] == g[pre + "generated_lengths"].tolist()
+    assert np.abs(r["mel_pre"] - g[pre + "mel_pre"]).max() < 1e-3
+    assert np.abs(r["mel_aft"] - g[pre + "mel_aft"]).max() < 1e-3
+    for i in range(cfg.n_decoder_layer):
+        assert (r["alignments"]["encdec"][i].argmax(axis=2) == g[pre + "align_argmax_%d" % i]).all()
+
+
+def test_fullsize_spot_checks_fp32():
+    """Default hparams (83.5 M parameters), B=4, S=100, T=600: slices, losses, stop indices, gradient norms (G5)."""
+    from transformer.tacotron import compute_loss
+    g = load("g5_fullsize")
+    m, cfg, st, hp = build("transformer_dropout_rate=0.0,decoder_dropout_rate=0.0", seed=4321)
+    nb = synth.synthetic_batch(cfg, B=4, S=100, T=600, seed=0, in_lens=[100, 90, 80, 70], tgt_lens=[600, 550, 500, 450],
+                               n_spk=572, n_lang=38)
+    b = dev_batch(nb)
+    m.train()
+    o = m(**b)
+    losses = compute_loss(m, b["mel_targets"], b["target_lengths"], o, hp)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    mb = o["mel_bef"].detach().cpu()
+    assert np.abs(mb[:, :4, :8].numpy() - g["mel_bef_slice"]).max() < 1e-3
+    assert np.abs(mb[:, 440:452, :4].numpy() - g["mel_bef_tail"]).max() < 1e-3
+    assert np.abs(o["mel_aft"].detach().cpu()[:, :4, :8].numpy() - g["mel_aft_slice"]).max() < 1e-3
+    assert np.abs(o["stop_logits"].detach().cpu()[:, :16].numpy() - g["stop_slice"]).max() < 1e-3
+    assert (o["stop_logits"].argmax(-1).cpu().numpy() == g["stop_argmax"]).all()
+    al = o["alignments"]["encdec"][5]
+    assert (al.argmax(2)[:, :, ::25].cpu().numpy() == g["align_encdec5_argmax"]).all()
+    for k in ("loss", "bef_loss", "aft_loss", "mse_loss", "l2", "stop_loss"):
+        assert abs(float(losses[k]) - float(g["loss_" + k])) < 1e-5 + 2e-4 * abs(float(g["loss_" + k])), k
+    bad = []
+    for n, p in m.named_parameters():
+        ref = float(g["gnorm/" + n])
+        mine = float(p.grad.double().norm())
+        if abs(mine - ref) > 5e-3 * ref + 1e-7:
+            bad.append((n, mine, ref))
+    assert not bad, bad[:8]

@@ -1,0 +1,203 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against plain fp32/fp64 torch-CPU math.
+
+fp32 mode uses the exact-fp32 MFMA: tolerance 2e-5 relative.  bf16 mode: operands are rounded to bf16 in the
+reference too, so only accumulation order / output rounding differ: tolerance 1e-2 relative (bf16 has 8 bits).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, bf16_round, to_dev_compute, from_dev_compute, relerr, report  # noqa: E402
+
+TOL = {0: 2e-5, 1: 1e-2}
+
+
+def _ops():
+    from b2s_hip import ops, lib
+    lib.load()
+    return ops, lib
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 80), (77, 40, 264), (16, 8, 8), (513, 257, 1032)])
+def test_gemm_forms(dtype, ta, tb, M, N, K):
+    ops, lib = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + dtype)
+    # asymmetric operands (transpose-detecting)
+    A = torch.randn(M, K, generator=g) + torch.arange(K)[None, :] * 0.01
+    B = torch.randn(N, K, generator=g) - torch.arange(N)[:, None] * 0.01
+    if dtype:
+        A, B = bf16_round(A), bf16_round(B)
+    ref = A.double() @ B.double().t()
+    # pad leading dims to multiples of 8 where the contiguous dim is M or N
+    def stored(X, trans):   # returns (device tensor, ld)
+        if not trans:
+            return to_dev_compute(X, dtype), X.shape[1]
+        Xt = X.t().contiguous()                       # [K, rows]
+        ld = (Xt.shape[1] + 7) // 8 * 8
+        buf = torch.zeros(Xt.shape[0], ld)
+        buf[:, :Xt.shape[1]] = Xt
+        return to_dev_compute(buf, dtype), ld
+    Ad, lda = stored(A, ta)
+    Bd, ldb = stored(B, tb)
+    C = ops.gemm(dtype, Ad, Bd, M, N, K, trans_a=ta, trans_b=tb, lda=lda, ldb=ldb)
+    torch.cuda.synchronize()
+    err = relerr(C.cpu(), ref)
+    assert err < TOL[dtype], report("gemm", C.cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_gemm_batched_heads_and_epilogue(dtype):
+    ops, lib = _ops()
+    g = torch.Generator().manual_seed(5)
+    B_, H, L, dh = 3, 2, 37, 32
+    D = H * dh
+    q = torch.randn(B_, L, D, generator=g); k = torch.randn(B_, L, D, generator=g)
+    if dtype:
+        q, k = bf16_round(q), bf16_round(k)
+    ref = torch.einsum("blhd,bmhd->bhlm", q.view(B_, L, H, dh).double(), k.view(B_, L, H, dh).double())
+    ldp = (L + 7) // 8 * 8
+    out = torch.zeros(B_ * H, L, ldp, device=DEV)
+    ops.gemm(dtype, to_dev_compute(q, dtype), to_dev_compute(k, dtype), L, L, dh, lda=D, ldb=D, ldc=ldp, out=out,
+             batch=B_ * H, batch_inner=H, a_bs=(L * D, dh), b_bs=(L * D, dh), c_bs=(H * L * ldp, L * ldp))
+    torch.cuda.synchronize()
+    got = out.cpu().view(B_, H, L, ldp)[..., :L]
+    assert relerr(got, ref) < TOL[dtype], report("batched", got, ref)
+    # epilogue: bias + relu + residual, compute-dtype output
+    M, N, K = 70, 48, 64
+    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g); res = torch.randn(M, N, generator=g)
+    if dtype:
+        A, W = bf16_round(A), bf16_round(W)
+    ref = torch.relu(A.double() @ W.double().t() + bias.double()) + res.double()
+    C = ops.gemm(dtype, to_dev_compute(A, dtype), to_dev_compute(W, dtype), M, N, K, bias=bias.to(DEV), relu=True,
+                 residual=res.to(DEV))
+    torch.cuda.synchronize()
+    assert relerr(C.cpu(), ref) < TOL[dtype], report("epilogue", C.cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_conv_gather_gemm(dtype):
+    """impute + Conv1d(k=5, pad=2) as an implicit GEMM (tacotron.py:84-85)."""
+    ops, lib = _ops()
+    g = torch.Generator().manual_seed(9)
+    B_, T, Cin, Cout = 3, 29, 16, 24
+    lens = torch.tensor([29, 17, 5], dtype=torch.int32)
+    x = torch.randn(B_, T, Cin, generator=g); w = torch.randn(Cout, Cin, 5, generator=g) * 0.2
+    if dtype:
+        x, w = bf16_round(x), bf16_round(w)
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float()
+    ref = torch.nn.functional.conv1d((x * mask[..., None]).transpose(1, 2).double(), w.double(), None, 1, 2).transpose(1, 2)
+    wf = w.permute(0, 2, 1).reshape(Cout, 5 * Cin).contiguous()            # [co][j*Cin+ci]
+    y = ops.gemm(dtype, to_dev_compute(x.reshape(B_ * T, Cin), dtype), to_dev_compute(wf, dtype), B_ * T, Cout, 5 * Cin,
+                 lda=Cin, ldb=5 * Cin, conv_cin_a=Cin, conv_T=T, conv_len=lens.to(DEV))
+    torch.cuda.synchronize()
+    got = y.cpu().view(B_, T, Cout)
+    assert relerr(got, ref) < TOL[dtype], report("conv", got, ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("D", [64, 512, 768])
+def test_layernorm_fwd_bwd(dtype, D):
+    ops, lib = _ops()
+    g = torch.Generator().manual_seed(D)
+    M = 45
+    x = (torch.randn(M, D, generator=g) * 2 + 0.5).requires_grad_(True)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).requires_grad_(True)
+    b = (0.1 * torch.randn(D, generator=g)).requires_grad_(True)
+    go = torch.randn(M, D, generator=g)
+    if dtype:
+        go = bf16_round(go)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-6)
+    ref.backward(go.double())
+    xd = x.detach().to(DEV).requires_grad_(True); wd = w.detach().to(DEV).requires_grad_(True); bd = b.detach().to(DEV).requires_grad_(True)
+    y = ops.layernorm(xd, wd, bd, 1e-6, dtype)
+    y.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    tol = 1e-5 if not dtype else 1e-2
+    assert relerr(y.detach().cpu(), ref.detach()) < tol, report("ln y", y.detach().cpu(), ref.detach())
+    assert relerr(xd.grad.cpu(), x.grad) < 2e-5 * (1 if not dtype else 500), report("ln dx", xd.grad.cpu(), x.grad)
+    assert relerr(wd.grad.cpu(), w.grad) < 2e-5 * (1 if not dtype else 500), report("ln dg", wd.grad.cpu(), w.grad)
+    assert relerr(bd.grad.cpu(), b.grad) < 2e-5 * (1 if not dtype else 500), report("ln db", bd.grad.cpu(), b.grad)
+
+
+def _attn_ref(q, k, v, H, mask_mode, klen):
+    B_, Lq, C = q.shape
+    Lk = k.shape[1]
+    dh = C // H
+    qh = q.view(B_, Lq, H, dh).permute(0, 2, 1, 3); kh = k.view(B_, Lk, H, dh).permute(0, 2, 1, 3)
+    vh = v.view(B_, Lk, H, dh).permute(0, 2, 1, 3)
+    logits = (qh * dh ** -0.5) @ kh.transpose(2, 3)
+    if mask_mode & 1:
+        m = torch.arange(Lk)[None, :] < klen[:, None]
+        logits = logits + ((1.0 - m.double()) * -1e20)[:, None, None, :]
+    if mask_mode & 2:
+        logits = logits + (torch.triu(torch.ones(Lq, Lk, dtype=torch.float64), 1) * -1e20)[None, None]
+    p = torch.softmax(logits, -1)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B_, Lq, C), p
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dh,mask_mode,Lq,Lk", [(32, 1, 21, 13), (64, 2, 40, 40), (96, 1, 150, 33), (96, 2, 130, 130)])
+def test_attention_core_fwd_bwd(dtype, dh, mask_mode, Lq, Lk):
+    ops, lib = _ops()
+    g = torch.Generator().manual_seed(dh + Lq)
+    B_, H = 2, 2
+    C = H * dh
+    q = torch.randn(B_, Lq, C, generator=g); k = torch.randn(B_, Lk, C, generator=g); v = torch.randn(B_, Lk, C, generator=g)
+    go = torch.randn(B_, Lq, C, generator=g)
+    if dtype:
+        q, k, v, go = bf16_round(q), bf16_round(k), bf16_round(v), bf16_round(go)
+    klen = torch.tensor([Lk, max(1, Lk - 5)], dtype=torch.int32)
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref, pref = _attn_ref(qr, kr, vr, H, mask_mode, klen)
+    ref.backward(go.double())
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out, probs = ops.attention_core(qd, kd, vd, H, mask_mode, klen.to(DEV) if mask_mode & 1 else None, None, 0.0, 0, dtype)
+    out.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    tol = 3e-5 if not dtype else 2e-2
+    assert relerr(out.detach().cpu(), ref.detach()) < tol, report("attn out", out.detach().cpu(), ref.detach())
+    assert relerr(probs.cpu(), pref.detach()) < tol, report("attn probs", probs.cpu(), pref.detach())
+    for name, a, b in (("dq", qd.grad, qr.grad), ("dk", kd.grad, kr.grad), ("dv", vd.grad, vr.grad)):
+        assert relerr(a.cpu(), b) < (1e-4 if not dtype else 3e-2), report("attn " + name, a.cpu(), b)
+
+
+def test_attention_dense_bias_matches_mask():
+    """A reference-style dense -1e20 bias tensor gives the same result as the in-kernel length mask."""
+    ops, lib = _ops()
+    g = torch.Generator().manual_seed(3)
+    B_, H, dh, Lq, Lk = 2, 2, 32, 9, 12
+    C = H * dh
+    q = torch.randn(B_, Lq, C, generator=g).to(DEV); k = torch.randn(B_, Lk, C, generator=g).to(DEV); v = torch.randn(B_, Lk, C, generator=g).to(DEV)
+    klen = torch.tensor([12, 7], dtype=torch.int32)
+    dense = ((1.0 - (torch.arange(Lk)[None, :] < klen[:, None]).float()) * -1e20)[:, None, None, :]
+    a, pa = ops.attention_core(q, k, v, H, 1, klen.to(DEV), None, 0.0, 0, 0)
+    b, pb = ops.attention_core(q, k, v, H, 0, None, dense.to(DEV), 0.0, 0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(pa, pb)
+
+
+def test_dropout_rng_statistics():
+    """Keep-rate of the counter-based RNG matches 1-p; different ops/seeds give different masks; same key replays."""
+    ops, lib = _ops()
+    l = lib.load()
+    n = 1 << 20
+    for p in (0.1, 0.5):
+        m = torch.empty(n, dtype=torch.uint8, device=DEV)
+        lib.check(l.b2s_dropout_mask(p, 1234, 5, lib.ptr(m), n, lib.stream()))
+        m2 = torch.empty_like(m); m3 = torch.empty_like(m)
+        lib.check(l.b2s_dropout_mask(p, 1234, 5, lib.ptr(m2), n, lib.stream()))
+        lib.check(l.b2s_dropout_mask(p, 1234, 6, lib.ptr(m3), n, lib.stream()))
+        torch.cuda.synchronize()
+        keep = m.float().mean().item()
+        assert abs(keep - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-4, keep
+        assert torch.equal(m, m2)
+        agree = (m == m3).float().mean().item()
+        assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 5e-3, agree
+        # no obvious serial correlation
+        c = (m[1:] & m[:-1]).float().mean().item()
+        assert abs(c - (1 - p) ** 2) < 5e-3, c
