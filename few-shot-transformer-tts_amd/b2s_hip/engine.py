@@ -262,7 +262,7 @@ def _param_list(module):
 class EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, prefix, names, inputs, lens32, spk, lang, train, *params):
-        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need = any(ctx.needs_input_grad)          # grad mode is off inside forward(); this reflects the caller's mode
         mem, c = eng.encoder_forward(inputs, lens32, spk, lang, train, eng.next_seed(), need)
         ctx.eng, ctx.c, ctx.names, ctx.prefix = eng, c, names, prefix
         ctx.req = [p.requires_grad for p in params]
@@ -301,7 +301,7 @@ class DecoderFn(torch.autograd.Function):
 class PostnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, prefix, names, inputs, len32, fuse_add, train, *params):
-        need = torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in params))
+        need = any(ctx.needs_input_grad)
         out, c = eng.postnet_forward(inputs, len32, inputs if fuse_add else None, train, eng.next_seed(), need)
         ctx.eng, ctx.c, ctx.names, ctx.prefix, ctx.fuse = eng, c, names, prefix, fuse_add
         ctx.req = [p.requires_grad for p in params]
