@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the Transformer-TTS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A "step" is one full training step (forward + loss + backward + gradient all-reduce + Adam) of the default
+83.5 M-parameter model on one LJSpeech-shaped packed batch per GPU (B=14, S=114, T=582: the mean batch the
+reference's packer produces), bf16 MFMA operands with fp32 accumulate / residual /
+optimizer, dropout ON at the reference rates, synthetic data, TF-style random init.  Metric: padded mel
+frames per second over the whole job.  --mode decode benchmarks the autoregressive loop instead.
+One JSON line is printed by rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "few-shot-transformer-tts_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def fwd_flops(B, S, T, De=512, Fe=2048, Dd=768, Fd=3072, Le=6, Ld=6):
+    """BASELINE.md section 3 (validated against torch.utils.flop_counter): forward FLOPs of one batch."""
+    return (Le * (B * S * (8 * De * De + 4 * De * Fe) + 4 * B * S * S * De)
+            + Ld * (B * T * (12 * Dd * Dd + 4 * Dd * Fd) + 4 * B * S * Dd * Dd + 4 * B * T * T * Dd + 4 * B * T * S * Dd)
+            + 2 * B * T * (80 * 256 + 256 * 256 + 256 * Dd) + 2 * B * T * Dd * 81
+            + 10 * B * T * (80 * 512 + 3 * 512 * 512 + 512 * 80) + 2 * B * (2 * 128 * 128 + 100 * 128))
+
+
+def make_batch(cfg, B, S, T, seed, device):
+    from oracle import synth
+    nb = synth.synthetic_batch(cfg, B, S, T, seed=seed, n_spk=1, n_lang=1)      # LJSpeech: one speaker, en-us
+    return {k: (torch.from_numpy(np.asarray(v)).to(device) if not isinstance(v, list) else v) for k, v in nb.items()}
+
+
+def cpu_baseline_train(budget_s=25.0):
+    """The CPU oracle (fp32 PyTorch-CPU restatement of the reference's op sequence, live dropout, dense masks) timed
+    on this host's cores at the reference's CPU config (B=4, S=100, T=600).  Reported baseline, not the target."""
+    from oracle import b2s_oracle as O, synth, make_config
+    cores = min(os.cpu_count() or 1, 16)          # more threads than this only adds contention for these shapes
+    torch.set_num_threads(cores)
+    cfg = make_config("")
+    P = O.to_torch_state(synth.synthetic_state(cfg, 1), requires_grad=True)
+    b = O.to_torch_batch(synth.synthetic_batch(cfg, 4, 100, 600, seed=0, in_lens=[100, 90, 80, 70],
+                                               tgt_lens=[600, 550, 500, 450], n_spk=1, n_lang=1))
+    opt = {}
+    best, t_all, n = None, time.time(), 0
+    for i in range(4):
+        t0 = time.time()
+        O.train_step(P, cfg, b, opt, i, train=True)
+        dt = time.time() - t0
+        if i > 0 or dt > budget_s:                     # a very slow host: keep the (cold) first step rather than run on
+            best = dt if best is None else min(best, dt)
+            n += 1
+        if time.time() - t_all > budget_s and n >= 1:
+            break
+    return {"value": round(4 * 600 / best, 1), "unit": "padded mel-frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle train step fwd+loss+bwd+Adam, B=4 S=100 T=600, dropout on, 1 warm-up + best of %d" % n,
+            "seconds_per_step": round(best, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="train", choices=["train", "decode"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=14)
+    ap.add_argument("--S", type=int, default=114)
+    ap.add_argument("--T", type=int, default=582)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-pass", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", init_method="env://", device_id=device)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+
+    if args.mode == "decode":
+        from bench_decode import run_decode
+        return run_decode(args, rank, world, device)
+
+    from hyperparams import hparams as hp
+    from transformer.tacotron import Tacotron, initialize_variables
+    from b2s_hip.trainer import HipTrainer
+    from b2s_hip import lib as L
+    from oracle import make_config
+    hp.parse("compute_dtype=%s" % args.dtype)
+    torch.manual_seed(0)                               # identical init on every rank (train.py:33)
+    model = Tacotron(hp)
+    initialize_variables(model)
+    model = model.to(device).train()
+    trainer = HipTrainer(model, hp)
+    cfg = make_config("")
+    B, S, T = args.batch, args.S, args.T
+    batch = make_batch(cfg, B, S, T, seed=rank, device=device)     # same shape on every rank, different data
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        vals = trainer.train_step(batch)
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        vals = trainer.train_step(batch)
+    ev1.record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(vals[0])
+    assert np.isfinite(loss), "training diverged: loss = %r" % loss
+
+    out = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        step_flops = 3.0 * fwd_flops(B, S, T)
+        out = {"metric": "padded mel-frames/sec, full training step (fwd+loss+bwd+allreduce+Adam)",
+               "value": round(world * B * T * args.steps / elapsed, 1), "unit": "mel-frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+               "data": "synthetic", "final_loss": round(loss, 5),
+               "config": {"workload": "LJSpeech-shaped packed batch per GPU: B=%d S=%d T=%d, default hparams (83.5M params), "
+                                      "dropout on, single speaker/language" % (B, S, T),
+                          "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world},
+               "device_ms_per_step": round(dev_ms / args.steps, 3)}
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS
+        ach = step_flops / (ms * 1e-3) / 1e12
+        out["roofline_step"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                                "frac": round(ach / peak, 4), "flops_per_step": step_flops}
+    if rank == 0 and world == 1 and not args.no_roofline_pass:
+        # dominant kernel (MFMA GEMM): per-launch HIP events on the launch stream, same steps, separate pass
+        lib = L.load()
+        lib.b2s_prof_enable(1)
+        nprof = max(2, min(5, args.steps))
+        for _ in range(nprof):
+            trainer.train_step(batch)
+        torch.cuda.synchronize()
+        lib.b2s_prof_enable(0)
+        res = (C.c_double * 24)()
+        L.check(lib.b2s_prof_collect(res, 8))
+        names = {4: "gemm_kernel<bf16,NT>", 5: "gemm_kernel<bf16,NN>", 6: "gemm_kernel<bf16,TN>", 7: "gemm_kernel<bf16,TT>",
+                 0: "gemm_kernel<f32,NT>", 1: "gemm_kernel<f32,NN>", 2: "gemm_kernel<f32,TN>", 3: "gemm_kernel<f32,TT>"}
+        variants = []
+        tot_f = tot_ms = 0.0
+        for v in range(8):
+            f, msv, cnt = res[v * 3], res[v * 3 + 1], res[v * 3 + 2]
+            if cnt:
+                variants.append({"kernel": names[v], "launches_per_step": cnt / nprof, "avg_us": round(msv * 1e3 / cnt, 2),
+                                 "ms_per_step": round(msv / nprof, 3), "tflops": round(f / (msv * 1e-3) / 1e12, 1)})
+                tot_f += f
+                tot_ms += msv
+        variants.sort(key=lambda d: -d["ms_per_step"])
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS
+        dom = variants[0]
+        out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(dom["tflops"] / peak, 4), "traffic": None, "avg_launch_us": dom["avg_us"],
+                           "launches_per_step": dom["launches_per_step"],
+                           "all_gemm": {"tflops": round(tot_f / (tot_ms * 1e-3) / 1e12, 1), "ms_per_step": round(tot_ms / nprof, 3)},
+                           "variants": variants,
+                           "note": "algorithmic FLOPs (2MNK per launch) / HIP-event duration on the launch stream, instrumented pass"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_train()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,15 +123,22 @@ class HipEngine(object):
             self._gviews = {}
             data = (L.P * len(ts))(*[t.data_ptr() for t in ts])
             grads = (L.P * len(ts))()
+            # flat gradient layout = backward execution order, so that every backward stage owns one contiguous
+            # range (a data-parallel bucket) that is complete when b2s_model_set_stage_hook fires for it
+            order = sorted((i for i, k in enumerate(self.kinds) if k == 1), key=lambda i: (self.stage_of(self.names[i]), i))
             off = 0
-            for i, (t, k, n) in enumerate(zip(ts, self.kinds, self.names)):
-                if k == 1:
-                    v = self._gflat[off:off + t.numel()].view(t.shape)
-                    self._gviews[n] = v
-                    grads[i] = v.data_ptr()
-                    off += t.numel()
-                else:
-                    grads[i] = None
+            self.stage_ranges = {}
+            self.param_offsets = {}
+            for i in order:
+                t, n = ts[i], self.names[i]
+                v = self._gflat[off:off + t.numel()].view(t.shape)
+                self._gviews[n] = v
+                grads[i] = v.data_ptr()
+                self.param_offsets[n] = (off, t.numel())
+                st = self.stage_of(n)
+                lo, hi = self.stage_ranges.get(st, (off, off))
+                self.stage_ranges[st] = (min(lo, off), off + t.numel())
+                off += t.numel()
             L.check(self.lib.b2s_model_bind(self.handle, data, grads, len(ts)))
             self._sig = sig
             self._versions = None
@@ -140,6 +147,35 @@ class HipEngine(object):
             L.check(self.lib.b2s_model_sync_weights(self.handle, L.stream()))
             self._versions = vers
         return dev
+
+    def n_stages(self):
+        return 5 + self.cfg.n_decoder_layer + self.cfg.n_encoder_layer
+
+    def stage_of(self, name):
+        """Backward stage that completes the gradient of parameter `name` (see b2s_model_set_stage_hook)."""
+        Ld, Le = self.cfg.n_decoder_layer, self.cfg.n_encoder_layer
+        parts = name.split(".")
+        if parts[0] == "postnet":
+            return 0
+        if parts[0] == "decoder":
+            if parts[1] in ("mel_net", "stop_net"):
+                return 1
+            if parts[1] == "prenet":
+                return 2 + Ld
+            if parts[2] == "output_layer_norm":
+                return 1
+            if parts[2] == "pe_scale":
+                return 2 + Ld
+            return 2 + (Ld - 1 - int(parts[3]))
+        if parts[1] in ("speaker_embed", "speaker_layer", "language_embed", "language_layer"):
+            return 3 + Ld
+        if parts[1] == "embed":
+            return 4 + Ld + Le
+        if parts[2] == "output_layer_norm":
+            return 3 + Ld
+        if parts[2] == "pe_scale":
+            return 4 + Ld + Le
+        return 4 + Ld + (Le - 1 - int(parts[3]))
 
     def next_seed(self):
         self._calls += 1

@@ -77,6 +77,9 @@ _PROTOS = {
     "b2s_add": (C.c_int, [P, P, P, C.c_int64, P]),
     "b2s_cast": (C.c_int, [C.c_int, P, P, C.c_int64, P]),
     "b2s_cast_back": (C.c_int, [C.c_int, P, P, C.c_int64, P]),
+    "b2s_model_set_stage_hook": (C.c_int, [P, P, P]),
+    "b2s_prof_enable": (None, [C.c_int]),
+    "b2s_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "b2s_dropout_mask": (C.c_int, [C.c_float, C.c_uint64, C.c_uint32, P, C.c_int64, P]),
 }
 EXPORTS = sorted(_PROTOS)

@@ -1,0 +1,105 @@
+"""Fused data-parallel training step on the HIP engine (the bench / production path).
+
+Replaces the reference's `m(**batch) -> compute_loss -> loss.backward() -> optim.step()` + DistributedDataParallel
+(train.py:118-131,165-191) with: one pass of engine calls that enqueue every forward / backward kernel, RCCL
+all-reduce of each backward stage's gradient range launched from the engine's stage hook while later stages still
+compute (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI), and one fused multi-tensor Adam
+kernel (bias-corrected, L2 folded in for the reference's member set, gradient mean = 1/world folded in).
+Semantics match the reference: per-rank loss normalisation and per-rank BatchNorm statistics, gradients averaged
+across ranks, LambdaLR schedule `learning_rate_schedule`.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .engine import _i32
+
+_HOOK_T = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+
+
+class HipTrainer(object):
+    def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0):
+        from transformer.tacotron import learning_rate_schedule
+        self.model, self.hp = model, hp
+        self.eng = model.engine()
+        self.eng.ensure_bound()
+        self.lib = self.eng.lib
+        self.lr_lambda = lambda step: learning_rate_schedule(step, hp)
+        self.beta1, self.beta2 = beta1, beta2
+        g = self.eng._gflat
+        self.exp_avg = torch.zeros_like(g)
+        self.exp_avg_sq = torch.zeros_like(g)
+        n = len(self.eng.names)
+        m_ptrs, v_ptrs = (L.P * n)(), (L.P * n)()
+        for i, name in enumerate(self.eng.names):
+            if name in self.eng.param_offsets:
+                off, _ = self.eng.param_offsets[name]
+                m_ptrs[i] = self.exp_avg.data_ptr() + 4 * off
+                v_ptrs[i] = self.exp_avg_sq.data_ptr() + 4 * off
+        L.check(self.lib.b2s_adam_bind(self.eng.handle, m_ptrs, v_ptrs, n))
+        self.global_step = 0
+        self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self._works = []
+        self._pending = None                      # (lo, hi) gradient range waiting to be merged into a bucket
+        self._bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
+        self._hook = _HOOK_T(self._on_stage)      # keep a reference: ctypes callbacks must outlive their use
+        if self.world > 1:
+            L.check(self.lib.b2s_model_set_stage_hook(self.eng.handle, C.cast(self._hook, L.P), None))
+            # broadcast parameters and BN buffers from rank 0 once (DDP constructor semantics, train.py:125)
+            for t in self.eng._tensors():
+                self.dist.broadcast(t, 0)
+            self.eng._versions = None
+
+    # ------------------------------------------------------------------ gradient exchange
+    def _flush(self, force=False):
+        if self._pending is None:
+            return
+        lo, hi = self._pending
+        if force or hi - lo >= self._bucket_elems:
+            self._works.append(self.dist.all_reduce(self.eng._gflat[lo:hi], async_op=True))
+            self._pending = None
+
+    def _on_stage(self, stage, _user):
+        rng = self.eng.stage_ranges.get(stage)
+        if rng is None:
+            return
+        if self._pending is None:
+            self._pending = rng
+        else:                                      # stages are contiguous in the flat buffer by construction
+            self._pending = (min(self._pending[0], rng[0]), max(self._pending[1], rng[1]))
+        self._flush(force=(stage == self.eng.n_stages() - 1))
+
+    # ------------------------------------------------------------------ one step
+    def train_step(self, batch):
+        """batch: the dataloader dict (dataloader.py:498-508) on the device.  Returns the 7 loss values (device)."""
+        eng, lib = self.eng, self.lib
+        L.check(lib.b2s_model_sync_weights(eng.handle, L.stream()))     # Adam updated the fp32 masters in place
+        in32, tgt32 = _i32(batch["input_lengths"]), _i32(batch["target_lengths"])
+        mem, c_enc = eng.encoder_forward(batch["inputs"], in32, batch.get("input_spk_ids"), batch.get("input_language_vecs"),
+                                         True, eng.next_seed(), True)
+        mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed(), True)
+        aft, c_post = eng.postnet_forward(mels, tgt32, mels, True, eng.next_seed(), True)
+        vals, per = eng.loss_forward(mels, aft, stop, batch["mel_targets"], tgt32)
+        L.check(lib.b2s_zero_grads(eng.handle, L.stream()))
+        eng._needs_zero = False
+        dbef, daft, dstop = eng.loss_backward(mels, aft, stop, batch["mel_targets"], tgt32, None)
+        din = eng.postnet_backward(c_post, daft)
+        dmel = eng.add(eng.add(din, daft), dbef)
+        dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape)
+        eng.encoder_backward(c_enc, dmem)
+        for c in (c_post, c_dec, c_enc):
+            c.free()
+        if self.world > 1:
+            self._flush(force=True)
+            for w in self._works:
+                w.wait()
+            self._works = []
+        lr = self.hp.max_lr * self.lr_lambda(self.global_step)
+        self.global_step += 1
+        L.check(lib.b2s_adam_step(eng.handle, lr, self.global_step, self.beta1, self.beta2, self.hp.adam_eps,
+                                  self.hp.reg_weight, 1.0 / self.world, L.stream()))
+        eng._needs_zero = True
+        self.last_aft_losses = per
+        return vals

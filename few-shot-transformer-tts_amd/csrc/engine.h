@@ -96,6 +96,9 @@ struct b2s_model {
     int n_l2_chunks = 0, n_adam_chunks = 0;
     float* small = nullptr;                         // device scratch: [0..15] misc scalars
     std::vector<void*> owned;                       // hipMalloc'ed buffers
+    void (*stage_hook)(int, void*) = nullptr;       // called on the host after each backward stage is enqueued
+    void* stage_user = nullptr;
+    void stage_done(int s) const { if (stage_hook) stage_hook(s, stage_user); }
 
     int id(const std::string& n) const;
     float* P(const std::string& n) const { return (float*)data[id(n)]; }

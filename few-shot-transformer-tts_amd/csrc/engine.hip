@@ -6,6 +6,7 @@
 // parameter gradients and logits are fp32; GEMM operands ("T") are bf16 in performance mode and fp32
 // in parity mode.  One caller-provided workspace per forward call holds the saved activations and the
 // scratch of both passes (288 GB of HBM3E: nothing is recomputed, nothing is aliased).
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include "engine.h"
@@ -172,6 +173,15 @@ int linear_dx(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
     g.M = M; g.N = Nin; g.K = Kout; g.C = out; g.c_fp32 = out_fp32; g.ldc = ldo; g.epi = e;
     return b2s_gemm_launch(g, m->dtype, false, true, st);
 }
+// weight-gradient GEMMs reduce over all B*L tokens into a small [out,in] matrix: split K over blocks so the
+// launch fills 256 CUs (>= ~1024 workgroups), partial sums combined with fp32 atomics into the zeroed gradient
+int pick_splitk(int Mo, int No, int K, int dtype) {
+    const int bk = dtype ? 64 : 16;
+    const long tiles = (long)cdiv(Mo, 128) * cdiv(No, 128);
+    const int nk = cdiv(K, bk);
+    int s = (int)std::min<long>(cdiv(512, tiles), std::max(1, nk / 8));     // fp32 atomics are the cost of splitting: stay near 2 blocks/CU
+    return std::max(1, std::min(s, 32));
+}
 // dW[Nout,Kin] = dY[M,Nout]^T * X[M,Kin]
 int linear_dw(const b2s_model* m, hipStream_t st, const void* dY, int lddy, const void* X, int ldx, int M, int Nout,
               int Kin, float* dW) {
@@ -180,6 +190,7 @@ int linear_dw(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
     g.B.p = X; g.B.ld = ldx; g.B.R = M; g.B.C = Kin;
     g.M = Nout; g.N = Kin; g.K = M; g.C = dW; g.c_fp32 = 1; g.ldc = Kin;
     g.epi.accumulate = 1;          // parameter gradients accumulate; the host zeroes them once per backward pass
+    g.splitk = pick_splitk(Nout, Kin, M, m->dtype);
     return b2s_gemm_launch(g, m->dtype, true, true, st);
 }
 
@@ -494,6 +505,11 @@ extern "C" int b2s_model_sync_weights(b2s_model* m, void* stream) {
 }
 
 extern "C" void b2s_ctx_free(b2s_ctx* ctx) { delete ctx; }
+extern "C" int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int, void*), void* user) {
+    B2S_CHECK(m, "null model");
+    m->stage_hook = hook; m->stage_user = user;
+    return 0;
+}
 
 // ================================================================================================ encoder
 extern "C" size_t b2s_encoder_ws_bytes(const b2s_model* m, int B, int S) {
@@ -645,15 +661,18 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
     }
     B2S_TRY(ro_layernorm_bwd(dt, d_memory, 1, Dm, c->x_final, m->P(p + "output_layer_norm.weight"), c->mean_f, c->rstd_f, sc.dx, 0,
                              m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, nullptr, 1, st));
+    m->stage_done(3 + cf.n_decoder_layer);
     for (int l = cf.n_encoder_layer - 1; l >= 0; --l) {
         const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lna = p + "attn_layer_norms." + std::to_string(l);
         B2S_TRY(ffn_bwd(m, st, c->ffn[l], sc, M, D, pt, c->seed, nm(p, "ffn_layers", l, "input_layer.weight"),
                         nm(p, "ffn_layers", l, "output_layer.weight"), lnf));
         B2S_TRY(self_attn_bwd(m, st, c->self_attn[l], sc, M, D, B, H, S, pt, c->seed, nm(p, "self_attentions", l, "qkv_transform.weight"),
                               nm(p, "self_attentions", l, "output_transform.weight"), lna));
+        m->stage_done(4 + cf.n_decoder_layer + (cf.n_encoder_layer - 1 - l));
     }
     B2S_TRY(ro_embed_prep_bwd(sc.dx, (const long*)c->ids, c->in_len, m->pe_enc, m->G("encoder.embed.weight"), m->G(p + "pe_scale"),
                               B, S, D, make_drop(pt, c->seed, opid(1, 0, 1)), st));
+    m->stage_done(4 + cf.n_decoder_layer + cf.n_encoder_layer);
     return 0;
 }
 
@@ -785,6 +804,7 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
     }
     B2S_TRY(ro_layernorm_bwd(dt, sc.doutT, 0, D, c->x_final, m->P(p + "output_layer_norm.weight"), c->mean_f, c->rstd_f, sc.dx, 0,
                              m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, c->tgt_len, T, st));
+    m->stage_done(1);
     bool first_mem = true;
     for (int l = cf.n_decoder_layer - 1; l >= 0; --l) {
         const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lnx = p + "encdec_layer_norms." + std::to_string(l),
@@ -814,6 +834,7 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
         }
         B2S_TRY(self_attn_bwd(m, st, c->self_attn[l], sc, M, D, B, H, T, pt, c->seed, nm(p, "self_attentions", l, "qkv_transform.weight"),
                               nm(p, "self_attentions", l, "output_transform.weight"), lna));
+        m->stage_done(2 + (cf.n_decoder_layer - 1 - l));
     }
     if (first_mem) B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
     B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, opid(2, 0, 3)), st));
@@ -829,6 +850,7 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
     B2S_TRY(ro_colsum(dt, sc.dz1, 0, HP, nullptr, m->G("decoder.prenet.dense0.bias"), 1, (int)M, HP, st));
     B2S_TRY(linear_dw(m, st, sc.dz1, HP, c->tgtT, NM, (int)M, HP, NM, m->G("decoder.prenet.dense0.weight")));
     B2S_LAUNCH_CHECK();
+    m->stage_done(2 + cf.n_decoder_layer);
     return 0;
 }
 
@@ -923,7 +945,7 @@ extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out
             g.B.p = c->u[i]; g.B.ld = cin; g.B.R = (int)M; g.B.C = 5 * cin; g.B.g_cin = cin; g.B.g_T = T; g.B.g_len = c->tgt_len;
             g.M = cout; g.N = 5 * cin; g.K = (int)M;
             g.C = m->G("postnet.conv_layers." + std::to_string(i) + ".weight"); g.c_fp32 = 1; g.ldc = 5 * cin;
-            g.epi.conv_dw_cin = cin; g.epi.accumulate = 1;
+            g.epi.conv_dw_cin = cin; g.epi.accumulate = 1; g.splitk = pick_splitk(cout, 5 * cin, (int)M, dt);
             B2S_TRY(b2s_gemm_launch(g, dt, true, true, st));
         }
         {   // dx[m, ci] = mask(m) * sum_{j', co} dy[m + j' - 2, co] * w[co, ci, 4 - j']
@@ -937,6 +959,7 @@ extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out
             B2S_TRY(b2s_gemm_launch(g, dt, false, false, st));
         }
     }
+    m->stage_done(0);
     return 0;
 }
 
@@ -988,8 +1011,19 @@ extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, floa
 }
 extern "C" int b2s_zero_grads(b2s_model* m, void* stream) {
     B2S_TRY(check_bound(m));
+    // coalesce adjacent gradient buffers (the host normally binds one flat buffer) into few memsets
+    std::vector<std::pair<char*, size_t>> r;
     for (size_t i = 0; i < m->tinfo.size(); ++i)
-        if (m->tinfo[i].kind == 1 && m->grad[i]) B2S_HIP(hipMemsetAsync(m->grad[i], 0, (size_t)m->tinfo[i].numel * 4, S_(stream)));
+        if (m->tinfo[i].kind == 1 && m->grad[i]) r.push_back({(char*)m->grad[i], (size_t)m->tinfo[i].numel * 4});
+    std::sort(r.begin(), r.end());
+    size_t i = 0;
+    while (i < r.size()) {
+        char* lo = r[i].first; char* hi = lo + r[i].second;
+        size_t j = i + 1;
+        while (j < r.size() && r[j].first <= hi + 0) { hi = std::max(hi, r[j].first + r[j].second); ++j; }
+        B2S_HIP(hipMemsetAsync(lo, 0, (size_t)(hi - lo), S_(stream)));
+        i = j;
+    }
     return 0;
 }
 

@@ -36,6 +36,7 @@ struct GemmArgs {
     GemmOperand A, B;
     int M = 0, N = 0, K = 0;
     int batch = 1, batch_inner = 1;       // z -> (z / batch_inner, z % batch_inner)
+    int splitk = 1;                       // >1: K is split over blockIdx.z, partial sums atomically added (fp32 C, accumulate)
     void* C = nullptr;
     int c_fp32 = 0;                       // 1: float*, 0: compute type T*
     int ldc = 0;

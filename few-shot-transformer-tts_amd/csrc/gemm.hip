@@ -90,15 +90,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     typedef typename FragT<T>::type frag_t_;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // NOTE: LDS addresses are formed as (shared base + integer offset) everywhere: keeping tile pointers in an
+    // array makes the compiler lose the LDS address space and emit FLAT loads/stores for the fragments.
     T* smem = reinterpret_cast<T*>(smem_raw);
-    T* sA[2] = {smem, smem + TILE_A};
-    T* sB[2] = {smem + 2 * TILE_A, smem + 2 * TILE_A + TILE_B};
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int z = blockIdx.z, zo = z / g.batch_inner, zi = z - zo * g.batch_inner;
+    const int z = blockIdx.z / g.splitk, ksplit = blockIdx.z - z * g.splitk;
+    const int zo = z / g.batch_inner, zi = z - zo * g.batch_inner;
     const T* Ab = reinterpret_cast<const T*>(g.A.p) + zo * g.A.bs_o + zi * g.A.bs_i;
     const T* Bb = reinterpret_cast<const T*>(g.B.p) + zo * g.B.bs_o + zi * g.B.bs_i;
 
@@ -118,10 +119,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int v = tid + i * 256;
-            if (TA) { int kr = v / VPR_T, c = (v % VPR_T) * VE; *reinterpret_cast<uint4*>(sA[buf] + kr * LDT + c) = ra[i]; }
-            else    { int r = v / VPR_N, c = (v % VPR_N) * VE;  *reinterpret_cast<uint4*>(sA[buf] + r * LDN + c) = ra[i]; }
-            if (TB) { int kr = v / VPR_T, c = (v % VPR_T) * VE; *reinterpret_cast<uint4*>(sB[buf] + kr * LDT + c) = rb[i]; }
-            else    { int r = v / VPR_N, c = (v % VPR_N) * VE;  *reinterpret_cast<uint4*>(sB[buf] + r * LDN + c) = rb[i]; }
+            const int oa = buf * TILE_A, ob = 2 * TILE_A + buf * TILE_B;
+            if (TA) { int kr = v / VPR_T, c = (v % VPR_T) * VE; *reinterpret_cast<uint4*>(smem + oa + kr * LDT + c) = ra[i]; }
+            else    { int r = v / VPR_N, c = (v % VPR_N) * VE;  *reinterpret_cast<uint4*>(smem + oa + r * LDN + c) = ra[i]; }
+            if (TB) { int kr = v / VPR_T, c = (v % VPR_T) * VE; *reinterpret_cast<uint4*>(smem + ob + kr * LDT + c) = rb[i]; }
+            else    { int r = v / VPR_N, c = (v % VPR_N) * VE;  *reinterpret_cast<uint4*>(smem + ob + r * LDN + c) = rb[i]; }
         }
     };
 
@@ -131,15 +133,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (g.K + BK - 1) / BK;
-    gload(0);
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int per = (nk_all + g.splitk - 1) / g.splitk;
+    const int kt0 = ksplit * per;
+    const int nk = min(nk_all, kt0 + per) - kt0;
+    if (nk <= 0) return;
+    gload(kt0);
     sstore(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const T* tA = sA[cur];
-        const T* tB = sB[cur];
+        if (kt + 1 < nk) gload(kt0 + kt + 1);
+        const T* tA = smem + cur * TILE_A;
+        const T* tB = smem + 2 * TILE_A + cur * TILE_B;
 #pragma unroll
         for (int ks = 0; ks < BK / KSTEP; ++ks) {
             frag_t_ fa[4], fb[4];
@@ -165,23 +171,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     float* Cf = reinterpret_cast<float*>(g.C);
     T* Ct = reinterpret_cast<T*>(g.C);
     const T* aux = reinterpret_cast<const T*>(e.relu_aux);
+    int ncol[4], nst[4];
+    float bv[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = n0 + wcol + b * 16 + li;
+        ncol[b] = n < g.N ? n : -1;
+        bv[b] = (e.bias && n < g.N) ? e.bias[n] : 0.f;
+        nst[b] = n;
+        if (e.conv_dw_cin > 0) { int j = n / e.conv_dw_cin; nst[b] = (n - j * e.conv_dw_cin) * 5 + j; }
+    }
+    const bool plain = !e.relu && !aux && !e.drop.thresh && !e.residual && !e.row_len;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + wrow + a * 16 + lg * 4 + r;
             if (m >= g.M) continue;
+            const long rowoff = cbase + (long)m * g.ldc;
+            if (plain) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (ncol[b] < 0) continue;
+                    const float v = acc[a][b][r] * e.alpha + bv[b];
+                    const long off = rowoff + nst[b];
+                    if (g.c_fp32) { if (g.splitk > 1) atomicAdd(Cf + off, v); else if (e.accumulate) Cf[off] += v; else Cf[off] = v; }
+                    else TT<T>::st(Ct + off, v);
+                }
+                continue;
+            }
             bool rowzero = false;
             if (e.row_len) {
-                int b = m / e.rows_per_batch, t = m - b * e.rows_per_batch;
-                rowzero = t >= e.row_len[b];
+                int bb = m / e.rows_per_batch, t = m - bb * e.rows_per_batch;
+                rowzero = t >= e.row_len[bb];
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int n = n0 + wcol + b * 16 + li;
-                if (n >= g.N) continue;
-                float v = acc[a][b][r] * e.alpha;
-                if (e.bias) v += e.bias[n];
+                const int n = ncol[b];
+                if (n < 0) continue;
+                float v = acc[a][b][r] * e.alpha + bv[b];
                 if (e.relu) v = fmaxf(v, 0.f);
                 if (aux) v = TT<T>::ld(aux + (long)m * e.ld_aux + n) > 0.f ? v * e.aux_scale : 0.f;
                 if (e.drop.thresh) {
@@ -190,9 +218,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 }
                 if (e.residual) v += e.residual[(long)m * e.ldr + n];
                 if (rowzero) v = 0.f;
-                int nn = n;
-                if (e.conv_dw_cin > 0) { int j = n / e.conv_dw_cin; nn = (n - j * e.conv_dw_cin) * 5 + j; }
-                const long off = cbase + (long)m * g.ldc + nn;
+                const long off = rowoff + nst[b];
                 if (g.c_fp32) { if (e.accumulate) Cf[off] += v; else Cf[off] = v; }
                 else TT<T>::st(Ct + off, v);
             }
@@ -213,7 +239,7 @@ int launch_t(const GemmArgs& g, hipStream_t stream) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch);
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch * g.splitk);
     hipLaunchKernelGGL((gemm_kernel<T, TA, TB>), grid, dim3(256), smem, stream, g);
     B2S_LAUNCH_CHECK();
     return 0;
@@ -229,7 +255,47 @@ int launch_d(const GemmArgs& g, bool ta, bool tb, hipStream_t s) {
 
 }  // namespace
 
+// ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
+#include <vector>
+#include <cstdlib>
+namespace {
+struct ProfRec { hipEvent_t a, b; int variant; double flops; int M, N, K, batch, splitk; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+extern "C" void b2s_prof_enable(int on) { g_prof_on = on != 0; }
+// out[v*3 + {0,1,2}] = total flops, total milliseconds, launches of GEMM variant v = dtype*4 + trans_a*2 + trans_b
+extern "C" int b2s_prof_collect(double* out, int n_variants) {
+    for (int i = 0; i < n_variants * 3; ++i) out[i] = 0.0;
+    FILE* dump = getenv("B2S_PROF_DUMP") ? fopen(getenv("B2S_PROF_DUMP"), "w") : nullptr;
+    for (auto& r : g_prof) {
+        B2S_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        B2S_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        if (r.variant < n_variants) { out[r.variant * 3] += r.flops; out[r.variant * 3 + 1] += ms; out[r.variant * 3 + 2] += 1.0; }
+        if (dump) fprintf(dump, "%d %d %d %d %d %d %.3f %.1f\n", r.variant, r.M, r.N, r.K, r.batch, r.splitk, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    if (dump) fclose(dump);
+    g_prof.clear();
+    return 0;
+}
+
+static int gemm_launch_inner(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t stream);
 int b2s_gemm_launch(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t stream) {
+    if (!g_prof_on) return gemm_launch_inner(g, dtype, ta, tb, stream);
+    ProfRec r;
+    B2S_HIP(hipEventCreate(&r.a)); B2S_HIP(hipEventCreate(&r.b));
+    r.variant = dtype * 4 + (ta ? 2 : 0) + (tb ? 1 : 0);
+    r.flops = 2.0 * g.M * g.N * (double)g.K * g.batch;
+    r.M = g.M; r.N = g.N; r.K = g.K; r.batch = g.batch; r.splitk = g.splitk;
+    B2S_HIP(hipEventRecord(r.a, stream));
+    int rc = gemm_launch_inner(g, dtype, ta, tb, stream);
+    B2S_HIP(hipEventRecord(r.b, stream));
+    g_prof.push_back(r);
+    return rc;
+}
+static int gemm_launch_inner(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t stream) {
     const int ve = dtype ? 8 : 4;
     B2S_CHECK(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.batch_inner > 0, "gemm: bad shape M=%d N=%d K=%d batch=%d",
               g.M, g.N, g.K, g.batch);
@@ -239,6 +305,9 @@ int b2s_gemm_launch(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t 
     B2S_CHECK(((uintptr_t)g.A.p % 16 == 0) && ((uintptr_t)g.B.p % 16 == 0), "gemm: operands must be 16-byte aligned");
     B2S_CHECK(g.A.bs_o % ve == 0 && g.A.bs_i % ve == 0 && g.B.bs_o % ve == 0 && g.B.bs_i % ve == 0,
               "gemm: batch strides must be multiples of %d elements", ve);
-    B2S_CHECK(g.batch <= 65535, "gemm: batch too large");
+    B2S_CHECK(g.batch * g.splitk <= 65535, "gemm: batch too large");
+    B2S_CHECK(g.splitk >= 1 && (g.splitk == 1 || (g.c_fp32 && g.epi.accumulate && !g.epi.relu && !g.epi.bias && !g.epi.residual &&
+                                                   !g.epi.relu_aux && !g.epi.drop.thresh)),
+              "gemm: split-K needs a linear fp32 accumulate epilogue");
     return dtype ? launch_d<bf16_t>(g, ta, tb, stream) : launch_d<float>(g, ta, tb, stream);
 }

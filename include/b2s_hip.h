@@ -91,6 +91,14 @@ int b2s_postnet_backward(b2s_model* m, b2s_ctx* ctx, const float* d_out, float* 
 
 void b2s_ctx_free(b2s_ctx* ctx);
 
+/* Data-parallel hook (train.py:125 DistributedDataParallel): `hook(stage, user)` is called on the host right
+ * after the kernels that complete the parameter gradients of a backward stage have been enqueued, so the
+ * caller can launch that stage's gradient all-reduce (RCCL) while later stages still compute.  Stages in
+ * execution order: 0 postnet; 1 decoder heads + output LayerNorm; 2..1+Ld decoder layers Ld-1..0; 2+Ld prenet
+ * + decoder pe_scale; 3+Ld speaker/language nets + encoder output LayerNorm; 4+Ld..3+Ld+Le encoder layers
+ * Le-1..0; 4+Ld+Le byte embedding + encoder pe_scale. */
+int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int stage, void* user), void* user);
+
 /* ---- compute_loss (tacotron.py:136-158) ------------------------------------------------------------
  * losses_out[7] = loss, bef_loss, aft_loss, mse_loss, l2, stop_loss, sum(lengths); aft_losses_out[B].
  * scratch: >= (4 + B) floats. */
@@ -154,6 +162,11 @@ int b2s_cast(int dtype, const float* in, void* out, int64_t n, void* stream);   
 int b2s_cast_back(int dtype, const void* in, float* out, int64_t n, void* stream); /* compute dtype -> fp32 */
 /* keep-mask of the dropout RNG for element indices [0,n): out[i] = 1 or 0 (statistical tests) */
 int b2s_dropout_mask(float p, uint64_t seed, uint32_t op_id, uint8_t* out, int64_t n, void* stream);
+
+/* ---- measurement: per-launch HIP-event timing of the MFMA GEMM kernel on its launch stream (bench.py).
+ * variant v = dtype*4 + trans_a*2 + trans_b; out[v*3 + {0,1,2}] = flops, milliseconds, launches. */
+void b2s_prof_enable(int on);
+int b2s_prof_collect(double* out, int n_variants);
 
 #ifdef __cplusplus
 }
