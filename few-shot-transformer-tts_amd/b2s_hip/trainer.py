@@ -14,6 +14,7 @@ import torch
 
 from . import lib as L
 from .engine import _i32
+from .dp import GradBucketer
 
 _HOOK_T = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
 
@@ -41,11 +42,11 @@ class HipTrainer(object):
         self.global_step = 0
         self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
-        self._works = []
-        self._pending = None                      # (lo, hi) gradient range waiting to be merged into a bucket
-        self._bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
+        self.bucketer = None
         self._hook = _HOOK_T(self._on_stage)      # keep a reference: ctypes callbacks must outlive their use
         if self.world > 1:
+            self.bucketer = GradBucketer(self.eng._gflat, self.eng.stage_ranges, self.eng.n_stages(),
+                                         bucket_mb * 1024 * 1024 / 4, dist=self.dist)
             L.check(self.lib.b2s_model_set_stage_hook(self.eng.handle, C.cast(self._hook, L.P), None))
             # broadcast parameters and BN buffers from rank 0 once (DDP constructor semantics, train.py:125)
             for t in self.eng._tensors():
@@ -53,23 +54,9 @@ class HipTrainer(object):
             self.eng._versions = None
 
     # ------------------------------------------------------------------ gradient exchange
-    def _flush(self, force=False):
-        if self._pending is None:
-            return
-        lo, hi = self._pending
-        if force or hi - lo >= self._bucket_elems:
-            self._works.append(self.dist.all_reduce(self.eng._gflat[lo:hi], async_op=True))
-            self._pending = None
-
     def _on_stage(self, stage, _user):
-        rng = self.eng.stage_ranges.get(stage)
-        if rng is None:
-            return
-        if self._pending is None:
-            self._pending = rng
-        else:                                      # stages are contiguous in the flat buffer by construction
-            self._pending = (min(self._pending[0], rng[0]), max(self._pending[1], rng[1]))
-        self._flush(force=(stage == self.eng.n_stages() - 1))
+        if self.bucketer is not None:
+            self.bucketer.stage_done(stage)
 
     # ------------------------------------------------------------------ one step
     def train_step(self, batch):
@@ -84,6 +71,8 @@ class HipTrainer(object):
         vals, per = eng.loss_forward(mels, aft, stop, batch["mel_targets"], tgt32)
         L.check(lib.b2s_zero_grads(eng.handle, L.stream()))
         eng._needs_zero = False
+        if self.bucketer is not None:
+            self.bucketer.begin_step()
         dbef, daft, dstop = eng.loss_backward(mels, aft, stop, batch["mel_targets"], tgt32, None)
         din = eng.postnet_backward(c_post, daft)
         dmel = eng.add(eng.add(din, daft), dbef)
@@ -91,11 +80,8 @@ class HipTrainer(object):
         eng.encoder_backward(c_enc, dmem)
         for c in (c_post, c_dec, c_enc):
             c.free()
-        if self.world > 1:
-            self._flush(force=True)
-            for w in self._works:
-                w.wait()
-            self._works = []
+        if self.bucketer is not None:
+            self.bucketer.finish()
         lr = self.hp.max_lr * self.lr_lambda(self.global_step)
         self.global_step += 1
         L.check(lib.b2s_adam_step(eng.handle, lr, self.global_step, self.beta1, self.beta2, self.hp.adam_eps,

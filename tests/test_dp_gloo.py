@@ -1,0 +1,87 @@
+"""Data-parallel path on CPU: 2 gloo ranks.  The bucketed, stage-driven all-reduce must (a) reduce every element of
+the flat gradient buffer exactly once and (b) give mean-of-per-rank gradients, i.e. the reference's DDP semantics
+(per-rank loss normalisation, train.py:125 + common.py:86), checked with the CPU oracle's gradients."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "few-shot-transformer-tts_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle import b2s_oracle as O          # noqa: E402
+from oracle import synth, make_config, TINY  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _stage_layout(names, sizes):
+    """Flat layout exactly as HipEngine lays gradients out: parameters sorted by backward stage."""
+    import hyperparams
+    from b2s_hip.engine import HipEngine
+    from transformer.tacotron import Tacotron
+    hp = hyperparams.hparams
+    hp.parse(TINY)
+    eng = HipEngine(Tacotron(hp), hp)
+    order = sorted(range(len(names)), key=lambda i: (eng.stage_of(names[i]), i))
+    off, ranges, offsets = 0, {}, {}
+    for i in order:
+        st = eng.stage_of(names[i])
+        lo, hi = ranges.get(st, (off, off))
+        ranges[st] = (min(lo, off), off + sizes[i])
+        offsets[names[i]] = (off, sizes[i])
+        off += sizes[i]
+    return ranges, offsets, off, eng.n_stages()
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from b2s_hip.dp import GradBucketer
+    torch.set_num_threads(2)
+    cfg = make_config(TINY)
+    P = O.to_torch_state(synth.synthetic_state(cfg, 1234), requires_grad=True)
+    batch = O.to_torch_batch(synth.synthetic_batch(cfg, B=2, S=9, T=14, seed=100 + rank))
+    o = O.tacotron_forward(P, cfg, batch, train=True)
+    loss = O.compute_loss(P, cfg, batch["mel_targets"], batch["target_lengths"], o)["loss"]
+    names = [n for n in P if O.is_parameter(n)]
+    grads = torch.autograd.grad(loss, [P[n] for n in names], allow_unused=True)
+    grads = [g if g is not None else torch.zeros_like(P[n]) for g, n in zip(grads, names)]
+    ranges, offsets, total, n_stages = _stage_layout(names, [g.numel() for g in grads])
+    flat = torch.zeros(total)
+    for n, g in zip(names, grads):
+        off, sz = offsets[n]
+        flat[off:off + sz] = g.flatten()
+    local = flat.clone()
+    b = GradBucketer(flat, ranges, n_stages, bucket_elems=60000, dist=dist)
+    b.begin_step()
+    for st in range(n_stages):                 # the engine reports stages in backward order
+        b.stage_done(st)
+    b.finish()
+    covered = sorted(b.launched)
+    assert covered[0][0] == 0 and covered[-1][1] == total
+    assert all(a[1] == c[0] for a, c in zip(covered, covered[1:])), "buckets must tile the buffer exactly once"
+    assert 1 < len(covered) < n_stages, "small stages are merged into buckets"
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    assert torch.allclose(flat / world, sum(gathered) / world, atol=1e-7)
+    if rank == 0:
+        np.save(out, (flat / world).numpy())
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_mean_of_rank_gradients(tmp_path):
+    out = str(tmp_path / "mean.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mean = np.load(out)
+    assert np.isfinite(mean).all() and np.abs(mean).max() > 0

@@ -1,0 +1,179 @@
+"""CPU-only tests of the host side: hparams, state_dict layout, schedule, helpers, checkpoint round trip, the
+C-ABI library (loads, exports every declared symbol, layout queries) and the loud-failure rule (no CPU fallback)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def fresh_hp(over=""):
+    import hyperparams
+    hp = hyperparams.hparams
+    if not hasattr(fresh_hp, "d"):
+        fresh_hp.d = dict(hp.values())
+    hp.override_from_dict(fresh_hp.d)
+    if over:
+        hp.parse(over)
+    return hp
+
+
+def test_hparams_surface():
+    hp = fresh_hp()
+    assert hp.vocab_size == 6000 and hp.decoder_hidden == 768 and hp.adam_eps == 5e-8 and hp.multi_speaker is True
+    hp.parse("transformer_dropout_rate=0.0,n_encoder_layer=2,multi_speaker=false,data_format=abc")
+    assert hp.transformer_dropout_rate == 0.0 and hp.n_encoder_layer == 2 and hp.multi_speaker is False and hp.data_format == "abc"
+    with pytest.raises(ValueError):
+        hp.parse("not_a_param=1")
+    with pytest.raises(ValueError):
+        hp.parse("n_encoder_layer=abc")
+    js = json.loads(hp.to_json())
+    assert js["num_mels"] == 80 and "compute_dtype" in js and "vocab_size" in hp
+    fresh_hp()
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny96", "default"])
+def test_state_dict_layout_matches_reference(tag):
+    from oracle import TINY, TINY96
+    from transformer.tacotron import Tacotron
+    hp = fresh_hp({"tiny": TINY, "tiny96": TINY96, "default": ""}[tag])
+    m = Tacotron(hp)
+    ref = json.load(open(os.path.join(G, "state_layout_%s.json" % tag)))
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == ref
+    fresh_hp()
+
+
+def test_lr_schedule_and_helpers_match_goldens():
+    from transformer.tacotron import learning_rate_schedule
+    from transformer import common
+    hp = fresh_hp()
+    g = dict(np.load(os.path.join(G, "g6_misc.npz")))
+    for s, v in zip(g["lr_steps"], g["lr_values"]):
+        assert learning_rate_schedule(int(s), hp) == pytest.approx(float(v), rel=1e-12)
+    g1 = dict(np.load(os.path.join(G, "g1_helpers.npz")))
+    assert np.array_equal(common.get_sinusoid_encoding_table(37, 64).numpy(), g1["pe_37_64"])
+    assert np.array_equal(common.get_sinusoid_encoding_table(9, 7).numpy(), g1["pe_9_7"])
+    assert np.array_equal(np.asarray(common.attention_bias(6, "causal")), g1["bias_causal_6"])
+    mask = torch.tensor([[1, 1, 1, 0, 0], [1, 1, 1, 1, 1]], dtype=torch.bool)
+    b = common.attention_bias(mask, "masking")
+    assert np.array_equal(np.asarray(b), g1["bias_masking"]) and b.b2s_lengths.tolist() == [3, 5]
+    with pytest.raises(ValueError):
+        common.attention_bias(mask, "other")
+    x3 = torch.arange(30, dtype=torch.float32).reshape(2, 5, 3) + 1
+    lens = torch.tensor([3, 5])
+    assert np.array_equal(common.impute(x3, lens).numpy(), g1["impute_cl"])
+    loss = torch.arange(10, dtype=torch.float32).reshape(2, 5) * 0.25 + 1
+    assert np.allclose(common.mask_reduce(loss, lens, True).numpy(), g1["mask_reduce_ps"])
+
+
+def test_initialize_variables_distribution():
+    from oracle import TINY
+    from transformer.tacotron import Tacotron, initialize_variables
+    hp = fresh_hp(TINY)
+    torch.manual_seed(0)
+    m = Tacotron(hp)
+    initialize_variables(m)
+    sd = m.state_dict()
+    w = sd["decoder.decoder.ffn_layers.0.input_layer.weight"]
+    std = float(np.sqrt(1.3 * 2.0 / ((w.shape[0] + w.shape[1]) / 2)))
+    assert float(w.abs().max()) <= 2 * std + 1e-6 and abs(float(w.std()) - 0.88 * std) < 0.05 * std
+    assert float(sd["encoder.speaker_layer.bias"].abs().max()) == 0.0
+    assert abs(float(sd["encoder.embed.weight"].std()) - 1.0) < 0.05
+    fresh_hp()
+
+
+def test_text_and_checkpoint_roundtrip(tmp_path):
+    from oracle import TINY
+    from transformer.tacotron import Tacotron
+    from utils import text, checkpoint, dict_send_to
+    assert text.text_to_byte_sequence("hé") == [2, 104, 195, 169, 1]
+    hp = fresh_hp(TINY)
+    m = Tacotron(hp)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, eps=hp.adam_eps)
+    checkpoint.save_model(str(tmp_path), m, opt, None, 7)
+    path = checkpoint.find_ckpt(str(tmp_path))
+    assert path.endswith("model.ckpt-7")
+    m2 = Tacotron(hp)
+    wrapped = torch.nn.DataParallel(m2)               # `.module` prefix handling (utils/checkpoint.py:22-25,41-44)
+    assert checkpoint.load_model(path, wrapped, None, None, "cpu") == 7
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert dict_send_to({"a": torch.ones(2), "names": ["x"]}, "cpu")["names"] == ["x"]
+    fresh_hp()
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from b2s_hip import lib
+    l = lib.load()
+    header = open(os.path.join(ROOT, "include", "b2s_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(b2s_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 35
+    for name in sorted(declared):
+        assert hasattr(l, name), "libb2s_hip.so does not export %s" % name
+    assert declared == set(lib.EXPORTS), (declared ^ set(lib.EXPORTS))
+    assert l.b2s_version() >= 100
+
+
+def test_c_abi_layout_queries_and_errors():
+    """Model creation / layout / workspace queries need no GPU; errors come back as codes + messages, never aborts."""
+    from b2s_hip import lib
+    from b2s_hip.engine import config_from_hparams
+    l = lib.load()
+    hp = fresh_hp()
+    cfg = config_from_hparams(hp)
+    h = lib.P()
+    lib.check(l.b2s_model_create(C.byref(cfg), C.byref(h)))
+    n = l.b2s_model_num_tensors(h)
+    ref = json.load(open(os.path.join(G, "state_layout_default.json")))
+    assert n == len(ref) == 177
+    buf = C.create_string_buffer(256); shape = (C.c_int64 * 8)(); nd = C.c_int(); kind = C.c_int()
+    for i in range(n):
+        lib.check(l.b2s_model_tensor_info(h, i, buf, 256, shape, C.byref(nd), C.byref(kind)))
+        assert [buf.value.decode(), [shape[k] for k in range(nd.value)]] == ref[i]
+    assert l.b2s_encoder_ws_bytes(h, 14, 114) > 0 and l.b2s_decoder_ws_bytes(h, 14, 114, 582) > 1 << 28
+    assert l.b2s_model_tensor_info(h, 999, buf, 256, shape, C.byref(nd), C.byref(kind)) != 0
+    assert b"out of range" in l.b2s_last_error()
+    # forward before binding -> error code, not a crash
+    assert l.b2s_model_sync_weights(h, None) != 0 and b"not bound" in l.b2s_last_error()
+    l.b2s_model_destroy(h)
+    bad = config_from_hparams(fresh_hp("decoder_hidden=512"))       # the reference crashes on this config too
+    assert l.b2s_model_create(C.byref(bad), C.byref(h)) != 0 and b"decoder_hidden" in l.b2s_last_error()
+    fresh_hp()
+
+
+def test_no_cpu_fallback():
+    """The HIP library is the only compute path: CPU tensors raise instead of silently running elsewhere."""
+    from oracle import TINY
+    from b2s_hip.lib import B2SError
+    from transformer.tacotron import Tacotron
+    from transformer.attention import MultiheadAttention
+    hp = fresh_hp(TINY)
+    m = Tacotron(hp)
+    with pytest.raises(B2SError):
+        m.encoder(torch.zeros(2, 5, dtype=torch.long), torch.tensor([5, 3]), torch.zeros(2, dtype=torch.long), torch.zeros(2, 8))
+    with pytest.raises(B2SError):
+        MultiheadAttention(64, 64, True, 2, 0.0)(torch.zeros(1, 4, 64), None, None)
+    fresh_hp()
+
+
+def test_stage_order_covers_all_parameters():
+    from oracle import TINY
+    from b2s_hip.engine import HipEngine
+    from transformer.tacotron import Tacotron
+    hp = fresh_hp(TINY)
+    m = Tacotron(hp)
+    eng = HipEngine(m, hp)                              # creating the handle needs no GPU
+    stages = [eng.stage_of(n) for n, k in zip(eng.names, eng.kinds) if k == 1]
+    assert min(stages) == 0 and max(stages) == eng.n_stages() - 1 and len(set(stages)) == eng.n_stages()
+    assert eng.stage_of("postnet.conv_layers.0.weight") == 0
+    assert eng.stage_of("decoder.decoder.ffn_layers.1.input_layer.weight") == 2
+    assert eng.stage_of("decoder.decoder.self_attentions.0.qkv_transform.weight") == 3
+    assert eng.stage_of("encoder.embed.weight") == eng.n_stages() - 1
+    fresh_hp()
