@@ -77,6 +77,13 @@ _PROTOS = {
     "b2s_add": (C.c_int, [P, P, P, C.c_int64, P]),
     "b2s_cast": (C.c_int, [C.c_int, P, P, C.c_int64, P]),
     "b2s_cast_back": (C.c_int, [C.c_int, P, P, C.c_int64, P]),
+    "b2s_decode_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "b2s_decode_begin": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, P, C.c_size_t, P, C.POINTER(P)]),
+    "b2s_decode_run": (C.c_int, [P, P, C.c_int, C.c_int, P]),
+    "b2s_decode_status": (C.c_int, [P, C.POINTER(C.c_int), C.POINTER(C.c_int), P]),
+    "b2s_decode_fetch": (C.c_int, [P, P, C.c_int, P, P, P]),
+    "b2s_decode_alignment": (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, P, P]),
+    "b2s_decode_end": (None, [P]),
     "b2s_model_set_stage_hook": (C.c_int, [P, P, P]),
     "b2s_prof_enable": (None, [C.c_int]),
     "b2s_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.c_int]),

@@ -1,0 +1,352 @@
+// Autoregressive mel / stop-token decoding (reference: synthesize.py:17-72 eval_batch) with a per-layer
+// self-attention KV cache, encoder-decoder K/V projected once, and the whole per-frame step captured in a
+// hipGraph that is replayed once per frame (the step index, stop flags and lengths live in device memory,
+// so the same graph serves every frame; the host only polls `all finished` every few frames).
+//
+// The reference re-runs prenet + all decoder layers over the whole prefix every frame (no cache, O(t) GEMM +
+// O(t^2) attention per frame, memory K/V re-projected every frame).  With dropout off the cached step is
+// results-equivalent: position t only ever depends on positions <= t, and the
+// reference's masking of finished samples (impute by target_lengths) is reproduced per step.
+//
+// Per-step HBM traffic (the roofline that bounds this path): decoder-stack weights once (49.9 M params) +
+// self K/V cache read (Ld*2*B*t*Dd) + cross K/V read (Ld*2*B*S*Dd) + cache append.
+#include "engine.h"
+
+struct b2s_decode_state {
+    int B = 0, S = 0, maxT = 0, train = 0;
+    uint64_t seed = 0;
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    const int32_t* in_len = nullptr;
+    int* t = nullptr;            // device: current frame index
+    int* finished = nullptr;     // device [B]
+    int* lengths = nullptr;      // device [B] (target_lengths of the reference loop)
+    int* status = nullptr;       // device [2]: {t, all_finished}
+    float* mels = nullptr;       // [B, maxT, NM]
+    void* memT = nullptr;
+    std::vector<void*> crossKV, selfK, selfV;
+    std::vector<float*> crossP, selfP;   // attention rows of every step: [B,H,maxT,S] / [B,H,maxT,maxT]
+    void *tgt = nullptr, *a1 = nullptr, *a2 = nullptr, *h = nullptr, *qkv = nullptr, *ctx = nullptr, *f = nullptr, *outT = nullptr;
+    float *a3 = nullptr, *x = nullptr, *mean = nullptr, *rstd = nullptr, *mel_step = nullptr, *stop_step = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t graph_stream = nullptr;
+    bool keep_self = false;
+};
+
+int b2s_ensure_pe_export(b2s_model* m, int len);      // engine.hip
+
+namespace {
+inline hipStream_t S_(void* s) { return (hipStream_t)s; }
+
+__global__ void k_dec_begin(int* t, int* finished, int* lengths, int* status, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { finished[i] = 0; lengths[i] = 1; }
+    if (i == 0) { *t = 0; status[0] = 0; status[1] = 0; }
+}
+// tgt[b,:] = mels[b, t-1, :] (zero at t = 0)
+template <typename T>
+__global__ void k_dec_prep(const float* mels, const int* tptr, T* tgt, int maxT, int NM) {
+    const int b = blockIdx.x, t = *tptr;
+    for (int c = threadIdx.x; c < NM; c += blockDim.x)
+        TT<T>::st(tgt + (long)b * NM + c, t > 0 ? mels[((long)b * maxT + (t - 1)) * NM + c] : 0.f);
+}
+// x[b,:] = (t>0 && t-1 < len[b] ? a3[b,:] : 0) + pe[t,:]*pe_scale ; dropout (modules.py:113-120 at position t)
+__global__ void k_dec_x0(const float* a3, const int* lengths, const float* pe, const float* pe_scale, const int* tptr, float* x,
+                         int D, DropCfg drop) {
+    const int b = blockIdx.x, t = *tptr;
+    const bool have = t > 0 && (t - 1) < lengths[b];
+    const float sc = *pe_scale;
+    DropCfg d = drop;
+    d.key ^= b2s_hash32((uint32_t)t + 0x9e3779b9u);
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float v = (have ? a3[(long)b * D + c] : 0.f) + pe[(long)t * D + c] * sc;
+        if (d.thresh) v = b2s_keep(d, (uint32_t)(b * D + c)) ? v * d.scale : 0.f;
+        x[(long)b * D + c] = v;
+    }
+}
+// append this frame's k, v (from qkv [B,3D]) to the caches [B,maxT,D] at position t
+template <typename T>
+__global__ void k_dec_append(const T* qkv, const int* tptr, T* Kc, T* Vc, int maxT, int D) {
+    const int b = blockIdx.x, t = *tptr;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        Kc[((long)b * maxT + t) * D + c] = qkv[(long)b * 3 * D + D + c];
+        Vc[((long)b * maxT + t) * D + c] = qkv[(long)b * 3 * D + 2 * D + c];
+    }
+}
+// single-query attention for one (b, h) per wave: keys [0, n), n = t+1 (self) or klen[b] (cross)
+template <typename T>
+__global__ __launch_bounds__(64) void k_dec_attn(const T* q, int ldq, const T* Kc, const T* Vc, int ldkv, long kv_bstride, T* out,
+                                                 int ldo, float* probs, int probs_rows, int probs_ld, const int* tptr,
+                                                 const int* klen, int self, int H, int dh, float scale, DropCfg drop) {
+    extern __shared__ float sh[];            // [dh] q + [nmax] p
+    const int lane = threadIdx.x, b = blockIdx.x / H, h = blockIdx.x - b * H, t = *tptr;
+    const int n = self ? t + 1 : klen[b];
+    float* sq = sh;
+    float* p = sh + dh;
+    for (int d = lane; d < dh; d += 64) sq[d] = TT<T>::ld(q + (long)b * ldq + h * dh + d);
+    __syncthreads();
+    const T* Kb = Kc + b * kv_bstride + h * dh;
+    const T* Vb = Vc + b * kv_bstride + h * dh;
+    float mx = -INFINITY;
+    for (int j = lane; j < n; j += 64) {
+        const T* kr = Kb + (long)j * ldkv;
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s += sq[d] * TT<T>::ld(kr + d);
+        s *= scale;
+        p[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < n; j += 64) { float e = __expf(p[j] - mx); p[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    __syncthreads();
+    DropCfg dc = drop;
+    dc.key ^= b2s_hash32((uint32_t)t * 2654435761u + 77u);
+    float* prow = probs ? probs + (((long)b * H + h) * probs_rows + t) * probs_ld : nullptr;   // alignment row of this frame
+    for (int j = lane; j < n; j += 64) {
+        float w = p[j] * inv;
+        if (prow) prow[j] = w;
+        if (dc.thresh) w = b2s_keep(dc, (uint32_t)((b * H + h) * 4096 + j)) ? w * dc.scale : 0.f;
+        p[j] = w;
+    }
+    __syncthreads();
+    for (int d = lane; d < dh; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) acc += p[j] * TT<T>::ld(Vb + (long)j * ldkv + d);
+        TT<T>::st(out + (long)b * ldo + h * dh + d, acc);
+    }
+}
+// finish the frame: mask by activity, write mels[:, t], update stop state (synthesize.py:42-45)
+__global__ void k_dec_finish(const float* mel_step, const float* stop_step, const int* tptr, int* finished, int* lengths, float* mels,
+                             int maxT, int NM) {
+    const int b = blockIdx.x, t = *tptr;
+    const bool active = t < lengths[b];
+    for (int c = threadIdx.x; c < NM; c += blockDim.x) mels[((long)b * maxT + t) * NM + c] = active ? mel_step[(long)b * NM + c] : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool stop = active && stop_step[b] > 0.f;
+        const int fin = finished[b] | (stop ? 1 : 0);
+        finished[b] = fin;
+        if (!fin) lengths[b] += 1;
+    }
+}
+__global__ void k_dec_advance(int* t, const int* finished, int* status, int B) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int all = 1;
+        for (int b = 0; b < B; ++b) all &= finished[b];
+        *t += 1;
+        status[0] = *t; status[1] = all;
+    }
+}
+
+struct DecPlan {
+    size_t bytes;
+};
+void plan_decode(const b2s_model* m, b2s_decode_state& s, Arena& a) {
+    const b2s_config& cf = m->cfg;
+    const int B = s.B, S = s.S, T = s.maxT, D = cf.decoder_hidden, H = cf.n_attention_head, L = cf.n_decoder_layer, esz = m->esz;
+    s.t = (int*)a.take(256); s.finished = (int*)a.take((size_t)B * 4); s.lengths = (int*)a.take((size_t)B * 4);
+    s.status = (int*)a.take(256);
+    s.mels = a.f32((long)B * T * cf.num_mels);
+    s.memT = a.T((long)B * S * D, esz);
+    s.crossKV.assign(L, nullptr); s.selfK.assign(L, nullptr); s.selfV.assign(L, nullptr); s.crossP.assign(L, nullptr); s.selfP.assign(L, nullptr);
+    for (int l = 0; l < L; ++l) {
+        s.crossKV[l] = a.T((long)B * S * 2 * D, esz);
+        s.selfK[l] = a.T((long)B * T * D, esz);
+        s.selfV[l] = a.T((long)B * T * D, esz);
+        s.crossP[l] = a.f32((long)B * H * T * S);
+        if (s.keep_self) s.selfP[l] = a.f32((long)B * H * T * T);
+    }
+    s.tgt = a.T((long)B * cf.num_mels, esz); s.a1 = a.T((long)B * cf.prenet_hidden, esz); s.a2 = a.T((long)B * cf.prenet_hidden, esz);
+    s.a3 = a.f32((long)B * D); s.x = a.f32((long)B * D); s.mean = a.f32(B); s.rstd = a.f32(B);
+    s.h = a.T((long)B * D, esz); s.qkv = a.T((long)B * 3 * D, esz); s.ctx = a.T((long)B * D, esz); s.f = a.T((long)B * 4 * D, esz);
+    s.outT = a.T((long)B * D, esz); s.mel_step = a.f32((long)B * cf.num_mels); s.stop_step = a.f32(B);
+}
+
+int lin(const b2s_model* m, hipStream_t st, const void* X, int ldx, const void* W, int M, int N, int K, void* out, int out_fp32, int ldo,
+        const GemmEpilogue& e) {
+    GemmArgs g;
+    g.A.p = X; g.A.ld = ldx; g.A.R = M; g.A.C = K;
+    g.B.p = W; g.B.ld = K; g.B.R = N; g.B.C = K;
+    g.M = M; g.N = N; g.K = K; g.C = out; g.c_fp32 = out_fp32; g.ldc = ldo; g.epi = e;
+    return b2s_gemm_launch(g, m->dtype, false, false, st);
+}
+std::string nm2(const std::string& p, const char* list, int i, const char* leaf) { return p + list + "." + std::to_string(i) + "." + leaf; }
+
+template <typename T>
+int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
+    const b2s_config& cf = m->cfg;
+    const int B = s->B, S = s->S, maxT = s->maxT, D = cf.decoder_hidden, H = cf.n_attention_head, dh = D / H, L = cf.n_decoder_layer;
+    const int NM = cf.num_mels, HP = cf.prenet_hidden, dt = m->dtype;
+    const float pt = s->train ? cf.transformer_dropout_rate : 0.f, pd = s->train ? cf.decoder_dropout_rate : 0.f;
+    const float scale = 1.f / sqrtf((float)dh);
+    const std::string p = "decoder.decoder.";
+    hipLaunchKernelGGL((k_dec_prep<T>), dim3(B), dim3(128), 0, st, s->mels, s->t, (T*)s->tgt, maxT, NM);
+    GemmEpilogue e0; e0.bias = m->P("decoder.prenet.dense0.bias"); e0.relu = 1; e0.drop = make_drop(pd, s->seed, 9001); e0.drop_salt = s->t;
+    B2S_TRY(lin(m, st, s->tgt, NM, m->W("decoder.prenet.dense0.weight"), B, HP, NM, s->a1, 0, HP, e0));
+    GemmEpilogue e1; e1.bias = m->P("decoder.prenet.dense1.bias"); e1.relu = 1; e1.drop = make_drop(pd, s->seed, 9002); e1.drop_salt = s->t;
+    B2S_TRY(lin(m, st, s->a1, HP, m->W("decoder.prenet.dense1.weight"), B, HP, HP, s->a2, 0, HP, e1));
+    B2S_TRY(lin(m, st, s->a2, HP, m->W("decoder.prenet.dense_final.weight"), B, D, HP, s->a3, 1, D, GemmEpilogue()));
+    hipLaunchKernelGGL(k_dec_x0, dim3(B), dim3(256), 0, st, s->a3, s->lengths, m->pe_dec, m->P(p + "pe_scale"), s->t, s->x, D,
+                       make_drop(pt, s->seed, 9003));
+    const size_t sh_self = (size_t)(dh + maxT) * 4, sh_cross = (size_t)(dh + S) * 4;
+    for (int l = 0; l < L; ++l) {
+        const std::string lna = p + "attn_layer_norms." + std::to_string(l), lnx = p + "encdec_layer_norms." + std::to_string(l),
+                          lnf = p + "ffn_layer_norms." + std::to_string(l);
+        // causal self-attention over the cache
+        B2S_TRY(ro_layernorm_fwd(dt, s->x, m->P(lna + ".weight"), m->P(lna + ".bias"), s->h, D, nullptr, 0, s->mean, s->rstd, B, D, 1e-6f,
+                                 nullptr, 1, st));
+        B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "self_attentions", l, "qkv_transform.weight")), B, 3 * D, D, s->qkv, 0, 3 * D, GemmEpilogue()));
+        hipLaunchKernelGGL((k_dec_append<T>), dim3(B), dim3(256), 0, st, (const T*)s->qkv, s->t, (T*)s->selfK[l], (T*)s->selfV[l], maxT, D);
+        hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(64), sh_self, st, (const T*)s->qkv, 3 * D, (const T*)s->selfK[l],
+                           (const T*)s->selfV[l], D, (long)maxT * D, (T*)s->ctx, D, s->selfP[l], maxT, maxT, s->t, (const int*)nullptr, 1, H, dh,
+                           scale, make_drop(pt, s->seed, 9010 + l));
+        GemmEpilogue ea; ea.drop = make_drop(pt, s->seed, 9020 + l); ea.drop_salt = s->t; ea.residual = s->x; ea.ldr = D;
+        B2S_TRY(lin(m, st, s->ctx, D, m->W(nm2(p, "self_attentions", l, "output_transform.weight")), B, D, D, s->x, 1, D, ea));
+        // encoder-decoder attention over the pre-projected memory K/V
+        B2S_TRY(ro_layernorm_fwd(dt, s->x, m->P(lnx + ".weight"), m->P(lnx + ".bias"), s->h, D, nullptr, 0, s->mean, s->rstd, B, D, 1e-6f,
+                                 nullptr, 1, st));
+        B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "encdec_attentions", l, "q_transform.weight")), B, D, D, s->qkv, 0, D, GemmEpilogue()));
+        hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(64), sh_cross, st, (const T*)s->qkv, D, (const T*)s->crossKV[l],
+                           (const T*)s->crossKV[l] + D, 2 * D, (long)S * 2 * D, (T*)s->ctx, D, s->crossP[l], maxT, S, s->t, s->in_len, 0, H, dh,
+                           scale, make_drop(pt, s->seed, 9030 + l));
+        GemmEpilogue ex; ex.drop = make_drop(pt, s->seed, 9040 + l); ex.drop_salt = s->t; ex.residual = s->x; ex.ldr = D;
+        B2S_TRY(lin(m, st, s->ctx, D, m->W(nm2(p, "encdec_attentions", l, "output_transform.weight")), B, D, D, s->x, 1, D, ex));
+        // FFN
+        B2S_TRY(ro_layernorm_fwd(dt, s->x, m->P(lnf + ".weight"), m->P(lnf + ".bias"), s->h, D, nullptr, 0, s->mean, s->rstd, B, D, 1e-6f,
+                                 nullptr, 1, st));
+        GemmEpilogue f1; f1.relu = 1; f1.drop = make_drop(pt, s->seed, 9050 + l); f1.drop_salt = s->t;
+        B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "ffn_layers", l, "input_layer.weight")), B, 4 * D, D, s->f, 0, 4 * D, f1));
+        GemmEpilogue f2; f2.drop = make_drop(pt, s->seed, 9060 + l); f2.drop_salt = s->t; f2.residual = s->x; f2.ldr = D;
+        B2S_TRY(lin(m, st, s->f, 4 * D, m->W(nm2(p, "ffn_layers", l, "output_layer.weight")), B, D, 4 * D, s->x, 1, D, f2));
+    }
+    B2S_TRY(ro_layernorm_fwd(dt, s->x, m->P(p + "output_layer_norm.weight"), m->P(p + "output_layer_norm.bias"), s->outT, D, nullptr, 0,
+                             s->mean, s->rstd, B, D, 1e-6f, nullptr, 1, st));
+    B2S_TRY(lin(m, st, s->outT, D, m->W("decoder.mel_net.weight"), B, NM, D, s->mel_step, 1, NM, GemmEpilogue()));
+    B2S_TRY(ro_rowdot_fwd(dt, s->outT, D, m->P("decoder.stop_net.weight"), m->P("decoder.stop_net.bias"), s->stop_step, B, D, nullptr, 1, st));
+    hipLaunchKernelGGL(k_dec_finish, dim3(B), dim3(128), 0, st, s->mel_step, s->stop_step, s->t, s->finished, s->lengths, s->mels, maxT, NM);
+    hipLaunchKernelGGL(k_dec_advance, dim3(1), dim3(64), 0, st, s->t, s->finished, s->status, B);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
+int step(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
+    return m->dtype ? step_t<bf16_t>(m, s, st) : step_t<float>(m, s, st);
+}
+}  // namespace
+
+extern "C" size_t b2s_decode_ws_bytes(const b2s_model* m, int B, int S, int max_frames, int keep_self_alignments) {
+    if (!m || B <= 0 || S <= 0 || max_frames <= 0) return 0;
+    b2s_decode_state s; s.B = B; s.S = S; s.maxT = max_frames; s.keep_self = keep_self_alignments != 0;
+    Arena a;
+    plan_decode(m, s, a);
+    return a.off + 4096;
+}
+
+extern "C" int b2s_decode_begin(b2s_model* m, const float* memory, const int32_t* input_lengths, int B, int S, int max_frames, int train,
+                                uint64_t seed, int keep_self_alignments, void* ws, size_t ws_bytes, void* stream,
+                                b2s_decode_state** out) {
+    B2S_CHECK(m && m->bound, "model parameters are not bound");
+    B2S_CHECK(memory && input_lengths && ws && out && B > 0 && S > 0 && max_frames > 0, "bad argument");
+    hipStream_t st = S_(stream);
+    b2s_decode_state* s = new b2s_decode_state();
+    s->B = B; s->S = S; s->maxT = max_frames; s->train = train; s->seed = seed; s->in_len = input_lengths;
+    s->keep_self = keep_self_alignments != 0;
+    s->ws = (char*)ws; s->ws_bytes = ws_bytes;
+    Arena a; a.base = (char*)ws; a.cap = ws_bytes;
+    plan_decode(m, *s, a);
+    if (a.overflow || a.off > ws_bytes) { delete s; return b2s_fail(__FILE__, __LINE__, "decode workspace too small: need %zu bytes, got %zu", a.off, ws_bytes); }
+    const b2s_config& cf = m->cfg;
+    const int D = cf.decoder_hidden;
+    int rc = b2s_ensure_pe_export(m, max_frames + 1);
+    if (rc) { delete s; return rc; }
+    hipLaunchKernelGGL(k_dec_begin, dim3(cdiv(B, 64)), dim3(64), 0, st, s->t, s->finished, s->lengths, s->status, B);
+    rc = ro_cast(m->dtype, memory, s->memT, (long)B * S * D, st);
+    for (int l = 0; l < cf.n_decoder_layer && !rc; ++l) {
+        rc = lin(m, st, s->memT, D, m->W(nm2("decoder.decoder.", "encdec_attentions", l, "kv_transform.weight")), B * S, 2 * D, D, s->crossKV[l], 0,
+                 2 * D, GemmEpilogue());
+        if (!rc) rc = hipMemsetAsync(s->crossP[l], 0, (size_t)B * cf.n_attention_head * max_frames * S * 4, st) == hipSuccess ? 0 : 1;
+        if (!rc && s->selfP[l]) rc = hipMemsetAsync(s->selfP[l], 0, (size_t)B * cf.n_attention_head * max_frames * max_frames * 4, st) == hipSuccess ? 0 : 1;
+    }
+    if (rc) { delete s; return rc ? rc : 1; }
+    *out = s;
+    return 0;
+}
+
+// Run n frames.  use_graph: capture the step once into a hipGraph and replay it (stream must not be the NULL stream).
+extern "C" int b2s_decode_run(b2s_model* m, b2s_decode_state* s, int n_steps, int use_graph, void* stream) {
+    B2S_CHECK(m && s && n_steps >= 0, "bad argument");
+    hipStream_t st = S_(stream);
+    if (!use_graph) {
+        for (int i = 0; i < n_steps; ++i) B2S_TRY(step(m, s, st));
+        return 0;
+    }
+    if (!s->exec) {
+        B2S_CHECK(st != nullptr, "graph capture needs a non-default stream");
+        B2S_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        int rc = step(m, s, st);
+        hipError_t e = hipStreamEndCapture(st, &s->graph);
+        if (rc) return rc;
+        B2S_HIP(e);
+        B2S_HIP(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
+        s->graph_stream = st;
+    }
+    for (int i = 0; i < n_steps; ++i) B2S_HIP(hipGraphLaunch(s->exec, st));
+    return 0;
+}
+
+// Blocking read of {frames generated, all finished} (one small D2H copy; the only host sync of the loop).
+extern "C" int b2s_decode_status(b2s_decode_state* s, int* frames_host, int* all_finished_host, void* stream) {
+    B2S_CHECK(s && frames_host && all_finished_host, "bad argument");
+    int h[2] = {0, 0};
+    B2S_HIP(hipMemcpyAsync(h, s->status, sizeof(h), hipMemcpyDeviceToHost, S_(stream)));
+    B2S_HIP(hipStreamSynchronize(S_(stream)));
+    *frames_host = h[0]; *all_finished_host = h[1];
+    return 0;
+}
+
+// Copy out the first n_frames frames [B, n_frames, NM], the lengths [B] (int32) and optionally the alignment rows
+// of the encoder-decoder attention of `layer`: align_out [B, H, S, n_frames] (attention.py:88 layout).
+extern "C" int b2s_decode_fetch(b2s_model* m, b2s_decode_state* s, int n_frames, float* mels_out, int32_t* lengths_out, void* stream) {
+    B2S_CHECK(m && s && mels_out && lengths_out && n_frames >= 0 && n_frames <= s->maxT, "bad argument");
+    hipStream_t st = S_(stream);
+    const int NM = m->cfg.num_mels;
+    if (n_frames > 0)
+        B2S_HIP(hipMemcpy2DAsync(mels_out, (size_t)n_frames * NM * 4, s->mels, (size_t)s->maxT * NM * 4, (size_t)n_frames * NM * 4, s->B,
+                                 hipMemcpyDeviceToDevice, st));
+    B2S_HIP(hipMemcpyAsync(lengths_out, s->lengths, (size_t)s->B * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+namespace {
+__global__ void k_dec_align(const float* P, float* out, int H, int maxT, int ldp, int nk, int n_frames) {
+    // P [B*H, maxT(query), ldp(key)] -> out [B*H, nk(key), n_frames(query)]   (attention.py:88 layout)
+    const int bh = blockIdx.y;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)nk * n_frames; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / n_frames), q = (int)(i - (long)k * n_frames);
+        out[((long)bh * nk + k) * n_frames + q] = P[((long)bh * maxT + q) * ldp + k];
+    }
+}
+}  // namespace
+extern "C" int b2s_decode_alignment(b2s_model* m, b2s_decode_state* s, int which, int layer, int n_frames, float* align_out, void* stream) {
+    B2S_CHECK(m && s && align_out && layer >= 0 && layer < m->cfg.n_decoder_layer && n_frames > 0 && n_frames <= s->maxT, "bad argument");
+    B2S_CHECK(which == 1 || (which == 0 && s->keep_self), "self-attention rows were not kept (keep_self_alignments = 0)");
+    const int H = m->cfg.n_attention_head;
+    if (which == 0)     // [B,H,maxT(q),maxT(k)] -> [B,H,n_frames(k),n_frames(q)]
+        hipLaunchKernelGGL(k_dec_align, dim3(64, s->B * H), dim3(256), 0, S_(stream), (const float*)s->selfP[layer], align_out, H, s->maxT,
+                           s->maxT, n_frames, n_frames);
+    else
+        hipLaunchKernelGGL(k_dec_align, dim3(64, s->B * H), dim3(256), 0, S_(stream), (const float*)s->crossP[layer], align_out, H, s->maxT,
+                           s->S, s->S, n_frames);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" void b2s_decode_end(b2s_decode_state* s) {
+    if (!s) return;
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    delete s;
+}

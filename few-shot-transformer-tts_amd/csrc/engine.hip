@@ -1027,6 +1027,8 @@ extern "C" int b2s_zero_grads(b2s_model* m, void* stream) {
     return 0;
 }
 
+int b2s_ensure_pe_export(b2s_model* m, int len) { return ensure_pe(m, len); }
+
 // exported to capi_ops.hip
 int b2s_attn_core_fwd_export(int dtype, hipStream_t st, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                              void* ctx, int ldc, int B, int H, int Lq, int Lk, int dh, int mask_mode, const int* klen,

@@ -24,6 +24,7 @@ struct GemmEpilogue {
     int ld_aux = 0;
     float aux_scale = 1.f;
     DropCfg drop = {0, 0, 1.f};           // dropout on the result, element index (z*M + m)*N + n
+    const int* drop_salt = nullptr;       // optional device int mixed into the dropout key (decode step index under hipGraph replay)
     const float* residual = nullptr;      // fp32, added after dropout
     int ldr = 0;
     const int* row_len = nullptr;         // zero rows with (m % rows_per_batch) >= row_len[m / rows_per_batch]

@@ -182,6 +182,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         if (e.conv_dw_cin > 0) { int j = n / e.conv_dw_cin; nst[b] = (n - j * e.conv_dw_cin) * 5 + j; }
     }
     const bool plain = !e.relu && !aux && !e.drop.thresh && !e.residual && !e.row_len;
+    DropCfg dcfg = e.drop;
+    if (e.drop.thresh && e.drop_salt) dcfg.key ^= b2s_hash32((uint32_t)(*e.drop_salt) * 2246822519u + 3266489917u);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 if (aux) v = TT<T>::ld(aux + (long)m * e.ld_aux + n) > 0.f ? v * e.aux_scale : 0.f;
                 if (e.drop.thresh) {
                     uint32_t idx = (uint32_t)(((long)z * g.M + m) * g.N + n);
-                    v = b2s_keep(e.drop, idx) ? v * e.drop.scale : 0.f;
+                    v = b2s_keep(dcfg, idx) ? v * dcfg.scale : 0.f;
                 }
                 if (e.residual) v += e.residual[(long)m * e.ldr + n];
                 if (rowzero) v = 0.f;

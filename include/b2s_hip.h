@@ -113,6 +113,25 @@ int b2s_loss_backward(b2s_model* m, const float* mel_bef, const float* mel_aft, 
 /* grad[p] += reg_weight * (*grad_scale) * p for the L2 member set (tacotron.py:144-146). */
 int b2s_l2_backward(b2s_model* m, const float* grad_scale, void* stream);
 
+/* ---- autoregressive decode (synthesize.py:17-72 eval_batch) -----------------------------------------
+ * KV-cached single-frame steps; with use_graph the step is captured once in a hipGraph and replayed per
+ * frame (step index / stop flags / lengths live in device memory).  Reference semantics are kept: a sample
+ * stops when its stop logit > 0, finished samples emit exact zeros, lengths follow the reference's
+ * target_lengths (incl. its off-by-one for samples that never stop).  Dropout (train != 0, the reference
+ * synthesises with decoder.train()) uses the in-kernel RNG salted with the step index. */
+typedef struct b2s_decode_state b2s_decode_state;
+size_t b2s_decode_ws_bytes(const b2s_model* m, int B, int S, int max_frames, int keep_self_alignments);
+int b2s_decode_begin(b2s_model* m, const float* memory, const int32_t* input_lengths, int B, int S, int max_frames, int train,
+                     uint64_t seed, int keep_self_alignments, void* ws, size_t ws_bytes, void* stream, b2s_decode_state** out);
+int b2s_decode_run(b2s_model* m, b2s_decode_state* s, int n_steps, int use_graph, void* stream);
+/* blocking: frames generated so far and whether every sample has stopped (the only host sync of the loop) */
+int b2s_decode_status(b2s_decode_state* s, int* frames_host, int* all_finished_host, void* stream);
+/* mels_out [B, n_frames, num_mels], lengths_out [B] int32 (device) */
+int b2s_decode_fetch(b2s_model* m, b2s_decode_state* s, int n_frames, float* mels_out, int32_t* lengths_out, void* stream);
+/* which = 1: encoder-decoder rows -> [B,H,S,n_frames]; which = 0: self rows -> [B,H,n_frames,n_frames] */
+int b2s_decode_alignment(b2s_model* m, b2s_decode_state* s, int which, int layer, int n_frames, float* align_out, void* stream);
+void b2s_decode_end(b2s_decode_state* s);
+
 /* ---- optimizer (train.py:130-131,188-189): Adam(lr, eps) with bias correction, over all bound
  * parameters; m/v are caller-owned flat fp32 state laid out like the bound grads.  step is 1-based.
  * l2 > 0 folds the L2 gradient (l2 * p) in; grad_scale multiplies the bound gradient first (1/world). */

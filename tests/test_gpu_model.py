@@ -215,13 +215,24 @@ def test_decode_eval_batch(tag, over, case):
     m.eval()
     nb = synth.synthetic_batch(cfg, B=3, S=10, T=4, seed=11, in_lens=[10, 6, 8])
     nb.pop("mel_targets"); nb.pop("target_lengths")
-    r = synthesize.eval_batch(m, dev_batch(nb), use_bar=False, bar_interval=-1)
+    b = dev_batch(nb)
+    r = synthesize.eval_batch(m, b, use_bar=False, bar_interval=-1, sync_interval=7, keep_self_alignments=True)
     pre = "%s_%s/" % (tag, case)
     assert [int(x) for x in r["generated_lengths"]] == g[pre + "generated_lengths"].tolist()
     assert np.abs(r["mel_pre"] - g[pre + "mel_pre"]).max() < 1e-3
     assert np.abs(r["mel_aft"] - g[pre + "mel_aft"]).max() < 1e-3
     for i in range(cfg.n_decoder_layer):
         assert (r["alignments"]["encdec"][i].argmax(axis=2) == g[pre + "align_argmax_%d" % i]).all()
+    # the KV-cached hipGraph loop agrees with the cache-free loop (the reference's algorithm) on the same kernels,
+    # and eager step launches agree with graph replay bit for bit
+    rr = synthesize.eval_batch_recompute(m, b)
+    assert [int(x) for x in rr["generated_lengths"]] == [int(x) for x in r["generated_lengths"]]
+    assert np.abs(rr["mel_pre"] - r["mel_pre"]).max() < 2e-4
+    for i in range(cfg.n_decoder_layer):
+        assert np.abs(rr["alignments"]["encdec"][i] - r["alignments"]["encdec"][i]).max() < 1e-4
+        assert np.abs(rr["alignments"]["self"][i] - r["alignments"]["self"][i]).max() < 1e-4
+    re_ = synthesize.eval_batch(m, b, use_bar=False, bar_interval=-1, use_graph=False)
+    assert np.array_equal(re_["mel_pre"], r["mel_pre"]) and np.array_equal(re_["mel_aft"], r["mel_aft"])
 
 
 def test_fullsize_spot_checks_fp32():
