@@ -1,0 +1,99 @@
+"""Decode leg of bench.py: autoregressive eval_batch-equivalent (encoder + KV-cached hipGraph frame loop + postnet).
+
+Workload (BASELINE.json configs[3]): 64 utterances x 1000 mel frames, S=160, stop bias -100 so that exactly
+max_generation_frames=1000 steps run, default hparams, bf16, dropout at the reference's rates (the reference
+synthesises with decoder.train()).  Metric: generated frames per second over the whole job.
+"""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+PEAK_HBM_GBS = 8000.0
+
+
+def decode_bytes_per_step(B, S, t, e, Dd=768, Ld=6, weights=49.9e6):
+    """weights once + self-KV read + cross-KV read + KV append."""
+    return weights * e + Ld * 2 * B * Dd * e * (t + S + 1)
+
+
+def cpu_baseline_decode(frames=60, B=8, S=100):
+    from oracle import b2s_oracle as O, synth, make_config
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    cfg = make_config("max_generation_frames=%d,transformer_dropout_rate=0.0,decoder_dropout_rate=0.0" % frames)
+    st = synth.synthetic_state(cfg, 1)
+    st["decoder.stop_net.bias"] = np.full((1,), -100.0, dtype=np.float32)
+    P = O.to_torch_state(st)
+    nb = synth.synthetic_batch(cfg, B, S, 4, seed=0, n_spk=1, n_lang=1)
+    nb.pop("mel_targets"); nb.pop("target_lengths")
+    t0 = time.time()
+    r = O.eval_batch(P, cfg, O.to_torch_batch(nb))
+    dt = time.time() - t0
+    return {"value": round(B * frames / dt, 1), "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle eval_batch (reference algorithm, no KV cache), B=%d S=%d, %d frames, dropout 0; cost grows ~quadratically "
+                      "per frame, so 64x1000 is not run on the CPU" % (B, S, frames), "seconds": round(dt, 2)}
+
+
+def run_decode(args, rank, world, device):
+    from hyperparams import hparams as hp
+    from transformer.tacotron import Tacotron, initialize_variables
+    import synthesize
+    from oracle import synth, make_config
+    B, S, frames = 64, 160, 1000
+    hp.parse("compute_dtype=%s,max_generation_frames=%d" % (args.dtype, frames))
+    torch.manual_seed(0)
+    model = Tacotron(hp)
+    initialize_variables(model)
+    with torch.no_grad():
+        model.decoder.stop_net.bias.fill_(-100.0)
+    model = model.to(device)
+    model.eval()
+    model.decoder.train()                      # the reference's synthesis mode (eval.py:116-117): decoder dropout live
+    cfg = make_config("")
+    nb = synth.synthetic_batch(cfg, B, S, 4, seed=rank, in_lens=[S] * B, n_spk=1, n_lang=1)
+    nb.pop("mel_targets"); nb.pop("target_lengths")
+    batch = {k: (torch.from_numpy(np.asarray(v)).to(device) if not isinstance(v, list) else v) for k, v in nb.items()}
+    for _ in range(max(1, min(args.warmup, 1))):
+        hp.parse("max_generation_frames=32")
+        synthesize.eval_batch(model, batch, use_bar=False, bar_interval=-1)
+        hp.parse("max_generation_frames=%d" % frames)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    reps = max(1, args.steps // 10)
+    t0 = time.perf_counter()
+    total = 0
+    for _ in range(reps):
+        r = synthesize.eval_batch(model, batch, use_bar=False, bar_interval=-1, sync_interval=64)
+        total += int(np.minimum(np.asarray(r["generated_lengths"]), frames).sum())
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert np.isfinite(r["mel_aft"]).all()
+    if rank == 0:
+        e = 2 if args.dtype == "bf16" else 4
+        step_ms = elapsed / reps / frames * 1e3
+        avg_bytes = float(np.mean([decode_bytes_per_step(B, S, t, e) for t in range(frames)]))
+        ach = avg_bytes / (step_ms * 1e-3) / 1e9
+        out = {"metric": "autoregressive decode mel-frames/sec (encoder + KV-cached hipGraph frame loop + postnet)",
+               "value": round(world * total / elapsed, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": reps * frames,
+               "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "eval_batch: %d utterances x %d frames, S=%d, stop bias -100, decoder dropout on, default hparams"
+                                      % (B, frames, S), "parallelism": "replicas x%d" % world},
+               "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_step_avg": avg_bytes,
+                            "note": "algorithmic bytes per frame step (weights + KV) / wall time per frame incl. encoder and postnet"}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_decode()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
