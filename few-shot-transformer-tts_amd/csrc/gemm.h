@@ -47,3 +47,5 @@ struct GemmArgs {
 
 // dtype: 0 = fp32 (mfma_f32_16x16x4f32), 1 = bf16 (mfma_f32_16x16x32_bf16, fp32 accumulate)
 int b2s_gemm_launch(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t stream);
+// bf16 LDS-DMA (global_load_lds) + swizzled-LDS main loop (gemm_glds.hip)
+int b2s_gemm_glds_launch(const GemmArgs& g, bool ta, bool tb, hipStream_t stream);

@@ -1,0 +1,334 @@
+// bf16 MFMA GEMM, second-generation main loop for gfx950: operands go HBM -> LDS directly with
+// global_load_lds_dwordx4 (LDS-DMA, no staging VGPRs, no ds_write pass), LDS tiles are dense and XOR-swizzled so
+// that both the K-contiguous fragment reads (ds_read_b128) and the reduction-major fragment reads
+// (ds_read_b64_tr_b16) are bank-conflict free, and the next K tile's DMA is in flight while the current tile's
+// MFMAs run (one s_barrier per K tile).  Same contract / epilogues as gemm_kernel in gemm.hip.
+//
+// The LDS-DMA writes lane-linearly (wave base + lane*16 B), so the swizzle is applied on the SOURCE side: lane L
+// of a DMA instruction owns LDS slot L and fetches the global chunk whose swizzled position is L.
+//   N tile  [128 rows][32 k]   (64 B rows, 4 chunks):   physical chunk = chunk ^ ((-(row >> 2)) & 3)
+//   T tile  [32 k][128 cols]   (256 B rows, 16 chunks): physical chunk = chunk ^ (((k & 3) | ((k >> 1) & 4)) << 1)
+// K is walked in BK = 32 steps through an NSTAGE-deep LDS ring: NSTAGE-1 tiles are in flight, each wave waits only for
+// its own DMA of the tile it is about to use (counted s_waitcnt vmcnt, never 0 in steady state) and one raw s_barrier
+// per tile publishes it to the other waves and frees the oldest slot.
+#include "gemm.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int TILE = 128 * 32;            // elements per operand tile (8 KB)
+constexpr int NSTAGE = 4;
+
+typedef __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
+
+__device__ inline int swz_t(int k) { return ((k & 3) | ((k >> 1) & 4)) << 1; }
+__device__ inline int swz_n(int r) { return (-(r >> 2)) & 3; }
+
+// global address of the 16-byte chunk (stored row r, stored col c) of an operand, or the zero page
+__device__ inline const bf16_t* chunk_src(const GemmOperand& o, const bf16_t* base, int r, int c, const bf16_t* zero) {
+    if (r >= o.R || c >= o.C) return zero;
+    if (o.g_cin > 0) {
+        int j = c / o.g_cin, ci = c - j * o.g_cin;
+        int b = r / o.g_T, t = r - b * o.g_T;
+        int ts = t + j - 2;
+        int lim = o.g_len ? min(o.g_len[b], o.g_T) : o.g_T;
+        if (ts < 0 || ts >= lim) return zero;
+        return base + (long)(b * o.g_T + ts) * o.ld + ci;
+    }
+    return base + (long)r * o.ld + c;
+}
+
+template <bool TA, bool TB, bool GATHER>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf16_t* zero) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);      // [buf][A tile | B tile]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z = blockIdx.z / g.splitk, ksplit = blockIdx.z - z * g.splitk;
+    const int zo = z / g.batch_inner, zi = z - zo * g.batch_inner;
+    const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.p) + zo * g.A.bs_o + zi * g.A.bs_i;
+    const bf16_t* Bb = reinterpret_cast<const bf16_t*>(g.B.p) + zo * g.B.bs_o + zi * g.B.bs_i;
+
+    // DMA issue: wave w owns instructions q = w*2 + i (i = 0..1) of each operand tile; instruction q fills LDS bytes
+    // [q*1024, q*1024 + 1024) of the tile.  For plain (non-gather) operands the source address of a lane is affine
+    // in the K-tile index, so it is computed once: pointer at tile 0, a per-tile step and a validity bound.
+    const bf16_t* pa[2]; const bf16_t* pb[2];
+    int ka[2], kb_[2];            // reduction index (relative to the tile start) this lane's chunk covers; -1 = never valid
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave * 2 + i;
+        if (TA) { int kr = q * 4 + (lane >> 4), pc = lane & 15; int c = m0 + ((pc ^ swz_t(kr)) << 3);
+                  ka[i] = c < g.A.C ? kr : -1; pa[i] = Ab + (long)kr * g.A.ld + c; }
+        else    { int r = q * 16 + (lane >> 2), pc = lane & 3; int c = (pc ^ swz_n(r)) << 3;
+                  ka[i] = (m0 + r) < g.A.R ? c : -1; pa[i] = Ab + (long)(m0 + r) * g.A.ld + c; }
+        if (TB) { int kr = q * 4 + (lane >> 4), pc = lane & 15; int c = n0 + ((pc ^ swz_t(kr)) << 3);
+                  kb_[i] = c < g.B.C ? kr : -1; pb[i] = Bb + (long)kr * g.B.ld + c; }
+        else    { int r = q * 16 + (lane >> 2), pc = lane & 3; int c = (pc ^ swz_n(r)) << 3;
+                  kb_[i] = (n0 + r) < g.B.R ? c : -1; pb[i] = Bb + (long)(n0 + r) * g.B.ld + c; }
+    }
+    const long stepA = TA ? (long)BK * g.A.ld : BK, stepB = TB ? (long)BK * g.B.ld : BK;
+    const int limA = TA ? g.A.R : g.A.C, limB = TB ? g.B.R : g.B.C;      // bound of the reduction index
+
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int per = (nk_all + g.splitk - 1) / g.splitk;
+    const int kt0 = ksplit * per;
+    const int kt_end = min(nk_all, kt0 + per);
+    const int nk = kt_end - kt0;
+    if (nk <= 0) return;
+
+    // Always issues exactly 4 DMA instructions per wave (tiles past the end fetch the zero page into a slot nobody
+    // reads again), so the in-flight count is a compile-time constant and the waits below never drain the queue.
+    auto issue = [&](int kt, int buf) {
+        const int kb = kt < kt_end ? kt * BK : (1 << 28);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = wave * 2 + i;
+            const bf16_t *sa, *sb;
+            if (GATHER) {
+                if (TA) { int kr = q * 4 + (lane >> 4), pc = lane & 15; int c = pc ^ swz_t(kr); sa = chunk_src(g.A, Ab, kb + kr, m0 + c * 8, zero); }
+                else    { int r = q * 16 + (lane >> 2), pc = lane & 3; int c = pc ^ swz_n(r);   sa = chunk_src(g.A, Ab, m0 + r, kb + c * 8, zero); }
+                if (TB) { int kr = q * 4 + (lane >> 4), pc = lane & 15; int c = pc ^ swz_t(kr); sb = chunk_src(g.B, Bb, kb + kr, n0 + c * 8, zero); }
+                else    { int r = q * 16 + (lane >> 2), pc = lane & 3; int c = pc ^ swz_n(r);   sb = chunk_src(g.B, Bb, n0 + r, kb + c * 8, zero); }
+            } else {
+                sa = (ka[i] >= 0 && kb + ka[i] < limA) ? pa[i] + kt * stepA : zero;
+                sb = (kb_[i] >= 0 && kb + kb_[i] < limB) ? pb[i] + kt * stepB : zero;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(smem + buf * 2 * TILE + q * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(smem + buf * 2 * TILE + TILE + q * 512), 16, 0, 0);
+        }
+    };
+    // fragment of the 16 x 32 block (rows row0.., k = ks*32..) of an operand tile
+    auto frag = [&](const bf16_t* tile, bool trans, int row0) -> bf16x8_t {
+        if (!trans) {
+            const int r = row0 + li;
+            return *reinterpret_cast<const bf16x8_t*>(tile + r * 32 + ((lg ^ swz_n(r)) << 3));
+        }
+        const int k = lg * 8 + (li >> 2);
+        const int col = row0 + (li & 3) * 4;
+        const int sw = ((li >> 2) | ((lg & 1) << 2)) << 1;              // = swz_t(k) = swz_t(k + 4)
+        const int off = (((col >> 3) ^ sw) << 3) + (col & 7);
+        bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)(tile + k * 128 + off));
+        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)(tile + (k + 4) * 128 + off));
+        bf16x8_t r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // Software pipeline: the DMA ring keeps NSTAGE-1 tiles in flight; the fragments of tile kt+1 are read from LDS while
+    // the 16 MFMAs of tile kt execute (register double buffer), so neither HBM nor LDS latency is exposed.
+#define B2S_MMA16(CA, CB)                                                                                         \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < 4; ++b)                   \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CA[a], CB[b], acc[a][b], 0, 0, 0);
+#define B2S_STEP(KT, CA, CB, NA, NB)                                                                              \
+    {                                                                                                              \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTAGE - 3)) : "memory"); /* tile KT+1 landed (own DMAs) */    \
+        __builtin_amdgcn_s_barrier();             /* ... for every wave; tile KT-1 is fully consumed */             \
+        issue(kt0 + (KT) + NSTAGE - 1, ((KT) + NSTAGE - 1) % NSTAGE);                                              \
+        const bf16_t* tA_ = smem + (((KT) + 1) % NSTAGE) * 2 * TILE;                                               \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                            \
+            NA[t] = frag(tA_, TA, wrow + t * 16);                                                                  \
+            NB[t] = frag(tA_ + TILE, TB, wcol + t * 16);                                                           \
+        }                                                                                                          \
+        B2S_MMA16(CA, CB)                                                                                          \
+    }
+#pragma unroll
+    for (int p = 0; p < NSTAGE - 1; ++p) issue(kt0 + p, p);
+    bf16x8_t fa0[4], fb0[4], fa1[4], fb1[4];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTAGE - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { fa0[t] = frag(smem, TA, wrow + t * 16); fb0[t] = frag(smem + TILE, TB, wcol + t * 16); }
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+        B2S_STEP(kt, fa0, fb0, fa1, fb1)
+        B2S_STEP(kt + 1, fa1, fb1, fa0, fb0)
+    }
+    if (kt + 1 < nk) {          // two tiles left
+        B2S_STEP(kt, fa0, fb0, fa1, fb1)
+        B2S_MMA16(fa1, fb1)
+    } else {                    // one tile left
+        B2S_MMA16(fa0, fb0)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the trailing zero-page DMAs before the LDS goes away
+#undef B2S_STEP
+#undef B2S_MMA16
+
+    // ---------------- epilogue.  The accumulators (MFMA layout: col = lane & 15, row = (lane >> 4)*4 + r) are staged
+    // through LDS (the operand ring is dead now) so that every lane owns 8 consecutive output columns of one row:
+    // bf16 results leave as 16-byte stores, residual / ReLU-mask / bias operands arrive as 16-byte loads.
+    const GemmEpilogue& e = g.epi;
+    if (g.splitk > 1 || e.conv_dw_cin > 0) {
+        // weight-gradient forms: linear fp32 accumulate straight from the MFMA layout (16 lanes = 64 contiguous bytes
+        // per atomic / store instruction)
+        float* Cw = reinterpret_cast<float*>(g.C) + zo * g.cs_o + zi * g.cs_i;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wrow + a * 16 + lg * 4 + r;
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    int nn = n0 + wcol + b * 16 + li;
+                    if (nn >= g.N) continue;
+                    if (e.conv_dw_cin > 0) { int jj = nn / e.conv_dw_cin; nn = (nn - jj * e.conv_dw_cin) * 5 + jj; }
+                    const float v = acc[a][b][r] * e.alpha;
+                    float* dst = Cw + (long)m * g.ldc + nn;
+                    if (g.splitk > 1) atomicAdd(dst, v); else if (e.accumulate) *dst += v; else *dst = v;
+                }
+            }
+        return;
+    }
+    __builtin_amdgcn_s_barrier();                          // every wave is done reading the operand ring
+    float* stg = reinterpret_cast<float*>(smem_raw) + wave * (64 * 64);      // 16 KB per wave
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = a * 16 + lg * 4 + r;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) stg[row * 64 + ((b * 16 + li) ^ (((row >> 2) & 1) << 4))] = acc[a][b][r];
+        }
+    // (same-wave LDS hand-off: DS operations of one wave complete in order)
+    const long cbase = zo * g.cs_o + zi * g.cs_i;
+    float* Cf = reinterpret_cast<float*>(g.C);
+    bf16_t* Ct = reinterpret_cast<bf16_t*>(g.C);
+    const bf16_t* aux = reinterpret_cast<const bf16_t*>(e.relu_aux);
+    DropCfg dcfg = e.drop;
+    if (e.drop.thresh && e.drop_salt) dcfg.key ^= b2s_hash32((uint32_t)(*e.drop_salt) * 2246822519u + 3266489917u);
+    const bool vec_ok = (g.ldc & 7) == 0 && (cbase & 7) == 0 && e.conv_dw_cin == 0 && g.splitk == 1 &&
+                        ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+    const int cchunk = lane & 7;
+    const int n = n0 + wcol + cchunk * 8;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = (e.bias && n + j < g.N) ? e.bias[n + j] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int row = p * 8 + (lane >> 3);
+        const int m = m0 + wrow + row;
+        const float4 v0 = *reinterpret_cast<const float4*>(stg + row * 64 + ((cchunk * 8) ^ (((row >> 2) & 1) << 4)));
+        const float4 v1 = *reinterpret_cast<const float4*>(stg + row * 64 + ((cchunk * 8) ^ (((row >> 2) & 1) << 4)) + 4);
+        if (m >= g.M || n >= g.N) continue;
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + bv[j];
+        if (e.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        const bool full = n + 8 <= g.N;
+        if (aux) {
+            if (full && (e.ld_aux & 7) == 0) {
+                const uint4 u = *reinterpret_cast<const uint4*>(aux + (long)m * e.ld_aux + n);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t bits = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;      // bf16 > 0  <=>  sign clear and non-zero
+                    v[j] = (bits != 0 && !(bits & 0x8000u)) ? v[j] * e.aux_scale : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (n + j < g.N) v[j] = bf2f(aux[(long)m * e.ld_aux + n + j]) > 0.f ? v[j] * e.aux_scale : 0.f;
+            }
+        }
+        if (e.drop.thresh) {
+            const uint32_t idx = (uint32_t)(((long)z * g.M + m) * g.N + n);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = b2s_keep(dcfg, idx + j) ? v[j] * dcfg.scale : 0.f;
+        }
+        if (e.residual) {
+            if (full && (e.ldr & 3) == 0) {
+                const float4 r0 = *reinterpret_cast<const float4*>(e.residual + (long)m * e.ldr + n);
+                const float4 r1 = *reinterpret_cast<const float4*>(e.residual + (long)m * e.ldr + n + 4);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (n + j < g.N) v[j] += e.residual[(long)m * e.ldr + n + j];
+            }
+        }
+        if (e.row_len) {
+            const int bb = m / e.rows_per_batch, t = m - bb * e.rows_per_batch;
+            if (t >= e.row_len[bb]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+        }
+        const long off = cbase + (long)m * g.ldc + n;
+        if (vec_ok && full) {
+            if (g.c_fp32) {
+                float4* dst = reinterpret_cast<float4*>(Cf + off);
+                float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+                if (e.accumulate) {
+                    const float4 c0 = dst[0], c1 = dst[1];
+                    o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
+                }
+                dst[0] = o0; dst[1] = o1;
+            } else {
+                uint4 o;
+                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+                *reinterpret_cast<uint4*>(Ct + off) = o;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (n + j >= g.N) continue;
+                int nn = n + j;
+                if (e.conv_dw_cin > 0) { int jj = nn / e.conv_dw_cin; nn = (nn - jj * e.conv_dw_cin) * 5 + jj; }
+                const long o = cbase + (long)m * g.ldc + nn;
+                if (g.c_fp32) { if (g.splitk > 1) atomicAdd(Cf + o, v[j]); else if (e.accumulate) Cf[o] += v[j]; else Cf[o] = v[j]; }
+                else Ct[o] = f2bf(v[j]);
+            }
+        }
+    }
+}
+
+bf16_t* g_zero_page = nullptr;
+
+template <bool TA, bool TB, bool GATHER>
+int launch_t(const GemmArgs& g, hipStream_t stream) {
+    constexpr size_t smem = NSTAGE * 2 * (size_t)TILE * sizeof(bf16_t);     // 16 KB per stage
+    static bool attr_set = false;
+    if (!attr_set) {
+        B2S_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<TA, TB, GATHER>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch * g.splitk);
+    hipLaunchKernelGGL((gemm_glds_kernel<TA, TB, GATHER>), grid, dim3(256), smem, stream, g, (const bf16_t*)g_zero_page);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+int b2s_gemm_glds_launch(const GemmArgs& g, bool ta, bool tb, hipStream_t stream) {
+    if (!g_zero_page) {
+        B2S_HIP(hipMalloc(&g_zero_page, 256));
+        B2S_HIP(hipMemset(g_zero_page, 0, 256));
+    }
+    const bool gather = g.A.g_cin > 0 || g.B.g_cin > 0;
+    if (gather) {       // conv1d forms: forward / backward-data (NT, gather on A) and weight gradient (TN, gather on B)
+        if (!ta && !tb) return launch_t<false, false, true>(g, stream);
+        if (ta && tb) return launch_t<true, true, true>(g, stream);
+        return b2s_fail(__FILE__, __LINE__, "conv gather is supported for the NT and TN forms only");
+    }
+    if (!ta && !tb) return launch_t<false, false, false>(g, stream);
+    if (!ta && tb) return launch_t<false, true, false>(g, stream);
+    if (ta && !tb) return launch_t<true, false, false>(g, stream);
+    return launch_t<true, true, false>(g, stream);
+}
