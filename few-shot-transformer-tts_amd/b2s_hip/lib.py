@@ -73,6 +73,13 @@ _PROTOS = {
                                         C.c_int, C.c_int, C.c_int, P, P, C.c_int64, C.c_int64, C.c_float, C.c_uint64, P, P, P, P]),
     "b2s_attention_backward": (C.c_int, [C.c_int, P, C.c_int, P, C.c_int, P, C.c_int, P, C.c_int, P, P, P, C.c_int, P, C.c_int,
                                          P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, P, P]),
+    "b2s_flash_attention_forward": (C.c_int, [C.c_int, P, C.c_int, P, C.c_int, P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, P, C.c_float, C.c_uint64, P, P]),
+    "b2s_flash_attention_backward": (C.c_int, [C.c_int, P, P, C.c_int, P, C.c_int, P, C.c_int, P, C.c_int, P, P, P, C.c_int, P, C.c_int,
+                                               P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_float,
+                                               C.c_uint64, P]),
+    "b2s_flash_attention_align": (C.c_int, [C.c_int, P, C.c_int, P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P,
+                                            P]),
     "b2s_align_from_probs": (C.c_int, [C.c_int, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P]),
     "b2s_add": (C.c_int, [P, P, P, C.c_int64, P]),
     "b2s_cast": (C.c_int, [C.c_int, P, P, C.c_int64, P]),

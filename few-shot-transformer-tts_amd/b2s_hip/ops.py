@@ -176,5 +176,55 @@ class AttentionCoreFn(torch.autograd.Function):
         return (from_compute(dq, dtype), from_compute(dk, dtype), from_compute(dv, dtype)) + (None,) * 7
 
 
-def attention_core(q, k, v, H, mask_mode=0, klen=None, bias=None, drop_p=0.0, seed=0, dtype=0):
+class FlashAttentionFn(torch.autograd.Function):
+    """Fused attention core (csrc/attention.hip): same contract as AttentionCoreFn, logits never materialised; the
+    returned weights are recomputed on demand from the saved log-sum-exp."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H, mask_mode, klen, drop_p, seed, dtype, want_probs):
+        B, Lq, Cq = q.shape
+        Lk = k.shape[1]
+        dh = Cq // H
+        lib = L.load()
+        qT, kT, vT = to_compute(q, dtype), to_compute(k, dtype), to_compute(v, dtype)
+        out = torch.empty(B, Lq, Cq, dtype=qT.dtype, device=q.device)
+        lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+        L.check(lib.b2s_flash_attention_forward(dtype, L.ptr(qT), Cq, L.ptr(kT), Cq, L.ptr(vT), Cq, L.ptr(out), Cq, B, H, Lq, Lk, dh,
+                                                mask_mode, L.ptr(klen), drop_p, seed, L.ptr(lse), L.stream()))
+        probs = torch.empty(0, device=q.device)
+        if want_probs:
+            al = torch.empty(B, H, Lk, Lq, dtype=torch.float32, device=q.device)
+            L.check(lib.b2s_flash_attention_align(dtype, L.ptr(qT), Cq, L.ptr(kT), Cq, L.ptr(lse), B, H, Lq, Lk, dh, mask_mode,
+                                                  L.ptr(klen), L.ptr(al), L.stream()))
+            probs = al.permute(0, 1, 3, 2)
+        ctx.save_for_backward(qT, kT, vT, out, lse, klen)
+        ctx.cfg = (B, H, Lq, Lk, dh, mask_mode, drop_p, seed, dtype)
+        ctx.mark_non_differentiable(probs)
+        return from_compute(out, dtype), probs
+
+    @staticmethod
+    def backward(ctx, dctx, _dprobs):
+        qT, kT, vT, out, lse, klen = ctx.saved_tensors
+        B, H, Lq, Lk, dh, mask_mode, drop_p, seed, dtype = ctx.cfg
+        lib = L.load()
+        Cq = H * dh
+        dT = to_compute(dctx, dtype)
+        dsum = torch.empty(B, H, Lq, dtype=torch.float32, device=dctx.device)
+        dq, dk, dv = torch.empty_like(qT), torch.empty_like(kT), torch.empty_like(vT)
+        L.check(lib.b2s_flash_attention_backward(dtype, L.ptr(dT), L.ptr(out), Cq, L.ptr(qT), Cq, L.ptr(kT), Cq, L.ptr(vT), Cq, L.ptr(lse),
+                                                 L.ptr(dsum), L.ptr(dq), Cq, L.ptr(dk), Cq, L.ptr(dv), Cq, B, H, Lq, Lk, dh, mask_mode,
+                                                 L.ptr(klen), drop_p, seed, L.stream()))
+        return (from_compute(dq, dtype), from_compute(dk, dtype), from_compute(dv, dtype)) + (None,) * 7
+
+
+def attention_core(q, k, v, H, mask_mode=0, klen=None, bias=None, drop_p=0.0, seed=0, dtype=0, fused=None):
+    """fused=None: use the fused kernel whenever it applies (head size 32/64/96 and no dense bias)."""
+    dh = q.shape[-1] // H
+    can = bias is None and dh in (32, 64, 96)
+    if fused is None:
+        fused = can
+    if fused:
+        if not can:
+            raise ValueError("fused attention needs head size 32/64/96 and no dense bias")
+        return FlashAttentionFn.apply(q, k, v, H, mask_mode, klen, drop_p, seed, dtype, True)
     return AttentionCoreFn.apply(q, k, v, H, mask_mode, klen, bias, drop_p, seed, dtype)

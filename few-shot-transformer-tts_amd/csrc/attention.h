@@ -1,0 +1,26 @@
+// Fused (flash-style) attention kernels, see attention.hip.
+#pragma once
+#include "b2s_common.h"
+
+struct AttnArgs {
+    const void *q = nullptr, *k = nullptr, *v = nullptr;   // [B, L, H*dh] rows with leading dimensions ldq / ldk / ldv
+    int ldq = 0, ldk = 0, ldv = 0;
+    void* out = nullptr;                                   // forward: context [B, Lq, H*dh] (ld ldo)
+    int ldo = 0;
+    int B = 0, H = 0, Lq = 0, Lk = 0;
+    float scale = 1.f;
+    int mask_mode = 0;                                     // bit0: keys >= klen[b] masked, bit1: causal
+    const int* klen = nullptr;
+    DropCfg drop = {0, 0, 1.f};                            // dropout on the weights, element index ((z*Lq + q)*Lk + k)
+    float* lse = nullptr;                                  // [B*H, Lq] log-sum-exp of the scaled, masked logits
+    // backward
+    const void* dout = nullptr;                            // d context (ld ldo)
+    float* dsum = nullptr;                                 // [B*H, Lq] scratch: rowsum(dO * O)
+    void *dq = nullptr, *dk = nullptr, *dv = nullptr;
+    int lddq = 0, lddk = 0, lddv = 0;
+};
+
+bool b2s_flash_supported(int dh);
+int b2s_flash_fwd(int dtype, const AttnArgs& a, int dh, hipStream_t st);
+int b2s_flash_bwd(int dtype, const AttnArgs& a, int dh, const void* O, hipStream_t st);
+int b2s_flash_align(int dtype, const AttnArgs& a, int dh, float* align, hipStream_t st);

@@ -1,0 +1,435 @@
+// Fused multi-head attention for gfx950 (reference: transformer/attention.py:72-92 dot_product_attention and its
+// autograd backward).  Flash-style: the [Lq, Lk] logits / weights are never written to HBM.
+//
+//   forward   one workgroup = 64 query rows of one (batch, head): 4 waves x 16 rows.  K and V tiles of 64 keys are
+//             staged in LDS; S^T = K Q^T and O^T += V^T P^T run on MFMA (bf16: 16x16x32, fp32 parity mode: 16x16x4);
+//             the swapped products leave every lane with 16 logits of ONE query row per tile, so the online softmax
+//             needs only two wavefront shuffles (across the four 16-lane groups) per tile.  Masks come from the
+//             lengths / causal structure, dropout from the counter RNG (same element index as the backward).
+//   backward  two kernels that recompute P from the saved log-sum-exp: dQ (per 64 query rows, loops over key tiles)
+//             and dK/dV (per 64 keys, loops over query tiles).  D = rowsum(dO * O) comes from a tiny prep kernel.
+//
+// Operand layouts: q [B, Lq, H*dh] with leading dimension ldq (heads interleaved, exactly as the fused QKV / KV
+// projection GEMMs write them), k, v likewise; ctx [B, Lq, H*dh].
+#include "b2s_common.h"
+#include "attention.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
+
+template <typename T> struct AT;
+template <> struct AT<float> {
+    static constexpr int PAD = 4, VE = 4;
+    typedef float frag;                      // one fp32 per lane per 16x16x4 MFMA operand
+};
+template <> struct AT<bf16_t> {
+    static constexpr int PAD = 8, VE = 8;
+    typedef bf16x8_t frag;                   // 8 bf16 per lane per 16x16x32 MFMA operand
+};
+
+__device__ inline f32x4_t mma(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ inline f32x4_t mma(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// cooperative load of a [64][DH] tile (rows row0.. of a [rows, ld] matrix, zero beyond nrows) into LDS [64][DH+PAD]
+template <typename T, int DH>
+__device__ inline void load_tile(T* lds, const T* src, long ld, int row0, int nrows, int tid) {
+    constexpr int VE = AT<T>::VE, LD = DH + AT<T>::PAD, VPR = DH / VE;
+    for (int v = tid; v < 64 * VPR; v += 256) {
+        const int r = v / VPR, c = (v - r * VPR) * VE;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (row0 + r < nrows) val = *reinterpret_cast<const uint4*>(src + (long)(row0 + r) * ld + c);
+        *reinterpret_cast<uint4*>(lds + r * LD + c) = val;
+    }
+}
+
+// ---- fragment helpers (lane: li = lane & 15, lg = lane >> 4)
+// row-operand fragment: element rows (row0 + li), k columns of step ks            (K-contiguous read)
+template <int LD> __device__ inline float frag_row(const float* t, int row0, int ks, int li, int lg) { return t[(row0 + li) * LD + ks * 4 + lg]; }
+template <int LD> __device__ inline bf16x8_t frag_row(const bf16_t* t, int row0, int ks, int li, int lg) {
+    return *reinterpret_cast<const bf16x8_t*>(t + (row0 + li) * LD + ks * 32 + lg * 8);
+}
+// same fragment taken straight from global memory (the wave's own 16 rows; rows beyond nrows read row `clamp`)
+template <typename T> __device__ inline typename AT<T>::frag frag_global(const T* base, long ld, int row, int ks, int lg);
+template <> __device__ inline float frag_global<float>(const float* base, long ld, int row, int ks, int lg) { return base[row * ld + ks * 4 + lg]; }
+template <> __device__ inline bf16x8_t frag_global<bf16_t>(const bf16_t* base, long ld, int row, int ks, int lg) {
+    return *reinterpret_cast<const bf16x8_t*>(base + row * ld + ks * 32 + lg * 8);
+}
+// transposed fragment for the "second" products (reduction over the tile's 64 rows, output dim = tile columns):
+// bf16: rows {r0 + lg*4 + j, r1 + lg*4 + j}, column c0 + li, via two transpose reads; the matching P fragment packs
+// p[t0][0..3], p[t1][0..3].
+template <int LD> __device__ inline bf16x8_t frag_tr(const bf16_t* t, int r0, int r1, int c0, int li, int lg) {
+    const bf16_t* p0 = t + (r0 + lg * 4 + (li >> 2)) * LD + c0 + (li & 3) * 4;
+    const bf16_t* p1 = t + (r1 + lg * 4 + (li >> 2)) * LD + c0 + (li & 3) * 4;
+    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)p0);
+    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)p1);
+    bf16x8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+__device__ inline bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
+    bf16x8_t r;
+    r[0] = (short)f2bf(a[0]); r[1] = (short)f2bf(a[1]); r[2] = (short)f2bf(a[2]); r[3] = (short)f2bf(a[3]);
+    r[4] = (short)f2bf(b[0]); r[5] = (short)f2bf(b[1]); r[6] = (short)f2bf(b[2]); r[7] = (short)f2bf(b[3]);
+    return r;
+}
+
+// acc[dt] (+)= sum over the tile's 64 rows of  tile[row][dt*16 + i] * w[row][j]     (w in the MFMA C layout of a
+// [64 rows x 16] block: w[t][r] belongs to row t*16 + lg*4 + r, column li)          -> result col = li, row = dt*16+lg*4+r
+template <typename T, int DH, int LD>
+__device__ inline void second_product(f32x4_t (&acc)[DH / 16], const T* tile, const f32x4_t (&w)[4], int li, int lg);
+template <int DH, int LD>
+__device__ inline void second_product_f32(f32x4_t (&acc)[DH / 16], const float* tile, const f32x4_t (&w)[4], int li, int lg) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float b = w[t][r];
+            const float* row = tile + (t * 16 + lg * 4 + r) * LD + li;
+#pragma unroll
+            for (int dt = 0; dt < DH / 16; ++dt) acc[dt] = mma(row[dt * 16], b, acc[dt]);
+        }
+}
+template <int DH, int LD>
+__device__ inline void second_product_bf16(f32x4_t (&acc)[DH / 16], const bf16_t* tile, const f32x4_t (&w)[4], int li, int lg) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const bf16x8_t b = pack8(w[2 * kb], w[2 * kb + 1]);
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt)
+            acc[dt] = mma(frag_tr<LD>(tile, kb * 32, kb * 32 + 16, dt * 16, li, lg), b, acc[dt]);
+    }
+}
+template <typename T, int DH, int LD> struct SP;
+template <int DH, int LD> struct SP<float, DH, LD> {
+    __device__ static inline void run(f32x4_t (&acc)[DH / 16], const float* tile, const f32x4_t (&w)[4], int li, int lg) { second_product_f32<DH, LD>(acc, tile, w, li, lg); }
+};
+template <int DH, int LD> struct SP<bf16_t, DH, LD> {
+    __device__ static inline void run(f32x4_t (&acc)[DH / 16], const bf16_t* tile, const f32x4_t (&w)[4], int li, int lg) { second_product_bf16<DH, LD>(acc, tile, w, li, lg); }
+};
+
+// first product: c[t] = sum_d tile[t*16 + i][d] * own[d][j]  -> c[t][r] = value(row t*16 + lg*4 + r of the tile, own row li)
+template <typename T, int DH, int LD>
+__device__ inline void first_product(f32x4_t (&c)[4], const T* tile, const typename AT<T>::frag (&own)[DH / (sizeof(T) == 2 ? 32 : 4)], int li, int lg) {
+    constexpr int NKS = DH / (sizeof(T) == 2 ? 32 : 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        c[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) c[t] = mma(frag_row<LD>(tile, t * 16, ks, li, lg), own[ks], c[t]);
+    }
+}
+
+__device__ inline float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ inline float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+// store a transposed accumulator (col = own row li, rows = feature dt*16 + lg*4 + r) as 4 consecutive features
+template <typename T, int DH>
+__device__ inline void store_rows(T* dst, const f32x4_t (&acc)[DH / 16], float mul, int lg) {
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+        T* p = dst + dt * 16 + lg * 4;
+        if (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(p) = make_float4(acc[dt][0] * mul, acc[dt][1] * mul, acc[dt][2] * mul, acc[dt][3] * mul);
+        } else {
+            uint2 u;
+            u.x = (uint32_t)f2bf(acc[dt][0] * mul) | ((uint32_t)f2bf(acc[dt][1] * mul) << 16);
+            u.y = (uint32_t)f2bf(acc[dt][2] * mul) | ((uint32_t)f2bf(acc[dt][3] * mul) << 16);
+            *reinterpret_cast<uint2*>(p) = u;
+        }
+    }
+}
+
+// ================================================================================================ forward
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
+    __shared__ __attribute__((aligned(16))) T sK[64 * LD];
+    __shared__ __attribute__((aligned(16))) T sV[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
+    const int qb0 = blockIdx.x * 64, q = qb0 + wave * 16 + li;
+    const int qc = min(q, a.Lq - 1);
+    const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
+    const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
+    typename AT<T>::frag qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = frag_global<T>(Q, a.ldq, qc, ks, lg);
+
+    int kend = a.Lk;
+    if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
+    int ktiles = (kend + 63) / 64;
+    if (a.mask_mode & 2) ktiles = min(ktiles, (min(qb0 + 63, a.Lq - 1)) / 64 + 1);
+    f32x4_t o[DH / 16];
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    const long drow = ((long)z * a.Lq + qc) * a.Lk;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int k0 = kt * 64;
+        __syncthreads();
+        load_tile<T, DH>(sK, K, a.ldk, k0, a.Lk, tid);
+        load_tile<T, DH>(sV, V, a.ldv, k0, a.Lk, tid);
+        __syncthreads();
+        f32x4_t s[4];
+        first_product<T, DH, LD>(s, sK, qf, li, lg);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + t * 16 + lg * 4 + r;
+                const bool ok = key < kend && (!(a.mask_mode & 2) || key <= q);
+                s[t][r] = ok ? s[t][r] * a.scale : -INFINITY;
+                mx = fmaxf(mx, s[t][r]);
+            }
+        mx = group_max(mx);
+        const float mn = fmaxf(m, mx);
+        const float msafe = mn == -INFINITY ? 0.f : mn;
+        const float alpha = __expf(m - msafe);          // m = -inf -> 0
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt) { o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __expf(s[t][r] - msafe);
+                l += p;
+                if (a.drop.thresh) {
+                    const int key = k0 + t * 16 + lg * 4 + r;
+                    p = b2s_keep(a.drop, (uint32_t)(drow + key)) ? p * a.drop.scale : 0.f;
+                }
+                s[t][r] = p;
+            }
+        SP<T, DH, LD>::run(o, sV, s, li, lg);
+    }
+    l = group_sum(l);
+    if (q < a.Lq) {
+        const float inv = 1.f / l;
+        T* out = reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q) * a.ldo + h * DH;
+        store_rows<T, DH>(out, o, inv, lg);
+        if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = m + __logf(l);
+    }
+}
+
+// ================================================================================================ backward
+// D[z, q] = sum_d dO[q][d] * O[q][d]
+template <typename T>
+__global__ void attn_bwd_prep_kernel(const T* dO, const T* O, int ldo, float* D, int H, int Lq, int dh, long rows) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);           // r = (b*Lq + q)*H + h
+    if (r >= rows) return;
+    const int h = (int)(r % H);
+    const long bq = r / H;
+    const int q = (int)(bq % Lq), b = (int)(bq / Lq);
+    float acc = 0.f;
+    for (int d = lane; d < dh; d += 64) acc += TT<T>::ld(dO + bq * ldo + h * dh + d) * TT<T>::ld(O + bq * ldo + h * dh + d);
+    acc = wave_sum(acc);
+    if (lane == 0) D[((long)b * H + h) * Lq + q] = acc;
+}
+
+// dQ: per workgroup 64 query rows; loops over key tiles
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
+    __shared__ __attribute__((aligned(16))) T sK[64 * LD];
+    __shared__ __attribute__((aligned(16))) T sV[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
+    const int qb0 = blockIdx.x * 64, q = qb0 + wave * 16 + li;
+    const int qc = min(q, a.Lq - 1);
+    const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
+    const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
+    const T* dO = reinterpret_cast<const T*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
+    typename AT<T>::frag qf[NKS], dof[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) { qf[ks] = frag_global<T>(Q, a.ldq, qc, ks, lg); dof[ks] = frag_global<T>(dO, a.ldo, qc, ks, lg); }
+    const float lse = a.lse[(long)z * a.Lq + qc], Dq = a.dsum[(long)z * a.Lq + qc];
+    int kend = a.Lk;
+    if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
+    int ktiles = (kend + 63) / 64;
+    if (a.mask_mode & 2) ktiles = min(ktiles, (min(qb0 + 63, a.Lq - 1)) / 64 + 1);
+    f32x4_t dq[DH / 16];
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const long drow = ((long)z * a.Lq + qc) * a.Lk;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int k0 = kt * 64;
+        __syncthreads();
+        load_tile<T, DH>(sK, K, a.ldk, k0, a.Lk, tid);
+        load_tile<T, DH>(sV, V, a.ldv, k0, a.Lk, tid);
+        __syncthreads();
+        f32x4_t s[4], dp[4];
+        first_product<T, DH, LD>(s, sK, qf, li, lg);
+        first_product<T, DH, LD>(dp, sV, dof, li, lg);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + t * 16 + lg * 4 + r;
+                const bool ok = key < kend && (!(a.mask_mode & 2) || key <= q);
+                const float p = ok ? __expf(s[t][r] * a.scale - lse) : 0.f;
+                float d = dp[t][r];
+                if (a.drop.thresh) d = b2s_keep(a.drop, (uint32_t)(drow + key)) ? d * a.drop.scale : 0.f;
+                s[t][r] = p * (d - Dq) * a.scale;
+            }
+        SP<T, DH, LD>::run(dq, sK, s, li, lg);
+    }
+    if (q < a.Lq) store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)b * a.Lq + q) * a.lddq + h * DH, dq, 1.f, lg);
+}
+
+// dK, dV: per workgroup 64 keys; loops over query tiles
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
+    __shared__ __attribute__((aligned(16))) T sQ[64 * LD];
+    __shared__ __attribute__((aligned(16))) T sO[64 * LD];
+    __shared__ float sL[64], sD[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
+    const int kb0 = blockIdx.x * 64, key = kb0 + wave * 16 + li;
+    const int kc = min(key, a.Lk - 1);
+    const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
+    const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
+    const T* dO = reinterpret_cast<const T*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
+    typename AT<T>::frag kf[NKS], vf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) { kf[ks] = frag_global<T>(K, a.ldk, kc, ks, lg); vf[ks] = frag_global<T>(V, a.ldv, kc, ks, lg); }
+    int kend = a.Lk;
+    if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
+    const bool key_ok = key < kend;
+    f32x4_t dk[DH / 16], dv[DH / 16];
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+    const int qtiles = (a.Lq + 63) / 64;
+    const int qt0 = (a.mask_mode & 2) ? kb0 / 64 : 0;          // causal: queries before this key tile never see it
+    for (int qt = qt0; qt < qtiles; ++qt) {
+        const int q0 = qt * 64;
+        __syncthreads();
+        load_tile<T, DH>(sQ, Q, a.ldq, q0, a.Lq, tid);
+        load_tile<T, DH>(sO, dO, a.ldo, q0, a.Lq, tid);
+        if (tid < 64) {
+            const int qq = min(q0 + tid, a.Lq - 1);
+            sL[tid] = a.lse[(long)z * a.Lq + qq]; sD[tid] = a.dsum[(long)z * a.Lq + qq];
+        }
+        __syncthreads();
+        f32x4_t s[4], dp[4], pd[4];
+        first_product<T, DH, LD>(s, sQ, kf, li, lg);          // s[t][r] = S[q = q0 + t*16 + lg*4 + r][key = own]
+        first_product<T, DH, LD>(dp, sO, vf, li, lg);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = t * 16 + lg * 4 + r, qq = q0 + ql;
+                const bool ok = key_ok && qq < a.Lq && (!(a.mask_mode & 2) || key <= qq);
+                const float p = ok ? __expf(s[t][r] * a.scale - sL[ql]) : 0.f;
+                float d = dp[t][r], pdv = p;
+                if (a.drop.thresh) {
+                    const bool keep = b2s_keep(a.drop, (uint32_t)(((long)z * a.Lq + min(qq, a.Lq - 1)) * a.Lk + kc));
+                    d = keep ? d * a.drop.scale : 0.f;
+                    pdv = keep ? p * a.drop.scale : 0.f;
+                }
+                pd[t][r] = pdv;
+                s[t][r] = p * (d - sD[ql]) * a.scale;
+            }
+        SP<T, DH, LD>::run(dv, sO, pd, li, lg);                // dV^T[d][key] += sum_q dO[q][d] * Pd[q][key]
+        SP<T, DH, LD>::run(dk, sQ, s, li, lg);                 // dK^T[d][key] += sum_q Q[q][d]  * dS[q][key]
+    }
+    if (key < a.Lk) {
+        store_rows<T, DH>(reinterpret_cast<T*>(a.dk) + ((long)b * a.Lk + key) * a.lddk + h * DH, dk, 1.f, lg);
+        store_rows<T, DH>(reinterpret_cast<T*>(a.dv) + ((long)b * a.Lk + key) * a.lddv + h * DH, dv, 1.f, lg);
+    }
+}
+
+// alignment rows on demand: align[z][k][q] = softmax weight, recomputed from q, k and the saved log-sum-exp
+template <typename T>
+__global__ __launch_bounds__(256) void attn_align_kernel(AttnArgs a, float* align, int dh) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);           // r = z*Lq + q
+    if (r >= (long)a.B * a.H * a.Lq) return;
+    const int q = (int)(r % a.Lq), z = (int)(r / a.Lq), b = z / a.H, h = z - b * a.H;
+    const T* Q = reinterpret_cast<const T*>(a.q) + ((long)b * a.Lq + q) * a.ldq + h * dh;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * dh;
+    int kend = a.Lk;
+    if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
+    if (a.mask_mode & 2) kend = min(kend, q + 1);
+    const float lse = a.lse[r];
+    for (int k = lane; k < a.Lk; k += 64) {
+        float p = 0.f;
+        if (k < kend) {
+            float s = 0.f;
+            for (int d = 0; d < dh; ++d) s += TT<T>::ld(Q + d) * TT<T>::ld(K + (long)k * a.ldk + d);
+            p = __expf(s * a.scale - lse);
+        }
+        align[((long)z * a.Lk + k) * a.Lq + q] = p;
+    }
+}
+
+template <typename T, int DH>
+int launch_dh(const AttnArgs& a, int which, hipStream_t st) {
+    if (which == 0) {
+        dim3 grid(cdiv(a.Lq, 64), a.B * a.H);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(256), 0, st, a);
+    } else if (which == 1) {
+        dim3 grid(cdiv(a.Lq, 64), a.B * a.H);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid(cdiv(a.Lk, 64), a.B * a.H);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DH>), grid, dim3(256), 0, st, a);
+    }
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+int launch_t(const AttnArgs& a, int dh, int which, hipStream_t st) {
+    switch (dh) {
+        case 32: return launch_dh<T, 32>(a, which, st);
+        case 64: return launch_dh<T, 64>(a, which, st);
+        case 96: return launch_dh<T, 96>(a, which, st);
+    }
+    return b2s_fail(__FILE__, __LINE__, "fused attention supports head sizes 32/64/96 (got %d)", dh);
+}
+int check(const AttnArgs& a, int dtype, int dh) {
+    const int ve = dtype ? 8 : 4;
+    B2S_CHECK(a.q && a.k && a.v && a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, "attention: bad argument");
+    B2S_CHECK(a.ldq % ve == 0 && a.ldk % ve == 0 && a.ldv % ve == 0 && (a.ldo % ve == 0), "attention: leading dimensions must be multiples of %d", ve);
+    B2S_CHECK(!(a.mask_mode & 1) || a.klen, "attention: key-length mask needs klen");
+    (void)dh;
+    return 0;
+}
+}  // namespace
+
+bool b2s_flash_supported(int dh) { return dh == 32 || dh == 64 || dh == 96; }
+
+int b2s_flash_fwd(int dtype, const AttnArgs& a, int dh, hipStream_t st) {
+    B2S_TRY(check(a, dtype, dh));
+    B2S_CHECK(a.out, "attention: null output");
+    return dtype ? launch_t<bf16_t>(a, dh, 0, st) : launch_t<float>(a, dh, 0, st);
+}
+int b2s_flash_bwd(int dtype, const AttnArgs& a, int dh, const void* O, hipStream_t st) {
+    B2S_TRY(check(a, dtype, dh));
+    B2S_CHECK(a.dout && a.dq && a.dk && a.dv && a.lse && a.dsum && O, "attention backward: null argument");
+    const long rows = (long)a.B * a.Lq * a.H;
+    if (dtype)
+        hipLaunchKernelGGL((attn_bwd_prep_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)a.dout, (const bf16_t*)O, a.ldo,
+                           a.dsum, a.H, a.Lq, dh, rows);
+    else
+        hipLaunchKernelGGL((attn_bwd_prep_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)a.dout, (const float*)O, a.ldo,
+                           a.dsum, a.H, a.Lq, dh, rows);
+    B2S_LAUNCH_CHECK();
+    B2S_TRY(dtype ? launch_t<bf16_t>(a, dh, 1, st) : launch_t<float>(a, dh, 1, st));
+    return dtype ? launch_t<bf16_t>(a, dh, 2, st) : launch_t<float>(a, dh, 2, st);
+}
+int b2s_flash_align(int dtype, const AttnArgs& a, int dh, float* align, hipStream_t st) {
+    B2S_CHECK(a.q && a.k && a.lse && align, "attention align: null argument");
+    const long rows = (long)a.B * a.H * a.Lq;
+    if (dtype) hipLaunchKernelGGL((attn_align_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, st, a, align, dh);
+    else hipLaunchKernelGGL((attn_align_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, a, align, dh);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}

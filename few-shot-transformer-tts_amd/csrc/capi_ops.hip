@@ -1,6 +1,7 @@
 // Op-level C ABI: thin wrappers used by the standalone modules (MultiheadAttention, FFNLayer, ...) and by
 // the op parity tests.  See include/b2s_hip.h.
 #include "engine.h"
+#include "attention.h"
 
 namespace {
 inline hipStream_t S_(void* s) { return (hipStream_t)s; }
@@ -75,6 +76,38 @@ extern "C" int b2s_attention_backward(int dtype, const void* dctx, int ldc, cons
     void* dS = (void*)((float*)ws + 2 * pn);
     return b2s_attn_core_bwd_export(dtype, S_(stream), dctx, ldc, q, ldq, k, ldk, v, ldv, P, Pd, dq, lddq, dk, lddk, dv, lddv, B, H,
                                     Lq, Lk, dh, make_drop(drop_p, seed, 11u), dP, dS);
+}
+// ---- fused attention (attention.hip)
+namespace {
+AttnArgs mk_args(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int H, int Lq, int Lk, int dh, int mask_mode,
+                 const int32_t* klen, float drop_p, uint64_t seed, float* lse) {
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
+    a.scale = 1.f / sqrtf((float)dh); a.mask_mode = mask_mode; a.klen = klen; a.drop = make_drop(drop_p, seed, 11u); a.lse = lse;
+    return a;
+}
+}  // namespace
+extern "C" int b2s_flash_attention_forward(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* ctx, int ldc,
+                                           int B, int H, int Lq, int Lk, int dh, int mask_mode, const int32_t* klen, float drop_p,
+                                           uint64_t seed, float* lse_out, void* stream) {
+    B2S_CHECK(ctx && lse_out, "null argument");
+    AttnArgs a = mk_args(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, mask_mode, klen, drop_p, seed, lse_out);
+    a.out = ctx; a.ldo = ldc;
+    return b2s_flash_fwd(dtype, a, dh, S_(stream));
+}
+extern "C" int b2s_flash_attention_backward(int dtype, const void* dctx, const void* ctx, int ldc, const void* q, int ldq, const void* k, int ldk,
+                                            const void* v, int ldv, const float* lse, float* dsum_scratch, void* dq, int lddq, void* dk,
+                                            int lddk, void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, int mask_mode,
+                                            const int32_t* klen, float drop_p, uint64_t seed, void* stream) {
+    B2S_CHECK(dctx && ctx && lse && dsum_scratch, "null argument");
+    AttnArgs a = mk_args(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, mask_mode, klen, drop_p, seed, const_cast<float*>(lse));
+    a.dout = dctx; a.ldo = ldc; a.dsum = dsum_scratch; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    return b2s_flash_bwd(dtype, a, dh, ctx, S_(stream));
+}
+extern "C" int b2s_flash_attention_align(int dtype, const void* q, int ldq, const void* k, int ldk, const float* lse, int B, int H, int Lq, int Lk,
+                                         int dh, int mask_mode, const int32_t* klen, float* align_out, void* stream) {
+    AttnArgs a = mk_args(q, ldq, k, ldk, nullptr, 0, B, H, Lq, Lk, dh, mask_mode, klen, 0.f, 0, const_cast<float*>(lse));
+    return b2s_flash_align(dtype, a, dh, align_out, S_(stream));
 }
 extern "C" int b2s_align_from_probs(int dtype, const void* P, float* align, int B, int H, int Lq, int Lk, void* stream) {
     B2S_CHECK(P && align, "null argument");

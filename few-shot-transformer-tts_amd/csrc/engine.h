@@ -40,6 +40,8 @@ struct AttnSave {            // one attention sub-layer
     void* kv = nullptr;      // cross: [B*S,2D]
     void *P = nullptr, *Pd = nullptr;   // softmax weights (T) [B,H,Lq,ldp] ; Pd == P when no dropout
     void* ctx = nullptr;     // [M,D] (T)
+    float* lse = nullptr;    // fused path: log-sum-exp [B*H, Lq]
+    int mask_mode = 0;
     int Lq = 0, Lk = 0, ldp = 0;
     uint32_t op_attn = 0, op_res = 0;
 };

@@ -9,7 +9,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include "engine.h"
+#include "attention.h"
 
 thread_local char g_b2s_err[512] = "";
 int b2s_fail(const char* file, int line, const char* fmt, ...) {
@@ -197,11 +199,28 @@ int linear_dw(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
 }
 
 struct AttnScratch { float* S; float* dP; void* dS; };
+// fused attention (attention.hip) unless B2S_ATTN_V1 is set (A/B switch: materialised logits through the GEMM)
+bool use_flash(int dh) {
+    static const bool v1 = getenv("B2S_ATTN_V1") != nullptr;
+    return !v1 && b2s_flash_supported(dh);
+}
+AttnArgs flash_args(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int H, int Lq, int Lk, int dh,
+                    int mask_mode, const int* klen, DropCfg drop, float* lse) {
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
+    a.scale = 1.f / sqrtf((float)dh); a.mask_mode = mask_mode; a.klen = klen; a.drop = drop; a.lse = lse;
+    return a;
+}
 
 // softmax(scale * Q K^T + mask) V on head-interleaved rows (attention.py:72-92)
 int attn_core_fwd(int dtype, hipStream_t st, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                   void* ctx, int ldc, int B, int H, int Lq, int Lk, int dh, int mask_mode, const int* klen,
-                  const float* bias, long bias_sb, long bias_sq, DropCfg drop, float* S, void* P, void* Pd) {
+                  const float* bias, long bias_sb, long bias_sq, DropCfg drop, float* S, void* P, void* Pd, float* lse = nullptr) {
+    if (lse && !bias && use_flash(dh)) {
+        AttnArgs a = flash_args(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, mask_mode, klen, drop, lse);
+        a.out = ctx; a.ldo = ldc;
+        return b2s_flash_fwd(dtype, a, dh, st);
+    }
     const int ldp = rup8(Lk);
     GemmArgs g;
     g.A.p = q; g.A.ld = ldq; g.A.R = Lq; g.A.C = dh; g.A.bs_o = (long)Lq * ldq; g.A.bs_i = dh;
@@ -221,7 +240,13 @@ int attn_core_fwd(int dtype, hipStream_t st, const void* q, int ldq, const void*
 }
 int attn_core_bwd(int dtype, hipStream_t st, const void* dctx, int ldc, const void* q, int ldq, const void* k, int ldk,
                   const void* v, int ldv, const void* P, const void* Pd, void* dq, int lddq, void* dk, int lddk,
-                  void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, DropCfg drop, float* dP, void* dS) {
+                  void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, DropCfg drop, float* dP, void* dS,
+                  float* lse = nullptr, const void* O = nullptr, int mask_mode = 0, const int* klen = nullptr) {
+    if (lse && use_flash(dh)) {
+        AttnArgs a = flash_args(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, mask_mode, klen, drop, lse);
+        a.dout = dctx; a.ldo = ldc; a.dsum = dP; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+        return b2s_flash_bwd(dtype, a, dh, O, st);
+    }
     const int ldp = rup8(Lk);
     const long ps_o = (long)H * Lq * ldp, ps_i = (long)Lq * ldp;
     const void* Pdrop = drop.thresh ? Pd : P;
@@ -278,8 +303,13 @@ void plan_attn(Arena& a, AttnSave& s, int esz, long M, int D, int B, int H, int 
     s.qkv = a.T(M * (cross ? D : 3 * D), esz);
     if (cross) s.kv = a.T(Mk * 2 * D, esz);
     const long pn = (long)B * H * Lq * s.ldp;
-    s.P = a.T(pn, esz);
-    s.Pd = dropout ? a.T(pn, esz) : s.P;
+    if (use_flash(D / H)) {
+        s.lse = a.f32((long)B * H * Lq);
+        s.P = s.Pd = nullptr;
+    } else {
+        s.P = a.T(pn, esz);
+        s.Pd = dropout ? a.T(pn, esz) : s.P;
+    }
     s.ctx = a.T(M * D, esz);
 }
 void plan_ffn(Arena& a, FfnSave& s, int esz, long M, int D) {
@@ -564,7 +594,8 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
             s.op_attn = opid(1, l, 2); s.op_res = opid(1, l, 3);
             const char* q = (const char*)s.qkv;
             B2S_TRY(attn_core_fwd(dt, st, q, 3 * D, q + (size_t)D * m->esz, 3 * D, q + (size_t)2 * D * m->esz, 3 * D, s.ctx, D,
-                                  B, H, S, S, dh, 1, input_lengths, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd));
+                                  B, H, S, S, dh, 1, input_lengths, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd, s.lse));
+            s.mask_mode = 1;
             GemmEpilogue e; e.drop = make_drop(pt, seed, s.op_res); e.residual = x0; e.ldr = D;
             B2S_TRY(linear(m, st, s.ctx, D, m->W(nm(p, "self_attentions", l, "output_transform.weight")), (int)M, D, D, x1, 1, D, e));
             const std::string lnf = p + "ffn_layer_norms." + std::to_string(l);
@@ -617,7 +648,8 @@ int ffn_bwd(b2s_model* m, hipStream_t st, const FfnSave& f, Scratch& sc, long M,
 }
 // backward of x_out = x_in + drop(SelfAttn(LN(x_in)))
 int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, long M, int D, int B, int H, int L,
-                  float p, uint64_t seed, const std::string& wq, const std::string& wo, const std::string& lnp) {
+                  float p, uint64_t seed, const std::string& wq, const std::string& wo, const std::string& lnp,
+                  const int* klen = nullptr) {
     const int dt = m->dtype, dh = D / H, esz = m->esz;
     DropCfg dres = make_drop(p, seed, s.op_res), datt = make_drop(p, seed, s.op_attn);
     const void* dy = sc.dx;
@@ -626,7 +658,8 @@ int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, 
     B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, sc.dctx, 0, D, GemmEpilogue()));
     const char* q = (const char*)s.qkv; char* dq = (char*)sc.dqkv;
     B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, q, 3 * D, q + (size_t)D * esz, 3 * D, q + (size_t)2 * D * esz, 3 * D, s.P, s.Pd,
-                          dq, 3 * D, dq + (size_t)D * esz, 3 * D, dq + (size_t)2 * D * esz, 3 * D, B, H, L, L, dh, datt, sc.dP, sc.dS));
+                          dq, 3 * D, dq + (size_t)D * esz, 3 * D, dq + (size_t)2 * D * esz, 3 * D, B, H, L, L, dh, datt, sc.dP, sc.dS,
+                          s.lse, s.ctx, s.mask_mode, klen));
     B2S_TRY(linear_dw(m, st, sc.dqkv, 3 * D, s.h, D, (int)M, 3 * D, D, m->G(wq)));
     B2S_TRY(linear_dx(m, st, sc.dqkv, 3 * D, m->W(wq), (int)M, D, 3 * D, sc.dh, 0, D, GemmEpilogue()));
     B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, s.x_in, m->P(lnp + ".weight"), s.mean, s.rstd, sc.dx, 1, m->G(lnp + ".weight"),
@@ -669,7 +702,7 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
         B2S_TRY(ffn_bwd(m, st, c->ffn[l], sc, M, D, pt, c->seed, nm(p, "ffn_layers", l, "input_layer.weight"),
                         nm(p, "ffn_layers", l, "output_layer.weight"), lnf));
         B2S_TRY(self_attn_bwd(m, st, c->self_attn[l], sc, M, D, B, H, S, pt, c->seed, nm(p, "self_attentions", l, "qkv_transform.weight"),
-                              nm(p, "self_attentions", l, "output_transform.weight"), lna));
+                              nm(p, "self_attentions", l, "output_transform.weight"), lna, c->in_len));
         m->stage_done(4 + cf.n_decoder_layer + (cf.n_encoder_layer - 1 - l));
     }
     B2S_TRY(ro_embed_prep_bwd(sc.dx, (const long*)c->ids, c->in_len, m->pe_enc, m->G("encoder.embed.weight"), m->G(p + "pe_scale"),
@@ -732,7 +765,8 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
             s.op_attn = opid(2, l, 4); s.op_res = opid(2, l, 5);
             const char* q = (const char*)s.qkv;
             B2S_TRY(attn_core_fwd(dt, st, q, 3 * D, q + (size_t)D * esz, 3 * D, q + (size_t)2 * D * esz, 3 * D, s.ctx, D, B, H, T, T, dh,
-                                  2, nullptr, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd));
+                                  2, nullptr, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd, s.lse));
+            s.mask_mode = 2;
             GemmEpilogue ea; ea.drop = make_drop(pt, seed, s.op_res); ea.residual = x0; ea.ldr = D;
             B2S_TRY(linear(m, st, s.ctx, D, m->W(nm(p, "self_attentions", l, "output_transform.weight")), (int)M, D, D, x1, 1, D, ea));
             // encoder-decoder attention
@@ -745,7 +779,8 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
             x.op_attn = opid(2, l, 6); x.op_res = opid(2, l, 7);
             const char* kv = (const char*)x.kv;
             B2S_TRY(attn_core_fwd(dt, st, x.qkv, D, kv, 2 * D, kv + (size_t)D * esz, 2 * D, x.ctx, D, B, H, T, S, dh, 1, input_lengths,
-                                  nullptr, 0, 0, make_drop(pt, seed, x.op_attn), sc.S, x.P, x.Pd));
+                                  nullptr, 0, 0, make_drop(pt, seed, x.op_attn), sc.S, x.P, x.Pd, x.lse));
+            x.mask_mode = 1;
             GemmEpilogue ex; ex.drop = make_drop(pt, seed, x.op_res); ex.residual = x1; ex.ldr = D;
             B2S_TRY(linear(m, st, x.ctx, D, m->W(nm(p, "encdec_attentions", l, "output_transform.weight")), (int)M, D, D, x2, 1, D, ex));
             // FFN
@@ -824,7 +859,7 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
             B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, sc.dctx, 0, D, GemmEpilogue()));
             const char* kv = (const char*)x.kv; char* dkv = (char*)sc.dkv;
             B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, x.qkv, D, kv, 2 * D, kv + (size_t)D * esz, 2 * D, x.P, x.Pd, sc.dqkv, D, dkv, 2 * D,
-                                  dkv + (size_t)D * esz, 2 * D, B, H, T, S, dh, datt, sc.dP, sc.dS));
+                                  dkv + (size_t)D * esz, 2 * D, B, H, T, S, dh, datt, sc.dP, sc.dS, x.lse, x.ctx, x.mask_mode, c->in_len));
             B2S_TRY(linear_dw(m, st, sc.dqkv, D, x.h, D, (int)M, D, D, m->G(wq)));
             B2S_TRY(linear_dx(m, st, sc.dqkv, D, m->W(wq), (int)M, D, D, sc.dh, 0, D, GemmEpilogue()));
             B2S_TRY(linear_dw(m, st, sc.dkv, 2 * D, c->memT, D, (int)Mk, 2 * D, D, m->G(wkv)));
@@ -860,6 +895,13 @@ extern "C" int b2s_decoder_alignment(b2s_model* m, b2s_ctx* c, int which, int la
     B2S_CHECK(m && c && c->kind == 2 && out, "bad decoder context");
     B2S_CHECK(layer >= 0 && layer < m->cfg.n_decoder_layer && (which == 0 || which == 1), "bad alignment selector");
     const AttnSave& s = which ? c->cross_attn[layer] : c->self_attn[layer];
+    if (s.lse) {
+        const int D = m->cfg.decoder_hidden, H = m->cfg.n_attention_head, dh = D / H, esz = m->esz;
+        AttnArgs a;
+        if (which) a = flash_args(s.qkv, D, s.kv, 2 * D, nullptr, 0, c->B, H, s.Lq, s.Lk, dh, 1, c->in_len, DropCfg{0, 0, 1.f}, s.lse);
+        else a = flash_args(s.qkv, 3 * D, (const char*)s.qkv + (size_t)D * esz, 3 * D, nullptr, 0, c->B, H, s.Lq, s.Lk, dh, 2, nullptr, DropCfg{0, 0, 1.f}, s.lse);
+        return b2s_flash_align(m->dtype, a, dh, out, S_(stream));
+    }
     return ro_align_transpose(m->dtype, s.P, out, c->B * m->cfg.n_attention_head, s.Lq, s.Lk, s.ldp, S_(stream));
 }
 

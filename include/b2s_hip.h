@@ -174,6 +174,19 @@ int b2s_attention_backward(int dtype, const void* dctx, int ldc, const void* q, 
                            const void* v, int ldv, const void* P, const void* Pd, void* dq, int lddq, void* dk,
                            int lddk, void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, float drop_p,
                            uint64_t seed, void* ws, void* stream);
+/* Fused (flash-style) form of the same attention core: logits never reach HBM; lse_out [B,H,Lq] = log-sum-exp
+ * of the scaled masked logits (saved for backward / alignments).  Head sizes 32, 64, 96; no dense bias. */
+int b2s_flash_attention_forward(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* ctx,
+                                int ldc, int B, int H, int Lq, int Lk, int dh, int mask_mode, const int32_t* klen,
+                                float drop_p, uint64_t seed, float* lse_out, void* stream);
+int b2s_flash_attention_backward(int dtype, const void* dctx, const void* ctx, int ldc, const void* q, int ldq,
+                                 const void* k, int ldk, const void* v, int ldv, const float* lse, float* dsum_scratch,
+                                 void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H, int Lq,
+                                 int Lk, int dh, int mask_mode, const int32_t* klen, float drop_p, uint64_t seed,
+                                 void* stream);
+/* align_out [B,H,Lk,Lq] (attention.py:88), recomputed from q, k and lse */
+int b2s_flash_attention_align(int dtype, const void* q, int ldq, const void* k, int ldk, const float* lse, int B, int H,
+                              int Lq, int Lk, int dh, int mask_mode, const int32_t* klen, float* align_out, void* stream);
 int b2s_align_from_probs(int dtype, const void* P, float* align, int B, int H, int Lq, int Lk, void* stream);
 /* out = a + b (fp32, n elements) */
 int b2s_add(const float* a, const float* b, float* out, int64_t n, void* stream);

@@ -140,9 +140,10 @@ def _attn_ref(q, k, v, H, mask_mode, klen):
     return (p @ vh).permute(0, 2, 1, 3).reshape(B_, Lq, C), p
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("dh,mask_mode,Lq,Lk", [(32, 1, 21, 13), (64, 2, 40, 40), (96, 1, 150, 33), (96, 2, 130, 130)])
-def test_attention_core_fwd_bwd(dtype, dh, mask_mode, Lq, Lk):
+@pytest.mark.parametrize("dh,mask_mode,Lq,Lk", [(32, 1, 21, 13), (64, 2, 40, 40), (96, 1, 150, 33), (96, 2, 130, 130), (64, 1, 70, 200)])
+def test_attention_core_fwd_bwd(fused, dtype, dh, mask_mode, Lq, Lk):
     ops, lib = _ops()
     g = torch.Generator().manual_seed(dh + Lq)
     B_, H = 2, 2
@@ -156,7 +157,7 @@ def test_attention_core_fwd_bwd(dtype, dh, mask_mode, Lq, Lk):
     ref, pref = _attn_ref(qr, kr, vr, H, mask_mode, klen)
     ref.backward(go.double())
     qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
-    out, probs = ops.attention_core(qd, kd, vd, H, mask_mode, klen.to(DEV) if mask_mode & 1 else None, None, 0.0, 0, dtype)
+    out, probs = ops.attention_core(qd, kd, vd, H, mask_mode, klen.to(DEV) if mask_mode & 1 else None, None, 0.0, 0, dtype, fused=fused)
     out.backward(go.to(DEV))
     torch.cuda.synchronize()
     tol = 3e-5 if not dtype else 2e-2
@@ -175,10 +176,32 @@ def test_attention_dense_bias_matches_mask():
     q = torch.randn(B_, Lq, C, generator=g).to(DEV); k = torch.randn(B_, Lk, C, generator=g).to(DEV); v = torch.randn(B_, Lk, C, generator=g).to(DEV)
     klen = torch.tensor([12, 7], dtype=torch.int32)
     dense = ((1.0 - (torch.arange(Lk)[None, :] < klen[:, None]).float()) * -1e20)[:, None, None, :]
-    a, pa = ops.attention_core(q, k, v, H, 1, klen.to(DEV), None, 0.0, 0, 0)
+    a, pa = ops.attention_core(q, k, v, H, 1, klen.to(DEV), None, 0.0, 0, 0, fused=False)
     b, pb = ops.attention_core(q, k, v, H, 0, None, dense.to(DEV), 0.0, 0, 0)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_fused_attention_matches_materialised_with_dropout(dtype):
+    """Same seed -> the fused kernels and the GEMM+softmax path draw the same dropout mask: outputs and gradients agree."""
+    ops, lib = _ops()
+    g = torch.Generator().manual_seed(17)
+    B_, H, dh, Lq, Lk = 2, 2, 96, 75, 140
+    C = H * dh
+    q = torch.randn(B_, Lq, C, generator=g); k = torch.randn(B_, Lk, C, generator=g); v = torch.randn(B_, Lk, C, generator=g)
+    go = torch.randn(B_, Lq, C, generator=g)
+    klen = torch.tensor([Lk, Lk - 17], dtype=torch.int32).to(DEV)
+    res = []
+    for fused in (True, False):
+        qd, kd, vd = (t.clone().to(DEV).requires_grad_(True) for t in (q, k, v))
+        out, _ = ops.attention_core(qd, kd, vd, H, 1, klen, None, 0.3, 4242, dtype, fused=fused)
+        out.backward(go.to(DEV))
+        torch.cuda.synchronize()
+        res.append((out.detach().cpu(), qd.grad.cpu(), kd.grad.cpu(), vd.grad.cpu()))
+    tol = 1e-4 if not dtype else 3e-2
+    for a, b, name in zip(res[0], res[1], ("out", "dq", "dk", "dv")):
+        assert relerr(a, b) < tol, report("fused vs materialised " + name, a, b)
 
 
 def test_dropout_rng_statistics():
