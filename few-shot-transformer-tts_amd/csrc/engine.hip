@@ -183,7 +183,7 @@ int pick_splitk(int Mo, int No, int K, int dtype) {
     const int nk = cdiv(K, bk);
     // one full round of 2 workgroups per CU (512 slots), never spilling into a second, mostly empty round;
     // fp32 atomics are the cost of splitting, so each split keeps >= 8 K tiles
-    int s = (int)std::min<long>(std::max<long>(1, 512 / tiles), std::max(1, nk / 8));
+    int s = (int)std::min<long>(std::max<long>(1, 512 / tiles), std::max(1, nk / 4));
     return std::max(1, std::min(s, 32));
 }
 // dW[Nout,Kin] = dY[M,Nout]^T * X[M,Kin]

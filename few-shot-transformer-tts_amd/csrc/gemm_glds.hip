@@ -11,6 +11,7 @@
 // K is walked in BK = 32 steps through an NSTAGE-deep LDS ring: NSTAGE-1 tiles are in flight, each wave waits only for
 // its own DMA of the tile it is about to use (counted s_waitcnt vmcnt, never 0 in steady state) and one raw s_barrier
 // per tile publishes it to the other waves and frees the oldest slot.
+#include <algorithm>
 #include "gemm.h"
 
 namespace {
@@ -41,7 +42,7 @@ __device__ inline const bf16_t* chunk_src(const GemmOperand& o, const bf16_t* ba
 }
 
 template <bool TA, bool TB, bool GATHER>
-__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf16_t* zero) {
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf16_t* zero, float* splitk_ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);      // [buf][A tile | B tile]
 
@@ -168,7 +169,13 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
     // ---------------- epilogue.  The accumulators (MFMA layout: col = lane & 15, row = (lane >> 4)*4 + r) are staged
     // through LDS (the operand ring is dead now) so that every lane owns 8 consecutive output columns of one row:
     // bf16 results leave as 16-byte stores, residual / ReLU-mask / bias operands arrive as 16-byte loads.
-    const GemmEpilogue& e = g.epi;
+    GemmEpilogue e = g.epi;
+    if (g.splitk > 1 && splitk_ws) {
+        // split-K partial tile: plain vector stores into workspace slab `ksplit` ([splitk][M][N] fp32); a reduce kernel
+        // adds the slabs into the gradient (fp32 atomics cost ~8 ns per 64-lane instruction and were the bottleneck)
+        g.C = splitk_ws + (long)ksplit * g.M * g.N; g.c_fp32 = 1; g.ldc = g.N; g.cs_o = 0; g.cs_i = 0; g.splitk = 1;
+        e.accumulate = 0; e.conv_dw_cin = 0;
+    }
     if (g.splitk > 1 || e.conv_dw_cin > 0) {
         // weight-gradient forms: linear fp32 accumulate straight from the MFMA layout (16 lanes = 64 contiguous bytes
         // per atomic / store instruction)
@@ -298,9 +305,39 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
 }
 
 bf16_t* g_zero_page = nullptr;
+float* g_splitk_ws = nullptr;
+size_t g_splitk_ws_floats = 0;
+
+// dst[m*ldc + col(n)] += alpha-scaled sum over splits of ws[s][m][n]
+__global__ void splitk_reduce_kernel(const float* ws, float* dst, int M, int N, int ldc, int splitk, int conv_dw_cin) {
+    const long total = (long)M * N;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (long)gridDim.x * blockDim.x * 4) {
+        float4 acc = *reinterpret_cast<const float4*>(ws + i);
+        for (int s = 1; s < splitk; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + (long)s * total + i);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const int m = (int)(i / N), n = (int)(i - (long)m * N);
+        const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+        if (conv_dw_cin > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { int nn = n + j, jj = nn / conv_dw_cin; dst[(long)m * ldc + (nn - jj * conv_dw_cin) * 5 + jj] += a4[j]; }
+        } else {
+            float4* d = reinterpret_cast<float4*>(dst + (long)m * ldc + n);
+            float4 c = *d;
+            c.x += acc.x; c.y += acc.y; c.z += acc.z; c.w += acc.w;
+            *d = c;
+        }
+    }
+}
 
 template <bool TA, bool TB, bool GATHER>
-int launch_t(const GemmArgs& g, hipStream_t stream) {
+int launch_t(const GemmArgs& g_in, hipStream_t stream) {
+    GemmArgs g = g_in;
+    if (g.splitk > 1) {                     // every split must own at least one K tile (empty splits would leave slabs unwritten)
+        const int nk_all = cdiv(g.K, BK), per = cdiv(nk_all, g.splitk);
+        g.splitk = cdiv(nk_all, per);
+    }
     constexpr size_t smem = NSTAGE * 2 * (size_t)TILE * sizeof(bf16_t);     // 16 KB per stage
     static bool attr_set = false;
     if (!attr_set) {
@@ -309,8 +346,19 @@ int launch_t(const GemmArgs& g, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch * g.splitk);
-    hipLaunchKernelGGL((gemm_glds_kernel<TA, TB, GATHER>), grid, dim3(256), smem, stream, g, (const bf16_t*)g_zero_page);
+    float* ws = nullptr;
+    if (g.splitk > 1 && g.batch == 1 && g.c_fp32 && g.epi.accumulate && (g.N & 3) == 0 && (g.ldc & 3) == 0 &&
+        (size_t)g.splitk * g.M * g.N <= g_splitk_ws_floats)
+        ws = g_splitk_ws;
+    hipLaunchKernelGGL((gemm_glds_kernel<TA, TB, GATHER>), grid, dim3(256), smem, stream, g, (const bf16_t*)g_zero_page, ws);
     B2S_LAUNCH_CHECK();
+    if (ws) {
+        const long total4 = (long)g.M * g.N / 4;
+        int blocks = (int)std::min<long>((total4 + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)ws, (float*)g.C, g.M, g.N, g.ldc, g.splitk,
+                           g.epi.conv_dw_cin);
+        B2S_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -320,6 +368,8 @@ int b2s_gemm_glds_launch(const GemmArgs& g, bool ta, bool tb, hipStream_t stream
     if (!g_zero_page) {
         B2S_HIP(hipMalloc(&g_zero_page, 256));
         B2S_HIP(hipMemset(g_zero_page, 0, 256));
+        g_splitk_ws_floats = (size_t)24 << 20;                       // 96 MB of split-K slabs
+        if (hipMalloc(&g_splitk_ws, g_splitk_ws_floats * sizeof(float)) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_ws_floats = 0; }
     }
     const bool gather = g.A.g_cin > 0 || g.B.g_cin > 0;
     if (gather) {       // conv1d forms: forward / backward-data (NT, gather on A) and weight gradient (TN, gather on B)
