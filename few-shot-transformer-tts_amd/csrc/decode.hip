@@ -74,49 +74,100 @@ __global__ void k_dec_append(const T* qkv, const int* tptr, T* Kc, T* Vc, int ma
         Vc[((long)b * maxT + t) * D + c] = qkv[(long)b * 3 * D + 2 * D + c];
     }
 }
-// single-query attention for one (b, h) per wave: keys [0, n), n = t+1 (self) or klen[b] (cross)
+// single-query attention for one (b, h) per 256-thread workgroup: keys [0, n), n = t+1 (self) or klen[b] (cross).
+// Scores: 4 lanes share one key row (each 16-byte load instruction covers 64 contiguous bytes of a row), softmax
+// through LDS, weighted V sum with one 16-byte column chunk per thread and a cross-row LDS reduction.
 template <typename T>
-__global__ __launch_bounds__(64) void k_dec_attn(const T* q, int ldq, const T* Kc, const T* Vc, int ldkv, long kv_bstride, T* out,
-                                                 int ldo, float* probs, int probs_rows, int probs_ld, const int* tptr,
-                                                 const int* klen, int self, int H, int dh, float scale, DropCfg drop) {
-    extern __shared__ float sh[];            // [dh] q + [nmax] p
-    const int lane = threadIdx.x, b = blockIdx.x / H, h = blockIdx.x - b * H, t = *tptr;
+__global__ __launch_bounds__(256) void k_dec_attn(const T* q, int ldq, const T* Kc, const T* Vc, int ldkv, long kv_bstride, T* out,
+                                                  int ldo, float* probs, int probs_rows, int probs_ld, const int* tptr,
+                                                  const int* klen, int self, int H, int dh, int nmax, float scale, DropCfg drop) {
+    constexpr int VE = TT<T>::VE;
+    extern __shared__ float sh[];            // [dh] q | [nmax] p | [R*dh] partial outputs | [8] reductions
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H, t = *tptr;
     const int n = self ? t + 1 : klen[b];
     float* sq = sh;
     float* p = sh + dh;
-    for (int d = lane; d < dh; d += 64) sq[d] = TT<T>::ld(q + (long)b * ldq + h * dh + d);
+    const int CH = dh / VE, R = 256 / CH;
+    float* part = p + nmax;
+    float* red = part + R * dh;
+    for (int d = tid; d < dh; d += 256) sq[d] = TT<T>::ld(q + (long)b * ldq + h * dh + d);
     __syncthreads();
     const T* Kb = Kc + b * kv_bstride + h * dh;
     const T* Vb = Vc + b * kv_bstride + h * dh;
+    // ---- scores
+    const int part4 = tid & 3, kslot = tid >> 2;      // 64 keys per pass
+    const int nch = CH / 4;                           // chunks per lane (dh is a multiple of 4*VE)
     float mx = -INFINITY;
-    for (int j = lane; j < n; j += 64) {
-        const T* kr = Kb + (long)j * ldkv;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + kslot;
         float s = 0.f;
-        for (int d = 0; d < dh; ++d) s += sq[d] * TT<T>::ld(kr + d);
-        s *= scale;
-        p[j] = s;
-        mx = fmaxf(mx, s);
+        if (j < n) {
+            const T* kr = Kb + (long)j * ldkv;
+            for (int i = 0; i < nch; ++i) {
+                const int c = (i * 4 + part4) * VE;
+                uint4 u = *reinterpret_cast<const uint4*>(kr + c);
+                if (sizeof(T) == 2) {
+                    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s += sq[c + 2 * e] * bf2f(w[e] & 0xffff) + sq[c + 2 * e + 1] * bf2f(w[e] >> 16); }
+                } else {
+                    const float* f = reinterpret_cast<const float*>(&u);
+                    s += sq[c] * f[0] + sq[c + 1] * f[1] + sq[c + 2] * f[2] + sq[c + 3] * f[3];
+                }
+            }
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (j < n && part4 == 0) { s *= scale; p[j] = s; mx = fmaxf(mx, s); }
     }
     mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < n; j += 64) { float e = __expf(p[j] - mx); p[j] = e; sum += e; }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
+    if (lane == 0) red[wave] = mx;
     __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < n; j += 256) { float e = __expf(p[j] - mx); p[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
     DropCfg dc = drop;
     dc.key ^= b2s_hash32((uint32_t)t * 2654435761u + 77u);
     float* prow = probs ? probs + (((long)b * H + h) * probs_rows + t) * probs_ld : nullptr;   // alignment row of this frame
-    for (int j = lane; j < n; j += 64) {
+    for (int j = tid; j < n; j += 256) {
         float w = p[j] * inv;
         if (prow) prow[j] = w;
         if (dc.thresh) w = b2s_keep(dc, (uint32_t)((b * H + h) * 4096 + j)) ? w * dc.scale : 0.f;
         p[j] = w;
     }
     __syncthreads();
-    for (int d = lane; d < dh; d += 64) {
-        float acc = 0.f;
-        for (int j = 0; j < n; ++j) acc += p[j] * TT<T>::ld(Vb + (long)j * ldkv + d);
-        TT<T>::st(out + (long)b * ldo + h * dh + d, acc);
+    // ---- weighted sum of V rows
+    const int tx = tid % CH, ty = tid / CH;
+    if (ty < R) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int j = ty; j < n; j += R) {
+            const float w = p[j];
+            uint4 u = *reinterpret_cast<const uint4*>(Vb + (long)j * ldkv + tx * VE);
+            if (sizeof(T) == 2) {
+                const uint32_t ww[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[2 * e] += w * bf2f(ww[e] & 0xffff); acc[2 * e + 1] += w * bf2f(ww[e] >> 16); }
+            } else {
+                const float* f = reinterpret_cast<const float*>(&u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += w * f[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) part[ty * dh + tx * VE + e] = acc[e];
+    }
+    __syncthreads();
+    for (int d = tid; d < dh; d += 256) {
+        float o = 0.f;
+        for (int r = 0; r < R; ++r) o += part[r * dh + d];
+        TT<T>::st(out + (long)b * ldo + h * dh + d, o);
     }
 }
 // finish the frame: mask by activity, write mels[:, t], update stop state (synthesize.py:42-45)
@@ -172,6 +223,10 @@ int lin(const b2s_model* m, hipStream_t st, const void* X, int ldx, const void* 
     g.A.p = X; g.A.ld = ldx; g.A.R = M; g.A.C = K;
     g.B.p = W; g.B.ld = K; g.B.R = N; g.B.C = K;
     g.M = M; g.N = N; g.K = K; g.C = out; g.c_fp32 = out_fp32; g.ldc = ldo; g.epi = e;
+    if (M <= 64) {                               // the per-frame GEMMs: stream W once with N/16 workgroups
+        const int rc = b2s_gemm_skinny_launch(g, m->dtype, st);
+        if (rc >= 0) return rc;
+    }
     return b2s_gemm_launch(g, m->dtype, false, false, st);
 }
 std::string nm2(const std::string& p, const char* list, int i, const char* leaf) { return p + list + "." + std::to_string(i) + "." + leaf; }
@@ -192,7 +247,8 @@ int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
     B2S_TRY(lin(m, st, s->a2, HP, m->W("decoder.prenet.dense_final.weight"), B, D, HP, s->a3, 1, D, GemmEpilogue()));
     hipLaunchKernelGGL(k_dec_x0, dim3(B), dim3(256), 0, st, s->a3, s->lengths, m->pe_dec, m->P(p + "pe_scale"), s->t, s->x, D,
                        make_drop(pt, s->seed, 9003));
-    const size_t sh_self = (size_t)(dh + maxT) * 4, sh_cross = (size_t)(dh + S) * 4;
+    const int ve = dt ? 8 : 4, Rr = 256 / (dh / ve);
+    const size_t sh_self = (size_t)(dh + maxT + Rr * dh + 8) * 4, sh_cross = (size_t)(dh + S + Rr * dh + 8) * 4;
     for (int l = 0; l < L; ++l) {
         const std::string lna = p + "attn_layer_norms." + std::to_string(l), lnx = p + "encdec_layer_norms." + std::to_string(l),
                           lnf = p + "ffn_layer_norms." + std::to_string(l);
@@ -201,18 +257,18 @@ int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
                                  nullptr, 1, st));
         B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "self_attentions", l, "qkv_transform.weight")), B, 3 * D, D, s->qkv, 0, 3 * D, GemmEpilogue()));
         hipLaunchKernelGGL((k_dec_append<T>), dim3(B), dim3(256), 0, st, (const T*)s->qkv, s->t, (T*)s->selfK[l], (T*)s->selfV[l], maxT, D);
-        hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(64), sh_self, st, (const T*)s->qkv, 3 * D, (const T*)s->selfK[l],
+        hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(256), sh_self, st, (const T*)s->qkv, 3 * D, (const T*)s->selfK[l],
                            (const T*)s->selfV[l], D, (long)maxT * D, (T*)s->ctx, D, s->selfP[l], maxT, maxT, s->t, (const int*)nullptr, 1, H, dh,
-                           scale, make_drop(pt, s->seed, 9010 + l));
+                           maxT, scale, make_drop(pt, s->seed, 9010 + l));
         GemmEpilogue ea; ea.drop = make_drop(pt, s->seed, 9020 + l); ea.drop_salt = s->t; ea.residual = s->x; ea.ldr = D;
         B2S_TRY(lin(m, st, s->ctx, D, m->W(nm2(p, "self_attentions", l, "output_transform.weight")), B, D, D, s->x, 1, D, ea));
         // encoder-decoder attention over the pre-projected memory K/V
         B2S_TRY(ro_layernorm_fwd(dt, s->x, m->P(lnx + ".weight"), m->P(lnx + ".bias"), s->h, D, nullptr, 0, s->mean, s->rstd, B, D, 1e-6f,
                                  nullptr, 1, st));
         B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "encdec_attentions", l, "q_transform.weight")), B, D, D, s->qkv, 0, D, GemmEpilogue()));
-        hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(64), sh_cross, st, (const T*)s->qkv, D, (const T*)s->crossKV[l],
+        hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(256), sh_cross, st, (const T*)s->qkv, D, (const T*)s->crossKV[l],
                            (const T*)s->crossKV[l] + D, 2 * D, (long)S * 2 * D, (T*)s->ctx, D, s->crossP[l], maxT, S, s->t, s->in_len, 0, H, dh,
-                           scale, make_drop(pt, s->seed, 9030 + l));
+                           S, scale, make_drop(pt, s->seed, 9030 + l));
         GemmEpilogue ex; ex.drop = make_drop(pt, s->seed, 9040 + l); ex.drop_salt = s->t; ex.residual = s->x; ex.ldr = D;
         B2S_TRY(lin(m, st, s->ctx, D, m->W(nm2(p, "encdec_attentions", l, "output_transform.weight")), B, D, D, s->x, 1, D, ex));
         // FFN

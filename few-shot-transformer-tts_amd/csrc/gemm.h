@@ -49,3 +49,5 @@ struct GemmArgs {
 int b2s_gemm_launch(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t stream);
 // bf16 LDS-DMA (global_load_lds) + swizzled-LDS main loop (gemm_glds.hip)
 int b2s_gemm_glds_launch(const GemmArgs& g, bool ta, bool tb, hipStream_t stream);
+// decode-step weight-streaming kernel (gemm_skinny.hip); returns -1 when the problem does not fit it
+int b2s_gemm_skinny_launch(const GemmArgs& g, int dtype, hipStream_t stream);

@@ -1,0 +1,79 @@
+// Weight-streaming GEMM for the autoregressive decode step: out[M <= 64, N] = X[M, K] * W[N, K]^T with the usual
+// epilogues.  The step is HBM-bound on W (every weight is read once per frame), so the launch is shaped for
+// bandwidth, not MFMA occupancy: one workgroup per 16 output columns (N/16 workgroups stream disjoint 16-row
+// slabs of W), its 4 waves split K four ways and meet in LDS; X (<= 64 rows) comes from L2.
+#include "gemm.h"
+
+namespace {
+
+template <typename T> struct SK;
+template <> struct SK<float>  { static constexpr int KS = 4;  typedef float frag; };
+template <> struct SK<bf16_t> { static constexpr int KS = 32; typedef bf16x8_t frag; };
+
+__device__ inline float ldfrag(const float* p, int lg) { return p[lg]; }
+__device__ inline bf16x8_t ldfrag(const bf16_t* p, int lg) { return *reinterpret_cast<const bf16x8_t*>(p + lg * 8); }
+__device__ inline f32x4_t mma(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ inline f32x4_t mma(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void skinny_kernel(GemmArgs g) {
+    constexpr int KS = SK<T>::KS;
+    __shared__ float red[4][64][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const T* X = reinterpret_cast<const T*>(g.A.p);
+    const T* W = reinterpret_cast<const T*>(g.B.p);
+    const int nsteps = (g.K + KS - 1) / KS, per = (nsteps + 3) / 4;
+    const int s0 = wave * per, s1 = min(nsteps, s0 + per);
+    const T* wrow = W + (long)min(n0 + li, g.N - 1) * g.B.ld;
+    const T* xrow[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xrow[mt] = X + (long)min(mt * 16 + li, g.M - 1) * g.A.ld;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int mtiles = (g.M + 15) / 16;
+    for (int s = s0; s < s1; ++s) {
+        const int k = s * KS;
+        const typename SK<T>::frag b = ldfrag(wrow + k, lg);          // K is a multiple of KS on this path (checked on the host)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            if (mt < mtiles) acc[mt] = mma(ldfrag(xrow[mt] + k, lg), b, acc[mt]);
+    }
+    // D layout: col = n (li), row = m (lg*4 + r) within the m tile
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][mt * 16 + lg * 4 + r][li] = acc[mt][r];
+    __syncthreads();
+    const GemmEpilogue& e = g.epi;
+    DropCfg dcfg = e.drop;
+    if (e.drop.thresh && e.drop_salt) dcfg.key ^= b2s_hash32((uint32_t)(*e.drop_salt) * 2246822519u + 3266489917u);
+    for (int i = tid; i < 64 * 16; i += 256) {
+        const int m = i >> 4, nl = i & 15, n = n0 + nl;
+        if (m >= g.M || n >= g.N) continue;
+        float v = (red[0][m][nl] + red[1][m][nl] + red[2][m][nl] + red[3][m][nl]) * e.alpha;
+        if (e.bias) v += e.bias[n];
+        if (e.relu) v = fmaxf(v, 0.f);
+        if (e.drop.thresh) v = b2s_keep(dcfg, (uint32_t)((long)m * g.N + n)) ? v * dcfg.scale : 0.f;
+        if (e.residual) v += e.residual[(long)m * e.ldr + n];
+        if (e.row_len) { int bb = m / e.rows_per_batch, t = m - bb * e.rows_per_batch; if (t >= e.row_len[bb]) v = 0.f; }
+        const long off = (long)m * g.ldc + n;
+        if (g.c_fp32) { float* C = reinterpret_cast<float*>(g.C); if (e.accumulate) C[off] += v; else C[off] = v; }
+        else TT<T>::st(reinterpret_cast<T*>(g.C) + off, v);
+    }
+}
+
+}  // namespace
+
+// NT form, M <= 64, no batching / gather / split-K / relu_aux.  Returns -1 if the problem does not fit this kernel.
+int b2s_gemm_skinny_launch(const GemmArgs& g, int dtype, hipStream_t stream) {
+    const int ks = dtype ? 32 : 4;
+    if (g.M > 64 || g.batch != 1 || g.splitk != 1 || g.A.g_cin || g.B.g_cin || g.epi.relu_aux || g.epi.conv_dw_cin || (g.K % ks) != 0)
+        return -1;
+    dim3 grid(cdiv(g.N, 16));
+    if (dtype) hipLaunchKernelGGL((skinny_kernel<bf16_t>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((skinny_kernel<float>), grid, dim3(256), 0, stream, g);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
