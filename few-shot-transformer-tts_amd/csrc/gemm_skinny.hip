@@ -1,7 +1,7 @@
 // Weight-streaming GEMM for the autoregressive decode step: out[M <= 64, N] = X[M, K] * W[N, K]^T with the usual
 // epilogues.  The step is HBM-bound on W (every weight is read once per frame), so the launch is shaped for
 // bandwidth, not MFMA occupancy: one workgroup per 16 output columns (N/16 workgroups stream disjoint 16-row
-// slabs of W), its 4 waves split K four ways and meet in LDS; X (<= 64 rows) comes from L2.
+// slabs of W), its 8 waves split K eight ways and meet in LDS, each issuing the loads of 4 K steps at a time; X (<= 64 rows) comes from L2.
 #include "gemm.h"
 
 namespace {
@@ -15,15 +15,18 @@ __device__ inline bf16x8_t ldfrag(const bf16_t* p, int lg) { return *reinterpret
 __device__ inline f32x4_t mma(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ inline f32x4_t mma(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
+constexpr int NW = 8;          // waves per workgroup: K is split NW ways
+constexpr int UN = 4;          // K steps whose loads are issued together (memory-level parallelism per wave)
+
 template <typename T>
-__global__ __launch_bounds__(256) void skinny_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NW * 64) void skinny_kernel(GemmArgs g) {
     constexpr int KS = SK<T>::KS;
-    __shared__ float red[4][64][17];
+    __shared__ float red[NW][64][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const T* X = reinterpret_cast<const T*>(g.A.p);
     const T* W = reinterpret_cast<const T*>(g.B.p);
-    const int nsteps = (g.K + KS - 1) / KS, per = (nsteps + 3) / 4;
+    const int nsteps = (g.K + KS - 1) / KS, per = (nsteps + NW - 1) / NW;
     const int s0 = wave * per, s1 = min(nsteps, s0 + per);
     const T* wrow = W + (long)min(n0 + li, g.N - 1) * g.B.ld;
     const T* xrow[4];
@@ -33,12 +36,23 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmArgs g) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int mtiles = (g.M + 15) / 16;
-    for (int s = s0; s < s1; ++s) {
-        const int k = s * KS;
-        const typename SK<T>::frag b = ldfrag(wrow + k, lg);          // K is a multiple of KS on this path (checked on the host)
+    for (int s = s0; s < s1; s += UN) {
+        typename SK<T>::frag wb[UN], xa[UN][4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            if (mt < mtiles) acc[mt] = mma(ldfrag(xrow[mt] + k, lg), b, acc[mt]);
+        for (int u = 0; u < UN; ++u) {                     // issue every load of the group before the first MFMA
+            const int k = min(s + u, s1 - 1) * KS;         // (tail steps re-read the last valid step; their MFMAs are skipped)
+            wb[u] = ldfrag(wrow + k, lg);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                if (mt < mtiles) xa[u][mt] = ldfrag(xrow[mt] + k, lg);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (s + u < s1) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    if (mt < mtiles) acc[mt] = mma(xa[u][mt], wb[u], acc[mt]);
+            }
     }
     // D layout: col = n (li), row = m (lg*4 + r) within the m tile
 #pragma unroll
@@ -49,10 +63,13 @@ __global__ __launch_bounds__(256) void skinny_kernel(GemmArgs g) {
     const GemmEpilogue& e = g.epi;
     DropCfg dcfg = e.drop;
     if (e.drop.thresh && e.drop_salt) dcfg.key ^= b2s_hash32((uint32_t)(*e.drop_salt) * 2246822519u + 3266489917u);
-    for (int i = tid; i < 64 * 16; i += 256) {
+    for (int i = tid; i < 64 * 16; i += NW * 64) {
         const int m = i >> 4, nl = i & 15, n = n0 + nl;
         if (m >= g.M || n >= g.N) continue;
-        float v = (red[0][m][nl] + red[1][m][nl] + red[2][m][nl] + red[3][m][nl]) * e.alpha;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][m][nl];
+        v *= e.alpha;
         if (e.bias) v += e.bias[n];
         if (e.relu) v = fmaxf(v, 0.f);
         if (e.drop.thresh) v = b2s_keep(dcfg, (uint32_t)((long)m * g.N + n)) ? v * dcfg.scale : 0.f;
@@ -72,8 +89,8 @@ int b2s_gemm_skinny_launch(const GemmArgs& g, int dtype, hipStream_t stream) {
     if (g.M > 64 || g.batch != 1 || g.splitk != 1 || g.A.g_cin || g.B.g_cin || g.epi.relu_aux || g.epi.conv_dw_cin || (g.K % ks) != 0)
         return -1;
     dim3 grid(cdiv(g.N, 16));
-    if (dtype) hipLaunchKernelGGL((skinny_kernel<bf16_t>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((skinny_kernel<float>), grid, dim3(256), 0, stream, g);
+    if (dtype) hipLaunchKernelGGL((skinny_kernel<bf16_t>), grid, dim3(NW * 64), 0, stream, g);
+    else hipLaunchKernelGGL((skinny_kernel<float>), grid, dim3(NW * 64), 0, stream, g);
     B2S_LAUNCH_CHECK();
     return 0;
 }
