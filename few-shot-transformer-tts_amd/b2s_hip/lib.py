@@ -48,6 +48,7 @@ _PROTOS = {
     "b2s_model_tensor_info": (C.c_int, [P, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "b2s_model_bind": (C.c_int, [P, C.POINTER(P), C.POINTER(P), C.c_int]),
     "b2s_model_sync_weights": (C.c_int, [P, P]),
+    "b2s_model_sync_weights_ex": (C.c_int, [P, P, C.c_int]),
     "b2s_encoder_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int]),
     "b2s_encoder_forward": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, C.POINTER(P)]),
     "b2s_encoder_backward": (C.c_int, [P, P, P, P]),

@@ -62,7 +62,8 @@ class HipTrainer(object):
     def train_step(self, batch):
         """batch: the dataloader dict (dataloader.py:498-508) on the device.  Returns the 7 loss values (device)."""
         eng, lib = self.eng, self.lib
-        L.check(lib.b2s_model_sync_weights(eng.handle, L.stream()))     # Adam updated the fp32 masters in place
+        # the fused Adam kernel rewrote the fp32 masters AND their bf16 shadows; only conv re-layouts remain
+        L.check(lib.b2s_model_sync_weights_ex(eng.handle, L.stream(), int(self.global_step > 0)))
         in32, tgt32 = _i32(batch["input_lengths"]), _i32(batch["target_lengths"])
         mem, c_enc = eng.encoder_forward(batch["inputs"], in32, batch.get("input_spk_ids"), batch.get("input_language_vecs"),
                                          True, eng.next_seed(), True)

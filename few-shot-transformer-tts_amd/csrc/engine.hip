@@ -291,7 +291,7 @@ int attn_core_bwd(int dtype, hipStream_t st, const void* dctx, int ldc, const vo
 struct Scratch {
     float *S = nullptr, *dP = nullptr; void* dS = nullptr;
     void *dyT = nullptr, *dz = nullptr, *dqkv = nullptr, *dctx = nullptr, *dh = nullptr, *dkv = nullptr;
-    float *dx = nullptr, *a3 = nullptr, *dmem = nullptr, *dstop_m = nullptr;
+    float *dx = nullptr, *a3 = nullptr, *dmem = nullptr, *dstop_m = nullptr, *lnws = nullptr;
     void *dmelT = nullptr, *doutT = nullptr, *da3 = nullptr, *dz1 = nullptr, *dz2 = nullptr;
 };
 
@@ -345,6 +345,7 @@ void plan_encoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     sc.S = a.f32(pn); sc.dP = a.f32(pn); sc.dS = a.T(pn, esz);
     sc.dyT = a.T(M * D, esz); sc.dz = a.T(M * 4 * D, esz); sc.dqkv = a.T(M * 3 * D, esz);
     sc.dctx = a.T(M * D, esz); sc.dh = a.T(M * D, esz); sc.dx = a.f32(M * D);
+    sc.lnws = a.f32((long)RO_LN_WS_ROWS * 2 * D);
 }
 
 void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::vector<float*>& xs) {
@@ -384,6 +385,7 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     sc.dmelT = a.T(M * cf.num_mels, esz); sc.doutT = a.T(M * D, esz); sc.da3 = a.T(M * D, esz);
     sc.dz1 = a.T(M * cf.prenet_hidden, esz); sc.dz2 = a.T(M * cf.prenet_hidden, esz);
     sc.dstop_m = a.f32(M);
+    sc.lnws = a.f32((long)RO_LN_WS_ROWS * 2 * D);
 }
 
 struct PostScratch { std::vector<void*> du; float* stat; };
@@ -474,6 +476,7 @@ int build_chunks(b2s_model* m, bool l2only, bool with_state, MtChunk** out, int*
             c.c = with_state ? (float*)m->exp_avg[i] + o : nullptr;
             c.d = with_state ? (float*)m->exp_avg_sq[i] + o : nullptr;
             c.n = (int)std::min<long>(CH, t.numel - o); c.pad = t.l2 ? 1 : 0;
+            c.s = (with_state && m->dtype == 1 && t.gemm_weight && m->shadow[i] && m->shadow[i] != m->data[i]) ? (bf16_t*)m->shadow[i] + o : nullptr;
             h.push_back(c);
         }
     }
@@ -523,10 +526,11 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
     return 0;
 }
 
-extern "C" int b2s_model_sync_weights(b2s_model* m, void* stream) {
+extern "C" int b2s_model_sync_weights(b2s_model* m, void* stream) { return b2s_model_sync_weights_ex(m, stream, 0); }
+extern "C" int b2s_model_sync_weights_ex(b2s_model* m, void* stream, int shadows_fresh) {
     B2S_TRY(check_bound(m));
     hipStream_t st = S_(stream);
-    if (m->dtype)
+    if (m->dtype && !shadows_fresh)
         for (size_t i = 0; i < m->tinfo.size(); ++i)
             if (m->tinfo[i].gemm_weight) B2S_TRY(ro_cast(1, (const float*)m->data[i], m->shadow[i], m->tinfo[i].numel, st));
     for (int l = 0; l < m->cfg.n_postnet_layer; ++l) {
@@ -643,7 +647,7 @@ int ffn_bwd(b2s_model* m, hipStream_t st, const FfnSave& f, Scratch& sc, long M,
     B2S_TRY(linear_dw(m, st, sc.dz, 4 * D, f.h, D, (int)M, 4 * D, D, m->G(wp_in)));
     B2S_TRY(linear_dx(m, st, sc.dz, 4 * D, m->W(wp_in), (int)M, D, 4 * D, sc.dh, 0, D, GemmEpilogue()));
     B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, f.x_in, m->P(lnp + ".weight"), f.mean, f.rstd, sc.dx, 1, m->G(lnp + ".weight"),
-                             m->G(lnp + ".bias"), (int)M, D, nullptr, 1, st));
+                             m->G(lnp + ".bias"), (int)M, D, nullptr, 1, st, sc.lnws));
     return 0;
 }
 // backward of x_out = x_in + drop(SelfAttn(LN(x_in)))
@@ -663,7 +667,7 @@ int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, 
     B2S_TRY(linear_dw(m, st, sc.dqkv, 3 * D, s.h, D, (int)M, 3 * D, D, m->G(wq)));
     B2S_TRY(linear_dx(m, st, sc.dqkv, 3 * D, m->W(wq), (int)M, D, 3 * D, sc.dh, 0, D, GemmEpilogue()));
     B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, s.x_in, m->P(lnp + ".weight"), s.mean, s.rstd, sc.dx, 1, m->G(lnp + ".weight"),
-                             m->G(lnp + ".bias"), (int)M, D, nullptr, 1, st));
+                             m->G(lnp + ".bias"), (int)M, D, nullptr, 1, st, sc.lnws));
     return 0;
 }
 }  // namespace
@@ -695,7 +699,7 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
                                   m->G("encoder.language_layer.bias"), B, S, cf.language_embedding_size, st));
     }
     B2S_TRY(ro_layernorm_bwd(dt, d_memory, 1, Dm, c->x_final, m->P(p + "output_layer_norm.weight"), c->mean_f, c->rstd_f, sc.dx, 0,
-                             m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, nullptr, 1, st));
+                             m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, nullptr, 1, st, sc.lnws));
     m->stage_done(3 + cf.n_decoder_layer);
     for (int l = cf.n_encoder_layer - 1; l >= 0; --l) {
         const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lna = p + "attn_layer_norms." + std::to_string(l);
@@ -840,7 +844,7 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
         B2S_TRY(ro_colsum(0, sc.dstop_m, 1, 1, nullptr, m->G("decoder.stop_net.bias"), 1, (int)M, 1, st));
     }
     B2S_TRY(ro_layernorm_bwd(dt, sc.doutT, 0, D, c->x_final, m->P(p + "output_layer_norm.weight"), c->mean_f, c->rstd_f, sc.dx, 0,
-                             m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, c->tgt_len, T, st));
+                             m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, c->tgt_len, T, st, sc.lnws));
     m->stage_done(1);
     bool first_mem = true;
     for (int l = cf.n_decoder_layer - 1; l >= 0; --l) {
@@ -867,7 +871,7 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
             B2S_TRY(linear_dx(m, st, sc.dkv, 2 * D, m->W(wkv), (int)Mk, D, 2 * D, d_memory_out, 1, D, em));
             first_mem = false;
             B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, x.x_in, m->P(lnx + ".weight"), x.mean, x.rstd, sc.dx, 1, m->G(lnx + ".weight"),
-                                     m->G(lnx + ".bias"), (int)M, D, nullptr, 1, st));
+                                     m->G(lnx + ".bias"), (int)M, D, nullptr, 1, st, sc.lnws));
         }
         B2S_TRY(self_attn_bwd(m, st, c->self_attn[l], sc, M, D, B, H, T, pt, c->seed, nm(p, "self_attentions", l, "qkv_transform.weight"),
                               nm(p, "self_attentions", l, "output_transform.weight"), lna));

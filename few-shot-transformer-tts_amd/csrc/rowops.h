@@ -18,7 +18,9 @@ int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float*
 // dx (+)= LN'(dy); dgamma += ..., dbeta += ... (atomic; caller zeroes).  dy is T (dy_fp32=0) or fp32, ld lddy.
 int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const float* x, const float* gamma,
                      const float* mean, const float* rstd, float* dx, int accumulate, float* dgamma, float* dbeta,
-                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st);
+                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws = nullptr);
+// ws (optional): RO_LN_WS_ROWS * 2 * D floats of scratch for the parameter-gradient partials (avoids global atomics)
+constexpr int RO_LN_WS_ROWS = 768;
 
 // P = softmax(scale*S + mask) per row; rows [Z=B*H][Lq][ldp].  mask_mode bit0: keys >= klen[b] masked,
 // bit1: causal (key > query masked); bias: optional dense additive fp32 bias [bias_sb*b + bias_sq*q + k].
@@ -89,7 +91,7 @@ int ro_loss_bwd(const float* bef, const float* aft, const float* stop, const flo
                 hipStream_t st);
 
 // multi-tensor ops over a chunk table (device array of MtChunk)
-struct MtChunk { float* a; float* b; float* c; float* d; int n; int pad; };   // pad: 1 = member of the L2 set
+struct MtChunk { float* a; float* b; float* c; float* d; bf16_t* s; int n; int pad; };   // pad: 1 = member of the L2 set; s: bf16 shadow (or null)
 int ro_mt_sumsq(const MtChunk* chunks, int nchunks, float* out, float scale, hipStream_t st);         // out += scale*sum a^2
 int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gscale, hipStream_t st);  // b += alpha*gscale*a
 // Adam: a=param b=grad c=m d=v ; lr and step read from device (hp[0]=lr, hp[1]=bias_corr1, hp[2]=bias_corr2)

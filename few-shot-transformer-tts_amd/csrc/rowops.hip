@@ -2,6 +2,7 @@
 // Every kernel reads its rows with 16-byte (fp32x4) or 8/16-byte (bf16) coalesced accesses and reduces
 // with 64-lane wavefront shuffles; sequence masks come from the per-utterance lengths (no dense
 // bias tensors are built, unlike transformer/common.py:32-48).
+#include <algorithm>
 #include "rowops.h"
 
 namespace {
@@ -121,7 +122,7 @@ template <typename TD>
 __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const float* x, const float* gamma,
                                                 const float* mean, const float* rstd, float* dx, int accumulate,
                                                 float* dgamma, float* dbeta, int M, int D, const int* row_len,
-                                                int rpb) {
+                                                int rpb, float* ws) {
     __shared__ float sacc[2 * LN_MAXC * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
@@ -178,7 +179,18 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < D; i += 256) { atomicAdd(dgamma + i, sacc[i]); atomicAdd(dbeta + i, sacc[D + i]); }
+    if (ws) {       // per-workgroup partial row [dgamma | dbeta]; k_ln_param_reduce adds the column sums (no global atomics)
+        for (int i = threadIdx.x; i < 2 * D; i += 256) ws[(long)blockIdx.x * 2 * D + i] = sacc[i];
+    } else {
+        for (int i = threadIdx.x; i < D; i += 256) { atomicAdd(dgamma + i, sacc[i]); atomicAdd(dbeta + i, sacc[D + i]); }
+    }
+}
+__global__ void k_ln_param_reduce(const float* ws, int nblk, int D, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * D) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += ws[(long)b * 2 * D + c];
+    if (c < D) dgamma[c] += s; else dbeta[c - D] += s;
 }
 
 // ---------------------------------------------------------------------------------- softmax
@@ -502,23 +514,27 @@ __device__ inline float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(__exp
 __global__ __launch_bounds__(256) void k_loss_partial(const float* bef, const float* aft, const float* stop,
                                                       const float* tgt, const int* lens, float* scratch, int B, int T,
                                                       int C, float pw) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B * T) return;
-    const int b = row / T, t = row - b * T, len = lens[b];
-    if (t >= len) return;
-    float sb = 0.f, sa = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        float y = tgt[(long)row * C + c];
-        float d1 = bef[(long)row * C + c] - y, d2 = aft[(long)row * C + c] - y;
-        sb += d1 * d1; sa += d2 * d2;
+    // one wave per row, grid-stride; per-wave partial sums, one atomic per quantity per wave at the end
+    const int lane = threadIdx.x & 63;
+    float tb = 0.f, ta = 0.f, tc = 0.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < B * T; row += gridDim.x * 4) {
+        const int b = row / T, t = row - b * T, len = lens[b];
+        if (t >= len) continue;
+        float sb = 0.f, sa = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float y = tgt[(long)row * C + c];
+            float d1 = bef[(long)row * C + c] - y, d2 = aft[(long)row * C + c] - y;
+            sb += d1 * d1; sa += d2 * d2;
+        }
+        sb = wave_sum(sb) / C; sa = wave_sum(sa) / C;
+        tb += sb; ta += sa;
+        if (lane == 0) {
+            float x = stop[row];
+            tc += (t == len - 1) ? pw * softplusf(-x) : softplusf(x);
+            atomicAdd(scratch + 3 + b, sa);               // per-sample sums: B distinct addresses, low contention
+        }
     }
-    sb = wave_sum(sb) / C; sa = wave_sum(sa) / C;
-    if (lane == 0) {
-        float x = stop[row];
-        float ce = (t == len - 1) ? pw * softplusf(-x) : softplusf(x);
-        atomicAdd(scratch + 0, sb); atomicAdd(scratch + 1, sa); atomicAdd(scratch + 2, ce);
-        atomicAdd(scratch + 3 + b, sa);
-    }
+    if (lane == 0) { atomicAdd(scratch + 0, tb); atomicAdd(scratch + 1, ta); atomicAdd(scratch + 2, tc); }
 }
 __global__ void k_loss_finalize(const float* scratch, const int* lens, const float* l2, float* out, float* aft_losses,
                                 int B) {
@@ -582,7 +598,9 @@ __global__ __launch_bounds__(256) void k_mt_adam(const MtChunk* ch, const float*
         m = b1 * m + (1.f - b1) * g;
         v = b2 * v + (1.f - b2) * g * g;
         c.c[i] = m; c.d[i] = v;
-        c.a[i] = p - (lr / bc1) * m / (sqrtf(v) / sbc2 + eps);
+        p -= (lr / bc1) * m / (sqrtf(v) / sbc2 + eps);
+        c.a[i] = p;
+        if (c.s) c.s[i] = f2bf(p);                       // refresh the compute-dtype shadow in the same pass
     }
 }
 
@@ -629,15 +647,21 @@ int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float*
 }
 int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const float* x, const float* gamma,
                      const float* mean, const float* rstd, float* dx, int accumulate, float* dgamma, float* dbeta,
-                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st) {
+                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws) {
     B2S_CHECK(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
-    int grid = cdiv(M, 4); if (grid > 512) grid = 512;
+    int grid = cdiv(M, 4); if (grid > (ws ? RO_LN_WS_ROWS : 512)) grid = ws ? RO_LN_WS_ROWS : 512;
     if (dy_fp32 || !dtype)
         hipLaunchKernelGGL((k_ln_bwd<float>), dim3(grid), dim3(256), 0, st, (const float*)dy, lddy, x, gamma, mean, rstd,
-                           dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch);
+                           dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch, ws);
     else
         hipLaunchKernelGGL((k_ln_bwd<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, lddy, x, gamma, mean,
-                           rstd, dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch);
+                           rstd, dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch, ws);
+    if (ws) {      // column sums of the [grid, 2D] partials: 64 columns x (rows split over gy workgroups), few atomics per column
+        int gy = cdiv(grid, 64); if (gy < 1) gy = 1;
+        dim3 g2(cdiv(D, 64), gy);
+        hipLaunchKernelGGL((k_colsum<float>), g2, dim3(256), 0, st, (const float*)ws, 2 * D, (const float*)nullptr, dgamma, grid, D);
+        hipLaunchKernelGGL((k_colsum<float>), g2, dim3(256), 0, st, (const float*)ws + D, 2 * D, (const float*)nullptr, dbeta, grid, D);
+    }
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_softmax_fwd(int dtype, const float* S, void* P, void* Pd, int B, int H, int Lq, int Lk, int ldp, float scale,
@@ -790,7 +814,7 @@ int ro_loss_fwd(const float* bef, const float* aft, const float* stop, const flo
                 const float* l2, float* out, float* aft_losses, int B, int T, int C, float pos_weight, float* scratch,
                 hipStream_t st) {
     B2S_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * (3 + B), st));
-    hipLaunchKernelGGL(k_loss_partial, dim3(cdiv((long)B * T, 4)), dim3(256), 0, st, bef, aft, stop, tgt, lens, scratch, B,
+    hipLaunchKernelGGL(k_loss_partial, dim3(std::min(cdiv((long)B * T, 4), 512)), dim3(256), 0, st, bef, aft, stop, tgt, lens, scratch, B,
                        T, C, pos_weight);
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, (const float*)scratch, lens, l2, out, aft_losses, B);
     B2S_LAUNCH_CHECK(); return 0;

@@ -57,6 +57,9 @@ int b2s_model_tensor_info(const b2s_model* m, int i, char* name, int name_cap, i
 int b2s_model_bind(b2s_model* m, void* const* data_host, void* const* grad_host, int n);
 /* Refresh the compute-dtype weight shadows (bf16 copies, conv re-layouts) after parameters changed. */
 int b2s_model_sync_weights(b2s_model* m, void* stream);
+/* shadows_fresh != 0: b2s_adam_step already refreshed the bf16 shadows (it writes them in the same pass); only the conv
+ * weight re-layouts are redone. */
+int b2s_model_sync_weights_ex(b2s_model* m, void* stream, int shadows_fresh);
 
 /* ---- Encoder.forward (tacotron.py:33-44; modules.py:49-69) ---------------------------------------
  * memory_out: [B, S, encoder_hidden (+spk) (+lang)].  train != 0 enables dropout (seeded by `seed`).
