@@ -49,9 +49,11 @@ class HipTrainer(object):
                                          bucket_mb * 1024 * 1024 / 4, dist=self.dist)
             L.check(self.lib.b2s_model_set_stage_hook(self.eng.handle, C.cast(self._hook, L.P), None))
             # broadcast parameters and BN buffers from rank 0 once (DDP constructor semantics, train.py:125)
-            for t in self.eng._tensors():
-                self.dist.broadcast(t, 0)
+            with torch.no_grad():
+                for t in self.eng._tensors():
+                    self.dist.broadcast(t.data, 0)
             self.eng._versions = None
+            self.eng.ensure_bound()                   # re-sync the compute-dtype shadows with the broadcast values
 
     # ------------------------------------------------------------------ gradient exchange
     def _on_stage(self, stage, _user):

@@ -1,0 +1,130 @@
+"""GPU tests: edge-case shapes against the oracle, and the data-parallel trainer with 2 ranks sharing one GPU
+(gloo backend over device tensors -- RCCL refuses two ranks on one device; the driver's multi-GPU bench uses nccl)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "few-shot-transformer-tts_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle import b2s_oracle as O            # noqa: E402  (checker only)
+from oracle import synth, make_config, TINY    # noqa: E402
+
+DEV = "cuda"
+
+
+def _build(over, seed=1234, compute_dtype="fp32"):
+    from hyperparams import hparams as hp
+    from transformer.tacotron import Tacotron
+    if not hasattr(_build, "d"):
+        _build.d = dict(hp.values())
+    hp.override_from_dict(_build.d)
+    hp.parse(over)
+    hp.parse("compute_dtype=%s" % compute_dtype)
+    cfg = make_config(over)
+    m = Tacotron(hp)
+    st = synth.synthetic_state(cfg, seed)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()}, strict=True)
+    return m.to(DEV), cfg, st, hp
+
+
+def _dev(nb):
+    return {k: (torch.from_numpy(np.asarray(v)).to(DEV) if not isinstance(v, list) else v) for k, v in nb.items()}
+
+
+@pytest.mark.parametrize("B,S,T,in_lens,tgt_lens", [
+    (1, 5, 9, [5], [9]),                      # single utterance
+    (2, 3, 2, [3, 2], [2, 1]),                # minimal lengths (target length 1: stop target on frame 0)
+    (3, 70, 131, [70, 1 + 1, 33], [131, 64, 1]),      # ragged, tiles straddle 64/128 boundaries
+    (2, 130, 257, [130, 65], [257, 129]),     # > 2 attention tiles in both directions
+])
+def test_edge_shapes_forward_backward(B, S, T, in_lens, tgt_lens):
+    from transformer.tacotron import compute_loss
+    m, cfg, st, hp = _build(TINY)
+    nb = synth.synthetic_batch(cfg, B=B, S=S, T=T, seed=B * 31 + T, in_lens=in_lens, tgt_lens=tgt_lens)
+    b = _dev(nb)
+    m.train()
+    o = m(**b)
+    losses = compute_loss(m, b["mel_targets"], b["target_lengths"], o, hp)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    P = O.to_torch_state(st, requires_grad=True)
+    ob = O.to_torch_batch(nb)
+    ro = O.tacotron_forward(P, cfg, ob, train=True)
+    rl = O.compute_loss(P, cfg, ob["mel_targets"], ob["target_lengths"], ro)
+    names = [n for n in P if O.is_parameter(n)]
+    grads = torch.autograd.grad(rl["loss"], [P[n] for n in names], allow_unused=True)
+    for k in ("mel_bef", "mel_aft", "stop_logits"):
+        d = float((o[k].detach().cpu() - ro[k].detach()).abs().max())
+        assert d < 3e-4, (k, d)
+    assert abs(float(losses["loss"]) - float(rl["loss"])) < 1e-4 * max(1.0, abs(float(rl["loss"])))
+    al = o["alignments"]["encdec"][1].cpu()
+    assert float((al - ro["alignments"]["encdec"][1].detach()).abs().max()) < 1e-5
+    got = dict(m.named_parameters())
+    for n, g in zip(names, grads):
+        ref = g if g is not None else torch.zeros_like(P[n])
+        err = float((got[n].grad.cpu() - ref).abs().max())
+        assert err < 3e-4 * max(1.0, float(ref.norm())), (n, err)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _dp_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from b2s_hip.trainer import HipTrainer
+    torch.manual_seed(0)
+    m, cfg, st, hp = _build(TINY, seed=1234 if rank == 0 else 999)      # rank 1 starts different: the trainer must broadcast rank 0's
+    m.train()
+    tr = HipTrainer(m, hp, bucket_mb=0.05)
+    assert tr.world == 2 and tr.bucketer is not None
+    for step in range(2):
+        nb = synth.synthetic_batch(cfg, B=2, S=9, T=14, seed=100 + 10 * step + rank)
+        vals = tr.train_step(_dev(nb))
+        assert len(tr.bucketer.launched) > 1
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **sd)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_trainer_two_ranks(tmp_path):
+    """2 ranks: identical parameters afterwards, equal to the oracle's mean-of-rank-gradients Adam steps."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = dict(np.load(os.path.join(str(tmp_path), "rank0.npz")))
+    r1 = dict(np.load(os.path.join(str(tmp_path), "rank1.npz")))
+    cfg = make_config(TINY)
+    P = O.to_torch_state(synth.synthetic_state(cfg, 1234), requires_grad=True)
+    opt = {}
+    names = [n for n in P if O.is_parameter(n)]
+    for step in range(2):
+        gsum = None
+        for rank in range(2):
+            ob = O.to_torch_batch(synth.synthetic_batch(cfg, B=2, S=9, T=14, seed=100 + 10 * step + rank))
+            o = O.tacotron_forward(P, cfg, ob, train=True)
+            loss = O.compute_loss(P, cfg, ob["mel_targets"], ob["target_lengths"], o)["loss"]
+            g = torch.autograd.grad(loss, [P[n] for n in names], allow_unused=True)
+            g = [x if x is not None else torch.zeros_like(P[n]) for x, n in zip(g, names)]
+            gsum = g if gsum is None else [a + b for a, b in zip(gsum, g)]
+        with torch.no_grad():
+            O.adam_step(P, {n: x / 2 for n, x in zip(names, gsum)}, opt, step, cfg)
+    for n in names:
+        assert np.array_equal(r0[n], r1[n]), n                      # replicas stay bit-identical
+        ref = P[n].detach().numpy()
+        assert abs(np.linalg.norm(r0[n]) - np.linalg.norm(ref)) <= 2e-4 * np.linalg.norm(ref) + 1e-5, n
+        assert np.abs(r0[n] - ref).max() < 4.5e-3, n               # <= 2 steps x lr on ill-conditioned (|g|~0) elements
