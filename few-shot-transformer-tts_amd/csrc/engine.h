@@ -98,9 +98,18 @@ struct b2s_model {
     int n_l2_chunks = 0, n_adam_chunks = 0;
     float* small = nullptr;                         // device scratch: [0..15] misc scalars
     std::vector<void*> owned;                       // hipMalloc'ed buffers
+    // second HIP stream for the weight-gradient GEMMs: they depend only on (dY, X) and feed nothing in the backward chain,
+    // so they run concurrently with the dX / attention / LayerNorm kernels of the same layer (the 128x128-tile GEMMs leave
+    // CUs idle in their last, partial wave of workgroups).  Hazards on re-used scratch buffers are tracked per buffer.
+    mutable hipStream_t aux = nullptr;
+    mutable std::vector<hipEvent_t> ev_pool;
+    mutable size_t ev_next = 0;
+    mutable std::map<const void*, hipEvent_t> aux_readers;     // scratch buffer -> event after its last aux-stream reader
+    mutable bool aux_dirty = false;
+    hipEvent_t next_event() const { hipEvent_t e = ev_pool[ev_next % ev_pool.size()]; ++ev_next; return e; }
     void (*stage_hook)(int, void*) = nullptr;       // called on the host after each backward stage is enqueued
     void* stage_user = nullptr;
-    void stage_done(int s) const { if (stage_hook) stage_hook(s, stage_user); }
+    void stage_done(int s) const { if (stage_hook) stage_hook(s, stage_user); }   // callers join the aux stream first
 
     int id(const std::string& n) const;
     float* P(const std::string& n) const { return (float*)data[id(n)]; }

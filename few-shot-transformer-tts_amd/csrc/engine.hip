@@ -175,6 +175,22 @@ int linear_dx(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
     g.M = M; g.N = Nin; g.K = Kout; g.C = out; g.c_fp32 = out_fp32; g.ldc = ldo; g.epi = e;
     return b2s_gemm_launch(g, m->dtype, false, true, st);
 }
+// ---- aux-stream plumbing (see b2s_model::aux)
+int guard_write(const b2s_model* m, const void* buf, hipStream_t st) {       // main stream is about to overwrite `buf`
+    auto it = m->aux_readers.find(buf);
+    if (it != m->aux_readers.end()) { B2S_HIP(hipStreamWaitEvent(st, it->second, 0)); m->aux_readers.erase(it); }
+    return 0;
+}
+int join_aux(const b2s_model* m, hipStream_t st) {                           // main stream waits for every queued dW GEMM
+    if (m->aux && m->aux_dirty) {
+        hipEvent_t e = m->next_event();
+        B2S_HIP(hipEventRecord(e, m->aux));
+        B2S_HIP(hipStreamWaitEvent(st, e, 0));
+        m->aux_dirty = false;
+        m->aux_readers.clear();
+    }
+    return 0;
+}
 // weight-gradient GEMMs reduce over all B*L tokens into a small [out,in] matrix: split K over blocks so the
 // launch fills 256 CUs (>= ~1024 workgroups), partial sums combined with fp32 atomics into the zeroed gradient
 int pick_splitk(int Mo, int No, int K, int dtype) {
@@ -195,7 +211,16 @@ int linear_dw(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
     g.M = Nout; g.N = Kin; g.K = M; g.C = dW; g.c_fp32 = 1; g.ldc = Kin;
     g.epi.accumulate = 1;          // parameter gradients accumulate; the host zeroes them once per backward pass
     g.splitk = pick_splitk(Nout, Kin, M, m->dtype);
-    return b2s_gemm_launch(g, m->dtype, true, true, st);
+    if (!m->aux) return b2s_gemm_launch(g, m->dtype, true, true, st);
+    hipEvent_t ready = m->next_event();
+    B2S_HIP(hipEventRecord(ready, st));                    // dY (and X) are complete at this point of the main stream
+    B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
+    B2S_TRY(b2s_gemm_launch(g, m->dtype, true, true, m->aux));
+    hipEvent_t done = m->next_event();
+    B2S_HIP(hipEventRecord(done, m->aux));
+    m->aux_readers[dY] = done;
+    m->aux_dirty = true;
+    return 0;
 }
 
 struct AttnScratch { float* S; float* dP; void* dS; };
@@ -519,6 +544,11 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
         m->conv_wf[l] = a; m->conv_wb[l] = b;
     }
     if (!m->small) { B2S_HIP(hipMalloc(&m->small, 64 * sizeof(float))); m->owned.push_back(m->small); }
+    if (!m->aux && !getenv("B2S_NO_AUX")) {
+        B2S_HIP(hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking));
+        m->ev_pool.resize(256);
+        for (auto& ev : m->ev_pool) B2S_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
     B2S_TRY(ensure_pe(m, 2048));
     m->n_l2_chunks = 0; m->l2_chunks = nullptr;
     B2S_TRY(build_chunks(m, true, false, &m->l2_chunks, &m->n_l2_chunks));
@@ -640,12 +670,15 @@ int ffn_bwd(b2s_model* m, hipStream_t st, const FfnSave& f, Scratch& sc, long M,
     const int dt = m->dtype;
     DropCfg dres = make_drop(p, seed, f.op_res), dhid = make_drop(p, seed, f.op_hid);
     const void* dy = sc.dx;
+    B2S_TRY(guard_write(m, sc.dyT, st));
     if (dt || dres.thresh) { B2S_TRY(ro_cast_drop(dt, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); dy = sc.dyT; }
     B2S_TRY(linear_dw(m, st, dy, D, f.f, 4 * D, (int)M, D, 4 * D, m->G(wp_out)));
     GemmEpilogue e; e.relu_aux = f.f; e.ld_aux = 4 * D; e.aux_scale = dhid.scale;
+    B2S_TRY(guard_write(m, sc.dz, st));
     B2S_TRY(linear_dx(m, st, dy, D, m->W(wp_out), (int)M, 4 * D, D, sc.dz, 0, 4 * D, e));
     B2S_TRY(linear_dw(m, st, sc.dz, 4 * D, f.h, D, (int)M, 4 * D, D, m->G(wp_in)));
     B2S_TRY(linear_dx(m, st, sc.dz, 4 * D, m->W(wp_in), (int)M, D, 4 * D, sc.dh, 0, D, GemmEpilogue()));
+    B2S_TRY(guard_write(m, sc.dx, st));
     B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, f.x_in, m->P(lnp + ".weight"), f.mean, f.rstd, sc.dx, 1, m->G(lnp + ".weight"),
                              m->G(lnp + ".bias"), (int)M, D, nullptr, 1, st, sc.lnws));
     return 0;
@@ -657,15 +690,18 @@ int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, 
     const int dt = m->dtype, dh = D / H, esz = m->esz;
     DropCfg dres = make_drop(p, seed, s.op_res), datt = make_drop(p, seed, s.op_attn);
     const void* dy = sc.dx;
+    B2S_TRY(guard_write(m, sc.dyT, st));
     if (dt || dres.thresh) { B2S_TRY(ro_cast_drop(dt, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); dy = sc.dyT; }
     B2S_TRY(linear_dw(m, st, dy, D, s.ctx, D, (int)M, D, D, m->G(wo)));
     B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, sc.dctx, 0, D, GemmEpilogue()));
+    B2S_TRY(guard_write(m, sc.dqkv, st));
     const char* q = (const char*)s.qkv; char* dq = (char*)sc.dqkv;
     B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, q, 3 * D, q + (size_t)D * esz, 3 * D, q + (size_t)2 * D * esz, 3 * D, s.P, s.Pd,
                           dq, 3 * D, dq + (size_t)D * esz, 3 * D, dq + (size_t)2 * D * esz, 3 * D, B, H, L, L, dh, datt, sc.dP, sc.dS,
                           s.lse, s.ctx, s.mask_mode, klen));
     B2S_TRY(linear_dw(m, st, sc.dqkv, 3 * D, s.h, D, (int)M, 3 * D, D, m->G(wq)));
     B2S_TRY(linear_dx(m, st, sc.dqkv, 3 * D, m->W(wq), (int)M, D, 3 * D, sc.dh, 0, D, GemmEpilogue()));
+    B2S_TRY(guard_write(m, sc.dx, st));
     B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, s.x_in, m->P(lnp + ".weight"), s.mean, s.rstd, sc.dx, 1, m->G(lnp + ".weight"),
                              m->G(lnp + ".bias"), (int)M, D, nullptr, 1, st, sc.lnws));
     return 0;
@@ -700,6 +736,7 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
     }
     B2S_TRY(ro_layernorm_bwd(dt, d_memory, 1, Dm, c->x_final, m->P(p + "output_layer_norm.weight"), c->mean_f, c->rstd_f, sc.dx, 0,
                              m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, nullptr, 1, st, sc.lnws));
+    B2S_TRY(join_aux(m, st));
     m->stage_done(3 + cf.n_decoder_layer);
     for (int l = cf.n_encoder_layer - 1; l >= 0; --l) {
         const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lna = p + "attn_layer_norms." + std::to_string(l);
@@ -707,10 +744,12 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
                         nm(p, "ffn_layers", l, "output_layer.weight"), lnf));
         B2S_TRY(self_attn_bwd(m, st, c->self_attn[l], sc, M, D, B, H, S, pt, c->seed, nm(p, "self_attentions", l, "qkv_transform.weight"),
                               nm(p, "self_attentions", l, "output_transform.weight"), lna, c->in_len));
-        m->stage_done(4 + cf.n_decoder_layer + (cf.n_encoder_layer - 1 - l));
+        B2S_TRY(join_aux(m, st));
+    m->stage_done(4 + cf.n_decoder_layer + (cf.n_encoder_layer - 1 - l));
     }
     B2S_TRY(ro_embed_prep_bwd(sc.dx, (const long*)c->ids, c->in_len, m->pe_enc, m->G("encoder.embed.weight"), m->G(p + "pe_scale"),
                               B, S, D, make_drop(pt, c->seed, opid(1, 0, 1)), st));
+    B2S_TRY(join_aux(m, st));
     m->stage_done(4 + cf.n_decoder_layer + cf.n_encoder_layer);
     return 0;
 }
@@ -845,6 +884,7 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
     }
     B2S_TRY(ro_layernorm_bwd(dt, sc.doutT, 0, D, c->x_final, m->P(p + "output_layer_norm.weight"), c->mean_f, c->rstd_f, sc.dx, 0,
                              m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, c->tgt_len, T, st, sc.lnws));
+    B2S_TRY(join_aux(m, st));
     m->stage_done(1);
     bool first_mem = true;
     for (int l = cf.n_decoder_layer - 1; l >= 0; --l) {
@@ -858,9 +898,11 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
                               wo = nm(p, "encdec_attentions", l, "output_transform.weight");
             DropCfg dres = make_drop(pt, c->seed, x.op_res), datt = make_drop(pt, c->seed, x.op_attn);
             const void* dy = sc.dx;
-            if (dt || dres.thresh) { B2S_TRY(ro_cast_drop(dt, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); dy = sc.dyT; }
+            B2S_TRY(guard_write(m, sc.dyT, st));
+    if (dt || dres.thresh) { B2S_TRY(ro_cast_drop(dt, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); dy = sc.dyT; }
             B2S_TRY(linear_dw(m, st, dy, D, x.ctx, D, (int)M, D, D, m->G(wo)));
             B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, sc.dctx, 0, D, GemmEpilogue()));
+            B2S_TRY(guard_write(m, sc.dqkv, st)); B2S_TRY(guard_write(m, sc.dkv, st));
             const char* kv = (const char*)x.kv; char* dkv = (char*)sc.dkv;
             B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, x.qkv, D, kv, 2 * D, kv + (size_t)D * esz, 2 * D, x.P, x.Pd, sc.dqkv, D, dkv, 2 * D,
                                   dkv + (size_t)D * esz, 2 * D, B, H, T, S, dh, datt, sc.dP, sc.dS, x.lse, x.ctx, x.mask_mode, c->in_len));
@@ -870,12 +912,14 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
             GemmEpilogue em; em.accumulate = first_mem ? 0 : 1;
             B2S_TRY(linear_dx(m, st, sc.dkv, 2 * D, m->W(wkv), (int)Mk, D, 2 * D, d_memory_out, 1, D, em));
             first_mem = false;
+            B2S_TRY(guard_write(m, sc.dx, st));
             B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, x.x_in, m->P(lnx + ".weight"), x.mean, x.rstd, sc.dx, 1, m->G(lnx + ".weight"),
                                      m->G(lnx + ".bias"), (int)M, D, nullptr, 1, st, sc.lnws));
         }
         B2S_TRY(self_attn_bwd(m, st, c->self_attn[l], sc, M, D, B, H, T, pt, c->seed, nm(p, "self_attentions", l, "qkv_transform.weight"),
                               nm(p, "self_attentions", l, "output_transform.weight"), lna));
-        m->stage_done(2 + (cf.n_decoder_layer - 1 - l));
+        B2S_TRY(join_aux(m, st));
+    m->stage_done(2 + (cf.n_decoder_layer - 1 - l));
     }
     if (first_mem) B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
     B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, opid(2, 0, 3)), st));
@@ -891,6 +935,7 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
     B2S_TRY(ro_colsum(dt, sc.dz1, 0, HP, nullptr, m->G("decoder.prenet.dense0.bias"), 1, (int)M, HP, st));
     B2S_TRY(linear_dw(m, st, sc.dz1, HP, c->tgtT, NM, (int)M, HP, NM, m->G("decoder.prenet.dense0.weight")));
     B2S_LAUNCH_CHECK();
+    B2S_TRY(join_aux(m, st));
     m->stage_done(2 + cf.n_decoder_layer);
     return 0;
 }
@@ -1007,6 +1052,7 @@ extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out
             B2S_TRY(b2s_gemm_launch(g, dt, false, false, st));
         }
     }
+    B2S_TRY(join_aux(m, st));
     m->stage_done(0);
     return 0;
 }
