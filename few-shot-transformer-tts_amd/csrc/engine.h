@@ -71,7 +71,7 @@ struct b2s_ctx {
     std::vector<FfnSave> ffn;
     float* x_final = nullptr;           // input of the output LayerNorm
     float *mean_f = nullptr, *rstd_f = nullptr;
-    float *spk_e = nullptr, *spk_h = nullptr, *lang_e = nullptr, *lang_h = nullptr;
+    float *spk_e = nullptr, *spk_h = nullptr, *lang_e = nullptr, *lang_h = nullptr, *spk_dh = nullptr, *lang_dh = nullptr;
     // decoder
     void* memT = nullptr;
     void *tgtT = nullptr, *a1 = nullptr, *a2 = nullptr;

@@ -363,8 +363,8 @@ void plan_encoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     c.x_final = xs.back();
     c.mean_f = a.f32(M); c.rstd_f = a.f32(M);
     c.memT = a.T(M * m->Dm, esz);
-    if (cf.multi_speaker) { c.spk_e = a.f32((long)B * cf.speaker_embedding_size); c.spk_h = a.f32((long)B * cf.speaker_embedding_size); }
-    if (cf.multi_lingual) { c.lang_e = a.f32((long)B * cf.language_embedding_size); c.lang_h = a.f32((long)B * cf.language_embedding_size); }
+    if (cf.multi_speaker) { c.spk_e = a.f32((long)B * cf.speaker_embedding_size); c.spk_h = a.f32((long)B * cf.speaker_embedding_size); c.spk_dh = a.f32((long)2 * B * cf.speaker_embedding_size); }
+    if (cf.multi_lingual) { c.lang_e = a.f32((long)B * cf.language_embedding_size); c.lang_h = a.f32((long)B * cf.language_embedding_size); c.lang_dh = a.f32((long)2 * B * cf.language_embedding_size); }
     // scratch (forward + backward)
     const long pn = (long)B * H * S * rup8(S);
     sc.S = a.f32(pn); sc.dP = a.f32(pn); sc.dS = a.T(pn, esz);
@@ -725,14 +725,14 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
     if (cf.multi_speaker) {
         B2S_TRY(ro_spk_embed_bwd(d_memory, Dm, col, (const long*)c->spk_ids, c->spk_e, c->spk_h, m->P("encoder.speaker_layer.weight"),
                                  m->G("encoder.speaker_embed.weight"), m->G("encoder.speaker_layer.weight"),
-                                 m->G("encoder.speaker_layer.bias"), B, S, cf.speaker_embedding_size, st));
+                                 m->G("encoder.speaker_layer.bias"), c->spk_dh, B, S, cf.speaker_embedding_size, st));
         col += cf.speaker_embedding_size;
     }
     if (cf.multi_lingual) {
         B2S_TRY(ro_lang_embed_bwd(d_memory, Dm, col, c->lang_vecs, cf.max_num_language, c->lang_e, c->lang_h,
                                   m->P("encoder.language_embed.weight"), m->P("encoder.language_layer.weight"),
                                   m->G("encoder.language_embed.weight"), m->G("encoder.language_layer.weight"),
-                                  m->G("encoder.language_layer.bias"), B, S, cf.language_embedding_size, st));
+                                  m->G("encoder.language_layer.bias"), c->lang_dh, B, S, cf.language_embedding_size, st));
     }
     B2S_TRY(ro_layernorm_bwd(dt, d_memory, 1, Dm, c->x_final, m->P(p + "output_layer_norm.weight"), c->mean_f, c->rstd_f, sc.dx, 0,
                              m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, nullptr, 1, st, sc.lnws));

@@ -55,10 +55,10 @@ int ro_lang_embed_fwd(const float* vecs, int L, const float* Wl, const float* W,
                       hipStream_t st);
 // dmem32 [B*S, ldm] -> gradients of the tiny embedding nets (atomic adds; caller zeroes)
 int ro_spk_embed_bwd(const float* dmem, int ldm, int col0, const long* spk_ids, const float* e_raw, const float* h_pre,
-                     const float* W, float* d_table, float* dW, float* db, int B, int S, int E, hipStream_t st);
+                     const float* W, float* d_table, float* dW, float* db, float* dh_scratch, int B, int S, int E, hipStream_t st);
 int ro_lang_embed_bwd(const float* dmem, int ldm, int col0, const float* vecs, int L, const float* e_raw,
-                      const float* h_pre, const float* Wl, const float* W, float* dWl, float* dW, float* db, int B,
-                      int S, int E, hipStream_t st);
+                      const float* h_pre, const float* Wl, const float* W, float* dWl, float* dW, float* db, float* dh_scratch,
+                      int B, int S, int E, hipStream_t st);
 
 // out[m] = (t<len ? x[m,:].w + b : 0)     (stop_net on the detached decoder output, tacotron.py:114-115)
 int ro_rowdot_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* out, int M, int D,

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
     __shared__ float sacc[2 * LN_MAXC * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
-    for (int i = threadIdx.x; i < 2 * D; i += 256) sacc[i] = 0.f;
+    const int NW = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) sacc[i] = 0.f;
     __syncthreads();
     float4 pg[LN_MAXC], pb[LN_MAXC], gm[LN_MAXC];
 #pragma unroll
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
         int ci = lane + 64 * i;
         gm[i] = ci < nch ? ld4(gamma + ci * 4) : make_float4(0, 0, 0, 0);
     }
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * NW + wave; row < M; row += gridDim.x * NW) {
         bool zero = false;
         if (row_len) { int b = row / rpb; zero = (row - b * rpb) >= row_len[b]; }
         const float mu = mean[row], rs = rstd[row];
@@ -180,17 +181,25 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
     }
     __syncthreads();
     if (ws) {       // per-workgroup partial row [dgamma | dbeta]; k_ln_param_reduce adds the column sums (no global atomics)
-        for (int i = threadIdx.x; i < 2 * D; i += 256) ws[(long)blockIdx.x * 2 * D + i] = sacc[i];
+        for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) ws[(long)blockIdx.x * 2 * D + i] = sacc[i];
     } else {
-        for (int i = threadIdx.x; i < D; i += 256) { atomicAdd(dgamma + i, sacc[i]); atomicAdd(dbeta + i, sacc[D + i]); }
+        for (int i = threadIdx.x; i < D; i += blockDim.x) { atomicAdd(dgamma + i, sacc[i]); atomicAdd(dbeta + i, sacc[D + i]); }
     }
 }
-__global__ void k_ln_param_reduce(const float* ws, int nblk, int D, float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * D) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += ws[(long)b * 2 * D + c];
-    if (c < D) dgamma[c] += s; else dbeta[c - D] += s;
+__global__ __launch_bounds__(256) void k_ln_param_reduce(const float* ws, int nblk, int D, float* dgamma, float* dbeta) {
+    // column sums of ws [nblk, 2D]: 64 columns per workgroup, rows split over 4 row-lanes and gridDim.y workgroups
+    __shared__ float sh[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float acc = 0.f;
+    if (c < 2 * D)
+        for (int b = blockIdx.y * 4 + ry; b < nblk; b += gridDim.y * 4) acc += ws[(long)b * 2 * D + c];
+    sh[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && c < 2 * D) {
+        const float s = sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx];
+        atomicAdd(c < D ? dgamma + c : dbeta + (c - D), s);
+    }
 }
 
 // ---------------------------------------------------------------------------------- softmax
@@ -351,27 +360,41 @@ __global__ void k_embed_net_fwd(const long* ids, const float* table, const float
         }
     }
 }
-__global__ void k_embed_net_bwd(const float* dmem, int ldm, int col0, const long* ids, const float* vecs, int L,
-                                const float* e_raw, const float* h_pre, const float* Wl, const float* W, float* d_table,
-                                float* dWl, float* dW, float* db, int S, int E) {
-    extern __shared__ float sh[];        // 2E floats: dh, de
+// phase 1 (one workgroup per utterance): dh[b,n] = softsign'(h) * sum_s dmem[b,s,col0+n]
+__global__ void k_embed_net_bwd_dh(const float* dmem, int ldm, int col0, const float* h_pre, float* dh, int S, int E) {
     const int b = blockIdx.x, n = threadIdx.x;
-    if (n < E) {
-        float d = 0.f;
-        for (int s = 0; s < S; ++s) d += dmem[((long)b * S + s) * ldm + col0 + n];
-        float h = h_pre[b * E + n], den = 1.f + fabsf(h);
-        float dh = d / (den * den);
-        sh[n] = dh;
-        atomicAdd(db + n, dh);
-    }
+    if (n >= E) return;
+    float d = 0.f;
+    for (int s = 0; s < S; ++s) d += dmem[((long)b * S + s) * ldm + col0 + n];
+    const float h = h_pre[b * E + n], den = 1.f + fabsf(h);
+    dh[b * E + n] = d / (den * den);
+}
+// phase 2 (one workgroup per utterance): de[b,n] = sum_k W[k][n] dh[b,k]; embedding-table rows get it by atomics
+__global__ void k_embed_net_bwd_de(const float* dh, const long* ids, const float* W, float* de, float* d_table, int E) {
+    extern __shared__ float sh[];
+    const int b = blockIdx.x, n = threadIdx.x;
+    if (n < E) sh[n] = dh[b * E + n];
     __syncthreads();
-    if (n < E) {
-        float dh = sh[n];
-        for (int k = 0; k < E; ++k) atomicAdd(dW + n * E + k, dh * e_raw[b * E + k]);
-        float de = 0.f;
-        for (int k = 0; k < E; ++k) de += W[k * E + n] * sh[k];      // de[n] = sum_k W[k][n] dh[k]
-        if (ids) atomicAdd(d_table + ids[b] * E + n, de);
-        else for (int l = 0; l < L; ++l) atomicAdd(dWl + n * L + l, de * vecs[b * L + l]);
+    if (n >= E) return;
+    float v = 0.f;
+    for (int k = 0; k < E; ++k) v += W[k * E + n] * sh[k];
+    de[b * E + n] = v;
+    if (ids) atomicAdd(d_table + ids[b] * E + n, v);                       // rows of different utterances may coincide
+}
+// phase 3 (one workgroup per output row n): dW[n,:] += sum_b dh[b,n] e[b,:], db[n], dWl[n,:] += sum_b de[b,n] vec[b,:]
+__global__ void k_embed_net_bwd_w(const float* dh, const float* de, const float* e_raw, const float* vecs, int L, float* dW,
+                                  float* db, float* dWl, int B, int E) {
+    const int n = blockIdx.x, k = threadIdx.x;
+    if (k < E) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += dh[b * E + n] * e_raw[b * E + k];
+        dW[n * E + k] += acc;
+    }
+    if (k == 0) { float s = 0.f; for (int b = 0; b < B; ++b) s += dh[b * E + n]; db[n] += s; }
+    if (dWl && k < L) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += de[b * E + n] * vecs[b * L + k];
+        dWl[n * L + k] += acc;
     }
 }
 
@@ -656,11 +679,9 @@ int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const flo
     else
         hipLaunchKernelGGL((k_ln_bwd<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, lddy, x, gamma, mean,
                            rstd, dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch, ws);
-    if (ws) {      // column sums of the [grid, 2D] partials: 64 columns x (rows split over gy workgroups), few atomics per column
-        int gy = cdiv(grid, 64); if (gy < 1) gy = 1;
-        dim3 g2(cdiv(D, 64), gy);
-        hipLaunchKernelGGL((k_colsum<float>), g2, dim3(256), 0, st, (const float*)ws, 2 * D, (const float*)nullptr, dgamma, grid, D);
-        hipLaunchKernelGGL((k_colsum<float>), g2, dim3(256), 0, st, (const float*)ws + D, 2 * D, (const float*)nullptr, dbeta, grid, D);
+    if (ws) {
+        int gy = cdiv(grid, 32); if (gy < 1) gy = 1;
+        hipLaunchKernelGGL(k_ln_param_reduce, dim3(cdiv(2 * D, 64), gy), dim3(256), 0, st, (const float*)ws, grid, D, dgamma, dbeta);
     }
     B2S_LAUNCH_CHECK(); return 0;
 }
@@ -732,19 +753,26 @@ int ro_lang_embed_fwd(const float* vecs, int L, const float* Wl, const float* W,
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_spk_embed_bwd(const float* dmem, int ldm, int col0, const long* spk_ids, const float* e_raw, const float* h_pre,
-                     const float* W, float* d_table, float* dW, float* db, int B, int S, int E, hipStream_t st) {
+                     const float* W, float* d_table, float* dW, float* db, float* dh_scratch, int B, int S, int E, hipStream_t st) {
     int th = ((E + 63) / 64) * 64;
-    hipLaunchKernelGGL(k_embed_net_bwd, dim3(B), dim3(th), 2 * E * sizeof(float), st, dmem, ldm, col0, spk_ids,
-                       (const float*)nullptr, 0, e_raw, h_pre, (const float*)nullptr, W, d_table, (float*)nullptr, dW, db,
-                       S, E);
+    float* de = dh_scratch + (long)B * E;
+    hipLaunchKernelGGL(k_embed_net_bwd_dh, dim3(B), dim3(th), 0, st, dmem, ldm, col0, h_pre, dh_scratch, S, E);
+    hipLaunchKernelGGL(k_embed_net_bwd_de, dim3(B), dim3(th), E * sizeof(float), st, (const float*)dh_scratch, spk_ids, W, de, d_table, E);
+    hipLaunchKernelGGL(k_embed_net_bwd_w, dim3(E), dim3(th), 0, st, (const float*)dh_scratch, (const float*)de, e_raw,
+                       (const float*)nullptr, 0, dW, db, (float*)nullptr, B, E);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_lang_embed_bwd(const float* dmem, int ldm, int col0, const float* vecs, int L, const float* e_raw,
-                      const float* h_pre, const float* Wl, const float* W, float* dWl, float* dW, float* db, int B,
-                      int S, int E, hipStream_t st) {
-    int th = ((E + 63) / 64) * 64;
-    hipLaunchKernelGGL(k_embed_net_bwd, dim3(B), dim3(th), 2 * E * sizeof(float), st, dmem, ldm, col0,
-                       (const long*)nullptr, vecs, L, e_raw, h_pre, Wl, W, (float*)nullptr, dWl, dW, db, S, E);
+                      const float* h_pre, const float* Wl, const float* W, float* dWl, float* dW, float* db, float* dh_scratch,
+                      int B, int S, int E, hipStream_t st) {
+    (void)Wl;
+    int th = ((std::max(E, L) + 63) / 64) * 64;
+    float* de = dh_scratch + (long)B * E;
+    hipLaunchKernelGGL(k_embed_net_bwd_dh, dim3(B), dim3(th), 0, st, dmem, ldm, col0, h_pre, dh_scratch, S, E);
+    hipLaunchKernelGGL(k_embed_net_bwd_de, dim3(B), dim3(th), E * sizeof(float), st, (const float*)dh_scratch, (const long*)nullptr, W, de,
+                       (float*)nullptr, E);
+    hipLaunchKernelGGL(k_embed_net_bwd_w, dim3(E), dim3(th), 0, st, (const float*)dh_scratch, (const float*)de, e_raw, vecs, L, dW, db, dWl,
+                       B, E);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_rowdot_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* out, int M, int D,
