@@ -15,6 +15,7 @@ struct AttnArgs {
     float* lse = nullptr;                                  // [B*H, Lq] log-sum-exp of the scaled, masked logits
     // backward
     const void* dout = nullptr;                            // d context (ld ldo)
+    const void* oref = nullptr;                            // forward context O (ld ldo), for D = rowsum(dO * O)
     float* dsum = nullptr;                                 // [B*H, Lq] scratch: rowsum(dO * O)
     void *dq = nullptr, *dk = nullptr, *dv = nullptr;
     int lddq = 0, lddk = 0, lddv = 0;

@@ -120,6 +120,13 @@ __device__ inline void first_product(f32x4_t (&c)[4], const T* tile, const typen
     }
 }
 
+__device__ inline float frag_dot(float x, float y) { return x * y; }
+__device__ inline float frag_dot(bf16x8_t x, bf16x8_t y) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += bf2f((bf16_t)x[e]) * bf2f((bf16_t)y[e]);
+    return s;
+}
 __device__ inline float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ inline float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
@@ -248,7 +255,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     typename AT<T>::frag qf[NKS], dof[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) { qf[ks] = frag_global<T>(Q, a.ldq, qc, ks, lg); dof[ks] = frag_global<T>(dO, a.ldo, qc, ks, lg); }
-    const float lse = a.lse[(long)z * a.Lq + qc], Dq = a.dsum[(long)z * a.Lq + qc];
+    const float lse = a.lse[(long)z * a.Lq + qc];
+    // D[q] = sum_d dO[q][d] * O[q][d], from the same fragments (each lane holds 1/4 of the row; two shuffles finish it)
+    float Dq = 0.f;
+    {
+        const T* O = reinterpret_cast<const T*>(a.oref) + (long)b * a.Lq * a.ldo + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) Dq += frag_dot(frag_global<T>(O, a.ldo, qc, ks, lg), dof[ks]);
+        Dq = group_sum(Dq);
+        if (lg == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;          // the dK/dV kernel reads it
+    }
     int kend = a.Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     int ktiles = (kend + 63) / 64;
@@ -411,17 +427,11 @@ int b2s_flash_fwd(int dtype, const AttnArgs& a, int dh, hipStream_t st) {
     B2S_CHECK(a.out, "attention: null output");
     return dtype ? launch_t<bf16_t>(a, dh, 0, st) : launch_t<float>(a, dh, 0, st);
 }
-int b2s_flash_bwd(int dtype, const AttnArgs& a, int dh, const void* O, hipStream_t st) {
-    B2S_TRY(check(a, dtype, dh));
-    B2S_CHECK(a.dout && a.dq && a.dk && a.dv && a.lse && a.dsum && O, "attention backward: null argument");
-    const long rows = (long)a.B * a.Lq * a.H;
-    if (dtype)
-        hipLaunchKernelGGL((attn_bwd_prep_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)a.dout, (const bf16_t*)O, a.ldo,
-                           a.dsum, a.H, a.Lq, dh, rows);
-    else
-        hipLaunchKernelGGL((attn_bwd_prep_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)a.dout, (const float*)O, a.ldo,
-                           a.dsum, a.H, a.Lq, dh, rows);
-    B2S_LAUNCH_CHECK();
+int b2s_flash_bwd(int dtype, const AttnArgs& a_in, int dh, const void* O, hipStream_t st) {
+    B2S_TRY(check(a_in, dtype, dh));
+    B2S_CHECK(a_in.dout && a_in.dq && a_in.dk && a_in.dv && a_in.lse && a_in.dsum && O, "attention backward: null argument");
+    AttnArgs a = a_in;
+    a.oref = O;
     B2S_TRY(dtype ? launch_t<bf16_t>(a, dh, 1, st) : launch_t<float>(a, dh, 1, st));
     return dtype ? launch_t<bf16_t>(a, dh, 2, st) : launch_t<float>(a, dh, 2, st);
 }
