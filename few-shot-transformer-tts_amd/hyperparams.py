@@ -82,3 +82,6 @@ hparams = HParams(
     guided_attention_sigma=0.2,
     freeze_encoder=False,
 )
+
+# pristine copy of the defaults above (hparams is a mutable global that drivers override with --hparams)
+DEFAULTS = dict(hparams.values())

@@ -29,6 +29,7 @@ def _stage_layout(names, sizes):
     from b2s_hip.engine import HipEngine
     from transformer.tacotron import Tacotron
     hp = hyperparams.hparams
+    hp.override_from_dict(hyperparams.DEFAULTS)
     hp.parse(TINY)
     eng = HipEngine(Tacotron(hp), hp)
     order = sorted(range(len(names)), key=lambda i: (eng.stage_of(names[i]), i))

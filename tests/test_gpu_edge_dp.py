@@ -24,9 +24,8 @@ DEV = "cuda"
 def _build(over, seed=1234, compute_dtype="fp32"):
     from hyperparams import hparams as hp
     from transformer.tacotron import Tacotron
-    if not hasattr(_build, "d"):
-        _build.d = dict(hp.values())
-    hp.override_from_dict(_build.d)
+    import hyperparams
+    hp.override_from_dict(hyperparams.DEFAULTS)
     hp.parse(over)
     hp.parse("compute_dtype=%s" % compute_dtype)
     cfg = make_config(over)

@@ -26,10 +26,8 @@ def load(name):
 def build(over, seed=1234, compute_dtype="fp32", state_edit=None):
     from hyperparams import hparams as hp
     from transformer.tacotron import Tacotron
-    defaults = getattr(build, "_defaults", None)
-    if defaults is None:
-        defaults = build._defaults = dict(hp.values())
-    hp.override_from_dict(defaults)
+    import hyperparams
+    hp.override_from_dict(hyperparams.DEFAULTS)
     if over:
         hp.parse(over)
     hp.parse("compute_dtype=%s" % compute_dtype)

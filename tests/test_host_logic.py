@@ -16,9 +16,7 @@ G = os.path.join(ROOT, "tests", "golden")
 def fresh_hp(over=""):
     import hyperparams
     hp = hyperparams.hparams
-    if not hasattr(fresh_hp, "d"):
-        fresh_hp.d = dict(hp.values())
-    hp.override_from_dict(fresh_hp.d)
+    hp.override_from_dict(hyperparams.DEFAULTS)
     if over:
         hp.parse(over)
     return hp
