@@ -166,13 +166,19 @@ def main():
             trainer.train_step(batch)
         torch.cuda.synchronize()
         lib.b2s_prof_enable(0)
-        res = (C.c_double * 24)()
-        L.check(lib.b2s_prof_collect(res, 8))
-        names = {4: "gemm_kernel<bf16,NT>", 5: "gemm_kernel<bf16,NN>", 6: "gemm_kernel<bf16,TN>", 7: "gemm_kernel<bf16,TT>",
-                 0: "gemm_kernel<f32,NT>", 1: "gemm_kernel<f32,NN>", 2: "gemm_kernel<f32,TN>", 3: "gemm_kernel<f32,TT>"}
+        res = (C.c_double * 48)()
+        L.check(lib.b2s_prof_collect(res, 16))
+
+        def kname(v):               # the kernel names rocprofv3 reports (profiles/*kernel_stats.csv)
+            dt, ta, tb, ga = v >> 3, (v >> 2) & 1, (v >> 1) & 1, v & 1
+            tf = lambda x: "true" if x else "false"
+            if dt:
+                return "gemm_glds_kernel<%s, %s, %s>" % (tf(ta), tf(tb), tf(ga))
+            return "gemm_kernel<float, %s, %s>%s" % (tf(ta), tf(tb), " (conv gather)" if ga else "")
+        names = {v: kname(v) for v in range(16)}
         variants = []
         tot_f = tot_ms = 0.0
-        for v in range(8):
+        for v in range(16):
             f, msv, cnt = res[v * 3], res[v * 3 + 1], res[v * 3 + 2]
             if cnt:
                 variants.append({"kernel": names[v], "launches_per_step": cnt / nprof, "avg_us": round(msv * 1e3 / cnt, 2),
@@ -187,7 +193,9 @@ def main():
                            "launches_per_step": dom["launches_per_step"],
                            "all_gemm": {"tflops": round(tot_f / (tot_ms * 1e-3) / 1e12, 1), "ms_per_step": round(tot_ms / nprof, 3)},
                            "variants": variants,
-                           "note": "algorithmic FLOPs (2MNK per launch) / HIP-event duration on the launch stream, instrumented pass"}
+                           "note": "algorithmic FLOPs (2MNK per launch) / HIP-event duration on the kernel's launch stream, separate "
+                                   "instrumented pass of the same steps; the <true,true,*> weight-gradient GEMMs run on a second stream "
+                                   "concurrently with the rest of the backward pass, so their durations overlap other kernels"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_train()
     if rank == 0:

@@ -266,7 +266,7 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
 extern "C" void b2s_prof_enable(int on) { g_prof_on = on != 0; }
-// out[v*3 + {0,1,2}] = total flops, total milliseconds, launches of GEMM variant v = dtype*4 + trans_a*2 + trans_b
+// out[v*3 + {0,1,2}] = total flops, total milliseconds, launches of GEMM variant v = dtype*8 + trans_a*4 + trans_b*2 + conv_gather
 extern "C" int b2s_prof_collect(double* out, int n_variants) {
     for (int i = 0; i < n_variants * 3; ++i) out[i] = 0.0;
     FILE* dump = getenv("B2S_PROF_DUMP") ? fopen(getenv("B2S_PROF_DUMP"), "w") : nullptr;
@@ -288,7 +288,7 @@ int b2s_gemm_launch(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t 
     if (!g_prof_on) return gemm_launch_inner(g, dtype, ta, tb, stream);
     ProfRec r;
     B2S_HIP(hipEventCreate(&r.a)); B2S_HIP(hipEventCreate(&r.b));
-    r.variant = dtype * 4 + (ta ? 2 : 0) + (tb ? 1 : 0);
+    r.variant = dtype * 8 + (ta ? 4 : 0) + (tb ? 2 : 0) + ((g.A.g_cin > 0 || g.B.g_cin > 0) ? 1 : 0);
     r.flops = 2.0 * g.M * g.N * (double)g.K * g.batch;
     r.M = g.M; r.N = g.N; r.K = g.K; r.batch = g.batch; r.splitk = g.splitk;
     B2S_HIP(hipEventRecord(r.a, stream));

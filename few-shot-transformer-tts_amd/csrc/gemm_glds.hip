@@ -103,22 +103,30 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
             __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(smem + buf * 2 * TILE + TILE + q * 512), 16, 0, 0);
         }
     };
-    // fragment of the 16 x 32 block (rows row0.., k = ks*32..) of an operand tile
-    auto frag = [&](const bf16_t* tile, bool trans, int row0) -> bf16x8_t {
+    // Fragment reads are issued as inline-asm DS instructions so that the compiler cannot sink them next to their
+    // consumers (which exposes the LDS latency) nor wait for them early: all reads of tile kt+1 are issued before the
+    // MFMAs of tile kt and waited for (one lgkmcnt(0)) after them.  Per-lane byte offsets inside a tile:
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (TA) { const int k = lg * 8 + (li >> 2), col = wrow + t * 16 + (li & 3) * 4, sw = ((li >> 2) | ((lg & 1) << 2)) << 1;
+                  offA[t] = 2u * (k * 128 + (((col >> 3) ^ sw) << 3) + (col & 7)); }
+        else    { const int r = wrow + t * 16 + li; offA[t] = 2u * (r * 32 + ((lg ^ swz_n(r)) << 3)); }
+        if (TB) { const int k = lg * 8 + (li >> 2), col = wcol + t * 16 + (li & 3) * 4, sw = ((li >> 2) | ((lg & 1) << 2)) << 1;
+                  offB[t] = 2u * (TILE + k * 128 + (((col >> 3) ^ sw) << 3) + (col & 7)); }
+        else    { const int r = wcol + t * 16 + li; offB[t] = 2u * (TILE + r * 32 + ((lg ^ swz_n(r)) << 3)); }
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
+    auto frag_issue = [&](bf16x8_t& dst, bool trans, unsigned addr) {
         if (!trans) {
-            const int r = row0 + li;
-            return *reinterpret_cast<const bf16x8_t*>(tile + r * 32 + ((lg ^ swz_n(r)) << 3));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+        } else {
+            bf16x4_t lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"        // rows k and k + 4 (4 x 256 B)
+                         : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
+            dst[0] = lo[0]; dst[1] = lo[1]; dst[2] = lo[2]; dst[3] = lo[3];
+            dst[4] = hi[0]; dst[5] = hi[1]; dst[6] = hi[2]; dst[7] = hi[3];
         }
-        const int k = lg * 8 + (li >> 2);
-        const int col = row0 + (li & 3) * 4;
-        const int sw = ((li >> 2) | ((lg & 1) << 2)) << 1;              // = swz_t(k) = swz_t(k + 4)
-        const int off = (((col >> 3) ^ sw) << 3) + (col & 7);
-        bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)(tile + k * 128 + off));
-        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)(tile + (k + 4) * 128 + off));
-        bf16x8_t r;
-        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-        return r;
     };
 
     f32x4_t acc[4][4];
@@ -137,12 +145,15 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTAGE - 3)) : "memory"); /* tile KT+1 landed (own DMAs) */    \
         __builtin_amdgcn_s_barrier();             /* ... for every wave; tile KT-1 is fully consumed */             \
         issue(kt0 + (KT) + NSTAGE - 1, ((KT) + NSTAGE - 1) % NSTAGE);                                              \
-        const bf16_t* tA_ = smem + (((KT) + 1) % NSTAGE) * 2 * TILE;                                               \
+        const unsigned sb_ = lds_base + (unsigned)((((KT) + 1) % NSTAGE) * 2 * TILE * 2);                         \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                            \
-            NA[t] = frag(tA_, TA, wrow + t * 16);                                                                  \
-            NB[t] = frag(tA_ + TILE, TB, wcol + t * 16);                                                           \
+            frag_issue(NA[t], TA, sb_ + offA[t]);                                                                  \
+            frag_issue(NB[t], TB, sb_ + offB[t]);                                                                  \
         }                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
         B2S_MMA16(CA, CB)                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* tile KT+1 fragments are in registers */              \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
     }
 #pragma unroll
     for (int p = 0; p < NSTAGE - 1; ++p) issue(kt0 + p, p);
@@ -150,7 +161,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTAGE - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { fa0[t] = frag(smem, TA, wrow + t * 16); fb0[t] = frag(smem + TILE, TB, wcol + t * 16); }
+    for (int t = 0; t < 4; ++t) { frag_issue(fa0[t], TA, lds_base + offA[t]); frag_issue(fb0[t], TB, lds_base + offB[t]); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     int kt = 0;
     for (; kt + 2 < nk; kt += 2) {
         B2S_STEP(kt, fa0, fb0, fa1, fb1)
