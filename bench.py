@@ -76,7 +76,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="train", choices=["train", "decode"])
+    ap.add_argument("--mode", default="train", choices=["train", "decode", "finetune"],
+                    help="train: BASELINE configs[1-2]; decode: configs[3]; finetune: configs[4] (frozen encoder, guided "
+                         "attention on, batches of B drawn from a 30-utterance pool)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=14)
     ap.add_argument("--S", type=int, default=114)
@@ -92,8 +94,12 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dp = bool(os.environ.get("B2S_FORCE_DP"))     # 1-rank RCCL group: exercises the whole exchange path on one GPU
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.distributed.init_process_group("nccl", init_method="env://", device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
 
@@ -107,6 +113,9 @@ def main():
     from b2s_hip import lib as L
     from oracle import make_config
     hp.parse("compute_dtype=%s" % args.dtype)
+    finetune = args.mode == "finetune"
+    if finetune:
+        hp.parse("freeze_encoder=true,guided_attention_weight=1.0")
     torch.manual_seed(0)                               # identical init on every rank (train.py:33)
     model = Tacotron(hp)
     initialize_variables(model)
@@ -115,25 +124,33 @@ def main():
     cfg = make_config("")
     B, S, T = args.batch, args.S, args.T
     batch = make_batch(cfg, B, S, T, seed=rank, device=device)     # same shape on every rank, different data
+    batches = [batch]
+    if finetune:        # 30-utterance adaptation pool; every step trains on B of them (same padded shape, lengths vary)
+        pool = make_batch(cfg, 30, S, T, seed=1000 + rank, device=device)
+        rng = np.random.default_rng(rank)
+        batches = []
+        for _ in range(8):
+            idx = torch.from_numpy(np.sort(rng.choice(30, B, replace=False))).to(device)
+            batches.append({k: (v.index_select(0, idx) if torch.is_tensor(v) else v) for k, v in pool.items()})
 
     def sync():
-        if world > 1:
+        if world > 1 or force_dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        vals = trainer.train_step(batch)
+    for i in range(args.warmup):
+        vals = trainer.train_step(batches[i % len(batches)])
     sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        vals = trainer.train_step(batch)
+    for i in range(args.steps):
+        vals = trainer.train_step(batches[i % len(batches)])
     ev1.record()
     sync()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if world > 1 or force_dp:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -144,13 +161,18 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         step_flops = 3.0 * fwd_flops(B, S, T)
-        out = {"metric": "padded mel-frames/sec, full training step (fwd+loss+bwd+allreduce+Adam)",
+        if finetune:    # no encoder backward, no d(memory): drop 2 x encoder forward FLOPs and the cross-KV dX GEMMs
+            enc = 6 * (B * S * (8 * 512 * 512 + 4 * 512 * 2048) + 4 * B * S * S * 512) + 2 * B * (2 * 128 * 128 + 100 * 128)
+            step_flops -= 2.0 * enc + 6 * 4 * B * S * 768 * 768
+        out = {"metric": "padded mel-frames/sec, " + ("few-shot fine-tune step (frozen encoder, guided attention; fwd+loss+bwd+allreduce+Adam)"
+                                                      if finetune else "full training step (fwd+loss+bwd+allreduce+Adam)"),
                "value": round(world * B * T * args.steps / elapsed, 1), "unit": "mel-frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic", "final_loss": round(loss, 5),
                "config": {"workload": "LJSpeech-shaped packed batch per GPU: B=%d S=%d T=%d, default hparams (83.5M params), "
-                                      "dropout on, single speaker/language" % (B, S, T),
+                                      "dropout on, single speaker/language%s" % (B, S, T, ", frozen encoder, guided-attention weight 1.0, "
+                                                                                 "batches drawn from a 30-utterance pool" if finetune else ""),
                           "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world},
                "device_ms_per_step": round(dev_ms / args.steps, 3)}
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS
@@ -198,10 +220,11 @@ def main():
                                    "concurrently with the rest of the backward pass, so their durations overlap other kernels"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_train()
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dp:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        C.CDLL(None).fflush(None)          # RCCL prints its library path through C stdio: keep the JSON line last
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

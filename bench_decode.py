@@ -94,6 +94,9 @@ def run_decode(args, rank, world, device):
                             "note": "algorithmic bytes per frame step (weights + KV) / wall time per frame incl. encoder and postnet"}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_decode()
-        print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # keep the JSON line last (RCCL prints through C stdio)
+        print(json.dumps(out), flush=True)

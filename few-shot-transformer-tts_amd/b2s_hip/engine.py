@@ -14,6 +14,8 @@ import torch
 from . import lib as L
 
 DTYPES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+# extensions absent from the reference's hyperparams.py: an HParams object without them means "off"
+_EXT_DEFAULTS = {"guided_attention_weight": 0.0, "guided_attention_sigma": 0.2, "freeze_encoder": False}
 
 
 def config_from_hparams(hp):
@@ -21,7 +23,7 @@ def config_from_hparams(hp):
     for name, _ in L.Config._fields_:
         if name in ("compute_dtype",):
             continue
-        v = getattr(hp, name)
+        v = getattr(hp, name, _EXT_DEFAULTS[name]) if name in _EXT_DEFAULTS else getattr(hp, name)
         setattr(cfg, name, int(v) if isinstance(v, bool) else v)
     cd = getattr(hp, "compute_dtype", "fp32")
     if cd not in DTYPES:
@@ -227,13 +229,25 @@ class HipEngine(object):
         self._needs_zero = True
         return mels, stop, _Ctx(h, (ws, memory, in32, targets, tgt32))
 
-    def decoder_backward(self, ctx, dmels, dstop, mem_shape):
+    def decoder_backward(self, ctx, dmels, dstop, mem_shape, d_guided=None, want_dmem=True):
+        """d_guided: device scalar d loss / d guided-attention loss (None: that term gets no gradient)."""
         self.begin_backward()
-        dmem = torch.empty(mem_shape, dtype=torch.float32, device=dmels.device)
-        L.check(self.lib.b2s_decoder_backward(self.handle, ctx.handle, L.ptr(dmels.contiguous()),
-                                              L.ptr(dstop.contiguous()) if dstop is not None else None, L.ptr(dmem),
-                                              L.stream()))
+        dmem = torch.empty(mem_shape, dtype=torch.float32, device=dmels.device) if want_dmem else None
+        L.check(self.lib.b2s_decoder_backward_ex(self.handle, ctx.handle, L.ptr(dmels.contiguous()),
+                                                 L.ptr(dstop.contiguous()) if dstop is not None else None,
+                                                 L.ptr(d_guided.contiguous()) if d_guided is not None else None,
+                                                 0 if want_dmem else 1, L.ptr(dmem), L.stream()))
         return dmem
+
+    def guided_enabled(self):
+        return self.cfg.guided_attention_weight > 0
+
+    def guided_loss(self, ctx, add_to=None):
+        """weight * guided-attention loss of the decoder forward held in ctx (device scalar, shape [1]); also added to
+        add_to[0] when given."""
+        out = torch.empty(1, dtype=torch.float32, device=ctx.keep[0].device)
+        L.check(self.lib.b2s_decoder_guided_loss(self.handle, ctx.handle, L.ptr(out), L.ptr(add_to), L.stream()))
+        return out
 
     def decoder_alignment(self, ctx, which, layer, B, H, Lk, Lq):
         out = torch.empty(B, H, Lk, Lq, dtype=torch.float32, device=ctx.keep[0].device)
@@ -322,14 +336,16 @@ class DecoderFn(torch.autograd.Function):
         ctx.req = [p.requires_grad for p in params]
         ctx.mem_shape = memory.shape
         ctx.mem_req = memory.requires_grad
-        return mels, stop
+        guided = eng.guided_loss(c).reshape(()) if eng.guided_enabled() else None
+        return mels, stop, guided
 
     @staticmethod
-    def backward(ctx, dmels, dstop):
+    def backward(ctx, dmels, dstop, dguided):
         eng = ctx.eng
         if dmels is None:
-            dmels = torch.zeros(ctx.mem_shape[0], ctx.c.keep[3].shape[1], ctx.c.keep[3].shape[2], device=dstop.device)
-        dmem = eng.decoder_backward(ctx.c, dmels, dstop, ctx.mem_shape)
+            dmels = torch.zeros(ctx.mem_shape[0], ctx.c.keep[3].shape[1], ctx.c.keep[3].shape[2], device=ctx.c.keep[0].device)
+        dmem = eng.decoder_backward(ctx.c, dmels, dstop, ctx.mem_shape, dguided.reshape(1) if dguided is not None else None,
+                                    ctx.mem_req)
         grads = tuple(eng.grad_view(ctx.prefix + n) if r else None for n, r in zip(ctx.names, ctx.req))
         return (None, None, None, dmem if ctx.mem_req else None, None, None, None, None, None) + grads
 

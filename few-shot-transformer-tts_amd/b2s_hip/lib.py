@@ -26,7 +26,8 @@ class Config(C.Structure):
         "multi_speaker", "max_num_speaker", "speaker_embedding_size",
         "multi_lingual", "max_num_language", "language_embedding_size")] + [
         ("transformer_dropout_rate", C.c_float), ("decoder_dropout_rate", C.c_float),
-        ("reg_weight", C.c_float), ("compute_dtype", C.c_int32)]
+        ("reg_weight", C.c_float), ("compute_dtype", C.c_int32),
+        ("guided_attention_weight", C.c_float), ("guided_attention_sigma", C.c_float), ("freeze_encoder", C.c_int32)]
 
 
 class GemmDesc(C.Structure):
@@ -55,6 +56,8 @@ _PROTOS = {
     "b2s_decoder_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int, C.c_int]),
     "b2s_decoder_forward": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, P, C.POINTER(P)]),
     "b2s_decoder_backward": (C.c_int, [P, P, P, P, P, P]),
+    "b2s_decoder_backward_ex": (C.c_int, [P, P, P, P, P, C.c_int, P, P]),
+    "b2s_decoder_guided_loss": (C.c_int, [P, P, P, P, P]),
     "b2s_decoder_alignment": (C.c_int, [P, P, C.c_int, C.c_int, P, P]),
     "b2s_postnet_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int]),
     "b2s_postnet_forward": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, C.POINTER(P)]),

@@ -9,6 +9,7 @@ Semantics match the reference: per-rank loss normalisation and per-rank BatchNor
 across ranks, LambdaLR schedule `learning_rate_schedule`.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -40,11 +41,14 @@ class HipTrainer(object):
                 v_ptrs[i] = self.exp_avg_sq.data_ptr() + 4 * off
         L.check(self.lib.b2s_adam_bind(self.eng.handle, m_ptrs, v_ptrs, n))
         self.global_step = 0
+        self.freeze_encoder = bool(self.eng.cfg.freeze_encoder)
+        self._one = torch.ones(1, dtype=torch.float32, device=g.device)
+        self.last_ga_loss = None
         self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.bucketer = None
         self._hook = _HOOK_T(self._on_stage)      # keep a reference: ctypes callbacks must outlive their use
-        if self.world > 1:
+        if self.world > 1 or (self.dist and os.environ.get("B2S_FORCE_DP")):    # B2S_FORCE_DP: 1-rank group, test aid
             self.bucketer = GradBucketer(self.eng._gflat, self.eng.stage_ranges, self.eng.n_stages(),
                                          bucket_mb * 1024 * 1024 / 4, dist=self.dist)
             L.check(self.lib.b2s_model_set_stage_hook(self.eng.handle, C.cast(self._hook, L.P), None))
@@ -68,10 +72,13 @@ class HipTrainer(object):
         L.check(lib.b2s_model_sync_weights_ex(eng.handle, L.stream(), int(self.global_step > 0)))
         in32, tgt32 = _i32(batch["input_lengths"]), _i32(batch["target_lengths"])
         mem, c_enc = eng.encoder_forward(batch["inputs"], in32, batch.get("input_spk_ids"), batch.get("input_language_vecs"),
-                                         True, eng.next_seed(), True)
+                                         True, eng.next_seed(), not self.freeze_encoder)
         mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed(), True)
         aft, c_post = eng.postnet_forward(mels, tgt32, mels, True, eng.next_seed(), True)
         vals, per = eng.loss_forward(mels, aft, stop, batch["mel_targets"], tgt32)
+        guided = eng.guided_enabled()
+        if guided:
+            self.last_ga_loss = eng.guided_loss(c_dec, add_to=vals)       # vals[0] (total loss) += weight * guided loss
         L.check(lib.b2s_zero_grads(eng.handle, L.stream()))
         eng._needs_zero = False
         if self.bucketer is not None:
@@ -79,10 +86,12 @@ class HipTrainer(object):
         dbef, daft, dstop = eng.loss_backward(mels, aft, stop, batch["mel_targets"], tgt32, None)
         din = eng.postnet_backward(c_post, daft)
         dmel = eng.add(eng.add(din, daft), dbef)
-        dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape)
-        eng.encoder_backward(c_enc, dmem)
+        dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape, self._one if guided else None, not self.freeze_encoder)
+        if not self.freeze_encoder:
+            eng.encoder_backward(c_enc, dmem)
         for c in (c_post, c_dec, c_enc):
-            c.free()
+            if c is not None:
+                c.free()
         if self.bucketer is not None:
             self.bucketer.finish()
         lr = self.hp.max_lr * self.lr_lambda(self.global_step)

@@ -19,6 +19,13 @@ struct AttnArgs {
     float* dsum = nullptr;                                 // [B*H, Lq] scratch: rowsum(dO * O)
     void *dq = nullptr, *dk = nullptr, *dv = nullptr;
     int lddq = 0, lddk = 0, lddv = 0;
+    // guided-attention term (extension, engine.hip: decoder): loss += c * sum_{q < qlen[b]} sum_k P[q][k] * W[q][k] with
+    // W = 1 - exp(-(k / klen[b] - q / qlen[b])^2 * ga_inv2s2).  Forward writes ga_rows[z][q] = sum_k P W (0 for padded
+    // rows); backward adds c = *ga_scale times dW-term to dP and c * ga_rows to D.  Enabled when ga_rows != nullptr.
+    float* ga_rows = nullptr;                              // [B*H, Lq]
+    const int* qlen = nullptr;
+    const float* ga_scale = nullptr;                       // device scalar (backward only)
+    float ga_inv2s2 = 0.f;
 };
 
 bool b2s_flash_supported(int dh);

@@ -130,6 +130,12 @@ __device__ inline float frag_dot(bf16x8_t x, bf16x8_t y) {
 __device__ inline float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ inline float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
+// guided-attention weight of (query q, key k) for an utterance with inverse lengths iq = 1/qlen, ik = 1/klen
+__device__ inline float ga_w(int q, int k, float iq, float ik, float inv2s2) {
+    const float d = (float)k * ik - (float)q * iq;
+    return 1.f - __expf(-d * d * inv2s2);
+}
+
 // store a transposed accumulator (col = own row li, rows = feature dt*16 + lg*4 + r) as 4 consecutive features
 template <typename T, int DH>
 __device__ inline void store_rows(T* dst, const f32x4_t (&acc)[DH / 16], float mul, int lg) {
@@ -172,6 +178,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
+    const bool ga = a.ga_rows != nullptr;
+    float g = 0.f, ga_iq = 0.f, ga_ik = 0.f;
+    if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
     const long drow = ((long)z * a.Lq + qc) * a.Lk;
     for (int kt = 0; kt < ktiles; ++kt) {
         const int k0 = kt * 64;
@@ -197,6 +206,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         const float alpha = __expf(m - msafe);          // m = -inf -> 0
         m = mn;
         l *= alpha;
+        g *= alpha;
 #pragma unroll
         for (int dt = 0; dt < DH / 16; ++dt) { o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha; }
 #pragma unroll
@@ -205,6 +215,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             for (int r = 0; r < 4; ++r) {
                 float p = __expf(s[t][r] - msafe);
                 l += p;
+                if (ga) g += p * ga_w(q, k0 + t * 16 + lg * 4 + r, ga_iq, ga_ik, a.ga_inv2s2);
                 if (a.drop.thresh) {
                     const int key = k0 + t * 16 + lg * 4 + r;
                     p = b2s_keep(a.drop, (uint32_t)(drow + key)) ? p * a.drop.scale : 0.f;
@@ -214,11 +225,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         SP<T, DH, LD>::run(o, sV, s, li, lg);
     }
     l = group_sum(l);
+    if (ga) g = group_sum(g);
     if (q < a.Lq) {
         const float inv = 1.f / l;
         T* out = reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q) * a.ldo + h * DH;
         store_rows<T, DH>(out, o, inv, lg);
         if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = m + __logf(l);
+        if (lg == 0 && ga) a.ga_rows[(long)z * a.Lq + q] = q < a.qlen[b] ? g * inv : 0.f;
     }
 }
 
@@ -263,10 +276,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) Dq += frag_dot(frag_global<T>(O, a.ldo, qc, ks, lg), dof[ks]);
         Dq = group_sum(Dq);
-        if (lg == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;          // the dK/dV kernel reads it
     }
     int kend = a.Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
+    // guided attention: dP += c W, D += c * rowsum(P W) on valid query rows
+    float gc = 0.f, ga_iq = 0.f, ga_ik = 0.f;
+    if (a.ga_rows) {
+        const int ql = min(a.qlen[b], a.Lq);
+        if (q < ql) gc = *a.ga_scale;
+        ga_iq = 1.f / (float)max(ql, 1); ga_ik = 1.f / (float)max(kend, 1);
+        Dq += gc * a.ga_rows[(long)z * a.Lq + qc];
+    }
+    if (lg == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;              // the dK/dV kernel reads it
     int ktiles = (kend + 63) / 64;
     if (a.mask_mode & 2) ktiles = min(ktiles, (min(qb0 + 63, a.Lq - 1)) / 64 + 1);
     f32x4_t dq[DH / 16];
@@ -291,6 +312,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 const float p = ok ? __expf(s[t][r] * a.scale - lse) : 0.f;
                 float d = dp[t][r];
                 if (a.drop.thresh) d = b2s_keep(a.drop, (uint32_t)(drow + key)) ? d * a.drop.scale : 0.f;
+                if (gc != 0.f) d += gc * ga_w(q, key, ga_iq, ga_ik, a.ga_inv2s2);
                 s[t][r] = p * (d - Dq) * a.scale;
             }
         SP<T, DH, LD>::run(dq, sK, s, li, lg);
@@ -319,6 +341,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     int kend = a.Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     const bool key_ok = key < kend;
+    float gc = 0.f, ga_iq = 0.f, ga_ik = 0.f;
+    int ga_ql = 0;
+    if (a.ga_rows) {
+        ga_ql = min(a.qlen[b], a.Lq);
+        gc = *a.ga_scale;
+        ga_iq = 1.f / (float)max(ga_ql, 1); ga_ik = 1.f / (float)max(kend, 1);
+    }
     f32x4_t dk[DH / 16], dv[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -351,6 +380,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
                     pdv = keep ? p * a.drop.scale : 0.f;
                 }
                 pd[t][r] = pdv;
+                if (gc != 0.f && qq < ga_ql) d += gc * ga_w(qq, key, ga_iq, ga_ik, a.ga_inv2s2);
                 s[t][r] = p * (d - sD[ql]) * a.scale;
             }
         SP<T, DH, LD>::run(dv, sO, pd, li, lg);                // dV^T[d][key] += sum_q dO[q][d] * Pd[q][key]
@@ -415,6 +445,7 @@ int check(const AttnArgs& a, int dtype, int dh) {
     B2S_CHECK(a.q && a.k && a.v && a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, "attention: bad argument");
     B2S_CHECK(a.ldq % ve == 0 && a.ldk % ve == 0 && a.ldv % ve == 0 && (a.ldo % ve == 0), "attention: leading dimensions must be multiples of %d", ve);
     B2S_CHECK(!(a.mask_mode & 1) || a.klen, "attention: key-length mask needs klen");
+    B2S_CHECK(!a.ga_rows || a.qlen, "attention: the guided-attention term needs query lengths");
     (void)dh;
     return 0;
 }
@@ -430,6 +461,7 @@ int b2s_flash_fwd(int dtype, const AttnArgs& a, int dh, hipStream_t st) {
 int b2s_flash_bwd(int dtype, const AttnArgs& a_in, int dh, const void* O, hipStream_t st) {
     B2S_TRY(check(a_in, dtype, dh));
     B2S_CHECK(a_in.dout && a_in.dq && a_in.dk && a_in.dv && a_in.lse && a_in.dsum && O, "attention backward: null argument");
+    B2S_CHECK(!a_in.ga_rows || a_in.ga_scale, "attention backward: the guided-attention term needs its scale");
     AttnArgs a = a_in;
     a.oref = O;
     B2S_TRY(dtype ? launch_t<bf16_t>(a, dh, 1, st) : launch_t<float>(a, dh, 1, st));

@@ -76,6 +76,8 @@ struct b2s_ctx {
     void* memT = nullptr;
     void *tgtT = nullptr, *a1 = nullptr, *a2 = nullptr;
     void* outT = nullptr;               // imputed decoder output (T)
+    float* ga_rows = nullptr;           // guided attention: [Ld][B*H][T] rowsum(P W); ga_small: [0] fwd scale, [1] loss, [2] bwd scale
+    float* ga_small = nullptr;
     // postnet
     std::vector<void*> u;               // conv inputs (T), u[0] = cast(inputs)
     std::vector<float*> y, bn_mean, bn_rstd;

@@ -224,6 +224,7 @@ int linear_dw(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
 }
 
 struct AttnScratch { float* S; float* dP; void* dS; };
+struct GuidedArgs { float* rows = nullptr; const int* qlen = nullptr; const float* scale = nullptr; float inv2s2 = 0.f; };
 // fused attention (attention.hip) unless B2S_ATTN_V1 is set (A/B switch: materialised logits through the GEMM)
 bool use_flash(int dh) {
     static const bool v1 = getenv("B2S_ATTN_V1") != nullptr;
@@ -240,12 +241,15 @@ AttnArgs flash_args(const void* q, int ldq, const void* k, int ldk, const void* 
 // softmax(scale * Q K^T + mask) V on head-interleaved rows (attention.py:72-92)
 int attn_core_fwd(int dtype, hipStream_t st, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                   void* ctx, int ldc, int B, int H, int Lq, int Lk, int dh, int mask_mode, const int* klen,
-                  const float* bias, long bias_sb, long bias_sq, DropCfg drop, float* S, void* P, void* Pd, float* lse = nullptr) {
+                  const float* bias, long bias_sb, long bias_sq, DropCfg drop, float* S, void* P, void* Pd, float* lse = nullptr,
+                  const GuidedArgs* ga = nullptr) {
     if (lse && !bias && use_flash(dh)) {
         AttnArgs a = flash_args(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, mask_mode, klen, drop, lse);
         a.out = ctx; a.ldo = ldc;
+        if (ga) { a.ga_rows = ga->rows; a.qlen = ga->qlen; a.ga_inv2s2 = ga->inv2s2; }
         return b2s_flash_fwd(dtype, a, dh, st);
     }
+    B2S_CHECK(!ga, "the guided-attention term needs the fused attention kernels (head size 32/64/96, B2S_ATTN_V1 unset)");
     const int ldp = rup8(Lk);
     GemmArgs g;
     g.A.p = q; g.A.ld = ldq; g.A.R = Lq; g.A.C = dh; g.A.bs_o = (long)Lq * ldq; g.A.bs_i = dh;
@@ -266,12 +270,15 @@ int attn_core_fwd(int dtype, hipStream_t st, const void* q, int ldq, const void*
 int attn_core_bwd(int dtype, hipStream_t st, const void* dctx, int ldc, const void* q, int ldq, const void* k, int ldk,
                   const void* v, int ldv, const void* P, const void* Pd, void* dq, int lddq, void* dk, int lddk,
                   void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, DropCfg drop, float* dP, void* dS,
-                  float* lse = nullptr, const void* O = nullptr, int mask_mode = 0, const int* klen = nullptr) {
+                  float* lse = nullptr, const void* O = nullptr, int mask_mode = 0, const int* klen = nullptr,
+                  const GuidedArgs* ga = nullptr) {
     if (lse && use_flash(dh)) {
         AttnArgs a = flash_args(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, mask_mode, klen, drop, lse);
         a.dout = dctx; a.ldo = ldc; a.dsum = dP; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+        if (ga) { a.ga_rows = ga->rows; a.qlen = ga->qlen; a.ga_scale = ga->scale; a.ga_inv2s2 = ga->inv2s2; }
         return b2s_flash_bwd(dtype, a, dh, O, st);
     }
+    B2S_CHECK(!ga, "the guided-attention term needs the fused attention kernels");
     const int ldp = rup8(Lk);
     const long ps_o = (long)H * Lq * ldp, ps_i = (long)Lq * ldp;
     const void* Pdrop = drop.thresh ? Pd : P;
@@ -401,6 +408,7 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     c.x_final = xs.back();
     c.mean_f = a.f32(M); c.rstd_f = a.f32(M);
     c.outT = a.T(M * D, esz);
+    if (cf.guided_attention_weight > 0.f) { c.ga_rows = a.f32((long)cf.n_decoder_layer * B * H * T); c.ga_small = a.f32(4); }
     const long pn = (long)B * H * T * rup8(std::max(T, S));
     sc.S = a.f32(pn); sc.dP = a.f32(pn); sc.dS = a.T(pn, esz);
     sc.a3 = a.f32(M * D);
@@ -460,6 +468,8 @@ extern "C" int b2s_model_create(const b2s_config* cfg, b2s_model** out) {
     B2S_CHECK(c.num_mels % 8 == 0 && c.prenet_hidden % 8 == 0 && c.postnet_hidden % 8 == 0 && c.encoder_hidden % 8 == 0,
               "num_mels / prenet_hidden / postnet_hidden / hidden sizes must be multiples of 8");
     B2S_CHECK(c.encoder_hidden <= 1024 && c.decoder_hidden <= 1024, "hidden sizes above 1024 are not supported");
+    B2S_CHECK(c.guided_attention_weight >= 0.f && (c.guided_attention_weight == 0.f || c.guided_attention_sigma > 0.f),
+              "guided_attention_weight must be >= 0 and guided_attention_sigma > 0");
     b2s_model* m = new b2s_model();
     m->cfg = c; m->dtype = c.compute_dtype; m->esz = c.compute_dtype ? 2 : 4; m->Dm = Dm;
     build_layout(m);
@@ -495,6 +505,7 @@ int build_chunks(b2s_model* m, bool l2only, bool with_state, MtChunk** out, int*
         const TensorInfo& t = m->tinfo[i];
         if (t.kind != 1 || (l2only && !t.l2)) continue;
         if (!m->grad[i] && with_state) continue;
+        if (with_state && m->cfg.freeze_encoder && t.name.compare(0, 8, "encoder.") == 0) continue;   // frozen: never updated
         for (long o = 0; o < t.numel; o += CH) {
             MtChunk c;
             c.a = (float*)m->data[i] + o; c.b = m->grad[i] ? (float*)m->grad[i] + o : nullptr;
@@ -664,6 +675,29 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
 }
 
 namespace {
+// guided attention: scale = coef / sum_b min(T_b, T) * min(N_b, S)          (coef = weight / (layers * heads))
+__global__ void k_ga_scale(const int* in_len, const int* tgt_len, int B, int S, int T, float coef, float* small) {
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) acc += (float)min(in_len[b], S) * (float)min(tgt_len[b], T);
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) small[0] = coef / fmaxf(acc, 1.f);
+}
+// small[1] = small[0] * sum(rows)
+__global__ __launch_bounds__(1024) void k_ga_reduce(const float* rows, long n, float* small) {
+    __shared__ float part[16];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) acc += rows[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = threadIdx.x < 16 ? part[threadIdx.x] : 0.f;
+        v = wave_sum(v);
+        if (threadIdx.x == 0) small[1] = small[0] * v;
+    }
+}
+__global__ void k_ga_bscale(float* small, const float* d_guided) { small[2] = small[0] * (d_guided ? d_guided[0] : 0.f); }
+__global__ void k_ga_fetch(const float* small, float* out, float* add_to) { out[0] = small[1]; if (add_to) add_to[0] += small[1]; }
 // backward of  x_out = x_in + drop(FFN(LN(x_in)))  given dx (in place: dx becomes d x_in)
 int ffn_bwd(b2s_model* m, hipStream_t st, const FfnSave& f, Scratch& sc, long M, int D, float p, uint64_t seed,
             const std::string& wp_in, const std::string& wp_out, const std::string& lnp) {
@@ -796,6 +830,10 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
         B2S_TRY(linear(m, st, c->a2, HP, m->W("decoder.prenet.dense_final.weight"), (int)M, D, HP, sc.a3, 1, D, GemmEpilogue()));
         B2S_TRY(ro_shift_pe_fwd(sc.a3, target_lengths, m->pe_dec, m->P(p + "pe_scale"), xs[0], B, T, D,
                                 make_drop(pt, seed, opid(2, 0, 3)), st));
+        const bool guided = cf.guided_attention_weight > 0.f;
+        if (guided)
+            hipLaunchKernelGGL(k_ga_scale, dim3(1), dim3(64), 0, st, input_lengths, target_lengths, B, S, T,
+                               cf.guided_attention_weight / (float)(cf.n_decoder_layer * H), c->ga_small);
         for (int l = 0; l < cf.n_decoder_layer; ++l) {
             AttnSave& s = c->self_attn[l]; AttnSave& x = c->cross_attn[l]; FfnSave& f = c->ffn[l];
             float* x0 = xs[3 * l]; float* x1 = xs[3 * l + 1]; float* x2 = xs[3 * l + 2]; float* x3 = xs[3 * l + 3];
@@ -821,8 +859,13 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
                            GemmEpilogue()));
             x.op_attn = opid(2, l, 6); x.op_res = opid(2, l, 7);
             const char* kv = (const char*)x.kv;
+            GuidedArgs ga;
+            if (guided) {
+                ga.rows = c->ga_rows + (long)l * B * H * T; ga.qlen = target_lengths;
+                ga.inv2s2 = 1.f / (2.f * cf.guided_attention_sigma * cf.guided_attention_sigma);
+            }
             B2S_TRY(attn_core_fwd(dt, st, x.qkv, D, kv, 2 * D, kv + (size_t)D * esz, 2 * D, x.ctx, D, B, H, T, S, dh, 1, input_lengths,
-                                  nullptr, 0, 0, make_drop(pt, seed, x.op_attn), sc.S, x.P, x.Pd, x.lse));
+                                  nullptr, 0, 0, make_drop(pt, seed, x.op_attn), sc.S, x.P, x.Pd, x.lse, guided ? &ga : nullptr));
             x.mask_mode = 1;
             GemmEpilogue ex; ex.drop = make_drop(pt, seed, x.op_res); ex.residual = x1; ex.ldr = D;
             B2S_TRY(linear(m, st, x.ctx, D, m->W(nm(p, "encdec_attentions", l, "output_transform.weight")), (int)M, D, D, x2, 1, D, ex));
@@ -842,6 +885,8 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
         B2S_TRY(linear(m, st, c->outT, D, m->W("decoder.mel_net.weight"), (int)M, NM, D, mels_out, 1, NM, em));
         B2S_TRY(ro_rowdot_fwd(dt, c->outT, D, m->P("decoder.stop_net.weight"), m->P("decoder.stop_net.bias"), stop_out, (int)M, D,
                               target_lengths, T, st));
+        if (guided) hipLaunchKernelGGL(k_ga_reduce, dim3(1), dim3(1024), 0, st, c->ga_rows, (long)cf.n_decoder_layer * B * H * T, c->ga_small);
+        B2S_LAUNCH_CHECK();
         return 0;
     };
     int rc = run();
@@ -859,8 +904,20 @@ __global__ void k_rowmask_copy(const float* in, float* out, const int* lens, int
 
 extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mels, const float* d_stop, float* d_memory_out,
                                     void* stream) {
+    return b2s_decoder_backward_ex(m, c, d_mels, d_stop, nullptr, 0, d_memory_out, stream);
+}
+extern "C" int b2s_decoder_guided_loss(b2s_model* m, b2s_ctx* c, float* out, float* add_to, void* stream) {
+    B2S_CHECK(m && c && c->kind == 2 && out, "bad decoder context");
+    B2S_CHECK(c->ga_small, "guided_attention_weight is 0: this forward has no guided-attention term");
+    hipLaunchKernelGGL(k_ga_fetch, dim3(1), dim3(1), 0, S_(stream), c->ga_small, out, add_to);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_mels, const float* d_stop, const float* d_guided,
+                                       int flags, float* d_memory_out, void* stream) {
     B2S_TRY(check_bound(m));
-    B2S_CHECK(c && c->kind == 2 && d_mels && d_memory_out, "bad decoder context");
+    const bool want_dmem = !(flags & B2S_DEC_BWD_NO_DMEMORY);
+    B2S_CHECK(c && c->kind == 2 && d_mels && (d_memory_out || !want_dmem), "bad decoder context");
     const b2s_config& cf = m->cfg;
     hipStream_t st = S_(stream);
     const int B = c->B, S = c->S, T = c->T, D = cf.decoder_hidden, H = cf.n_attention_head, dh = D / H, dt = m->dtype, esz = m->esz;
@@ -872,6 +929,8 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
     Scratch sc; std::vector<float*> xs;
     plan_decoder(m, tmp, a, sc, xs);
     const std::string p = "decoder.decoder.";
+    const bool guided = c->ga_small != nullptr && d_guided != nullptr;
+    if (guided) hipLaunchKernelGGL(k_ga_bscale, dim3(1), dim3(1), 0, st, c->ga_small, d_guided);
     // heads (tacotron.py:112-115)
     B2S_TRY(ro_cast(dt, d_mels, sc.dmelT, M * NM, st));
     B2S_TRY(linear_dw(m, st, sc.dmelT, NM, c->outT, D, (int)M, NM, D, m->G("decoder.mel_net.weight")));
@@ -904,14 +963,22 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
             B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, sc.dctx, 0, D, GemmEpilogue()));
             B2S_TRY(guard_write(m, sc.dqkv, st)); B2S_TRY(guard_write(m, sc.dkv, st));
             const char* kv = (const char*)x.kv; char* dkv = (char*)sc.dkv;
+            GuidedArgs ga;
+            if (guided) {
+                ga.rows = c->ga_rows + (long)l * B * H * T; ga.qlen = c->tgt_len; ga.scale = c->ga_small + 2;
+                ga.inv2s2 = 1.f / (2.f * cf.guided_attention_sigma * cf.guided_attention_sigma);
+            }
             B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, x.qkv, D, kv, 2 * D, kv + (size_t)D * esz, 2 * D, x.P, x.Pd, sc.dqkv, D, dkv, 2 * D,
-                                  dkv + (size_t)D * esz, 2 * D, B, H, T, S, dh, datt, sc.dP, sc.dS, x.lse, x.ctx, x.mask_mode, c->in_len));
+                                  dkv + (size_t)D * esz, 2 * D, B, H, T, S, dh, datt, sc.dP, sc.dS, x.lse, x.ctx, x.mask_mode, c->in_len,
+                                  guided ? &ga : nullptr));
             B2S_TRY(linear_dw(m, st, sc.dqkv, D, x.h, D, (int)M, D, D, m->G(wq)));
             B2S_TRY(linear_dx(m, st, sc.dqkv, D, m->W(wq), (int)M, D, D, sc.dh, 0, D, GemmEpilogue()));
             B2S_TRY(linear_dw(m, st, sc.dkv, 2 * D, c->memT, D, (int)Mk, 2 * D, D, m->G(wkv)));
-            GemmEpilogue em; em.accumulate = first_mem ? 0 : 1;
-            B2S_TRY(linear_dx(m, st, sc.dkv, 2 * D, m->W(wkv), (int)Mk, D, 2 * D, d_memory_out, 1, D, em));
-            first_mem = false;
+            if (want_dmem) {
+                GemmEpilogue em; em.accumulate = first_mem ? 0 : 1;
+                B2S_TRY(linear_dx(m, st, sc.dkv, 2 * D, m->W(wkv), (int)Mk, D, 2 * D, d_memory_out, 1, D, em));
+                first_mem = false;
+            }
             B2S_TRY(guard_write(m, sc.dx, st));
             B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, x.x_in, m->P(lnx + ".weight"), x.mean, x.rstd, sc.dx, 1, m->G(lnx + ".weight"),
                                      m->G(lnx + ".bias"), (int)M, D, nullptr, 1, st, sc.lnws));
@@ -921,7 +988,7 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
         B2S_TRY(join_aux(m, st));
     m->stage_done(2 + (cf.n_decoder_layer - 1 - l));
     }
-    if (first_mem) B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
+    if (first_mem && want_dmem) B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
     B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, opid(2, 0, 3)), st));
     // prenet backward
     DropCfg d1 = make_drop(pd, c->seed, opid(2, 0, 1)), d2 = make_drop(pd, c->seed, opid(2, 0, 2));

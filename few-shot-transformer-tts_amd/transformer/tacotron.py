@@ -158,10 +158,11 @@ class Decoder(_Segment):
         eng = self._engine()
         names, params = self._params()
         holder = []
-        mels, stop = DecoderFn.apply(eng, self._prefix, names, encoder_outputs, _i32(input_lengths), targets,
-                                     _i32(target_lengths), self.training, holder, *params)
+        mels, stop, guided = DecoderFn.apply(eng, self._prefix, names, encoder_outputs, _i32(input_lengths), targets,
+                                             _i32(target_lengths), self.training, holder, *params)
         B, T = targets.shape[0], targets.shape[1]
         align = LazyAlignments(eng, holder[0], self._n_layers, B, self._heads, T, encoder_outputs.shape[1])
+        align.guided_loss = guided           # extension: weight * guided-attention loss (None when the weight is 0)
         return mels, stop, align
 
 
@@ -173,6 +174,9 @@ class Tacotron(nn.Module):
         self.postnet = Postnet(hparams)
         self.__dict__["_hp"] = hparams
         self.__dict__["_engine"] = None
+        if getattr(hparams, "freeze_encoder", False):       # extension: few-shot fine-tuning with a frozen encoder
+            for p in self.encoder.parameters():
+                p.requires_grad_(False)
         for seg in (self.encoder, self.decoder, self.postnet):
             seg.__dict__["_root_ref"] = weakref.ref(self)
 
@@ -187,7 +191,10 @@ class Tacotron(nn.Module):
         enc_outputs = self.encoder(inputs, input_lengths, input_spk_ids, input_language_vecs)
         mel_bef, stop_logits, alignments = self.decoder(enc_outputs, input_lengths, mel_targets, target_lengths)
         mel_aft = self.postnet(mel_bef, target_lengths, _fuse_add=True)          # mel_bef + postnet(mel_bef), fused
-        return {'mel_bef': mel_bef, 'mel_aft': mel_aft, 'stop_logits': stop_logits, 'alignments': alignments}
+        outputs = {'mel_bef': mel_bef, 'mel_aft': mel_aft, 'stop_logits': stop_logits, 'alignments': alignments}
+        if getattr(alignments, "guided_loss", None) is not None:
+            outputs['guided_attention_loss'] = alignments.guided_loss
+        return outputs
 
 
 def compute_loss(model, mel_targets, target_lengths, outputs, hparams):
@@ -197,8 +204,12 @@ def compute_loss(model, mel_targets, target_lengths, outputs, hparams):
     eng = root.engine()
     vals, per = LossFn.apply(eng, outputs['mel_bef'], outputs['mel_aft'], outputs['stop_logits'], mel_targets,
                              _i32(target_lengths))
-    return {'loss': vals[0], 'bef_loss': vals[1], 'aft_loss': vals[2], 'aft_losses': per,
-            'mse_loss': vals[3], 'l2': vals[4], 'stop_loss': vals[5]}
+    res = {'loss': vals[0], 'bef_loss': vals[1], 'aft_loss': vals[2], 'aft_losses': per,
+           'mse_loss': vals[3], 'l2': vals[4], 'stop_loss': vals[5]}
+    if outputs.get('guided_attention_loss') is not None:     # extension (hparams.guided_attention_weight > 0)
+        res['ga_loss'] = outputs['guided_attention_loss']
+        res['loss'] = res['loss'] + res['ga_loss']
+    return res
 
 
 def initialize_variables(model):

@@ -39,6 +39,11 @@ typedef struct b2s_config {
     float transformer_dropout_rate, decoder_dropout_rate;
     float reg_weight;
     int32_t compute_dtype; /* B2S_DTYPE_* */
+    /* Extensions named by the north-star, absent upstream (both OFF by default):
+     * guided-attention loss on every head of every encoder-decoder attention (weight 0 = off), and the few-shot
+     * fine-tuning mode in which every `encoder.*` parameter is frozen (no gradient, no all-reduce, no Adam update). */
+    float guided_attention_weight, guided_attention_sigma;
+    int32_t freeze_encoder;
 } b2s_config;
 
 typedef struct b2s_model b2s_model; /* replaces transformer.tacotron.Tacotron (tacotron.py:119-133)  */
@@ -79,6 +84,15 @@ int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_
 /* d_memory_out [B,S,Dm] is overwritten. */
 int b2s_decoder_backward(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, float* d_memory_out,
                          void* stream);
+/* Extended backward.  d_guided: device scalar = d loss / d guided_loss (NULL: the guided-attention term gets no
+ * gradient).  flags bit 0: do not compute d_memory (frozen encoder; d_memory_out may be NULL). */
+#define B2S_DEC_BWD_NO_DMEMORY 1
+int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, const float* d_guided,
+                            int flags, float* d_memory_out, void* stream);
+/* Guided-attention loss of the forward held in ctx (already multiplied by guided_attention_weight):
+ *   weight * mean over layers, heads and valid (b, t < T_b, n < N_b) of  A[b,h,t,n] * (1 - exp(-(n/N_b - t/T_b)^2 / (2 sigma^2)))
+ * written to out[0]; if add_to != NULL it is also added to add_to[0] (the total loss).  Error if the weight is 0. */
+int b2s_decoder_guided_loss(b2s_model* m, b2s_ctx* ctx, float* out, float* add_to, void* stream);
 /* Alignments of the last forward held in ctx (attention.py:88): which = 0 decoder self, 1 encoder-decoder;
  * out [B, H, Lk, Lq] fp32. */
 int b2s_decoder_alignment(b2s_model* m, b2s_ctx* ctx, int which, int layer, float* out, void* stream);

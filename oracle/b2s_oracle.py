@@ -248,8 +248,25 @@ def is_parameter(name):
     return not name.endswith(_NON_PARAM)
 
 
-def compute_loss(P, cfg, mel_targets, target_lengths, outputs):
-    """tacotron.py:136-158 (A14)."""
+def guided_attention_loss(encdec_aligns, input_lengths, target_lengths, sigma):
+    """EXTENSION (absent upstream; parity unpinned by the reference).  Guided-attention loss of
+    Tachibana et al. 2017 ("Efficiently trainable text-to-speech ...", eq. 3) applied to every head of every
+    encoder-decoder attention layer, masked to the valid (frame, byte) rectangle of each utterance:
+        W[n, t] = 1 - exp(-(n / N_b - t / T_b)^2 / (2 sigma^2)),   loss = mean over layers, heads and valid (b, n, t) of A * W
+    encdec_aligns: list of [B, H, S, T] tensors (attention.py:81 `align`, softmax weights before dropout)."""
+    A0 = encdec_aligns[0]
+    B, H, S, T = A0.shape
+    n = torch.arange(S, dtype=torch.float32)[None, :, None] / input_lengths[:, None, None].float()
+    t = torch.arange(T, dtype=torch.float32)[None, None, :] / target_lengths[:, None, None].float()
+    W = 1.0 - torch.exp(-((n - t) ** 2) / (2.0 * sigma * sigma))
+    valid = (length_mask(input_lengths, S)[:, :, None] * length_mask(target_lengths, T)[:, None, :]).float()
+    W = (W * valid)[:, None]
+    denom = valid.sum() * H * len(encdec_aligns)
+    return sum((A * W).sum() for A in encdec_aligns) / denom
+
+
+def compute_loss(P, cfg, mel_targets, target_lengths, outputs, input_lengths=None):
+    """tacotron.py:136-158 (A14); + the guided-attention extension when cfg.guided_attention_weight > 0."""
     bef = mask_reduce(((outputs["mel_bef"] - mel_targets) ** 2).mean(-1), target_lengths)
     aft_e = ((outputs["mel_aft"] - mel_targets) ** 2).mean(-1)
     aft_s = mask_reduce(aft_e, target_lengths, per_sample=True)
@@ -260,8 +277,14 @@ def compute_loss(P, cfg, mel_targets, target_lengths, outputs):
     ce = F.binary_cross_entropy_with_logits(outputs["stop_logits"], stop_target, reduction="none",
                                             pos_weight=torch.tensor([5.0]))
     ce = mask_reduce(ce, target_lengths)
-    return {"loss": bef + aft + l2 + ce, "bef_loss": bef, "aft_loss": aft, "aft_losses": aft_s,
-            "mse_loss": (bef + aft) / 2, "l2": l2, "stop_loss": ce}
+    res = {"loss": bef + aft + l2 + ce, "bef_loss": bef, "aft_loss": aft, "aft_losses": aft_s,
+           "mse_loss": (bef + aft) / 2, "l2": l2, "stop_loss": ce}
+    gw = getattr(cfg, "guided_attention_weight", 0.0)
+    if gw > 0:
+        res["ga_loss"] = gw * guided_attention_loss(outputs["alignments"]["encdec"], input_lengths, target_lengths,
+                                                    cfg.guided_attention_sigma)
+        res["loss"] = res["loss"] + res["ga_loss"]
+    return res
 
 
 def learning_rate_schedule(global_step, cfg):
@@ -305,8 +328,9 @@ def train_step(P, cfg, batch, opt_state, step_index, train=True):
     """One reference training step (train.py:171-174,188-189): fwd, loss, bwd, Adam.  In place."""
     bn_state = {}
     out = tacotron_forward(P, cfg, batch, train=train, bn_state=bn_state)
-    losses = compute_loss(P, cfg, batch["mel_targets"], batch["target_lengths"], out)
-    names = [n for n in P if is_parameter(n)]
+    losses = compute_loss(P, cfg, batch["mel_targets"], batch["target_lengths"], out, batch["input_lengths"])
+    # EXTENSION: frozen encoder (few-shot fine-tuning) = encoder parameters receive no update
+    names = [n for n in P if is_parameter(n) and not (getattr(cfg, "freeze_encoder", False) and n.startswith("encoder."))]
     gl = torch.autograd.grad(losses["loss"], [P[n] for n in names], allow_unused=True)
     grads = {n: (g if g is not None else torch.zeros_like(P[n])) for n, g in zip(names, gl)}
     with torch.no_grad():

@@ -34,6 +34,10 @@ _DEFAULTS = dict(
     lr_decay_step=550000,
     lr_decay_rate=1e-2,
     adam_eps=5e-8,
+    # extensions named by the north-star, absent upstream (default OFF)
+    guided_attention_weight=0.0,
+    guided_attention_sigma=0.2,
+    freeze_encoder=False,
 )
 
 # Small configurations used by the golden fixtures.  TINY exercises head sizes 32 (encoder)

@@ -127,3 +127,28 @@ def test_data_parallel_trainer_two_ranks(tmp_path):
         ref = P[n].detach().numpy()
         assert abs(np.linalg.norm(r0[n]) - np.linalg.norm(ref)) <= 2e-4 * np.linalg.norm(ref) + 1e-5, n
         assert np.abs(r0[n] - ref).max() < 4.5e-3, n               # <= 2 steps x lr on ill-conditioned (|g|~0) elements
+
+
+def test_rccl_exchange_path_single_rank():
+    """The production exchange path on RCCL itself (backend "nccl", one rank -- RCCL refuses two ranks on one device):
+    process-group init with device_id, asynchronous all-reduce launched from the engine's stage hook, work.wait(),
+    barrier and MAX-reduce of bench.py.  Same seeds => same loss as the run without a process group."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--no-roofline-pass", "--batch", "4", "--S", "40", "--T", "120"]
+    outs = []
+    for force in (True, False):
+        env = dict(os.environ)
+        env.pop("B2S_FORCE_DP", None)
+        if force:
+            env.update(B2S_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        outs.append(json.loads(lines[0]))
+    assert outs[0]["n_gpus"] == 1 and np.isfinite(outs[0]["final_loss"])
+    assert abs(outs[0]["final_loss"] - outs[1]["final_loss"]) < 1e-3 * abs(outs[1]["final_loss"])
