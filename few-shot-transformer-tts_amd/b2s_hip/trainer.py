@@ -20,6 +20,26 @@ from .dp import GradBucketer
 _HOOK_T = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
 
 
+class _SchedView(object):
+    def __init__(self, trainer):
+        self._t = trainer
+
+    @property
+    def last_epoch(self):
+        return self._t.global_step
+
+    def get_last_lr(self):
+        return [self._t.hp.max_lr * self._t.lr_lambda(self._t.global_step)]
+
+    def state_dict(self):           # torch.optim.lr_scheduler.LambdaLR.state_dict() layout (lambdas are not serialised)
+        t = self._t
+        return {"base_lrs": [t.hp.max_lr], "last_epoch": t.global_step, "_step_count": t.global_step + 1,
+                "_get_lr_called_within_step": False, "_last_lr": self.get_last_lr(), "lr_lambdas": [None]}
+
+    def load_state_dict(self, sd):
+        self._t.global_step = int(sd["last_epoch"])
+
+
 class HipTrainer(object):
     def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0):
         from transformer.tacotron import learning_rate_schedule
@@ -58,6 +78,60 @@ class HipTrainer(object):
                     self.dist.broadcast(t.data, 0)
             self.eng._versions = None
             self.eng.ensure_bound()                   # re-sync the compute-dtype shadows with the broadcast values
+
+    # ------------------------------------------------------------------ checkpoint interchange (utils/checkpoint.py)
+    def _param_names(self):
+        return [n for n, _ in self.model.named_parameters()]           # = torch.optim.Adam(m.parameters()) index order
+
+    def state_dict(self):
+        """Optimizer state in torch.optim.Adam.state_dict() layout (what train.py:130 + checkpoint.py:27 write), so a
+        checkpoint written from the fused trainer resumes under the reference loop and vice versa.  Parameters that
+        were never updated (no step yet, frozen encoder) have no entry, as in torch."""
+        names = self._param_names()
+        state = {}
+        if self.global_step > 0:
+            for i, n in enumerate(names):
+                if self.freeze_encoder and n.startswith("encoder."):
+                    continue
+                off, cnt = self.eng.param_offsets[n]
+                shape = self.eng.grad_view(n).shape
+                state[i] = {"step": torch.tensor(float(self.global_step)),
+                            "exp_avg": self.exp_avg[off:off + cnt].view(shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + cnt].view(shape).clone()}
+        lr = self.hp.max_lr * self.lr_lambda(self.global_step)
+        group = {"lr": lr, "betas": (self.beta1, self.beta2), "eps": self.hp.adam_eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "initial_lr": self.hp.max_lr, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        names = self._param_names()
+        groups = sd["param_groups"]
+        order = [i for g in groups for i in g["params"]]
+        if len(order) != len(names):
+            raise ValueError("optimizer state covers %d parameters, the model has %d" % (len(order), len(names)))
+        if groups and "betas" in groups[0]:
+            self.beta1, self.beta2 = (float(b) for b in groups[0]["betas"])
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for pos, idx in enumerate(order):
+            st = sd["state"].get(idx)
+            if not st:
+                continue
+            off, cnt = self.eng.param_offsets[names[pos]]
+            self.exp_avg[off:off + cnt].copy_(st["exp_avg"].reshape(-1).to(self.exp_avg))
+            self.exp_avg_sq[off:off + cnt].copy_(st["exp_avg_sq"].reshape(-1).to(self.exp_avg_sq))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter Adam step counts differ (%s): not a state the fused optimizer can resume" % sorted(steps))
+        self.global_step = steps.pop() if steps else 0
+        self.eng._versions = None          # parameters were (re)loaded alongside: refresh the bf16 shadows on the next step
+
+    @property
+    def sched(self):
+        """LambdaLR-shaped view of the trainer's step counter for utils.checkpoint.save_model / load_model."""
+        return _SchedView(self)
 
     # ------------------------------------------------------------------ gradient exchange
     def _on_stage(self, stage, _user):

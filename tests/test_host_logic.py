@@ -103,6 +103,24 @@ def test_text_and_checkpoint_roundtrip(tmp_path):
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
     assert dict_send_to({"a": torch.ones(2), "names": ["x"]}, "cpu")["names"] == ["x"]
+    # optimizer + scheduler round trip, highest step wins, 'module.'-prefixed model dicts are tolerated
+    from functools import partial
+    from transformer.tacotron import learning_rate_schedule
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=partial(learning_rate_schedule, hp=hp))
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step(); sched.step()
+    checkpoint.save_model(str(tmp_path), m, opt, sched, 12)
+    assert checkpoint.find_ckpt(str(tmp_path)).endswith("model.ckpt-12")
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3, eps=hp.adam_eps)
+    sched2 = torch.optim.lr_scheduler.LambdaLR(opt2, lr_lambda=partial(learning_rate_schedule, hp=hp))
+    assert checkpoint.load_model(checkpoint.find_ckpt(str(tmp_path)), m2, opt2, sched2, "cpu") == 12
+    assert sched2.last_epoch == 1 and len(opt2.state_dict()["state"]) == len(list(m.parameters()))
+    torch.save({"model": {"module." + k: v for k, v in m.state_dict().items()}}, str(tmp_path / "wrapped.pt"))
+    m3 = Tacotron(hp)
+    assert checkpoint.load_model(str(tmp_path / "wrapped.pt"), m3, None, None, "cpu") is None
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m3.state_dict().values()))
+    assert checkpoint.find_ckpt(str(tmp_path / "nowhere")) is None
     fresh_hp()
 
 
