@@ -99,6 +99,11 @@ struct b2s_model {
     MtChunk *l2_chunks = nullptr, *adam_chunks = nullptr;
     int n_l2_chunks = 0, n_adam_chunks = 0;
     float* small = nullptr;                         // device scratch: [0..15] misc scalars
+    // per-chunk sum of squares of the L2 members, written by the fused Adam step for the parameters it just produced:
+    // the next loss evaluation reads the regulariser from here instead of re-reading 83 M parameters.  l2_fresh is
+    // cleared whenever parameters may have changed behind the optimizer's back (bind / full weight sync).
+    float* l2_part = nullptr;
+    bool l2_fresh = false;
     std::vector<void*> owned;                       // hipMalloc'ed buffers
     // second HIP stream for the weight-gradient GEMMs: they depend only on (dY, X) and feed nothing in the backward chain,
     // so they run concurrently with the dX / attention / LayerNorm kernels of the same layer (the 128x128-tile GEMMs leave

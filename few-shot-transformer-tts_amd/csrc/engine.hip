@@ -561,7 +561,7 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
         for (auto& ev : m->ev_pool) B2S_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     B2S_TRY(ensure_pe(m, 2048));
-    m->n_l2_chunks = 0; m->l2_chunks = nullptr;
+    m->n_l2_chunks = 0; m->l2_chunks = nullptr; m->l2_fresh = false;
     B2S_TRY(build_chunks(m, true, false, &m->l2_chunks, &m->n_l2_chunks));
     m->bound = true;
     return 0;
@@ -571,6 +571,7 @@ extern "C" int b2s_model_sync_weights(b2s_model* m, void* stream) { return b2s_m
 extern "C" int b2s_model_sync_weights_ex(b2s_model* m, void* stream, int shadows_fresh) {
     B2S_TRY(check_bound(m));
     hipStream_t st = S_(stream);
+    if (!shadows_fresh) m->l2_fresh = false;
     if (m->dtype && !shadows_fresh)
         for (size_t i = 0; i < m->tinfo.size(); ++i)
             if (m->tinfo[i].gemm_weight) B2S_TRY(ro_cast(1, (const float*)m->data[i], m->shadow[i], m->tinfo[i].numel, st));
@@ -1132,8 +1133,12 @@ extern "C" int b2s_loss_forward(b2s_model* m, const float* mel_bef, const float*
     B2S_CHECK(mel_bef && mel_aft && stop_logits && mel_targets && target_lengths && losses_out && aft_losses_out && scratch, "null argument");
     hipStream_t st = S_(stream);
     float* l2 = scratch;                      // scratch[0] = l2, scratch[1..] partial sums
-    B2S_HIP(hipMemsetAsync(l2, 0, sizeof(float), st));
-    if (m->n_l2_chunks) B2S_TRY(ro_mt_sumsq(m->l2_chunks, m->n_l2_chunks, l2, 0.5f * m->cfg.reg_weight, st));
+    if (m->l2_fresh) {
+        B2S_TRY(ro_sum_scaled(m->l2_part, m->n_adam_chunks, 0.5f * m->cfg.reg_weight, l2, st));
+    } else {
+        B2S_HIP(hipMemsetAsync(l2, 0, sizeof(float), st));
+        if (m->n_l2_chunks) B2S_TRY(ro_mt_sumsq(m->l2_chunks, m->n_l2_chunks, l2, 0.5f * m->cfg.reg_weight, st));
+    }
     return ro_loss_fwd(mel_bef, mel_aft, stop_logits, mel_targets, target_lengths, l2, losses_out, aft_losses_out, B, T,
                        m->cfg.num_mels, 5.0f, scratch + 1, st);
 }
@@ -1157,7 +1162,10 @@ extern "C" int b2s_adam_bind(b2s_model* m, void* const* exp_avg_host, void* cons
         m->exp_avg[i] = exp_avg_host[i]; m->exp_avg_sq[i] = exp_avg_sq_host[i];
         B2S_CHECK(m->tinfo[i].kind != 1 || !m->grad[i] || (m->exp_avg[i] && m->exp_avg_sq[i]), "missing Adam state for %s", m->tinfo[i].name.c_str());
     }
-    return build_chunks(m, false, true, &m->adam_chunks, &m->n_adam_chunks);
+    B2S_TRY(build_chunks(m, false, true, &m->adam_chunks, &m->n_adam_chunks));
+    m->l2_fresh = false; m->l2_part = nullptr;
+    if (m->n_adam_chunks) { B2S_HIP(hipMalloc(&m->l2_part, (size_t)m->n_adam_chunks * sizeof(float))); m->owned.push_back(m->l2_part); }
+    return 0;
 }
 extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
                              void* stream) {
@@ -1168,7 +1176,11 @@ extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, floa
     float* dhp = m->small + 16 + (step % 8) * 4;         // rotate slots: earlier steps may still be in flight
     B2S_HIP(hipMemcpyAsync(dhp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
     // l2 is applied to the L2 member set only (chunk flag), i.e. g = grad*grad_scale + l2*p for members
-    return ro_mt_adam(m->adam_chunks, m->n_adam_chunks, dhp, beta1, beta2, eps, l2, grad_scale, st);
+    // the partial sums cover the L2 regulariser only if every member is in the chunk table (not with a frozen encoder)
+    const bool cover = !m->cfg.freeze_encoder;
+    B2S_TRY(ro_mt_adam(m->adam_chunks, m->n_adam_chunks, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part : nullptr, st));
+    m->l2_fresh = cover;
+    return 0;
 }
 extern "C" int b2s_zero_grads(b2s_model* m, void* stream) {
     B2S_TRY(check_bound(m));

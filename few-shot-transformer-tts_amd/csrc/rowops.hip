@@ -136,37 +136,61 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
         int ci = lane + 64 * i;
         gm[i] = ci < nch ? ld4(gamma + ci * 4) : make_float4(0, 0, 0, 0);
     }
-    for (int row = blockIdx.x * NW + wave; row < M; row += gridDim.x * NW) {
-        bool zero = false;
-        if (row_len) { int b = row / rpb; zero = (row - b * rpb) >= row_len[b]; }
-        const float mu = mean[row], rs = rstd[row];
-        float4 g[LN_MAXC], xh[LN_MAXC];
-        float s1 = 0.f, s2 = 0.f;
+    // two rows per wave iteration, every global load (dy, x and the dx being accumulated into) issued before the
+    // first reduction: the kernel is latency-bound, not bandwidth-bound, at ~3 rows per wave
+    const int rstride = gridDim.x * NW;
+    for (int row0 = blockIdx.x * NW + wave; row0 < M; row0 += 2 * rstride) {
+        int rows[2] = {row0, row0 + rstride};
+        float4 d[2][LN_MAXC], xv[2][LN_MAXC], av[2][LN_MAXC];
+        float mu[2], rs[2];
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
-            int ci = lane + 64 * i;
-            if (ci < nch) {
-                float4 d = zero ? make_float4(0, 0, 0, 0) : ld4(dy + (long)row * lddy + ci * 4);
-                float4 xv = ld4(x + (long)row * D + ci * 4);
-                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                pb[i].x += d.x; pb[i].y += d.y; pb[i].z += d.z; pb[i].w += d.w;
-                pg[i].x += d.x * xh[i].x; pg[i].y += d.y * xh[i].y; pg[i].z += d.z * xh[i].z; pg[i].w += d.w * xh[i].w;
-                g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
-                s1 += g[i].x + g[i].y + g[i].z + g[i].w;
-                s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+        for (int u = 0; u < 2; ++u) {
+            const int row = rows[u];
+            const bool live = row < M;
+            bool zero = !live;
+            if (live && row_len) { int b = row / rpb; zero = (row - b * rpb) >= row_len[b]; }
+            mu[u] = live ? mean[row] : 0.f; rs[u] = live ? rstd[row] : 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_MAXC; ++i) {
+                const int ci = lane + 64 * i;
+                d[u][i] = xv[u][i] = av[u][i] = make_float4(0, 0, 0, 0);
+                if (ci < nch && live) {
+                    if (!zero) d[u][i] = ld4(dy + (long)row * lddy + ci * 4);
+                    xv[u][i] = ld4(x + (long)row * D + ci * 4);
+                    if (accumulate) av[u][i] = ld4(dx + (long)row * D + ci * 4);
+                }
             }
         }
-        s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
-            int ci = lane + 64 * i;
-            if (ci < nch) {
-                float4 o;
-                o.x = rs * (g[i].x - s1 - xh[i].x * s2); o.y = rs * (g[i].y - s1 - xh[i].y * s2);
-                o.z = rs * (g[i].z - s1 - xh[i].z * s2); o.w = rs * (g[i].w - s1 - xh[i].w * s2);
-                float* p = dx + (long)row * D + ci * 4;
-                if (accumulate) { float4 a = ld4(p); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
-                st4(p, o);
+        for (int u = 0; u < 2; ++u) {
+            const int row = rows[u];
+            if (row >= M) continue;
+            float4 g[LN_MAXC], xh[LN_MAXC];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_MAXC; ++i) {
+                const int ci = lane + 64 * i;
+                if (ci < nch) {
+                    const float4 dd = d[u][i], xx = xv[u][i];
+                    xh[i] = make_float4((xx.x - mu[u]) * rs[u], (xx.y - mu[u]) * rs[u], (xx.z - mu[u]) * rs[u], (xx.w - mu[u]) * rs[u]);
+                    pb[i].x += dd.x; pb[i].y += dd.y; pb[i].z += dd.z; pb[i].w += dd.w;
+                    pg[i].x += dd.x * xh[i].x; pg[i].y += dd.y * xh[i].y; pg[i].z += dd.z * xh[i].z; pg[i].w += dd.w * xh[i].w;
+                    g[i] = make_float4(dd.x * gm[i].x, dd.y * gm[i].y, dd.z * gm[i].z, dd.w * gm[i].w);
+                    s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+                    s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+                }
+            }
+            s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+            for (int i = 0; i < LN_MAXC; ++i) {
+                const int ci = lane + 64 * i;
+                if (ci < nch) {
+                    const float4 a = av[u][i];
+                    float4 o;
+                    o.x = rs[u] * (g[i].x - s1 - xh[i].x * s2) + a.x; o.y = rs[u] * (g[i].y - s1 - xh[i].y * s2) + a.y;
+                    o.z = rs[u] * (g[i].z - s1 - xh[i].z * s2) + a.z; o.w = rs[u] * (g[i].w - s1 - xh[i].w * s2) + a.w;
+                    st4(dx + (long)row * D + ci * 4, o);
+                }
             }
         }
     }
@@ -316,19 +340,21 @@ __global__ void k_shift_pe_fwd(const float* a, const int* lens, const float* pe,
 }
 template <typename T_>
 __global__ void k_shift_pe_bwd(const float* dx, const int* lens, const float* pe, T_* da, float* d_pe_scale, int T,
-                               int D, DropCfg drop) {
+                               int D, DropCfg drop, int rows) {
     __shared__ float sh[4];
-    const int row = blockIdx.x, b = row / T, t = row - b * T;
-    // da[b,t] = g[b,t+1] if t+1 < T and t < len[b]
-    const bool have = (t + 1) < T && t < lens[b];
     float acc = 0.f;
-    for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
-        float4 g = drop4(ld4(dx + (long)row * D + c), drop, (uint32_t)((long)row * D + c));
-        float4 p = ld4(pe + (long)t * D + c);
-        acc += g.x * p.x + g.y * p.y + g.z * p.z + g.w * p.w;
-        float4 o = make_float4(0, 0, 0, 0);
-        if (have) o = drop4(ld4(dx + (long)(row + 1) * D + c), drop, (uint32_t)((long)(row + 1) * D + c));
-        st4(da + (long)row * D + c, o);
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {        // grid-stride: one pe_scale atomic per workgroup
+        const int b = row / T, t = row - b * T;
+        // da[b,t] = g[b,t+1] if t+1 < T and t < len[b]
+        const bool have = (t + 1) < T && t < lens[b];
+        for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+            float4 g = drop4(ld4(dx + (long)row * D + c), drop, (uint32_t)((long)row * D + c));
+            float4 p = ld4(pe + (long)t * D + c);
+            acc += g.x * p.x + g.y * p.y + g.z * p.z + g.w * p.w;
+            float4 o = make_float4(0, 0, 0, 0);
+            if (have) o = drop4(ld4(dx + (long)(row + 1) * D + c), drop, (uint32_t)((long)(row + 1) * D + c));
+            st4(da + (long)row * D + c, o);
+        }
     }
     acc = block_sum_256(acc, sh);
     if (threadIdx.x == 0) atomicAdd(d_pe_scale, acc);
@@ -361,13 +387,19 @@ __global__ void k_embed_net_fwd(const long* ids, const float* table, const float
     }
 }
 // phase 1 (one workgroup per utterance): dh[b,n] = softsign'(h) * sum_s dmem[b,s,col0+n]
-__global__ void k_embed_net_bwd_dh(const float* dmem, int ldm, int col0, const float* h_pre, float* dh, int S, int E) {
-    const int b = blockIdx.x, n = threadIdx.x;
-    if (n >= E) return;
+__global__ __launch_bounds__(1024) void k_embed_net_bwd_dh(const float* dmem, int ldm, int col0, const float* h_pre, float* dh, int S, int E) {
+    // threads = E columns x G row groups (the serial walk over S rows was latency-bound); partial sums meet in LDS
+    __shared__ float part[1024];
+    const int b = blockIdx.x, n = threadIdx.x % E, grp = threadIdx.x / E, G = blockDim.x / E;
     float d = 0.f;
-    for (int s = 0; s < S; ++s) d += dmem[((long)b * S + s) * ldm + col0 + n];
-    const float h = h_pre[b * E + n], den = 1.f + fabsf(h);
-    dh[b * E + n] = d / (den * den);
+    for (int s = grp; s < S; s += G) d += dmem[((long)b * S + s) * ldm + col0 + n];
+    part[threadIdx.x] = d;
+    __syncthreads();
+    if (grp == 0) {
+        for (int g = 1; g < G; ++g) d += part[g * E + n];
+        const float h = h_pre[b * E + n], den = 1.f + fabsf(h);
+        dh[b * E + n] = d / (den * den);
+    }
 }
 // phase 2 (one workgroup per utterance): de[b,n] = sum_k W[k][n] dh[b,k]; embedding-table rows get it by atomics
 __global__ void k_embed_net_bwd_de(const float* dh, const long* ids, const float* W, float* de, float* d_table, int E) {
@@ -537,27 +569,33 @@ __device__ inline float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(__exp
 __global__ __launch_bounds__(256) void k_loss_partial(const float* bef, const float* aft, const float* stop,
                                                       const float* tgt, const int* lens, float* scratch, int B, int T,
                                                       int C, float pw) {
-    // one wave per row, grid-stride; per-wave partial sums, one atomic per quantity per wave at the end
-    const int lane = threadIdx.x & 63;
+    // grid (x, B): one wave per frame of utterance blockIdx.y, strided over x; block-level sums, then 4 atomics per
+    // workgroup (bef, aft, stop, per-sample aft) -- same-address atomics serialise, so keep them to a few hundred
+    __shared__ float sh[4];
+    const int lane = threadIdx.x & 63, b = blockIdx.y;
+    const int len = min(lens[b], T);
     float tb = 0.f, ta = 0.f, tc = 0.f;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < B * T; row += gridDim.x * 4) {
-        const int b = row / T, t = row - b * T, len = lens[b];
-        if (t >= len) continue;
+    for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < len; t += gridDim.x * 4) {
+        const long row = (long)b * T + t;
         float sb = 0.f, sa = 0.f;
         for (int c = lane; c < C; c += 64) {
-            float y = tgt[(long)row * C + c];
-            float d1 = bef[(long)row * C + c] - y, d2 = aft[(long)row * C + c] - y;
+            float y = tgt[row * C + c];
+            float d1 = bef[row * C + c] - y, d2 = aft[row * C + c] - y;
             sb += d1 * d1; sa += d2 * d2;
         }
-        sb = wave_sum(sb) / C; sa = wave_sum(sa) / C;
-        tb += sb; ta += sa;
+        tb += sb; ta += sa;                       // lanes keep their partial sums; reduced once at the end
         if (lane == 0) {
             float x = stop[row];
             tc += (t == len - 1) ? pw * softplusf(-x) : softplusf(x);
-            atomicAdd(scratch + 3 + b, sa);               // per-sample sums: B distinct addresses, low contention
         }
     }
-    if (lane == 0) { atomicAdd(scratch + 0, tb); atomicAdd(scratch + 1, ta); atomicAdd(scratch + 2, tc); }
+    tb = block_sum_256(tb, sh) / C;
+    ta = block_sum_256(ta, sh) / C;
+    tc = block_sum_256(tc, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(scratch + 0, tb); atomicAdd(scratch + 1, ta); atomicAdd(scratch + 2, tc);
+        atomicAdd(scratch + 3 + b, ta);
+    }
 }
 __global__ void k_loss_finalize(const float* scratch, const int* lens, const float* l2, float* out, float* aft_losses,
                                 int B) {
@@ -613,9 +651,11 @@ __global__ __launch_bounds__(256) void k_mt_axpy(const MtChunk* ch, float alpha,
     for (int i = threadIdx.x; i < c.n; i += 256) c.b[i] += a * c.a[i];
 }
 __global__ __launch_bounds__(256) void k_mt_adam(const MtChunk* ch, const float* hp, float b1, float b2, float eps,
-                                                 float l2, float gs) {
+                                                 float l2, float gs, float* sumsq_part) {
+    __shared__ float sh[4];
     const MtChunk c = ch[blockIdx.x];
     const float lr = hp[0], bc1 = hp[1], sbc2 = hp[2];     // sbc2 = sqrt(1 - beta2^t)
+    float ss = 0.f;
     for (int i = threadIdx.x; i < c.n; i += 256) {
         float p = c.a[i], g = c.b[i] * gs + (c.pad ? l2 : 0.f) * p, m = c.c[i], v = c.d[i];
         m = b1 * m + (1.f - b1) * g;
@@ -624,7 +664,20 @@ __global__ __launch_bounds__(256) void k_mt_adam(const MtChunk* ch, const float*
         p -= (lr / bc1) * m / (sqrtf(v) / sbc2 + eps);
         c.a[i] = p;
         if (c.s) c.s[i] = f2bf(p);                       // refresh the compute-dtype shadow in the same pass
+        ss += p * p;
     }
+    if (sumsq_part) {            // sum of squares of the UPDATED L2 members: the next step's regulariser value for free
+        ss = block_sum_256(ss, sh);
+        if (threadIdx.x == 0) sumsq_part[blockIdx.x] = c.pad ? ss : 0.f;
+    }
+}
+// out[0] = scale * sum(part[0..n))
+__global__ __launch_bounds__(1024) void k_sum_scaled(const float* part, int n, float scale, float* out) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += part[i];
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) out[0] = acc * scale;
 }
 
 template <typename T>
@@ -728,8 +781,8 @@ int ro_shift_pe_fwd(const float* a, const int* lens, const float* pe, const floa
 }
 int ro_shift_pe_bwd(int dtype, const float* dx, const int* lens, const float* pe, void* da, float* d_pe_scale, int B,
                     int T, int D, DropCfg drop, hipStream_t st) {
-    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_shift_pe_bwd<TY>), dim3(B * T), dim3(128), 0, st, dx, lens, pe, (TY*)da,
-                                          d_pe_scale, T, D, drop));
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_shift_pe_bwd<TY>), dim3(std::min(B * T, 2048)), dim3(128), 0, st, dx, lens, pe, (TY*)da,
+                                          d_pe_scale, T, D, drop, B * T));
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_spk_embed_fwd(const long* spk_ids, const float* table, const float* W, const float* b, float* e_raw,
@@ -756,7 +809,7 @@ int ro_spk_embed_bwd(const float* dmem, int ldm, int col0, const long* spk_ids, 
                      const float* W, float* d_table, float* dW, float* db, float* dh_scratch, int B, int S, int E, hipStream_t st) {
     int th = ((E + 63) / 64) * 64;
     float* de = dh_scratch + (long)B * E;
-    hipLaunchKernelGGL(k_embed_net_bwd_dh, dim3(B), dim3(th), 0, st, dmem, ldm, col0, h_pre, dh_scratch, S, E);
+    hipLaunchKernelGGL(k_embed_net_bwd_dh, dim3(B), dim3(E * std::max(1, 1024 / E)), 0, st, dmem, ldm, col0, h_pre, dh_scratch, S, E);
     hipLaunchKernelGGL(k_embed_net_bwd_de, dim3(B), dim3(th), E * sizeof(float), st, (const float*)dh_scratch, spk_ids, W, de, d_table, E);
     hipLaunchKernelGGL(k_embed_net_bwd_w, dim3(E), dim3(th), 0, st, (const float*)dh_scratch, (const float*)de, e_raw,
                        (const float*)nullptr, 0, dW, db, (float*)nullptr, B, E);
@@ -768,7 +821,7 @@ int ro_lang_embed_bwd(const float* dmem, int ldm, int col0, const float* vecs, i
     (void)Wl;
     int th = ((std::max(E, L) + 63) / 64) * 64;
     float* de = dh_scratch + (long)B * E;
-    hipLaunchKernelGGL(k_embed_net_bwd_dh, dim3(B), dim3(th), 0, st, dmem, ldm, col0, h_pre, dh_scratch, S, E);
+    hipLaunchKernelGGL(k_embed_net_bwd_dh, dim3(B), dim3(E * std::max(1, 1024 / E)), 0, st, dmem, ldm, col0, h_pre, dh_scratch, S, E);
     hipLaunchKernelGGL(k_embed_net_bwd_de, dim3(B), dim3(th), E * sizeof(float), st, (const float*)dh_scratch, (const long*)nullptr, W, de,
                        (float*)nullptr, E);
     hipLaunchKernelGGL(k_embed_net_bwd_w, dim3(E), dim3(th), 0, st, (const float*)dh_scratch, (const float*)de, e_raw, vecs, L, dW, db, dWl,
@@ -842,7 +895,7 @@ int ro_loss_fwd(const float* bef, const float* aft, const float* stop, const flo
                 const float* l2, float* out, float* aft_losses, int B, int T, int C, float pos_weight, float* scratch,
                 hipStream_t st) {
     B2S_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * (3 + B), st));
-    hipLaunchKernelGGL(k_loss_partial, dim3(std::min(cdiv((long)B * T, 4), 512)), dim3(256), 0, st, bef, aft, stop, tgt, lens, scratch, B,
+    hipLaunchKernelGGL(k_loss_partial, dim3(std::min(cdiv(T, 4), 32), B), dim3(256), 0, st, bef, aft, stop, tgt, lens, scratch, B,
                        T, C, pos_weight);
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, (const float*)scratch, lens, l2, out, aft_losses, B);
     B2S_LAUNCH_CHECK(); return 0;
@@ -863,9 +916,13 @@ int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gsc
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1, float beta2, float eps, float l2,
-               float grad_scale, hipStream_t st) {
+               float grad_scale, float* sumsq_part, hipStream_t st) {
     if (nchunks > 0)
-        hipLaunchKernelGGL(k_mt_adam, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale);
+        hipLaunchKernelGGL(k_mt_adam, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_sum_scaled(const float* part, int n, float scale, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_sum_scaled, dim3(1), dim3(1024), 0, st, part, n, scale, out);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_conv_w_relayout(int dtype, const float* w, void* wf, void* wb, int Cout, int Cin, hipStream_t st) {
