@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--batch", type=int, default=14)
     ap.add_argument("--S", type=int, default=114)
     ap.add_argument("--T", type=int, default=582)
+    ap.add_argument("--hparams", default="", help="extra hparams overrides (experiments), e.g. transformer_dropout_rate=0.0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")
     args = ap.parse_args()
@@ -113,6 +114,8 @@ def main():
     from b2s_hip import lib as L
     from oracle import make_config
     hp.parse("compute_dtype=%s" % args.dtype)
+    if args.hparams:
+        hp.parse(args.hparams)
     finetune = args.mode == "finetune"
     if finetune:
         hp.parse("freeze_encoder=true,guided_attention_weight=1.0")

@@ -85,6 +85,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
     // Always issues exactly 4 DMA instructions per wave (tiles past the end fetch the zero page into a slot nobody
     // reads again), so the in-flight count is a compile-time constant and the waits below never drain the queue.
     auto issue = [&](int kt, int buf) {
+#ifdef B2S_EXP_NODMA
+        return;
+#endif
         const int kb = kt < kt_end ? kt * BK : (1 << 28);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -99,8 +102,20 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
                 sa = (ka[i] >= 0 && kb + ka[i] < limA) ? pa[i] + kt * stepA : zero;
                 sb = (kb_[i] >= 0 && kb + kb_[i] < limB) ? pb[i] + kt * stepB : zero;
             }
+#ifdef B2S_EXP_FULLLINE
+            // traffic-pattern experiment (results are garbage): K-contiguous operands fetched as 8 rows x 128 B per instruction
+            if (!TA) { int r = (q & 7) * 8 + (lane >> 3) + ((kt & 1) ? 64 : 0); sa = (m0 + r < g.A.R && kt < kt_end) ? Ab + (long)(m0 + r) * g.A.ld + (kt >> 1) * 64 + (lane & 7) * 8 : zero; }
+            if (!TB) { int r = (q & 7) * 8 + (lane >> 3) + ((kt & 1) ? 64 : 0); sb = (n0 + r < g.B.R && kt < kt_end) ? Bb + (long)(n0 + r) * g.B.ld + (kt >> 1) * 64 + (lane & 7) * 8 : zero; }
+#endif
+#ifdef B2S_EXP_DMAHOT
+            sa = zero + (lane & 15) * 8; sb = zero + (lane & 15) * 8;
+#endif
+#ifdef B2S_EXP_REGLOAD
+            { uint4 t0, t1; asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off" : "=&v"(t0), "=&v"(t1) : "v"(sa), "v"(sb) : "memory"); }
+#else
             __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(smem + buf * 2 * TILE + q * 512), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(smem + buf * 2 * TILE + TILE + q * 512), 16, 0, 0);
+#endif
         }
     };
     // Fragment reads are issued as inline-asm DS instructions so that the compiler cannot sink them next to their
@@ -137,21 +152,37 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
 
     // Software pipeline: the DMA ring keeps NSTAGE-1 tiles in flight; the fragments of tile kt+1 are read from LDS while
     // the 16 MFMAs of tile kt execute (register double buffer), so neither HBM nor LDS latency is exposed.
+#if defined(B2S_EXP_NOWAIT) || defined(B2S_EXP_NODMA)
+#define B2S_EXP_WAIT
+#else
+#define B2S_EXP_WAIT asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTAGE - 3)) : "memory");
+#endif
+#ifdef B2S_EXP_NOBAR
+#define B2S_EXP_BAR
+#else
+#define B2S_EXP_BAR __builtin_amdgcn_s_barrier();
+#endif
+#ifdef B2S_EXP_NOLDS
+#define B2S_EXP_FRAG(d, t, a) asm volatile("" : "+v"(d))
+#else
+#define B2S_EXP_FRAG(d, t, a) frag_issue(d, t, a)
+#endif
 #define B2S_MMA16(CA, CB)                                                                                         \
     _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < 4; ++b)                   \
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CA[a], CB[b], acc[a][b], 0, 0, 0);
 #define B2S_STEP(KT, CA, CB, NA, NB)                                                                              \
     {                                                                                                              \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTAGE - 3)) : "memory"); /* tile KT+1 landed (own DMAs) */    \
-        __builtin_amdgcn_s_barrier();             /* ... for every wave; tile KT-1 is fully consumed */             \
+        B2S_EXP_WAIT /* tile KT+1 landed (own DMAs) */    \
+        B2S_EXP_BAR             /* ... for every wave; tile KT-1 is fully consumed */             \
         issue(kt0 + (KT) + NSTAGE - 1, ((KT) + NSTAGE - 1) % NSTAGE);                                              \
         const unsigned sb_ = lds_base + (unsigned)((((KT) + 1) % NSTAGE) * 2 * TILE * 2);                         \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                            \
-            frag_issue(NA[t], TA, sb_ + offA[t]);                                                                  \
-            frag_issue(NB[t], TB, sb_ + offB[t]);                                                                  \
+            B2S_EXP_FRAG(NA[t], TA, sb_ + offA[t]);                                                                  \
+            B2S_EXP_FRAG(NB[t], TB, sb_ + offB[t]);                                                                  \
         }                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         B2S_MMA16(CA, CB)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);        /* keep the MFMAs ABOVE the wait (they are register-only) */      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* tile KT+1 fragments are in registers */              \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
     }

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
                                                 const float* mean, const float* rstd, float* dx, int accumulate,
                                                 float* dgamma, float* dbeta, int M, int D, const int* row_len,
                                                 int rpb, float* ws) {
-    __shared__ float sacc[2 * LN_MAXC * 256];
+    __shared__ float sacc[4 * 2 * LN_MAXC * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
     const int NW = blockDim.x >> 6;
@@ -136,78 +136,53 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
         int ci = lane + 64 * i;
         gm[i] = ci < nch ? ld4(gamma + ci * 4) : make_float4(0, 0, 0, 0);
     }
-    // two rows per wave iteration, every global load (dy, x and the dx being accumulated into) issued before the
-    // first reduction: the kernel is latency-bound, not bandwidth-bound, at ~3 rows per wave
-    const int rstride = gridDim.x * NW;
-    for (int row0 = blockIdx.x * NW + wave; row0 < M; row0 += 2 * rstride) {
-        int rows[2] = {row0, row0 + rstride};
-        float4 d[2][LN_MAXC], xv[2][LN_MAXC], av[2][LN_MAXC];
-        float mu[2], rs[2];
+    for (int row = blockIdx.x * NW + wave; row < M; row += gridDim.x * NW) {
+        bool zero = false;
+        if (row_len) { int b = row / rpb; zero = (row - b * rpb) >= row_len[b]; }
+        const float mu = mean[row], rs = rstd[row];
+        float4 g[LN_MAXC], xh[LN_MAXC];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = rows[u];
-            const bool live = row < M;
-            bool zero = !live;
-            if (live && row_len) { int b = row / rpb; zero = (row - b * rpb) >= row_len[b]; }
-            mu[u] = live ? mean[row] : 0.f; rs[u] = live ? rstd[row] : 0.f;
-#pragma unroll
-            for (int i = 0; i < LN_MAXC; ++i) {
-                const int ci = lane + 64 * i;
-                d[u][i] = xv[u][i] = av[u][i] = make_float4(0, 0, 0, 0);
-                if (ci < nch && live) {
-                    if (!zero) d[u][i] = ld4(dy + (long)row * lddy + ci * 4);
-                    xv[u][i] = ld4(x + (long)row * D + ci * 4);
-                    if (accumulate) av[u][i] = ld4(dx + (long)row * D + ci * 4);
-                }
+        for (int i = 0; i < LN_MAXC; ++i) {
+            int ci = lane + 64 * i;
+            if (ci < nch) {
+                float4 d = zero ? make_float4(0, 0, 0, 0) : ld4(dy + (long)row * lddy + ci * 4);
+                float4 xv = ld4(x + (long)row * D + ci * 4);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                pb[i].x += d.x; pb[i].y += d.y; pb[i].z += d.z; pb[i].w += d.w;
+                pg[i].x += d.x * xh[i].x; pg[i].y += d.y * xh[i].y; pg[i].z += d.z * xh[i].z; pg[i].w += d.w * xh[i].w;
+                g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+                s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+                s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
             }
         }
+        s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = rows[u];
-            if (row >= M) continue;
-            float4 g[LN_MAXC], xh[LN_MAXC];
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < LN_MAXC; ++i) {
-                const int ci = lane + 64 * i;
-                if (ci < nch) {
-                    const float4 dd = d[u][i], xx = xv[u][i];
-                    xh[i] = make_float4((xx.x - mu[u]) * rs[u], (xx.y - mu[u]) * rs[u], (xx.z - mu[u]) * rs[u], (xx.w - mu[u]) * rs[u]);
-                    pb[i].x += dd.x; pb[i].y += dd.y; pb[i].z += dd.z; pb[i].w += dd.w;
-                    pg[i].x += dd.x * xh[i].x; pg[i].y += dd.y * xh[i].y; pg[i].z += dd.z * xh[i].z; pg[i].w += dd.w * xh[i].w;
-                    g[i] = make_float4(dd.x * gm[i].x, dd.y * gm[i].y, dd.z * gm[i].z, dd.w * gm[i].w);
-                    s1 += g[i].x + g[i].y + g[i].z + g[i].w;
-                    s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
-                }
+        for (int i = 0; i < LN_MAXC; ++i) {
+            int ci = lane + 64 * i;
+            if (ci < nch) {
+                float4 o;
+                o.x = rs * (g[i].x - s1 - xh[i].x * s2); o.y = rs * (g[i].y - s1 - xh[i].y * s2);
+                o.z = rs * (g[i].z - s1 - xh[i].z * s2); o.w = rs * (g[i].w - s1 - xh[i].w * s2);
+                float* p = dx + (long)row * D + ci * 4;
+                if (accumulate) { float4 a = ld4(p); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+                st4(p, o);
             }
-            s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
-#pragma unroll
-            for (int i = 0; i < LN_MAXC; ++i) {
-                const int ci = lane + 64 * i;
-                if (ci < nch) {
-                    const float4 a = av[u][i];
-                    float4 o;
-                    o.x = rs[u] * (g[i].x - s1 - xh[i].x * s2) + a.x; o.y = rs[u] * (g[i].y - s1 - xh[i].y * s2) + a.y;
-                    o.z = rs[u] * (g[i].z - s1 - xh[i].z * s2) + a.z; o.w = rs[u] * (g[i].w - s1 - xh[i].w * s2) + a.w;
-                    st4(dx + (long)row * D + ci * 4, o);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        int ci = lane + 64 * i;
-        if (ci < nch) {
-            float* a = sacc + ci * 4; float* b = sacc + D + ci * 4;
-            atomicAdd(a, pg[i].x); atomicAdd(a + 1, pg[i].y); atomicAdd(a + 2, pg[i].z); atomicAdd(a + 3, pg[i].w);
-            atomicAdd(b, pb[i].x); atomicAdd(b + 1, pb[i].y); atomicAdd(b + 2, pb[i].z); atomicAdd(b + 3, pb[i].w);
         }
     }
     __syncthreads();
-    if (ws) {       // per-workgroup partial row [dgamma | dbeta]; k_ln_param_reduce adds the column sums (no global atomics)
-        for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) ws[(long)blockIdx.x * 2 * D + i] = sacc[i];
-    } else {
-        for (int i = threadIdx.x; i < D; i += blockDim.x) { atomicAdd(dgamma + i, sacc[i]); atomicAdd(dbeta + i, sacc[D + i]); }
+    // per-wave partial rows in LDS (plain stores), then a cross-wave sum: LDS float atomics measured ~2x the whole kernel
+    float* mine = sacc + wave * 2 * D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        int ci = lane + 64 * i;
+        if (ci < nch) { st4(mine + ci * 4, pg[i]); st4(mine + D + ci * 4, pb[i]); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) {
+        float v = 0.f;
+        for (int w = 0; w < NW; ++w) v += sacc[w * 2 * D + i];
+        if (ws) ws[(long)blockIdx.x * 2 * D + i] = v; else atomicAdd(i < D ? dgamma + i : dbeta + (i - D), v);
     }
 }
 __global__ __launch_bounds__(256) void k_ln_param_reduce(const float* ws, int nblk, int D, float* dgamma, float* dbeta) {

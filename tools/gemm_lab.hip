@@ -1,0 +1,103 @@
+// Standalone bench / check harness for the bf16 GEMM kernels (development tool; not part of libb2s_hip.so).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DLAB_KERNEL='"path/to/kernel.hip"'] [-D...] tools/gemm_lab.hip -o gemm_lab
+//   ./gemm_lab [iters]
+// Times each training-step shape in NT / NN / TN form with hipEvents over `iters` back-to-back launches (hot clocks),
+// and checks a sample of outputs against a double-precision host dot product.
+#include <cstdarg>
+#include <cstdlib>
+#include <vector>
+#ifndef LAB_KERNEL
+#define LAB_KERNEL "../few-shot-transformer-tts_amd/csrc/gemm_glds.hip"
+#endif
+#include LAB_KERNEL
+
+thread_local char g_b2s_err[512] = "";
+int b2s_fail(const char* file, int line, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_b2s_err, sizeof(g_b2s_err), fmt, ap); va_end(ap);
+    fprintf(stderr, "FAIL %s:%d: %s\n", file, line, g_b2s_err);
+    return 1;
+}
+#ifndef LAB_LAUNCH
+#define LAB_LAUNCH b2s_gemm_glds_launch
+#endif
+
+struct Shape { int M, N, K; int ta, tb; int splitk; const char* what; };
+
+static uint32_t rng_state = 12345;
+static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((rng_state >> 8) & 0xffff) / 65536.f - 0.5f; }
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 50;
+    const int only = argc > 2 ? atoi(argv[2]) : -1;
+    std::vector<Shape> shapes = {
+        {8148, 768, 768, 0, 0, 1, "fwd attn out / q proj"},
+        {8148, 2304, 768, 0, 0, 1, "fwd qkv"},
+        {8148, 3072, 768, 0, 0, 1, "fwd ffn in"},
+        {8148, 768, 3072, 0, 0, 1, "fwd ffn out"},
+        {1596, 2048, 512, 0, 0, 1, "fwd enc ffn in"},
+        {1596, 512, 2048, 0, 0, 1, "fwd enc ffn out"},
+        {8148, 768, 768, 0, 1, 1, "dX attn out"},
+        {8148, 768, 2304, 0, 1, 1, "dX qkv"},
+        {8148, 768, 3072, 0, 1, 1, "dX ffn in"},
+        {8148, 3072, 768, 0, 1, 1, "dX ffn out"},
+        {768, 768, 8148, 1, 1, 10, "dW attn out"},
+        {3072, 768, 8148, 1, 1, 3, "dW ffn in"},
+        {768, 3072, 8148, 1, 1, 3, "dW ffn out"},
+        {4096, 4096, 4096, 0, 0, 1, "4096^3 NT"},
+        {8192, 8192, 8192, 0, 0, 1, "8192^3 NT"},
+    };
+    size_t maxel = (size_t)8192 * 8192;
+    std::vector<bf16_t> hA(maxel), hB(maxel);
+    for (size_t i = 0; i < maxel; ++i) { hA[i] = f2bf(frand()); hB[i] = f2bf(frand()); }
+    bf16_t *dA, *dB; void* dC;
+    hipMalloc(&dA, maxel * 2); hipMalloc(&dB, maxel * 2); hipMalloc(&dC, maxel * 4);
+    hipMemcpy(dA, hA.data(), maxel * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dB, hB.data(), maxel * 2, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    std::vector<float> hC;
+    double tot_us = 0, tot_fl = 0;
+    for (size_t si = 0; si < shapes.size(); ++si) {
+        if (only >= 0 && (int)si != only) continue;
+        const Shape& s = shapes[si];
+        GemmArgs g;
+        g.M = s.M; g.N = s.N; g.K = s.K;
+        g.A.p = dA; g.B.p = dB;
+        if (s.ta) { g.A.ld = s.M; g.A.R = s.K; g.A.C = s.M; } else { g.A.ld = s.K; g.A.R = s.M; g.A.C = s.K; }
+        if (s.tb) { g.B.ld = s.N; g.B.R = s.K; g.B.C = s.N; } else { g.B.ld = s.K; g.B.R = s.N; g.B.C = s.K; }
+        g.C = dC; g.ldc = s.N; g.splitk = s.splitk;
+        if (s.splitk > 1) { g.c_fp32 = 1; g.epi.accumulate = 1; } else g.c_fp32 = 0;
+        hipMemset(dC, 0, (size_t)s.M * s.N * 4);
+        if (LAB_LAUNCH(g, s.ta, s.tb, 0)) return 1;
+        hipDeviceSynchronize();
+        // check a sample
+        const size_t nC = (size_t)s.M * s.N;
+        hC.resize(nC);
+        if (g.c_fp32) hipMemcpy(hC.data(), dC, nC * 4, hipMemcpyDeviceToHost);
+        else { std::vector<bf16_t> t(nC); hipMemcpy(t.data(), dC, nC * 2, hipMemcpyDeviceToHost); for (size_t i = 0; i < nC; ++i) hC[i] = bf2f(t[i]); }
+        double worst = 0;
+        for (int smp = 0; smp < 400; ++smp) {
+            int m = (smp * 7919 + 13) % s.M, n = (smp * 104729 + 7) % s.N;
+            if (smp < 8) { m = smp & 1 ? s.M - 1 - smp : smp; n = smp & 2 ? s.N - 1 - smp : smp; }
+            double ref = 0;
+            for (int k = 0; k < s.K; ++k) {
+                float a = s.ta ? bf2f(hA[(size_t)k * s.M + m]) : bf2f(hA[(size_t)m * s.K + k]);
+                float b = s.tb ? bf2f(hB[(size_t)k * s.N + n]) : bf2f(hB[(size_t)n * s.K + k]);
+                ref += (double)a * b;
+            }
+            double err = fabs(ref - hC[(size_t)m * s.N + n]) / (0.02 * sqrt((double)s.K) * 0.083 + 0.01 * fabs(ref));
+            if (err > worst) worst = err;
+        }
+        for (int w = 0; w < 5; ++w) LAB_LAUNCH(g, s.ta, s.tb, 0);
+        hipEventRecord(e0, 0);
+        for (int it = 0; it < iters; ++it) LAB_LAUNCH(g, s.ta, s.tb, 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double us = ms * 1e3 / iters, fl = 2.0 * s.M * s.N * s.K;
+        printf("%2zu %-22s M=%5d N=%5d K=%5d %s%s sk=%2d  %8.2f us  %7.1f TF  err=%.2f%s\n", si, s.what, s.M, s.N, s.K, s.ta ? "T" : "N",
+               s.tb ? "T" : "N", s.splitk, us, fl / us / 1e6, worst, worst > 1.0 ? "  <-- MISMATCH" : "");
+        if (si < 13) { tot_us += us; tot_fl += fl; }
+    }
+    printf("step-shape mix: %.1f us total, %.1f TF/s\n", tot_us, tot_fl / tot_us / 1e6);
+    return 0;
+}
