@@ -31,15 +31,29 @@ template <> struct AT<bf16_t> {
 __device__ inline f32x4_t mma(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ inline f32x4_t mma(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
-// cooperative load of a [64][DH] tile (rows row0.. of a [rows, ld] matrix, zero beyond nrows) into LDS [64][DH+PAD]
+// cooperative load of a [64][DH] tile (rows row0.. of a [rows, ld] matrix, zero beyond nrows) into LDS [64][DH+PAD], split
+// in two halves so that the global loads of the NEXT tile are in flight while the current tile is being consumed
+// (register double buffer; a single fused loop compiled to load -> wait -> store round trips, 3 per tile, and was the
+// whole cost of these kernels).
+template <typename T, int DH> struct TileRegs { uint4 v[64 * (DH / AT<T>::VE) / 256]; };
 template <typename T, int DH>
-__device__ inline void load_tile(T* lds, const T* src, long ld, int row0, int nrows, int tid) {
-    constexpr int VE = AT<T>::VE, LD = DH + AT<T>::PAD, VPR = DH / VE;
-    for (int v = tid; v < 64 * VPR; v += 256) {
-        const int r = v / VPR, c = (v - r * VPR) * VE;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (row0 + r < nrows) val = *reinterpret_cast<const uint4*>(src + (long)(row0 + r) * ld + c);
-        *reinterpret_cast<uint4*>(lds + r * LD + c) = val;
+__device__ inline void tile_fetch(TileRegs<T, DH>& r, const T* src, long ld, int row0, int nrows, int tid) {
+    constexpr int VE = AT<T>::VE, VPR = DH / VE, NV = 64 * VPR / 256;
+    static_assert(64 * VPR % 256 == 0, "tile must split evenly over 256 threads");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256, rr = v / VPR, c = (v - rr * VPR) * VE;
+        r.v[i] = make_uint4(0, 0, 0, 0);
+        if (row0 + rr < nrows) r.v[i] = *reinterpret_cast<const uint4*>(src + (long)(row0 + rr) * ld + c);
+    }
+}
+template <typename T, int DH>
+__device__ inline void tile_store(T* lds, const TileRegs<T, DH>& r, int tid) {
+    constexpr int VE = AT<T>::VE, LD = DH + AT<T>::PAD, VPR = DH / VE, NV = 64 * VPR / 256;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256, rr = v / VPR, c = (v - rr * VPR) * VE;
+        *reinterpret_cast<uint4*>(lds + rr * LD + c) = r.v[i];
     }
 }
 
@@ -182,12 +196,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     float g = 0.f, ga_iq = 0.f, ga_ik = 0.f;
     if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
     const long drow = ((long)z * a.Lq + qc) * a.Lk;
+    TileRegs<T, DH> rk, rv;
+    if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid); }
     for (int kt = 0; kt < ktiles; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
-        load_tile<T, DH>(sK, K, a.ldk, k0, a.Lk, tid);
-        load_tile<T, DH>(sV, V, a.ldv, k0, a.Lk, tid);
+        tile_store<T, DH>(sK, rk, tid);
+        tile_store<T, DH>(sV, rv, tid);
         __syncthreads();
+        if (kt + 1 < ktiles) { tile_fetch<T, DH>(rk, K, a.ldk, k0 + 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 64, a.Lk, tid); }
         f32x4_t s[4];
         first_product<T, DH, LD>(s, sK, qf, li, lg);
         float mx = -INFINITY;
@@ -294,12 +311,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const long drow = ((long)z * a.Lq + qc) * a.Lk;
+    TileRegs<T, DH> rk, rv;
+    if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid); }
     for (int kt = 0; kt < ktiles; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
-        load_tile<T, DH>(sK, K, a.ldk, k0, a.Lk, tid);
-        load_tile<T, DH>(sV, V, a.ldv, k0, a.Lk, tid);
+        tile_store<T, DH>(sK, rk, tid);
+        tile_store<T, DH>(sV, rv, tid);
         __syncthreads();
+        if (kt + 1 < ktiles) { tile_fetch<T, DH>(rk, K, a.ldk, k0 + 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 64, a.Lk, tid); }
         f32x4_t s[4], dp[4];
         first_product<T, DH, LD>(s, sK, qf, li, lg);
         first_product<T, DH, LD>(dp, sV, dof, li, lg);
@@ -353,16 +373,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     for (int dt = 0; dt < DH / 16; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     const int qtiles = (a.Lq + 63) / 64;
     const int qt0 = (a.mask_mode & 2) ? kb0 / 64 : 0;          // causal: queries before this key tile never see it
+    TileRegs<T, DH> rq, ro;
+    float r_l = 0.f, r_d = 0.f;
+    if (qt0 < qtiles) {
+        tile_fetch<T, DH>(rq, Q, a.ldq, qt0 * 64, a.Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, qt0 * 64, a.Lq, tid);
+        if (tid < 64) { const int qq = min(qt0 * 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq]; r_d = a.dsum[(long)z * a.Lq + qq]; }
+    }
     for (int qt = qt0; qt < qtiles; ++qt) {
         const int q0 = qt * 64;
         __syncthreads();
-        load_tile<T, DH>(sQ, Q, a.ldq, q0, a.Lq, tid);
-        load_tile<T, DH>(sO, dO, a.ldo, q0, a.Lq, tid);
-        if (tid < 64) {
-            const int qq = min(q0 + tid, a.Lq - 1);
-            sL[tid] = a.lse[(long)z * a.Lq + qq]; sD[tid] = a.dsum[(long)z * a.Lq + qq];
-        }
+        tile_store<T, DH>(sQ, rq, tid);
+        tile_store<T, DH>(sO, ro, tid);
+        if (tid < 64) { sL[tid] = r_l; sD[tid] = r_d; }
         __syncthreads();
+        if (qt + 1 < qtiles) {
+            tile_fetch<T, DH>(rq, Q, a.ldq, q0 + 64, a.Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, q0 + 64, a.Lq, tid);
+            if (tid < 64) { const int qq = min(q0 + 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq]; r_d = a.dsum[(long)z * a.Lq + qq]; }
+        }
         f32x4_t s[4], dp[4], pd[4];
         first_product<T, DH, LD>(s, sQ, kf, li, lg);          // s[t][r] = S[q = q0 + t*16 + lg*4 + r][key = own]
         first_product<T, DH, LD>(dp, sO, vf, li, lg);
