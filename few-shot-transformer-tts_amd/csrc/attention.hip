@@ -82,10 +82,9 @@ template <int LD> __device__ inline bf16x8_t frag_tr(const bf16_t* t, int r0, in
     return r;
 }
 __device__ inline bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
-    bf16x8_t r;
-    r[0] = (short)f2bf(a[0]); r[1] = (short)f2bf(a[1]); r[2] = (short)f2bf(a[2]); r[3] = (short)f2bf(a[3]);
-    r[4] = (short)f2bf(b[0]); r[5] = (short)f2bf(b[1]); r[6] = (short)f2bf(b[2]); r[7] = (short)f2bf(b[3]);
-    return r;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+    const u32x4_t u = {f2bf2(a[0], a[1]), f2bf2(a[2], a[3]), f2bf2(b[0], b[1]), f2bf2(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8_t, u);
 }
 
 // acc[dt] (+)= sum over the tile's 64 rows of  tile[row][dt*16 + i] * w[row][j]     (w in the MFMA C layout of a
@@ -144,6 +143,13 @@ __device__ inline float frag_dot(bf16x8_t x, bf16x8_t y) {
 __device__ inline float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ inline float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
+// v_exp_f32 / v_log_f32 directly (exp2(-inf) = 0); logits are kept in the log2 domain: p = 2^(s * scale * log2(e) - m)
+__device__ inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+constexpr float B2S_LOG2E = 1.4426950408889634f, B2S_LN2 = 0.6931471805599453f;
+// running-maximum slack of the forward pass: the reference m of a row only moves (and O, l are only rescaled) when a
+// tile's maximum exceeds it by more than 2^8; weights stay <= 2^8 * e^(row spread) in between, exact in fp32/bf16 range
+constexpr float B2S_LAZY = 8.f;
+
 // guided-attention weight of (query q, key k) for an utterance with inverse lengths iq = 1/qlen, ik = 1/klen
 __device__ inline float ga_w(int q, int k, float iq, float ik, float inv2s2) {
     const float d = (float)k * ik - (float)q * iq;
@@ -160,8 +166,8 @@ __device__ inline void store_rows(T* dst, const f32x4_t (&acc)[DH / 16], float m
             *reinterpret_cast<float4*>(p) = make_float4(acc[dt][0] * mul, acc[dt][1] * mul, acc[dt][2] * mul, acc[dt][3] * mul);
         } else {
             uint2 u;
-            u.x = (uint32_t)f2bf(acc[dt][0] * mul) | ((uint32_t)f2bf(acc[dt][1] * mul) << 16);
-            u.y = (uint32_t)f2bf(acc[dt][2] * mul) | ((uint32_t)f2bf(acc[dt][3] * mul) << 16);
+            u.x = f2bf2(acc[dt][0] * mul, acc[dt][1] * mul);
+            u.y = f2bf2(acc[dt][2] * mul, acc[dt][3] * mul);
             *reinterpret_cast<uint2*>(p) = u;
         }
     }
@@ -191,11 +197,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     f32x4_t o[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY, l = 0.f;                    // m: reference exponent (log2 domain), l: this lane's part of the row sum
     const bool ga = a.ga_rows != nullptr;
     float g = 0.f, ga_iq = 0.f, ga_ik = 0.f;
     if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
-    const long drow = ((long)z * a.Lq + qc) * a.Lk;
+    const float sl2 = a.scale * B2S_LOG2E;
+    const int qw0 = qb0 + wave * 16;                 // first query row of this wave
+    const uint32_t drow = (uint32_t)(((long)z * a.Lq + qc) * a.Lk);
     TileRegs<T, DH> rk, rv;
     if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid); }
     for (int kt = 0; kt < ktiles; ++kt) {
@@ -207,38 +215,54 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         if (kt + 1 < ktiles) { tile_fetch<T, DH>(rk, K, a.ldk, k0 + 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 64, a.Lk, tid); }
         f32x4_t s[4];
         first_product<T, DH, LD>(s, sK, qf, li, lg);
+        // every key of the tile visible to every row of this wave?  (wave-uniform; the common case skips all mask math)
+        const bool interior = k0 + 64 <= kend && (!(a.mask_mode & 2) || k0 + 63 <= qw0);
         float mx = -INFINITY;
+        if (interior) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+        } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + t * 16 + lg * 4 + r;
-                const bool ok = key < kend && (!(a.mask_mode & 2) || key <= q);
-                s[t][r] = ok ? s[t][r] * a.scale : -INFINITY;
-                mx = fmaxf(mx, s[t][r]);
-            }
-        mx = group_max(mx);
-        const float mn = fmaxf(m, mx);
-        const float msafe = mn == -INFINITY ? 0.f : mn;
-        const float alpha = __expf(m - msafe);          // m = -inf -> 0
-        m = mn;
-        l *= alpha;
-        g *= alpha;
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int dt = 0; dt < DH / 16; ++dt) { o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha; }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = __expf(s[t][r] - msafe);
-                l += p;
-                if (ga) g += p * ga_w(q, k0 + t * 16 + lg * 4 + r, ga_iq, ga_ik, a.ga_inv2s2);
-                if (a.drop.thresh) {
+                for (int r = 0; r < 4; ++r) {
                     const int key = k0 + t * 16 + lg * 4 + r;
-                    p = b2s_keep(a.drop, (uint32_t)(drow + key)) ? p * a.drop.scale : 0.f;
+                    const bool ok = key < kend && (!(a.mask_mode & 2) || key <= q);
+                    s[t][r] = ok ? s[t][r] : -INFINITY;
+                    mx = fmaxf(mx, s[t][r]);
                 }
+        }
+        mx = group_max(mx) * sl2;
+        const bool grow = mx > m + B2S_LAZY;             // also true for the first finite maximum (m = -inf)
+        if (__any(grow)) {
+            const float mn = grow ? mx : m;
+            const float alpha = mn == m ? 1.f : fast_exp2(m - mn);      // m = -inf -> 0
+            m = mn; l *= alpha; g *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DH / 16; ++dt) { o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha; }
+        }
+        const float mref = m == -INFINITY ? 0.f : m;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = fast_exp2(fmaf(s[t][r], sl2, -mref));   // masked: 2^-inf = 0
+                l += p;
                 s[t][r] = p;
             }
+        if (ga) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g += s[t][r] * ga_w(q, k0 + t * 16 + lg * 4 + r, ga_iq, ga_ik, a.ga_inv2s2);
+        }
+        if (a.drop.thresh) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s[t][r] = b2s_keep(a.drop, drow + (uint32_t)(k0 + t * 16 + lg * 4 + r)) ? s[t][r] * a.drop.scale : 0.f;
+        }
         SP<T, DH, LD>::run(o, sV, s, li, lg);
     }
     l = group_sum(l);
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         const float inv = 1.f / l;
         T* out = reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q) * a.ldo + h * DH;
         store_rows<T, DH>(out, o, inv, lg);
-        if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = m + __logf(l);
+        if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = (m + __log2f(l)) * B2S_LN2;
         if (lg == 0 && ga) a.ga_rows[(long)z * a.Lq + q] = q < a.qlen[b] ? g * inv : 0.f;
     }
 }
@@ -310,7 +334,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     f32x4_t dq[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const long drow = ((long)z * a.Lq + qc) * a.Lk;
+    const uint32_t drow = (uint32_t)(((long)z * a.Lq + qc) * a.Lk);
+    const float sl2 = a.scale * B2S_LOG2E, lse2 = lse * B2S_LOG2E;
+    const int qw0 = qb0 + wave * 16;
     TileRegs<T, DH> rk, rv;
     if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid); }
     for (int kt = 0; kt < ktiles; ++kt) {
@@ -323,18 +349,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         f32x4_t s[4], dp[4];
         first_product<T, DH, LD>(s, sK, qf, li, lg);
         first_product<T, DH, LD>(dp, sV, dof, li, lg);
+        const bool interior = k0 + 64 <= kend && (!(a.mask_mode & 2) || k0 + 63 <= qw0);
+        if (interior) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t][r] = fast_exp2(fmaf(s[t][r], sl2, -lse2));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + t * 16 + lg * 4 + r;
+                    const bool ok = key < kend && (!(a.mask_mode & 2) || key <= q);
+                    s[t][r] = ok ? fast_exp2(fmaf(s[t][r], sl2, -lse2)) : 0.f;
+                }
+        }
+        if (a.drop.thresh) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dp[t][r] = b2s_keep(a.drop, drow + (uint32_t)(k0 + t * 16 + lg * 4 + r)) ? dp[t][r] * a.drop.scale : 0.f;
+        }
+        if (__any(gc != 0.f)) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dp[t][r] += gc * ga_w(q, k0 + t * 16 + lg * 4 + r, ga_iq, ga_ik, a.ga_inv2s2);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + t * 16 + lg * 4 + r;
-                const bool ok = key < kend && (!(a.mask_mode & 2) || key <= q);
-                const float p = ok ? __expf(s[t][r] * a.scale - lse) : 0.f;
-                float d = dp[t][r];
-                if (a.drop.thresh) d = b2s_keep(a.drop, (uint32_t)(drow + key)) ? d * a.drop.scale : 0.f;
-                if (gc != 0.f) d += gc * ga_w(q, key, ga_iq, ga_ik, a.ga_inv2s2);
-                s[t][r] = p * (d - Dq) * a.scale;
-            }
+            for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - Dq) * a.scale;
         SP<T, DH, LD>::run(dq, sK, s, li, lg);
     }
     if (q < a.Lq) store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)b * a.Lq + q) * a.lddq + h * DH, dq, 1.f, lg);
@@ -346,7 +393,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
     __shared__ __attribute__((aligned(16))) T sQ[64 * LD];
     __shared__ __attribute__((aligned(16))) T sO[64 * LD];
-    __shared__ float sL[64], sD[64];
+    __shared__ __attribute__((aligned(16))) float sL[64], sD[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
     const int kb0 = blockIdx.x * 64, key = kb0 + wave * 16 + li;
@@ -375,9 +422,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int qt0 = (a.mask_mode & 2) ? kb0 / 64 : 0;          // causal: queries before this key tile never see it
     TileRegs<T, DH> rq, ro;
     float r_l = 0.f, r_d = 0.f;
+    const float sl2 = a.scale * B2S_LOG2E;
+    const int kw0 = kb0 + wave * 16;                 // first key of this wave
+    const uint32_t zq = (uint32_t)z * (uint32_t)a.Lq;
     if (qt0 < qtiles) {
         tile_fetch<T, DH>(rq, Q, a.ldq, qt0 * 64, a.Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, qt0 * 64, a.Lq, tid);
-        if (tid < 64) { const int qq = min(qt0 * 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq]; r_d = a.dsum[(long)z * a.Lq + qq]; }
+        if (tid < 64) { const int qq = min(qt0 * 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq] * B2S_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq]; }
     }
     for (int qt = qt0; qt < qtiles; ++qt) {
         const int q0 = qt * 64;
@@ -388,29 +438,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         __syncthreads();
         if (qt + 1 < qtiles) {
             tile_fetch<T, DH>(rq, Q, a.ldq, q0 + 64, a.Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, q0 + 64, a.Lq, tid);
-            if (tid < 64) { const int qq = min(q0 + 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq]; r_d = a.dsum[(long)z * a.Lq + qq]; }
+            if (tid < 64) { const int qq = min(q0 + 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq] * B2S_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq]; }
         }
         f32x4_t s[4], dp[4], pd[4];
         first_product<T, DH, LD>(s, sQ, kf, li, lg);          // s[t][r] = S[q = q0 + t*16 + lg*4 + r][key = own]
         first_product<T, DH, LD>(dp, sO, vf, li, lg);
+        // all 16 keys of this wave valid and visible to all 64 queries of the tile?  (wave-uniform)
+        const bool interior = kw0 + 16 <= kend && q0 + 64 <= a.Lq && (!(a.mask_mode & 2) || kw0 + 15 <= q0);
+        if (interior) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t) {
+                const f32x4_t lq = *reinterpret_cast<const f32x4_t*>(sL + t * 16 + lg * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = t * 16 + lg * 4 + r, qq = q0 + ql;
-                const bool ok = key_ok && qq < a.Lq && (!(a.mask_mode & 2) || key <= qq);
-                const float p = ok ? __expf(s[t][r] * a.scale - sL[ql]) : 0.f;
-                float d = dp[t][r], pdv = p;
-                if (a.drop.thresh) {
-                    const bool keep = b2s_keep(a.drop, (uint32_t)(((long)z * a.Lq + min(qq, a.Lq - 1)) * a.Lk + kc));
-                    d = keep ? d * a.drop.scale : 0.f;
-                    pdv = keep ? p * a.drop.scale : 0.f;
-                }
-                pd[t][r] = pdv;
-                if (gc != 0.f && qq < ga_ql) d += gc * ga_w(qq, key, ga_iq, ga_ik, a.ga_inv2s2);
-                s[t][r] = p * (d - sD[ql]) * a.scale;
+                for (int r = 0; r < 4; ++r) s[t][r] = fast_exp2(fmaf(s[t][r], sl2, -lq[r]));
             }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4_t lq = *reinterpret_cast<const f32x4_t*>(sL + t * 16 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = q0 + t * 16 + lg * 4 + r;
+                    const bool ok = key_ok && qq < a.Lq && (!(a.mask_mode & 2) || key <= qq);
+                    s[t][r] = ok ? fast_exp2(fmaf(s[t][r], sl2, -lq[r])) : 0.f;
+                }
+            }
+        }
+        if (a.drop.thresh) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool keep = b2s_keep(a.drop, (zq + (uint32_t)(q0 + t * 16 + lg * 4 + r)) * (uint32_t)a.Lk + (uint32_t)kc);
+                    dp[t][r] = keep ? dp[t][r] * a.drop.scale : 0.f;
+                    pd[t][r] = keep ? s[t][r] * a.drop.scale : 0.f;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pd[t] = s[t];
+        }
+        if (gc != 0.f) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = q0 + t * 16 + lg * 4 + r;
+                    dp[t][r] += qq < ga_ql ? gc * ga_w(qq, key, ga_iq, ga_ik, a.ga_inv2s2) : 0.f;
+                }
+        }
         SP<T, DH, LD>::run(dv, sO, pd, li, lg);                // dV^T[d][key] += sum_q dO[q][d] * Pd[q][key]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4_t dsum4 = *reinterpret_cast<const f32x4_t*>(sD + t * 16 + lg * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - dsum4[r]) * a.scale;
+        }
         SP<T, DH, LD>::run(dk, sQ, s, li, lg);                 // dK^T[d][key] += sum_q Q[q][d]  * dS[q][key]
     }
     if (key < a.Lk) {

@@ -26,7 +26,18 @@ int b2s_fail(const char* file, int line, const char* fmt, ...);
 __device__ __host__ inline float bf2f(bf16_t x) {
     union { uint32_t u; float f; } c; c.u = ((uint32_t)x) << 16; return c.f;
 }
+// packed conversion on the device: one v_cvt_pk_bf16_f32 (round to nearest even, NaN -> quiet NaN) per pair
+__device__ inline uint32_t f2bf2(float lo, float hi) {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t v = {lo, hi};
+    const bf2_t w = __builtin_convertvector(v, bf2_t);
+    return __builtin_bit_cast(uint32_t, w);
+}
 __device__ __host__ inline bf16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (bf16_t)(f2bf2(f, 0.f) & 0xffffu);
+#endif
     union { uint32_t u; float f; } c; c.f = f;
     uint32_t u = c.u;
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;   // NaN

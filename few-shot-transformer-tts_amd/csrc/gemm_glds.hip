@@ -330,8 +330,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
                 dst[0] = o0; dst[1] = o1;
             } else {
                 uint4 o;
-                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+                o.x = f2bf2(v[0], v[1]); o.y = f2bf2(v[2], v[3]); o.z = f2bf2(v[4], v[5]); o.w = f2bf2(v[6], v[7]);
                 *reinterpret_cast<uint4*>(Ct + off) = o;
             }
         } else {

@@ -17,8 +17,8 @@ __device__ inline float4 ld4(const bf16_t* p) {
 }
 __device__ inline void st4(bf16_t* p, float4 v) {
     uint2 u;
-    u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-    u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    u.x = f2bf2(v.x, v.y);
+    u.y = f2bf2(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = u;
 }
 __device__ inline float4 drop4(float4 v, const DropCfg& d, uint32_t idx) {
