@@ -51,3 +51,7 @@ int b2s_gemm_launch(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t 
 int b2s_gemm_glds_launch(const GemmArgs& g, bool ta, bool tb, hipStream_t stream);
 // decode-step weight-streaming kernel (gemm_skinny.hip); returns -1 when the problem does not fit it
 int b2s_gemm_skinny_launch(const GemmArgs& g, int dtype, hipStream_t stream);
+// 256x128-tile variant for the large-M forms (gemm_glds256.hip) and the split-K slab reduction shared by both
+long b2s_gemm_glds256_tiles(const GemmArgs& g);
+int b2s_gemm_glds256_launch(const GemmArgs& g, bool ta, bool tb, const bf16_t* zero, float* ws, size_t ws_floats, hipStream_t stream);
+int b2s_splitk_reduce_launch(const float* ws, float* dst, int M, int N, int ldc, int splitk, int conv_dw_cin, hipStream_t stream);

@@ -1,0 +1,144 @@
+// Epilogue shared by the bf16 LDS-DMA GEMM kernels (gemm_glds.hip: 128x128 tiles, gemm_glds256.hip: 256x128 tiles): one
+// wave owns a 64 x (NB*16) accumulator block at (mb, nb) in the MFMA layout and a private 16 KB LDS staging area `stg`.
+#pragma once
+#include "gemm.h"
+
+template <int NB>     // the wave's block is 64 rows x NB*16 columns
+__device__ inline void gemm_wave_epilogue(GemmArgs g, f32x4_t (&acc)[4][NB], float* stg, int mb, int nb, int lane, int z, int zo, int zi,
+                                          int ksplit, float* splitk_ws) {
+    const int li = lane & 15, lg = lane >> 4;
+    // ---------------- epilogue.  The accumulators (MFMA layout: col = lane & 15, row = (lane >> 4)*4 + r) are staged
+    // through LDS (the operand ring is dead now) so that every lane owns 8 consecutive output columns of one row:
+    // bf16 results leave as 16-byte stores, residual / ReLU-mask / bias operands arrive as 16-byte loads.
+    GemmEpilogue e = g.epi;
+    if (g.splitk > 1 && splitk_ws) {
+        // split-K partial tile: plain vector stores into workspace slab `ksplit` ([splitk][M][N] fp32); a reduce kernel
+        // adds the slabs into the gradient (fp32 atomics cost ~8 ns per 64-lane instruction and were the bottleneck)
+        g.C = splitk_ws + (long)ksplit * g.M * g.N; g.c_fp32 = 1; g.ldc = g.N; g.cs_o = 0; g.cs_i = 0; g.splitk = 1;
+        e.accumulate = 0; e.conv_dw_cin = 0;
+    }
+    if (g.splitk > 1 || e.conv_dw_cin > 0) {
+        // weight-gradient forms: linear fp32 accumulate straight from the MFMA layout (16 lanes = 64 contiguous bytes
+        // per atomic / store instruction)
+        float* Cw = reinterpret_cast<float*>(g.C) + zo * g.cs_o + zi * g.cs_i;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb + a * 16 + lg * 4 + r;
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    int nn = nb + b * 16 + li;
+                    if (nn >= g.N) continue;
+                    if (e.conv_dw_cin > 0) { int jj = nn / e.conv_dw_cin; nn = (nn - jj * e.conv_dw_cin) * 5 + jj; }
+                    const float v = acc[a][b][r] * e.alpha;
+                    float* dst = Cw + (long)m * g.ldc + nn;
+                    if (g.splitk > 1) atomicAdd(dst, v); else if (e.accumulate) *dst += v; else *dst = v;
+                }
+            }
+        return;
+    }
+    __builtin_amdgcn_s_barrier();                          // every wave is done reading the operand ring
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = a * 16 + lg * 4 + r;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) stg[row * 64 + ((b * 16 + li) ^ (((row >> 2) & 1) << 4))] = acc[a][b][r];
+        }
+    // (same-wave LDS hand-off: DS operations of one wave complete in order)
+    const long cbase = zo * g.cs_o + zi * g.cs_i;
+    float* Cf = reinterpret_cast<float*>(g.C);
+    bf16_t* Ct = reinterpret_cast<bf16_t*>(g.C);
+    const bf16_t* aux = reinterpret_cast<const bf16_t*>(e.relu_aux);
+    DropCfg dcfg = e.drop;
+    if (e.drop.thresh && e.drop_salt) dcfg.key ^= b2s_hash32((uint32_t)(*e.drop_salt) * 2246822519u + 3266489917u);
+    const bool vec_ok = (g.ldc & 7) == 0 && (cbase & 7) == 0 && e.conv_dw_cin == 0 && g.splitk == 1 &&
+                        ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+    const int cchunk = lane & 7;
+    const int n = nb + cchunk * 8;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = (e.bias && n + j < g.N) ? e.bias[n + j] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int row = p * 8 + (lane >> 3);
+        const int m = mb + row;
+        const float4 v0 = *reinterpret_cast<const float4*>(stg + row * 64 + ((cchunk * 8) ^ (((row >> 2) & 1) << 4)));
+        const float4 v1 = *reinterpret_cast<const float4*>(stg + row * 64 + ((cchunk * 8) ^ (((row >> 2) & 1) << 4)) + 4);
+        if (m >= g.M || n >= g.N || cchunk >= NB * 2) continue;
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * e.alpha + bv[j];
+        if (e.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        const bool full = n + 8 <= g.N;
+        if (aux) {
+            if (full && (e.ld_aux & 7) == 0) {
+                const uint4 u = *reinterpret_cast<const uint4*>(aux + (long)m * e.ld_aux + n);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t bits = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;      // bf16 > 0  <=>  sign clear and non-zero
+                    v[j] = (bits != 0 && !(bits & 0x8000u)) ? v[j] * e.aux_scale : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (n + j < g.N) v[j] = bf2f(aux[(long)m * e.ld_aux + n + j]) > 0.f ? v[j] * e.aux_scale : 0.f;
+            }
+        }
+        if (e.drop.thresh) {
+            const uint32_t idx = (uint32_t)(((long)z * g.M + m) * g.N + n);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = b2s_keep(dcfg, idx + j) ? v[j] * dcfg.scale : 0.f;
+        }
+        if (e.residual) {
+            if (full && (e.ldr & 3) == 0) {
+                const float4 r0 = *reinterpret_cast<const float4*>(e.residual + (long)m * e.ldr + n);
+                const float4 r1 = *reinterpret_cast<const float4*>(e.residual + (long)m * e.ldr + n + 4);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (n + j < g.N) v[j] += e.residual[(long)m * e.ldr + n + j];
+            }
+        }
+        if (e.row_len) {
+            const int bb = m / e.rows_per_batch, t = m - bb * e.rows_per_batch;
+            if (t >= e.row_len[bb]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+        }
+        const long off = cbase + (long)m * g.ldc + n;
+        if (vec_ok && full) {
+            if (g.c_fp32) {
+                float4* dst = reinterpret_cast<float4*>(Cf + off);
+                float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+                if (e.accumulate) {
+                    const float4 c0 = dst[0], c1 = dst[1];
+                    o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
+                }
+                dst[0] = o0; dst[1] = o1;
+            } else {
+                uint4 o;
+                o.x = f2bf2(v[0], v[1]); o.y = f2bf2(v[2], v[3]); o.z = f2bf2(v[4], v[5]); o.w = f2bf2(v[6], v[7]);
+                *reinterpret_cast<uint4*>(Ct + off) = o;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (n + j >= g.N) continue;
+                int nn = n + j;
+                if (e.conv_dw_cin > 0) { int jj = nn / e.conv_dw_cin; nn = (nn - jj * e.conv_dw_cin) * 5 + jj; }
+                const long o = cbase + (long)m * g.ldc + nn;
+                if (g.c_fp32) { if (g.splitk > 1) atomicAdd(Cf + o, v[j]); else if (e.accumulate) Cf[o] += v[j]; else Cf[o] = v[j]; }
+                else Ct[o] = f2bf(v[j]);
+            }
+        }
+    }
+}

@@ -1,0 +1,309 @@
+// bf16 MFMA GEMM, 256x128 tiles, for gfx950: the large-M forms of the training step (forward NT, dX NN, dW TN, conv).
+//
+// Why a second tile shape (measured, tools/gemm_lab.hip + tools/dma_lab.hip): the 128x128 kernel (gemm_glds.hip) is bound
+// by the L2 -> LDS operand stream, not by MFMA, LDS or latency (no-DMA variant: 1.75 PFLOP/s at 8192^3 against 0.87 with
+// it).  Two things make that stream cheaper here:
+//   * 256x128 tiles move 25 % fewer operand bytes per FLOP, and
+//   * K-contiguous operands are fetched in whole 128-byte lines: BK = 64, one LDS-DMA instruction = 8 rows x 128 B
+//     (16 rows x 64 B half lines stream at ~28 B/clk/CU, whole lines at ~47).
+// One workgroup = 8 waves (4 along M x 2 along N, 64x64 accumulators each, the same 4x4 MFMA block as the 128x128 kernel),
+// one workgroup per CU, 3-stage LDS ring of 48 KB stages (two stages in flight), one s_barrier per 64-deep K step.
+//
+// LDS images (the LDS-DMA writes lane-linearly, so every swizzle is applied on the SOURCE address):
+//   K-contiguous operand ("N layout"):  [rows][64 k], 128 B rows, physical 16-B chunk = chunk ^ ((row >> 1) & 7)
+//        -> ds_read_b128 of 16 consecutive rows x one chunk touches 16 distinct 16-B slots of the 256-B bank row.
+//   reduction-major operand ("T layout"): units of [32 k][128 cols] exactly as in gemm_glds.hip (ds_read_b64_tr_b16),
+//        A: 4 units (k half, column half), B: 2 units (k half).
+#include <algorithm>
+#include <cstdlib>
+#include "gemm.h"
+#include "gemm_epi.h"
+
+namespace t256 {
+
+constexpr int BM = 256, BK = 64, NSTAGE = 3;            // BN = 128 or 96 (template parameter NB = BN / 32)
+constexpr int A_BYTES = BM * BK * 2, B_BYTES = 128 * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;     // 32 KB + 16 KB (12 KB used at BN = 96)
+constexpr int UNIT = 8192;                                                                        // [32 k][128 cols] bf16
+
+typedef __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ inline int swz_t(int k) { return ((k & 3) | ((k >> 1) & 4)) << 1; }
+__device__ inline int swz_n(int r) { return (r >> 1) & 7; }
+
+__device__ inline const bf16_t* chunk_src(const GemmOperand& o, const bf16_t* base, int r, int c, const bf16_t* zero) {
+    if (r >= o.R || c >= o.C) return zero;
+    if (o.g_cin > 0) {
+        int j = c / o.g_cin, ci = c - j * o.g_cin;
+        int b = r / o.g_T, t = r - b * o.g_T;
+        int ts = t + j - 2;
+        int lim = o.g_len ? min(o.g_len[b], o.g_T) : o.g_T;
+        if (ts < 0 || ts >= lim) return zero;
+        return base + (long)(b * o.g_T + ts) * o.ld + ci;
+    }
+    return base + (long)r * o.ld + c;
+}
+
+// one LDS-DMA instruction of an operand tile: which stored (row offset, col offset) does this lane fetch?
+//   N layout, instruction q: rows q*8 .. q*8+7, whole 128-B lines.     returns (row in tile, k element offset)
+//   T layout, instruction idx = unit*8 + qi: unit = k half [* 2 + column half]; k row = khalf*32 + qi*4 + lane/16
+struct LaneSrc { int r, c; };     // r: offset along the operand's stored rows, c: offset along its stored columns (elements)
+template <bool T, bool IS_A>
+__device__ inline LaneSrc lane_src(int idx, int lane) {
+    LaneSrc s;
+    if (!T) {
+        const int row = idx * 8 + (lane >> 3), pc = lane & 7;
+        s.r = row; s.c = (pc ^ swz_n(row)) << 3;
+    } else {
+        const int unit = idx >> 3, qi = idx & 7;
+        const int khalf = IS_A ? (unit >> 1) : unit, chalf = IS_A ? (unit & 1) : 0;
+        const int krl = qi * 4 + (lane >> 4), pc = lane & 15;
+        s.r = khalf * 32 + krl; s.c = chalf * 128 + ((pc ^ swz_t(krl)) << 3);
+    }
+    return s;
+}
+
+template <bool TA, bool TB, bool GATHER, int NB>
+__global__ __launch_bounds__(512, 1) void gemm_glds256_kernel(GemmArgs g, const bf16_t* zero, float* splitk_ws, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    constexpr int BN = NB * 32;                      // two waves along N, NB 16-column MFMA blocks each
+    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * (NB * 16);
+    // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin (linear id % 8) and every XCD has its own
+    // L2: remap so that XCD x walks one contiguous range of the row-major tile list, i.e. the 32 workgroups resident on
+    // an XCD share a handful of A row panels and all of its B column panels instead of touching ~32 different ones.
+    int bx, by, bz;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        const int per_z = tiles_n * tiles_m;
+        bz = wg / per_z;
+        const int rem = wg - bz * per_z;
+        by = rem / tiles_n; bx = rem - by * tiles_n;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int z = bz / g.splitk, ksplit = bz - z * g.splitk;
+    const int zo = z / g.batch_inner, zi = z - zo * g.batch_inner;
+    const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.p) + zo * g.A.bs_o + zi * g.A.bs_i;
+    const bf16_t* Bb = reinterpret_cast<const bf16_t*>(g.B.p) + zo * g.B.bs_o + zi * g.B.bs_i;
+
+    // DMA issue: wave w owns A instructions w*4 .. w*4+3 and B instructions w*2, w*2+1 of every stage (6 per wave).
+    // Plain operands: the source address of a lane is affine in the stage index -> pointer at stage 0 + per-stage step.
+    const bf16_t* pa[4]; const bf16_t* pb[2];
+    int ka[4], kb_[2];            // reduction offset this lane's chunk covers inside a stage; -1 = never valid
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const LaneSrc s = lane_src<TA, true>(wave * 4 + i, lane);
+        if (TA) { ka[i] = (m0 + s.c) < g.A.C ? s.r : -1; pa[i] = Ab + (long)s.r * g.A.ld + m0 + s.c; }
+        else    { ka[i] = (m0 + s.r) < g.A.R ? s.c : -1; pa[i] = Ab + (long)(m0 + s.r) * g.A.ld + s.c; }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const LaneSrc s = lane_src<TB, false>(wave * 2 + i, lane);
+        // (at BN = 96 the last quarter of the 128-wide B image belongs to no wave: it is filled from the zero page)
+        if (TB) { kb_[i] = ((n0 + s.c) < g.B.C && s.c < BN) ? s.r : -1; pb[i] = Bb + (long)s.r * g.B.ld + n0 + s.c; }
+        else    { kb_[i] = ((n0 + s.r) < g.B.R && s.r < BN) ? s.c : -1; pb[i] = Bb + (long)(n0 + s.r) * g.B.ld + s.c; }
+    }
+    const long stepA = TA ? (long)BK * g.A.ld : BK, stepB = TB ? (long)BK * g.B.ld : BK;
+    const int limA = TA ? g.A.R : g.A.C, limB = TB ? g.B.R : g.B.C;      // bound of the reduction index
+
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int per = (nk_all + g.splitk - 1) / g.splitk;
+    const int kt0 = ksplit * per;
+    const int kt_end = min(nk_all, kt0 + per);
+    const int nk = kt_end - kt0;
+    if (nk <= 0) return;
+
+    // Always exactly 6 DMA instructions per wave and stage (stages past the end fetch the zero page into a slot nobody
+    // reads again): the in-flight count is a compile-time constant and the counted waits below never drain the queue.
+    auto issue = [&](int kt, int slot) {
+#ifdef B2S_EXP_NODMA
+        return;
+#endif
+        const int kb = kt < kt_end ? kt * BK : (1 << 28);
+        unsigned char* sbase = smem_raw + slot * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = wave * 4 + i;
+            const bf16_t* sa;
+            if (GATHER) {
+                const LaneSrc s = lane_src<TA, true>(idx, lane);
+                sa = TA ? chunk_src(g.A, Ab, kb + s.r, m0 + s.c, zero) : chunk_src(g.A, Ab, m0 + s.r, kb + s.c, zero);
+            } else {
+                sa = (ka[i] >= 0 && kb + ka[i] < limA) ? pa[i] + kt * stepA : zero;
+            }
+#ifdef B2S_EXP_DMAHOT
+            sa = zero + (lane & 15) * 8;
+#endif
+            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(sbase + idx * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = wave * 2 + i;
+            const bf16_t* sb;
+            if (GATHER) {
+                const LaneSrc s = lane_src<TB, false>(idx, lane);
+                sb = TB ? (s.c < BN ? chunk_src(g.B, Bb, kb + s.r, n0 + s.c, zero) : zero)
+                        : (s.r < BN ? chunk_src(g.B, Bb, n0 + s.r, kb + s.c, zero) : zero);
+            } else {
+                sb = (kb_[i] >= 0 && kb + kb_[i] < limB) ? pb[i] + kt * stepB : zero;
+            }
+#ifdef B2S_EXP_DMAHOT
+            sb = zero + (lane & 15) * 8;
+#endif
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(sbase + A_BYTES + idx * 1024), 16, 0, 0);
+        }
+    };
+
+    // per-lane byte offsets of the fragment reads inside a stage, for the two 32-deep halves of the K step
+    unsigned offA[2][4], offB[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {      // (offB[.][t] for t >= NB is never used)
+        if (TA) {
+            const int k = lg * 8 + (li >> 2), col = (wrow & 127) + t * 16 + (li & 3) * 4, sw = ((li >> 2) | ((lg & 1) << 2)) << 1;
+            const unsigned o = 2u * (k * 128 + (((col >> 3) ^ sw) << 3) + (col & 7)) + (unsigned)((wrow >> 7) * UNIT);
+            offA[0][t] = o; offA[1][t] = o + 2 * UNIT;
+        } else {
+            const int r = wrow + t * 16 + li;
+            offA[0][t] = (unsigned)(r * 128 + ((lg ^ swz_n(r)) << 4)); offA[1][t] = offA[0][t] ^ 64u;
+        }
+        if (TB) {
+            const int k = lg * 8 + (li >> 2), col = wcol + t * 16 + (li & 3) * 4, sw = ((li >> 2) | ((lg & 1) << 2)) << 1;
+            const unsigned o = (unsigned)A_BYTES + 2u * (k * 128 + (((col >> 3) ^ sw) << 3) + (col & 7));
+            offB[0][t] = o; offB[1][t] = o + UNIT;
+        } else {
+            const int r = wcol + t * 16 + li;
+            offB[0][t] = (unsigned)(A_BYTES + r * 128 + ((lg ^ swz_n(r)) << 4)); offB[1][t] = offB[0][t] ^ 64u;
+        }
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem_raw;
+    auto frag_issue = [&](bf16x8_t& dst, bool trans, unsigned addr) {
+        if (!trans) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+        } else {
+            bf16x4_t lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"        // rows k and k + 4 (4 x 256 B)
+                         : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
+            dst[0] = lo[0]; dst[1] = lo[1]; dst[2] = lo[2]; dst[3] = lo[3];
+            dst[4] = hi[0]; dst[5] = hi[1]; dst[6] = hi[2]; dst[7] = hi[3];
+        }
+    };
+
+    f32x4_t acc[4][NB];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+#define B2S_MMA16(CA, CB)                                                                                         \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < NB; ++b)                  \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CA[a], CB[b], acc[a][b], 0, 0, 0);
+#define B2S_READ8(FA, FB, SLOT, H)                                                                                \
+    {                                                                                                              \
+        const unsigned sb_ = lds_base + (unsigned)((SLOT) * STAGE_BYTES);                                          \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                            \
+            frag_issue(FA[t], TA, sb_ + offA[H][t]);                                                               \
+            if (t < NB) frag_issue(FB[t], TB, sb_ + offB[H][t]);                                                   \
+        }                                                                                                          \
+    }
+
+    // prologue: three stages in flight, stage 0 landed and published, its first-half fragments in registers
+#pragma unroll
+    for (int p = 0; p < NSTAGE; ++p) issue(kt0 + p, p);
+    bf16x8_t fa0[4], fb0[4], fa1[4], fb1[4];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (NSTAGE - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    B2S_READ8(fa0, fb0, 0, 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+        // first half: second-half fragments of this stage fly under the first-half MFMAs
+        B2S_READ8(fa1, fb1, slot, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        B2S_MMA16(fa0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave no longer reads stage kt
+        // stage kt+1 landed (own DMAs; the 6 of stage kt+2 stay in flight) ... for every wave, and slot `slot` is free
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(kt0 + kt + NSTAGE, slot);
+        // second half: first-half fragments of the next stage fly under the second-half MFMAs
+        B2S_READ8(fa0, fb0, nslot, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        B2S_MMA16(fa1, fb1)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        slot = nslot;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the trailing zero-page DMAs before the LDS is reused
+#undef B2S_READ8
+#undef B2S_MMA16
+
+    // ---------------- epilogue (gemm_epi.h): accumulators -> per-wave LDS staging -> vectorised, fused stores
+    gemm_wave_epilogue<NB>(g, acc, reinterpret_cast<float*>(smem_raw) + wave * (64 * 64), m0 + wrow, n0 + wcol, lane, z, zo, zi, ksplit, splitk_ws);
+}
+
+template <bool TA, bool TB, bool GATHER, int NB>
+int launch256_nb(const GemmArgs& g_in, const bf16_t* zero, float* ws_all, size_t ws_floats, hipStream_t stream) {
+    GemmArgs g = g_in;
+    if (g.splitk > 1) {                     // every split must own at least one K step (empty splits would leave slabs unwritten)
+        const int nk_all = cdiv(g.K, BK), per = cdiv(nk_all, g.splitk);
+        g.splitk = cdiv(nk_all, per);
+    }
+    constexpr size_t smem = (size_t)NSTAGE * STAGE_BYTES;           // 144 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        B2S_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<TA, TB, GATHER, NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, NB * 32);
+    dim3 grid(tiles_m * tiles_n * g.batch * g.splitk);               // 1-D: the kernel maps linear ids to tiles (XCD-aware)
+    float* ws = nullptr;
+    if (g.splitk > 1 && g.batch == 1 && g.c_fp32 && g.epi.accumulate && (g.N & 3) == 0 && (g.ldc & 3) == 0 &&
+        (size_t)g.splitk * g.M * g.N <= ws_floats)
+        ws = ws_all;
+    hipLaunchKernelGGL((gemm_glds256_kernel<TA, TB, GATHER, NB>), grid, dim3(512), smem, stream, g, zero, ws, tiles_m, tiles_n);
+    B2S_LAUNCH_CHECK();
+    if (ws) B2S_TRY(b2s_splitk_reduce_launch(ws, (float*)g.C, g.M, g.N, g.ldc, g.splitk, g.epi.conv_dw_cin, stream));
+    return 0;
+}
+
+// BN = 96 when that needs fewer (or cheaper) rounds of one workgroup per CU: N = 768 / 2304 with M = 8148 give exactly
+// 256 / 768 tiles of 256x96, against 192 / 576 tiles of 256x128 (a quarter of the CUs idle)
+inline int pick_nb(const GemmArgs& g) {
+    static const int force = getenv("B2S_GEMM256_NB") ? atoi(getenv("B2S_GEMM256_NB")) : 0;
+    if (force == 3 || force == 4) return force;
+    const long per = (long)cdiv(g.M, BM) * g.batch * std::max(1, g.splitk);
+    const long r128 = (per * cdiv(g.N, 128) + 255) / 256 * 128, r96 = (per * cdiv(g.N, 96) + 255) / 256 * 101;   // 96 * 1.05
+    return r96 < r128 ? 3 : 4;
+}
+template <bool TA, bool TB, bool GATHER>
+int launch256_t(const GemmArgs& g, const bf16_t* zero, float* ws_all, size_t ws_floats, hipStream_t stream) {
+    return pick_nb(g) == 3 ? launch256_nb<TA, TB, GATHER, 3>(g, zero, ws_all, ws_floats, stream)
+                           : launch256_nb<TA, TB, GATHER, 4>(g, zero, ws_all, ws_floats, stream);
+}
+
+}  // namespace t256
+
+// number of 256x128 tiles a problem decomposes into (the dispatcher in gemm_glds.hip uses it to pick the tile shape)
+long b2s_gemm_glds256_tiles(const GemmArgs& g) { return (long)cdiv(g.M, t256::BM) * cdiv(g.N, 128) * g.batch * std::max(1, g.splitk); }
+
+int b2s_gemm_glds256_launch(const GemmArgs& g, bool ta, bool tb, const bf16_t* zero, float* ws, size_t ws_floats, hipStream_t stream) {
+    const bool gather = g.A.g_cin > 0 || g.B.g_cin > 0;
+    if (gather) {
+        if (!ta && !tb) return t256::launch256_t<false, false, true>(g, zero, ws, ws_floats, stream);
+        if (ta && tb) return t256::launch256_t<true, true, true>(g, zero, ws, ws_floats, stream);
+        return b2s_fail(__FILE__, __LINE__, "conv gather is supported for the NT and TN forms only");
+    }
+    if (!ta && !tb) return t256::launch256_t<false, false, false>(g, zero, ws, ws_floats, stream);
+    if (!ta && tb) return t256::launch256_t<false, true, false>(g, zero, ws, ws_floats, stream);
+    if (ta && !tb) return t256::launch256_t<true, false, false>(g, zero, ws, ws_floats, stream);
+    return t256::launch256_t<true, true, false>(g, zero, ws, ws_floats, stream);
+}

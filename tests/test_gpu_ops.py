@@ -224,3 +224,20 @@ def test_dropout_rng_statistics():
         # no obvious serial correlation
         c = (m[1:] & m[:-1]).float().mean().item()
         assert abs(c - (1 - p) ** 2) < 5e-3, c
+
+
+@pytest.mark.parametrize("nb", ["3", "4"])
+def test_gemm_256_tile_kernel_all_forms(nb):
+    """The 256x128 / 256x96 tile kernel (gemm_glds256.hip) is normally chosen for M > 128 with a shape-dependent tile width;
+    force it for every non-batched bf16 GEMM (B2S_GEMM256_MIN_M=1) and re-run the GEMM / conv / bf16 model tests through it, both tile widths."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("B2S_GEMM256_MIN_M"):
+        pytest.skip("inner run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, B2S_GEMM256_MIN_M="1", B2S_GEMM256_NB=nb)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_ops.py", "tests/test_gpu_model.py",
+                        "-k", "test_gemm_forms or test_gemm_batched or test_conv_gather or bf16 or test_decode"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -10,6 +10,9 @@
 #define LAB_KERNEL "../few-shot-transformer-tts_amd/csrc/gemm_glds.hip"
 #endif
 #include LAB_KERNEL
+#ifndef LAB_NO256
+#include "../few-shot-transformer-tts_amd/csrc/gemm_glds256.hip"
+#endif
 
 thread_local char g_b2s_err[512] = "";
 int b2s_fail(const char* file, int line, const char* fmt, ...) {
