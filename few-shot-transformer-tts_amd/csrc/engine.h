@@ -114,6 +114,14 @@ struct b2s_model {
     mutable std::map<const void*, hipEvent_t> aux_readers;     // scratch buffer -> event after its last aux-stream reader
     mutable bool aux_dirty = false;
     hipEvent_t next_event() const { hipEvent_t e = ev_pool[ev_next % ev_pool.size()]; ++ev_next; return e; }
+    // Weight-gradient GEMMs of one backward stage are deferred and launched as ONE grouped GEMM on the aux stream when the
+    // stage ends (bf16 mode with an aux stream): 7 problems of 18..72 tiles each fill the chip together, no split-K slabs.
+    // The stage hook of stage s then fires one stage late (when stage s+1 has been enqueued), so the host never stalls
+    // the main stream on the group it has just launched.
+    mutable bool dw_group = false;
+    mutable std::vector<GemmArgs> dw_pending;
+    mutable int pending_stage = -1;
+    mutable hipEvent_t pending_ev = nullptr;
     void (*stage_hook)(int, void*) = nullptr;       // called on the host after each backward stage is enqueued
     void* stage_user = nullptr;
     void stage_done(int s) const { if (stage_hook) stage_hook(s, stage_user); }   // callers join the aux stream first

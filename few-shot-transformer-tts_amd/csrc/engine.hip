@@ -210,6 +210,7 @@ int linear_dw(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
     g.B.p = X; g.B.ld = ldx; g.B.R = M; g.B.C = Kin;
     g.M = Nout; g.N = Kin; g.K = M; g.C = dW; g.c_fp32 = 1; g.ldc = Kin;
     g.epi.accumulate = 1;          // parameter gradients accumulate; the host zeroes them once per backward pass
+    if (m->dw_group) { m->dw_pending.push_back(g); return 0; }      // launched by end_stage() as part of the stage's group
     g.splitk = pick_splitk(Nout, Kin, M, m->dtype);
     if (!m->aux) return b2s_gemm_launch(g, m->dtype, true, true, st);
     hipEvent_t ready = m->next_event();
@@ -220,6 +221,56 @@ int linear_dw(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
     B2S_HIP(hipEventRecord(done, m->aux));
     m->aux_readers[dY] = done;
     m->aux_dirty = true;
+    return 0;
+}
+
+// launch the deferred weight-gradient problems of the current stage as grouped GEMMs on the aux stream
+int flush_dw(const b2s_model* m, hipStream_t st) {
+    if (m->dw_pending.empty()) return 0;
+    std::vector<GemmArgs>& q = m->dw_pending;
+    std::stable_sort(q.begin(), q.end(), [](const GemmArgs& a, const GemmArgs& b) { return a.K > b.K; });    // long tiles first
+    static const bool serial = getenv("B2S_DW_GROUP_SERIAL") != nullptr;       // experiment: groups on the main stream
+    if (serial) {
+        for (size_t i = 0; i < q.size(); i += B2S_MAX_GROUP)
+            B2S_TRY(b2s_gemm_grouped_launch(q.data() + i, (int)std::min<size_t>(B2S_MAX_GROUP, q.size() - i), st));
+        q.clear();
+        return 0;
+    }
+    hipEvent_t ready = m->next_event();
+    B2S_HIP(hipEventRecord(ready, st));
+    B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
+    for (size_t i = 0; i < q.size(); i += B2S_MAX_GROUP)
+        B2S_TRY(b2s_gemm_grouped_launch(q.data() + i, (int)std::min<size_t>(B2S_MAX_GROUP, q.size() - i), m->aux));
+    hipEvent_t done = m->next_event();
+    B2S_HIP(hipEventRecord(done, m->aux));
+    for (const GemmArgs& g : q) m->aux_readers[g.A.p] = done;
+    m->aux_dirty = true;
+    m->pending_ev = done;
+    q.clear();
+    return 0;
+}
+// end of backward stage `stage`: its parameter gradients are complete once the aux stream has drained.  drain: last stage
+// of this C entry point -- the main stream rejoins the aux stream and every outstanding hook fires.
+int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain) {
+    if (!m->dw_group) {
+        B2S_TRY(join_aux(m, st));
+        m->stage_done(stage);
+        return 0;
+    }
+    const int prev = m->pending_stage;
+    hipEvent_t prev_ev = m->pending_ev;
+    m->pending_ev = nullptr;
+    B2S_TRY(flush_dw(m, st));                          // sets pending_ev when it launched something
+    if (m->stage_hook && prev >= 0) {
+        if (prev_ev) B2S_HIP(hipStreamWaitEvent(st, prev_ev, 0));
+        m->stage_done(prev);
+    }
+    m->pending_stage = stage;
+    if (drain) {
+        B2S_TRY(join_aux(m, st));
+        m->stage_done(stage);
+        m->pending_stage = -1; m->pending_ev = nullptr;
+    }
     return 0;
 }
 
@@ -321,6 +372,12 @@ int attn_core_bwd(int dtype, hipStream_t st, const void* dctx, int ldc, const vo
 
 // ------------------------------------------------------------------------------------------------ planning
 struct Scratch {
+    // operands of deferred weight-gradient GEMMs stay live until the stage's group has run: every use takes the next
+    // buffer of a ring that spans two stages (ring size 1 = the plain single scratch buffer when nothing is deferred)
+    std::vector<void*> r_dyT, r_dz, r_dqkv, r_dkv;
+    int i_dyT = 0, i_dz = 0, i_dqkv = 0, i_dkv = 0;
+    bool dy_ready = false;       // dyT already holds bf16(dropout(dx)) for the next sublayer (written by the LayerNorm backward)
+    static void* rot(const std::vector<void*>& r, int& i) { void* p = r[(size_t)i % r.size()]; ++i; return p; }
     float *S = nullptr, *dP = nullptr; void* dS = nullptr;
     void *dyT = nullptr, *dz = nullptr, *dqkv = nullptr, *dctx = nullptr, *dh = nullptr, *dkv = nullptr;
     float *dx = nullptr, *a3 = nullptr, *dmem = nullptr, *dstop_m = nullptr, *lnws = nullptr;
@@ -375,7 +432,10 @@ void plan_encoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     // scratch (forward + backward)
     const long pn = (long)B * H * S * rup8(S);
     sc.S = a.f32(pn); sc.dP = a.f32(pn); sc.dS = a.T(pn, esz);
-    sc.dyT = a.T(M * D, esz); sc.dz = a.T(M * 4 * D, esz); sc.dqkv = a.T(M * 3 * D, esz);
+    const int rings = m->dw_group ? 2 : 1;           // stages a deferred operand must survive
+    for (int i = 0; i < (rings == 1 ? 1 : 4); ++i) sc.r_dyT.push_back(a.T(M * D, esz));            // 2 uses per layer
+    for (int i = 0; i < rings; ++i) { sc.r_dz.push_back(a.T(M * 4 * D, esz)); sc.r_dqkv.push_back(a.T(M * 3 * D, esz)); }
+    sc.dyT = sc.r_dyT[0]; sc.dz = sc.r_dz[0]; sc.dqkv = sc.r_dqkv[0];
     sc.dctx = a.T(M * D, esz); sc.dh = a.T(M * D, esz); sc.dx = a.f32(M * D);
     sc.lnws = a.f32((long)RO_LN_WS_ROWS * 2 * D);
 }
@@ -412,8 +472,11 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     const long pn = (long)B * H * T * rup8(std::max(T, S));
     sc.S = a.f32(pn); sc.dP = a.f32(pn); sc.dS = a.T(pn, esz);
     sc.a3 = a.f32(M * D);
-    sc.dyT = a.T(M * D, esz); sc.dz = a.T(M * 4 * D, esz); sc.dqkv = a.T(M * 3 * D, esz);
-    sc.dkv = a.T(Mk * 2 * D, esz);
+    const int rings = m->dw_group ? 2 : 1;
+    for (int i = 0; i < (rings == 1 ? 1 : 6); ++i) sc.r_dyT.push_back(a.T(M * D, esz));            // 3 uses per layer
+    for (int i = 0; i < (rings == 1 ? 1 : 4); ++i) sc.r_dqkv.push_back(a.T(M * 3 * D, esz));       // 2 uses per layer
+    for (int i = 0; i < rings; ++i) { sc.r_dz.push_back(a.T(M * 4 * D, esz)); sc.r_dkv.push_back(a.T(Mk * 2 * D, esz)); }
+    sc.dyT = sc.r_dyT[0]; sc.dz = sc.r_dz[0]; sc.dqkv = sc.r_dqkv[0]; sc.dkv = sc.r_dkv[0];
     sc.dctx = a.T(M * D, esz); sc.dh = a.T(M * D, esz); sc.dx = a.f32(M * D);
     sc.dmelT = a.T(M * cf.num_mels, esz); sc.doutT = a.T(M * D, esz); sc.da3 = a.T(M * D, esz);
     sc.dz1 = a.T(M * cf.prenet_hidden, esz); sc.dz2 = a.T(M * cf.prenet_hidden, esz);
@@ -560,6 +623,10 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
         m->ev_pool.resize(256);
         for (auto& ev : m->ev_pool) B2S_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
+    // measured (MI355X, LJ-shaped step): the grouped launch is ~9 % cheaper in kernel time than split-K + slab reduce, but the
+    // many small split-K launches fill the tails of the main-stream kernels better -- the step is 0.1 ms faster without
+    // grouping.  Kept as an option (B2S_DW_GROUP=1) for shapes / parts where the balance differs.
+    m->dw_group = m->dtype == 1 && m->aux && getenv("B2S_DW_GROUP") != nullptr;
     B2S_TRY(ensure_pe(m, 2048));
     m->n_l2_chunks = 0; m->l2_chunks = nullptr; m->l2_fresh = false;
     B2S_TRY(build_chunks(m, true, false, &m->l2_chunks, &m->n_l2_chunks));
@@ -699,36 +766,59 @@ __global__ __launch_bounds__(1024) void k_ga_reduce(const float* rows, long n, f
 }
 __global__ void k_ga_bscale(float* small, const float* d_guided) { small[2] = small[0] * (d_guided ? d_guided[0] : 0.f); }
 __global__ void k_ga_fetch(const float* small, float* out, float* add_to) { out[0] = small[1]; if (add_to) add_to[0] += small[1]; }
+// entry of a sublayer's backward: its dY operand bf16(dropout(dx)) was either produced by the preceding LayerNorm
+// backward (fused) or is cast here
+int take_dy(b2s_model* m, hipStream_t st, Scratch& sc, long M, int D, const DropCfg& dres, const void** dy) {
+    if (sc.dy_ready) { sc.dy_ready = false; *dy = sc.dyT; return 0; }
+    *dy = sc.dx;
+    sc.dyT = Scratch::rot(sc.r_dyT, sc.i_dyT);
+    B2S_TRY(guard_write(m, sc.dyT, st));
+    if (m->dtype || dres.thresh) { B2S_TRY(ro_cast_drop(m->dtype, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); *dy = sc.dyT; }
+    return 0;
+}
+// LayerNorm backward at the exit of a sublayer (dx += ...), optionally also emitting the NEXT sublayer's dY operand
+int ln_bwd_exit(b2s_model* m, hipStream_t st, Scratch& sc, const void* dh, int dh_fp32, int lddh, const float* x_in,
+                const std::string& lnp, const float* mean, const float* rstd, int accumulate, long M, int D,
+                const int* row_len, int rpb, const DropCfg* next) {
+    void* dy2 = nullptr;
+    DropCfg nd = {0, 0, 1.f};
+    if (next && m->dtype == 1) {
+        sc.dyT = Scratch::rot(sc.r_dyT, sc.i_dyT);
+        B2S_TRY(guard_write(m, sc.dyT, st));
+        dy2 = sc.dyT; nd = *next;
+    }
+    B2S_TRY(guard_write(m, sc.dx, st));
+    B2S_TRY(ro_layernorm_bwd(m->dtype, dh, dh_fp32, lddh, x_in, m->P(lnp + ".weight"), mean, rstd, sc.dx, accumulate,
+                             m->G(lnp + ".weight"), m->G(lnp + ".bias"), (int)M, D, row_len, rpb, st, sc.lnws, dy2, nd));
+    sc.dy_ready = dy2 != nullptr;
+    return 0;
+}
 // backward of  x_out = x_in + drop(FFN(LN(x_in)))  given dx (in place: dx becomes d x_in)
 int ffn_bwd(b2s_model* m, hipStream_t st, const FfnSave& f, Scratch& sc, long M, int D, float p, uint64_t seed,
-            const std::string& wp_in, const std::string& wp_out, const std::string& lnp) {
-    const int dt = m->dtype;
+            const std::string& wp_in, const std::string& wp_out, const std::string& lnp, const DropCfg* next = nullptr) {
     DropCfg dres = make_drop(p, seed, f.op_res), dhid = make_drop(p, seed, f.op_hid);
-    const void* dy = sc.dx;
-    B2S_TRY(guard_write(m, sc.dyT, st));
-    if (dt || dres.thresh) { B2S_TRY(ro_cast_drop(dt, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); dy = sc.dyT; }
+    const void* dy;
+    B2S_TRY(take_dy(m, st, sc, M, D, dres, &dy));
     B2S_TRY(linear_dw(m, st, dy, D, f.f, 4 * D, (int)M, D, 4 * D, m->G(wp_out)));
     GemmEpilogue e; e.relu_aux = f.f; e.ld_aux = 4 * D; e.aux_scale = dhid.scale;
+    sc.dz = Scratch::rot(sc.r_dz, sc.i_dz);
     B2S_TRY(guard_write(m, sc.dz, st));
     B2S_TRY(linear_dx(m, st, dy, D, m->W(wp_out), (int)M, 4 * D, D, sc.dz, 0, 4 * D, e));
     B2S_TRY(linear_dw(m, st, sc.dz, 4 * D, f.h, D, (int)M, 4 * D, D, m->G(wp_in)));
     B2S_TRY(linear_dx(m, st, sc.dz, 4 * D, m->W(wp_in), (int)M, D, 4 * D, sc.dh, 0, D, GemmEpilogue()));
-    B2S_TRY(guard_write(m, sc.dx, st));
-    B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, f.x_in, m->P(lnp + ".weight"), f.mean, f.rstd, sc.dx, 1, m->G(lnp + ".weight"),
-                             m->G(lnp + ".bias"), (int)M, D, nullptr, 1, st, sc.lnws));
-    return 0;
+    return ln_bwd_exit(m, st, sc, sc.dh, 0, D, f.x_in, lnp, f.mean, f.rstd, 1, M, D, nullptr, 1, next);
 }
 // backward of x_out = x_in + drop(SelfAttn(LN(x_in)))
 int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, long M, int D, int B, int H, int L,
                   float p, uint64_t seed, const std::string& wq, const std::string& wo, const std::string& lnp,
-                  const int* klen = nullptr) {
+                  const int* klen = nullptr, const DropCfg* next = nullptr) {
     const int dt = m->dtype, dh = D / H, esz = m->esz;
     DropCfg dres = make_drop(p, seed, s.op_res), datt = make_drop(p, seed, s.op_attn);
-    const void* dy = sc.dx;
-    B2S_TRY(guard_write(m, sc.dyT, st));
-    if (dt || dres.thresh) { B2S_TRY(ro_cast_drop(dt, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); dy = sc.dyT; }
+    const void* dy;
+    B2S_TRY(take_dy(m, st, sc, M, D, dres, &dy));
     B2S_TRY(linear_dw(m, st, dy, D, s.ctx, D, (int)M, D, D, m->G(wo)));
     B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, sc.dctx, 0, D, GemmEpilogue()));
+    sc.dqkv = Scratch::rot(sc.r_dqkv, sc.i_dqkv);
     B2S_TRY(guard_write(m, sc.dqkv, st));
     const char* q = (const char*)s.qkv; char* dq = (char*)sc.dqkv;
     B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, q, 3 * D, q + (size_t)D * esz, 3 * D, q + (size_t)2 * D * esz, 3 * D, s.P, s.Pd,
@@ -736,10 +826,7 @@ int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, 
                           s.lse, s.ctx, s.mask_mode, klen));
     B2S_TRY(linear_dw(m, st, sc.dqkv, 3 * D, s.h, D, (int)M, 3 * D, D, m->G(wq)));
     B2S_TRY(linear_dx(m, st, sc.dqkv, 3 * D, m->W(wq), (int)M, D, 3 * D, sc.dh, 0, D, GemmEpilogue()));
-    B2S_TRY(guard_write(m, sc.dx, st));
-    B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, s.x_in, m->P(lnp + ".weight"), s.mean, s.rstd, sc.dx, 1, m->G(lnp + ".weight"),
-                             m->G(lnp + ".bias"), (int)M, D, nullptr, 1, st, sc.lnws));
-    return 0;
+    return ln_bwd_exit(m, st, sc, sc.dh, 0, D, s.x_in, lnp, s.mean, s.rstd, 1, M, D, nullptr, 1, next);
 }
 }  // namespace
 
@@ -769,23 +856,25 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
                                   m->G("encoder.language_embed.weight"), m->G("encoder.language_layer.weight"),
                                   m->G("encoder.language_layer.bias"), c->lang_dh, B, S, cf.language_embedding_size, st));
     }
-    B2S_TRY(ro_layernorm_bwd(dt, d_memory, 1, Dm, c->x_final, m->P(p + "output_layer_norm.weight"), c->mean_f, c->rstd_f, sc.dx, 0,
-                             m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, nullptr, 1, st, sc.lnws));
-    B2S_TRY(join_aux(m, st));
-    m->stage_done(3 + cf.n_decoder_layer);
+    // every LayerNorm backward below also emits the dY operand (bf16, residual dropout applied) of the sublayer that runs next
+    DropCfg nd;
+    if (cf.n_encoder_layer > 0) nd = make_drop(pt, c->seed, c->ffn[cf.n_encoder_layer - 1].op_res);
+    B2S_TRY(ln_bwd_exit(m, st, sc, d_memory, 1, Dm, c->x_final, p + "output_layer_norm", c->mean_f, c->rstd_f, 0, M, D, nullptr, 1,
+                        cf.n_encoder_layer > 0 ? &nd : nullptr));
+    B2S_TRY(end_stage(m, st, 3 + cf.n_decoder_layer, false));
     for (int l = cf.n_encoder_layer - 1; l >= 0; --l) {
         const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lna = p + "attn_layer_norms." + std::to_string(l);
+        nd = make_drop(pt, c->seed, c->self_attn[l].op_res);
         B2S_TRY(ffn_bwd(m, st, c->ffn[l], sc, M, D, pt, c->seed, nm(p, "ffn_layers", l, "input_layer.weight"),
-                        nm(p, "ffn_layers", l, "output_layer.weight"), lnf));
+                        nm(p, "ffn_layers", l, "output_layer.weight"), lnf, &nd));
+        if (l > 0) nd = make_drop(pt, c->seed, c->ffn[l - 1].op_res);
         B2S_TRY(self_attn_bwd(m, st, c->self_attn[l], sc, M, D, B, H, S, pt, c->seed, nm(p, "self_attentions", l, "qkv_transform.weight"),
-                              nm(p, "self_attentions", l, "output_transform.weight"), lna, c->in_len));
-        B2S_TRY(join_aux(m, st));
-    m->stage_done(4 + cf.n_decoder_layer + (cf.n_encoder_layer - 1 - l));
+                              nm(p, "self_attentions", l, "output_transform.weight"), lna, c->in_len, l > 0 ? &nd : nullptr));
+        B2S_TRY(end_stage(m, st, 4 + cf.n_decoder_layer + (cf.n_encoder_layer - 1 - l), false));
     }
     B2S_TRY(ro_embed_prep_bwd(sc.dx, (const long*)c->ids, c->in_len, m->pe_enc, m->G("encoder.embed.weight"), m->G(p + "pe_scale"),
                               B, S, D, make_drop(pt, c->seed, opid(1, 0, 1)), st));
-    B2S_TRY(join_aux(m, st));
-    m->stage_done(4 + cf.n_decoder_layer + cf.n_encoder_layer);
+    B2S_TRY(end_stage(m, st, 4 + cf.n_decoder_layer + cf.n_encoder_layer, true));
     return 0;
 }
 
@@ -942,26 +1031,28 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
         B2S_TRY(ro_colsum(dt, c->outT, 0, D, sc.dstop_m, m->G("decoder.stop_net.weight"), 1, (int)M, D, st));
         B2S_TRY(ro_colsum(0, sc.dstop_m, 1, 1, nullptr, m->G("decoder.stop_net.bias"), 1, (int)M, 1, st));
     }
-    B2S_TRY(ro_layernorm_bwd(dt, sc.doutT, 0, D, c->x_final, m->P(p + "output_layer_norm.weight"), c->mean_f, c->rstd_f, sc.dx, 0,
-                             m->G(p + "output_layer_norm.weight"), m->G(p + "output_layer_norm.bias"), (int)M, D, c->tgt_len, T, st, sc.lnws));
-    B2S_TRY(join_aux(m, st));
-    m->stage_done(1);
+    DropCfg nd;
+    if (cf.n_decoder_layer > 0) nd = make_drop(pt, c->seed, c->ffn[cf.n_decoder_layer - 1].op_res);
+    B2S_TRY(ln_bwd_exit(m, st, sc, sc.doutT, 0, D, c->x_final, p + "output_layer_norm", c->mean_f, c->rstd_f, 0, M, D, c->tgt_len, T,
+                        cf.n_decoder_layer > 0 ? &nd : nullptr));
+    B2S_TRY(end_stage(m, st, 1, false));
     bool first_mem = true;
     for (int l = cf.n_decoder_layer - 1; l >= 0; --l) {
         const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lnx = p + "encdec_layer_norms." + std::to_string(l),
                           lna = p + "attn_layer_norms." + std::to_string(l);
+        nd = make_drop(pt, c->seed, c->cross_attn[l].op_res);
         B2S_TRY(ffn_bwd(m, st, c->ffn[l], sc, M, D, pt, c->seed, nm(p, "ffn_layers", l, "input_layer.weight"),
-                        nm(p, "ffn_layers", l, "output_layer.weight"), lnf));
+                        nm(p, "ffn_layers", l, "output_layer.weight"), lnf, &nd));
         {   // encoder-decoder attention backward
             const AttnSave& x = c->cross_attn[l];
             const std::string wq = nm(p, "encdec_attentions", l, "q_transform.weight"), wkv = nm(p, "encdec_attentions", l, "kv_transform.weight"),
                               wo = nm(p, "encdec_attentions", l, "output_transform.weight");
             DropCfg dres = make_drop(pt, c->seed, x.op_res), datt = make_drop(pt, c->seed, x.op_attn);
-            const void* dy = sc.dx;
-            B2S_TRY(guard_write(m, sc.dyT, st));
-    if (dt || dres.thresh) { B2S_TRY(ro_cast_drop(dt, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); dy = sc.dyT; }
+            const void* dy;
+            B2S_TRY(take_dy(m, st, sc, M, D, dres, &dy));
             B2S_TRY(linear_dw(m, st, dy, D, x.ctx, D, (int)M, D, D, m->G(wo)));
             B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, sc.dctx, 0, D, GemmEpilogue()));
+            sc.dqkv = Scratch::rot(sc.r_dqkv, sc.i_dqkv); sc.dkv = Scratch::rot(sc.r_dkv, sc.i_dkv);
             B2S_TRY(guard_write(m, sc.dqkv, st)); B2S_TRY(guard_write(m, sc.dkv, st));
             const char* kv = (const char*)x.kv; char* dkv = (char*)sc.dkv;
             GuidedArgs ga;
@@ -980,14 +1071,13 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
                 B2S_TRY(linear_dx(m, st, sc.dkv, 2 * D, m->W(wkv), (int)Mk, D, 2 * D, d_memory_out, 1, D, em));
                 first_mem = false;
             }
-            B2S_TRY(guard_write(m, sc.dx, st));
-            B2S_TRY(ro_layernorm_bwd(dt, sc.dh, 0, D, x.x_in, m->P(lnx + ".weight"), x.mean, x.rstd, sc.dx, 1, m->G(lnx + ".weight"),
-                                     m->G(lnx + ".bias"), (int)M, D, nullptr, 1, st, sc.lnws));
+            nd = make_drop(pt, c->seed, c->self_attn[l].op_res);
+            B2S_TRY(ln_bwd_exit(m, st, sc, sc.dh, 0, D, x.x_in, lnx, x.mean, x.rstd, 1, M, D, nullptr, 1, &nd));
         }
+        if (l > 0) nd = make_drop(pt, c->seed, c->ffn[l - 1].op_res);
         B2S_TRY(self_attn_bwd(m, st, c->self_attn[l], sc, M, D, B, H, T, pt, c->seed, nm(p, "self_attentions", l, "qkv_transform.weight"),
-                              nm(p, "self_attentions", l, "output_transform.weight"), lna));
-        B2S_TRY(join_aux(m, st));
-    m->stage_done(2 + (cf.n_decoder_layer - 1 - l));
+                              nm(p, "self_attentions", l, "output_transform.weight"), lna, nullptr, l > 0 ? &nd : nullptr));
+        B2S_TRY(end_stage(m, st, 2 + (cf.n_decoder_layer - 1 - l), false));
     }
     if (first_mem && want_dmem) B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
     B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, opid(2, 0, 3)), st));
@@ -1003,8 +1093,7 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
     B2S_TRY(ro_colsum(dt, sc.dz1, 0, HP, nullptr, m->G("decoder.prenet.dense0.bias"), 1, (int)M, HP, st));
     B2S_TRY(linear_dw(m, st, sc.dz1, HP, c->tgtT, NM, (int)M, HP, NM, m->G("decoder.prenet.dense0.weight")));
     B2S_LAUNCH_CHECK();
-    B2S_TRY(join_aux(m, st));
-    m->stage_done(2 + cf.n_decoder_layer);
+    B2S_TRY(end_stage(m, st, 2 + cf.n_decoder_layer, true));
     return 0;
 }
 
@@ -1120,8 +1209,7 @@ extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out
             B2S_TRY(b2s_gemm_launch(g, dt, false, false, st));
         }
     }
-    B2S_TRY(join_aux(m, st));
-    m->stage_done(0);
+    B2S_TRY(end_stage(m, st, 0, true));
     return 0;
 }
 

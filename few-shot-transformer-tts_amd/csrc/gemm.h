@@ -55,3 +55,10 @@ int b2s_gemm_skinny_launch(const GemmArgs& g, int dtype, hipStream_t stream);
 long b2s_gemm_glds256_tiles(const GemmArgs& g);
 int b2s_gemm_glds256_launch(const GemmArgs& g, bool ta, bool tb, const bf16_t* zero, float* ws, size_t ws_floats, hipStream_t stream);
 int b2s_splitk_reduce_launch(const float* ws, float* dst, int M, int N, int ldc, int splitk, int conv_dw_cin, hipStream_t stream);
+// up to B2S_MAX_GROUP weight-gradient problems (TN form, fp32 accumulate, no split-K) in one launch
+#define B2S_MAX_GROUP 8
+struct b2s_gemm_group { int n; int tile0[B2S_MAX_GROUP + 1]; GemmArgs p[B2S_MAX_GROUP]; };
+int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* zero, hipStream_t stream);
+// (zero page / split-K workspace owned by gemm_glds.hip)
+const bf16_t* b2s_gemm_zero_page();
+int b2s_gemm_grouped_launch(const GemmArgs* probs, int n, hipStream_t stream);      // gemm.hip: + optional timing record

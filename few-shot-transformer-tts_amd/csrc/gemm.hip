@@ -297,6 +297,20 @@ int b2s_gemm_launch(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t 
     g_prof.push_back(r);
     return rc;
 }
+// grouped bf16 weight-gradient launch (gemm_glds256.hip), with the same optional timing record (variant 14 = bf16 TN)
+int b2s_gemm_grouped_launch(const GemmArgs* probs, int n, hipStream_t stream) {
+    if (!g_prof_on) return b2s_gemm_glds256_grouped_launch(probs, n, b2s_gemm_zero_page(), stream);
+    ProfRec r;
+    B2S_HIP(hipEventCreate(&r.a)); B2S_HIP(hipEventCreate(&r.b));
+    r.variant = 14; r.flops = 0.0;
+    for (int i = 0; i < n; ++i) r.flops += 2.0 * probs[i].M * probs[i].N * (double)probs[i].K;
+    r.M = probs[0].M; r.N = probs[0].N; r.K = probs[0].K; r.batch = n; r.splitk = 1;
+    B2S_HIP(hipEventRecord(r.a, stream));
+    int rc = b2s_gemm_glds256_grouped_launch(probs, n, b2s_gemm_zero_page(), stream);
+    B2S_HIP(hipEventRecord(r.b, stream));
+    g_prof.push_back(r);
+    return rc;
+}
 static int gemm_launch_inner(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t stream) {
     const int ve = dtype ? 8 : 4;
     B2S_CHECK(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.batch_inner > 0, "gemm: bad shape M=%d N=%d K=%d batch=%d",

@@ -278,13 +278,19 @@ int b2s_splitk_reduce_launch(const float* ws, float* dst, int M, int N, int ldc,
     return 0;
 }
 
-int b2s_gemm_glds_launch(const GemmArgs& g, bool ta, bool tb, hipStream_t stream) {
+static int ensure_globals() {
     if (!g_zero_page) {
         B2S_HIP(hipMalloc(&g_zero_page, 256));
         B2S_HIP(hipMemset(g_zero_page, 0, 256));
         g_splitk_ws_floats = (size_t)24 << 20;                       // 96 MB of split-K slabs
         if (hipMalloc(&g_splitk_ws, g_splitk_ws_floats * sizeof(float)) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_ws_floats = 0; }
     }
+    return 0;
+}
+const bf16_t* b2s_gemm_zero_page() { return ensure_globals() ? nullptr : g_zero_page; }
+
+int b2s_gemm_glds_launch(const GemmArgs& g, bool ta, bool tb, hipStream_t stream) {
+    B2S_TRY(ensure_globals());
     // tile shape: 256-row tiles with 64-deep K steps (gemm_glds256.hip) for every non-batched problem taller than one
     // 128-row tile -- measured faster in the training step down to the M = 1596 encoder shapes (half the barriers per
     // FLOP); the 128x128 kernel keeps the batched (per-head) and short problems.  B2S_GEMM256_MIN_M overrides.

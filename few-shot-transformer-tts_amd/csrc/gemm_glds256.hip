@@ -31,13 +31,21 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ inline int swz_t(int k) { return ((k & 3) | ((k >> 1) & 4)) << 1; }
 __device__ inline int swz_n(int r) { return (r >> 1) & 7; }
 
+// floor(x / d) for 0 <= x < 2^24, 1 <= d: one reciprocal multiply + a correction step (the gather indices below would
+// otherwise cost two ~30-instruction integer divisions per DMA instruction and K step)
+__device__ inline int fast_div(int x, int d, float inv_d) {
+    int q = (int)(((float)x + 0.5f) * inv_d);
+    const int r = x - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
 __device__ inline const bf16_t* chunk_src(const GemmOperand& o, const bf16_t* base, int r, int c, const bf16_t* zero) {
     if (r >= o.R || c >= o.C) return zero;
     if (o.g_cin > 0) {
-        int j = c / o.g_cin, ci = c - j * o.g_cin;
-        int b = r / o.g_T, t = r - b * o.g_T;
-        int ts = t + j - 2;
-        int lim = o.g_len ? min(o.g_len[b], o.g_T) : o.g_T;
+        const int j = fast_div(c, o.g_cin, __builtin_amdgcn_rcpf((float)o.g_cin)), ci = c - j * o.g_cin;
+        const int b = fast_div(r, o.g_T, __builtin_amdgcn_rcpf((float)o.g_T)), t = r - b * o.g_T;
+        const int ts = t + j - 2;
+        const int lim = o.g_len ? min(o.g_len[b], o.g_T) : o.g_T;
         if (ts < 0 || ts >= lim) return zero;
         return base + (long)(b * o.g_T + ts) * o.ld + ci;
     }
@@ -63,26 +71,22 @@ __device__ inline LaneSrc lane_src(int idx, int lane) {
     return s;
 }
 
+// linear workgroup id -> XCD-aware tile id.  Workgroups are dealt to the 8 XCDs round-robin (linear id % 8) and every XCD
+// has its own L2: remap so that XCD x walks one contiguous range of the row-major tile list, i.e. the 32 workgroups
+// resident on an XCD share a handful of A row panels and all of its B column panels instead of ~32 different ones.
+__device__ inline int xcd_tile_id(int orig, int nwg) {
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 template <bool TA, bool TB, bool GATHER, int NB>
-__global__ __launch_bounds__(512, 1) void gemm_glds256_kernel(GemmArgs g, const bf16_t* zero, float* splitk_ws, int tiles_m, int tiles_n) {
+__device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, float* splitk_ws, int bx, int by, int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     constexpr int BN = NB * 32;                      // two waves along N, NB 16-column MFMA blocks each
     const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * (NB * 16);
-    // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin (linear id % 8) and every XCD has its own
-    // L2: remap so that XCD x walks one contiguous range of the row-major tile list, i.e. the 32 workgroups resident on
-    // an XCD share a handful of A row panels and all of its B column panels instead of touching ~32 different ones.
-    int bx, by, bz;
-    {
-        const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        const int per_z = tiles_n * tiles_m;
-        bz = wg / per_z;
-        const int rem = wg - bz * per_z;
-        by = rem / tiles_n; bx = rem - by * tiles_n;
-    }
     const int m0 = by * BM, n0 = bx * BN;
     const int z = bz / g.splitk, ksplit = bz - z * g.splitk;
     const int zo = z / g.batch_inner, zi = z - zo * g.batch_inner;
@@ -250,6 +254,29 @@ __global__ __launch_bounds__(512, 1) void gemm_glds256_kernel(GemmArgs g, const 
 }
 
 template <bool TA, bool TB, bool GATHER, int NB>
+__global__ __launch_bounds__(512, 1) void gemm_glds256_kernel(GemmArgs g, const bf16_t* zero, float* splitk_ws, int tiles_m, int tiles_n) {
+    const int wg = xcd_tile_id(blockIdx.x, gridDim.x);
+    const int per_z = tiles_n * tiles_m;
+    const int bz = wg / per_z, rem = wg - bz * per_z;
+    const int by = rem / tiles_n, bx = rem - by * tiles_n;
+    gemm256_body<TA, TB, GATHER, NB>(g, zero, splitk_ws, bx, by, bz);
+}
+
+// Grouped weight-gradient launch: up to B2S_MAX_GROUP independent dW = dY^T X problems (TN form, fp32 accumulate) in one
+// grid.  A training layer's weight gradients are 18 .. 72 tiles each -- far too few to fill 256 CUs one at a time, which
+// is what split-K + a slab-reduce kernel used to paper over; together they are ~290 tiles with the full 8148-deep K.
+template <int NB>
+__global__ __launch_bounds__(512, 1) void gemm_glds256_grouped_kernel(b2s_gemm_group grp, const bf16_t* zero) {
+    const int wg = xcd_tile_id(blockIdx.x, gridDim.x);
+    int p = 0;
+    while (p + 1 < grp.n && wg >= grp.tile0[p + 1]) ++p;
+    const int local = wg - grp.tile0[p];
+    const int tiles_n = (grp.p[p].N + NB * 32 - 1) / (NB * 32);
+    const int by = local / tiles_n, bx = local - by * tiles_n;
+    gemm256_body<true, true, false, NB>(grp.p[p], zero, nullptr, bx, by, 0);
+}
+
+template <bool TA, bool TB, bool GATHER, int NB>
 int launch256_nb(const GemmArgs& g_in, const bf16_t* zero, float* ws_all, size_t ws_floats, hipStream_t stream) {
     GemmArgs g = g_in;
     if (g.splitk > 1) {                     // every split must own at least one K step (empty splits would leave slabs unwritten)
@@ -291,6 +318,31 @@ int launch256_t(const GemmArgs& g, const bf16_t* zero, float* ws_all, size_t ws_
 }
 
 }  // namespace t256
+
+int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* zero, hipStream_t stream) {
+    B2S_CHECK(n >= 1 && n <= B2S_MAX_GROUP, "grouped GEMM: %d problems (max %d)", n, B2S_MAX_GROUP);
+    b2s_gemm_group grp;
+    grp.n = n;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const GemmArgs& g = probs[i];
+        B2S_CHECK(g.batch == 1 && g.c_fp32 && g.epi.accumulate && g.A.g_cin == 0 && g.B.g_cin == 0, "grouped GEMM: problem %d is not a plain fp32-accumulate dW", i);
+        grp.p[i] = g; grp.p[i].splitk = 1;
+        grp.tile0[i] = tiles;
+        tiles += cdiv(g.M, t256::BM) * cdiv(g.N, 128);
+    }
+    grp.tile0[n] = tiles;
+    constexpr size_t smem = (size_t)t256::NSTAGE * t256::STAGE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        B2S_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t256::gemm_glds256_grouped_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((t256::gemm_glds256_grouped_kernel<4>), dim3(tiles), dim3(512), smem, stream, grp, zero);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
 
 // number of 256x128 tiles a problem decomposes into (the dispatcher in gemm_glds.hip uses it to pick the tile shape)
 long b2s_gemm_glds256_tiles(const GemmArgs& g) { return (long)cdiv(g.M, t256::BM) * cdiv(g.N, 128) * g.batch * std::max(1, g.splitk); }

@@ -18,7 +18,8 @@ int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float*
 // dx (+)= LN'(dy); dgamma += ..., dbeta += ... (atomic; caller zeroes).  dy is T (dy_fp32=0) or fp32, ld lddy.
 int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const float* x, const float* gamma,
                      const float* mean, const float* rstd, float* dx, int accumulate, float* dgamma, float* dbeta,
-                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws = nullptr);
+                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws = nullptr,
+                     void* dy2 = nullptr, DropCfg drop2 = DropCfg{0, 0, 1.f});
 // ws (optional): RO_LN_WS_ROWS * 2 * D floats of scratch for the parameter-gradient partials (avoids global atomics)
 constexpr int RO_LN_WS_ROWS = 768;
 

@@ -122,7 +122,7 @@ template <typename TD>
 __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const float* x, const float* gamma,
                                                 const float* mean, const float* rstd, float* dx, int accumulate,
                                                 float* dgamma, float* dbeta, int M, int D, const int* row_len,
-                                                int rpb, float* ws) {
+                                                int rpb, float* ws, bf16_t* dy2, DropCfg drop2) {
     __shared__ float sacc[4 * 2 * LN_MAXC * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
                 float* p = dx + (long)row * D + ci * 4;
                 if (accumulate) { float4 a = ld4(p); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
                 st4(p, o);
+                // the next backward op consumes bf16(dropout(dx)): write it here instead of a separate cast pass
+                if (dy2) st4(dy2 + (long)row * D + ci * 4, drop4(o, drop2, (uint32_t)((long)row * D + ci * 4)));
             }
         }
     }
@@ -698,15 +700,15 @@ int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float*
 }
 int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const float* x, const float* gamma,
                      const float* mean, const float* rstd, float* dx, int accumulate, float* dgamma, float* dbeta,
-                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws) {
+                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws, void* dy2, DropCfg drop2) {
     B2S_CHECK(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
     int grid = cdiv(M, 4); if (grid > (ws ? RO_LN_WS_ROWS : 512)) grid = ws ? RO_LN_WS_ROWS : 512;
     if (dy_fp32 || !dtype)
         hipLaunchKernelGGL((k_ln_bwd<float>), dim3(grid), dim3(256), 0, st, (const float*)dy, lddy, x, gamma, mean, rstd,
-                           dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch, ws);
+                           dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch, ws, (bf16_t*)dy2, drop2);
     else
         hipLaunchKernelGGL((k_ln_bwd<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, lddy, x, gamma, mean,
-                           rstd, dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch, ws);
+                           rstd, dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch, ws, (bf16_t*)dy2, drop2);
     if (ws) {
         int gy = cdiv(grid, 32); if (gy < 1) gy = 1;
         hipLaunchKernelGGL(k_ln_param_reduce, dim3(cdiv(2 * D, 64), gy), dim3(256), 0, st, (const float*)ws, grid, D, dgamma, dbeta);
