@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes) into per-kernel per-launch HBM traffic.
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [skip_launches_per_kernel]
+FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts 128-byte requests at 64 bytes, so it is doubled
+(MI355X_MICROARCH.md, section HBM); WRITE_SIZE is reported as is (uncalibrated per that guide).
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    name = re.sub(r"\(.*$", "", name)            # drop the argument list
+    return name.strip()
+
+
+def load(path, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
+    rows = []
+    for k in f:
+        fv, wv = f[k], w.get(k, [])
+        rows.append({"kernel": k, "launches": len(fv),
+                     "FETCH_SIZE_KB_per_launch": round(sum(fv) / len(fv), 1),
+                     "fetch_MB_per_launch_corrected_x2": round(2 * sum(fv) / len(fv) / 1024, 2),
+                     "WRITE_SIZE_KB_per_launch": round(sum(wv) / len(wv), 1) if wv else None,
+                     "total_fetch_MB_corrected": round(2 * sum(fv) / 1024, 1)})
+    rows.sort(key=lambda r: -r["total_fetch_MB_corrected"])
+    json.dump(rows, open(out, "w"), indent=1)
+    for r in rows[:12]:
+        print("%-60s launches %5d  fetch %9.2f MB/launch  write %9.2f MB/launch" % (
+            r["kernel"][:60], r["launches"], r["fetch_MB_per_launch_corrected_x2"], (r["WRITE_SIZE_KB_per_launch"] or 0) / 1024))
+
+
+if __name__ == "__main__":
+    main()
