@@ -197,8 +197,8 @@ def main():
         def kname(v):               # the kernel names rocprofv3 reports (profiles/*kernel_stats.csv)
             dt, ta, tb, ga = v >> 3, (v >> 2) & 1, (v >> 1) & 1, v & 1
             tf = lambda x: "true" if x else "false"
-            if dt:
-                return "gemm_glds_kernel<%s, %s, %s>" % (tf(ta), tf(tb), tf(ga))
+            if dt:                  # 256-row tile kernel, 128- or 96-column variant chosen per shape (NB = 4 | 3)
+                return "t256::gemm_glds256_kernel<%s, %s, %s, NB>" % (tf(ta), tf(tb), tf(ga))
             return "gemm_kernel<float, %s, %s>%s" % (tf(ta), tf(tb), " (conv gather)" if ga else "")
         names = {v: kname(v) for v in range(16)}
         variants = []
@@ -213,14 +213,26 @@ def main():
         variants.sort(key=lambda d: -d["ms_per_step"])
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS
         dom = variants[0]
+        # HBM-side traffic of that kernel from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/gpu_pmc.sh) -- counters cannot be read from inside this process
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_train_bf16_pmc_hbm_traffic.json")
+        if os.path.exists(pmc) and args.dtype == "bf16" and args.mode == "train" and (B, S, T) == (14, 114, 582):
+            pre = dom["kernel"].split(", NB>")[0]
+            rows = [r for r in json.load(open(pmc)) if r["kernel"].startswith(pre)]
+            n = sum(r["launches"] for r in rows)
+            if n:
+                traffic = round(sum(r["launches"] * (r["fetch_MB_per_launch_corrected_x2"] + (r["WRITE_SIZE_KB_per_launch"] or 0) / 1024)
+                                    for r in rows) / n * 1e6)
         out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(dom["tflops"] / peak, 4), "traffic": None, "avg_launch_us": dom["avg_us"],
-                           "launches_per_step": dom["launches_per_step"],
+                           "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM side, PMC)",
+                           "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                            "all_gemm": {"tflops": round(tot_f / (tot_ms * 1e-3) / 1e12, 1), "ms_per_step": round(tot_ms / nprof, 3)},
                            "variants": variants,
                            "note": "algorithmic FLOPs (2MNK per launch) / HIP-event duration on the kernel's launch stream, separate "
-                                   "instrumented pass of the same steps; the <true,true,*> weight-gradient GEMMs run on a second stream "
-                                   "concurrently with the rest of the backward pass, so their durations overlap other kernels"}
+                                   "instrumented pass of the same steps; the <true, true, *> weight-gradient GEMMs run on a second stream "
+                                   "concurrently with the rest of the backward pass, so their event durations include time spent "
+                                   "sharing the CUs with main-stream kernels (rocprofv3 reports the same kernels from first wave to last)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_train()
     if world > 1 or force_dp:
