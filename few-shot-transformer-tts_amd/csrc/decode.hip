@@ -255,8 +255,15 @@ int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
         // causal self-attention over the cache
         B2S_TRY(ro_layernorm_fwd(dt, s->x, m->P(lna + ".weight"), m->P(lna + ".bias"), s->h, D, nullptr, 0, s->mean, s->rstd, B, D, 1e-6f,
                                  nullptr, 1, st));
-        B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "self_attentions", l, "qkv_transform.weight")), B, 3 * D, D, s->qkv, 0, 3 * D, GemmEpilogue()));
-        hipLaunchKernelGGL((k_dec_append<T>), dim3(B), dim3(256), 0, st, (const T*)s->qkv, s->t, (T*)s->selfK[l], (T*)s->selfV[l], maxT, D);
+        // (B <= 64: the weight-streaming GEMM also appends this frame's k / v rows to the caches -- one kernel node fewer per
+        // layer; every node costs >= ~7 us in the graph.  LayerNorm-on-load was tried too and lost: 6x the operand loads
+        // in the streaming loop cost more than the saved node.)
+        const bool fuse_kv = B <= 64 && D % 32 == 0;
+        GemmEpilogue eq;
+        if (fuse_kv) { eq.kv_k = s->selfK[l]; eq.kv_v = s->selfV[l]; eq.kv_t = s->t; eq.kv_maxT = maxT; eq.kv_D = D; }
+        B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "self_attentions", l, "qkv_transform.weight")), B, 3 * D, D, s->qkv, 0, 3 * D, eq));
+        if (!fuse_kv)
+            hipLaunchKernelGGL((k_dec_append<T>), dim3(B), dim3(256), 0, st, (const T*)s->qkv, s->t, (T*)s->selfK[l], (T*)s->selfV[l], maxT, D);
         hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(256), sh_self, st, (const T*)s->qkv, 3 * D, (const T*)s->selfK[l],
                            (const T*)s->selfV[l], D, (long)maxT * D, (T*)s->ctx, D, s->selfP[l], maxT, maxT, s->t, (const int*)nullptr, 1, H, dh,
                            maxT, scale, make_drop(pt, s->seed, 9010 + l));

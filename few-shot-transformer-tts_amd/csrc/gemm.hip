@@ -325,6 +325,7 @@ static int gemm_launch_inner(const GemmArgs& g, int dtype, bool ta, bool tb, hip
     B2S_CHECK(g.splitk >= 1 && (g.splitk == 1 || (g.c_fp32 && g.epi.accumulate && !g.epi.relu && !g.epi.bias && !g.epi.residual &&
                                                    !g.epi.relu_aux && !g.epi.drop.thresh)),
               "gemm: split-K needs a linear fp32 accumulate epilogue");
+    B2S_CHECK(!g.epi.kv_k, "gemm: the cache-append fusion exists in the decode-step kernel only (M <= 64, K %% 32 == 0)");
     static const bool use_v1 = getenv("B2S_GEMM_V1") != nullptr;         // A/B switch: register-staged bf16 main loop
     if (dtype && !use_v1) return b2s_gemm_glds_launch(g, ta, tb, stream);
     return dtype ? launch_d<bf16_t>(g, ta, tb, stream) : launch_d<float>(g, ta, tb, stream);

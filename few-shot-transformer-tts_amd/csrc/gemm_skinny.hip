@@ -78,6 +78,11 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(GemmArgs g) {
         const long off = (long)m * g.ldc + n;
         if (g.c_fp32) { float* C = reinterpret_cast<float*>(g.C); if (e.accumulate) C[off] += v; else C[off] = v; }
         else TT<T>::st(reinterpret_cast<T*>(g.C) + off, v);
+        if (e.kv_k && n >= e.kv_D) {          // this frame's k / v columns also go to the caches at position *kv_t
+            const int which = n >= 2 * e.kv_D, c = n - (1 + which) * e.kv_D;
+            T* cache = reinterpret_cast<T*>(which ? e.kv_v : e.kv_k);
+            TT<T>::st(cache + ((long)m * e.kv_maxT + *e.kv_t) * e.kv_D + c, v);
+        }
     }
 }
 
@@ -88,6 +93,7 @@ int b2s_gemm_skinny_launch(const GemmArgs& g, int dtype, hipStream_t stream) {
     const int ks = dtype ? 32 : 4;
     if (g.M > 64 || g.batch != 1 || g.splitk != 1 || g.A.g_cin || g.B.g_cin || g.epi.relu_aux || g.epi.conv_dw_cin || (g.K % ks) != 0)
         return -1;
+    if (g.epi.kv_k && (!g.epi.kv_v || !g.epi.kv_t || g.N != 3 * g.epi.kv_D)) return -1;
     dim3 grid(cdiv(g.N, 16));
     if (dtype) hipLaunchKernelGGL((skinny_kernel<bf16_t>), grid, dim3(NW * 64), 0, stream, g);
     else hipLaunchKernelGGL((skinny_kernel<float>), grid, dim3(NW * 64), 0, stream, g);
