@@ -232,7 +232,8 @@ def main():
                            "note": "algorithmic FLOPs (2MNK per launch) / HIP-event duration on the kernel's launch stream, separate "
                                    "instrumented pass of the same steps; the <true, true, *> weight-gradient GEMMs run on a second stream "
                                    "concurrently with the rest of the backward pass, so their event durations include time spent "
-                                   "sharing the CUs with main-stream kernels (rocprofv3 reports the same kernels from first wave to last)"}
+                                   "sharing the CUs with main-stream kernels, and the split-K slab reduction that belongs to the launch "
+                                   "(rocprofv3 lists gemm_glds256_kernel and splitk_reduce_kernel separately, first wave to last)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_train()
     if world > 1 or force_dp:

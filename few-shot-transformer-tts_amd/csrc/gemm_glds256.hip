@@ -235,11 +235,13 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
         // stage kt+1 landed (own DMAs; the 6 of stage kt+2 stay in flight) ... for every wave, and slot `slot` is free
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        issue(kt0 + kt + NSTAGE, slot);
-        // second half: first-half fragments of the next stage fly under the second-half MFMAs
+        // second half: first-half fragments of the next stage fly under the second-half MFMAs; the DMA issue of stage kt+3
+        // (6 instructions + their address arithmetic) comes AFTER the MFMAs have been issued, so its VALU work runs while
+        // the matrix pipe drains instead of delaying this wave's MFMAs right after the barrier
         B2S_READ8(fa0, fb0, nslot, 0)
         __builtin_amdgcn_sched_barrier(0);
         B2S_MMA16(fa1, fb1)
+        issue(kt0 + kt + NSTAGE, slot);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
