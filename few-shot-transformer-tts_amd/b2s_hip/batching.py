@@ -1,0 +1,155 @@
+"""Batch producer -> device: what feeds the hot path every step.
+
+Host side of the reference's Feeder (dataloader.py:25-218, 401-508), re-done for a one-process-per-GPU MI355X job:
+
+* `BatchPacker`   -- the reference's greedy two-cap packing rule on plain lengths (no sample dicts are touched while
+                     packing), identical batches (pinned by the goldens through tests/test_batching.py);
+* `collate`       -- zero-padded arrays in the dataloader's batch contract (keys and tensor dtypes of get_input_proto),
+                     optionally padded up to a shape quantum so that only a handful of (S, T) shapes ever reach the
+                     engine (workspace sizes, and any captured graphs, are per shape);
+* `DeviceStager`  -- pinned, double-buffered host staging and asynchronous H2D copies on a side stream: batch k+1 is
+                     in flight while step k runs; `next()` hands out device tensors whose copy has been ordered
+                     before the caller's stream;
+* `shard`, `adapt_rate` -- per-rank sharding (every rank takes every world-th sample, dataloader.py:62-64) and the
+                     adaptation-sample ramp (:196-204).
+
+Everything here is host glue around the path; the math stays in libb2s_hip.so.
+"""
+import numpy as np
+import torch
+
+
+class BatchPacker(object):
+    def __init__(self, batch_frame_limit=8000, batch_frame_quad_limit=7000000):
+        self.frame_limit = int(batch_frame_limit)
+        self.quad_limit = int(batch_frame_quad_limit)
+
+    @classmethod
+    def from_hparams(cls, hp):
+        return cls(hp.batch_frame_limit, hp.batch_frame_quad_limit)
+
+    def pack(self, input_lengths, target_lengths=None, single=False):
+        """-> list of index lists, in input order.  A batch stays within n * (max_in^2 + T_last^2) <= quad_limit and
+        n * T_last <= frame_limit, T_last being the target length of the sample just added (the reference sorts a bucket by
+        target length first, so T_last is the batch maximum); without targets T = int(1.5 * input length).
+        Unlike the reference no empty leading batch is produced."""
+        groups, cur, cur_max_in = [], [], 0
+        for i, n_in in enumerate(input_lengths):
+            n_in = int(n_in)
+            t = int(target_lengths[i]) if target_lengths is not None else int(n_in * 1.5)
+            m = max(cur_max_in, n_in)
+            n = len(cur) + 1
+            if cur and (single or n * (m * m + t * t) > self.quad_limit or n * t > self.frame_limit):
+                groups.append(cur)
+                cur, m = [], n_in
+            cur.append(i)
+            cur_max_in = m
+        if cur:
+            groups.append(cur)
+        return groups
+
+
+def _round_up(n, q):
+    return (n + q - 1) // q * q
+
+
+def collate(samples, hparams, s_quantum=1, t_quantum=1):
+    """samples: dicts with 'name', 'input' (int array), optionally 'mel_target' [T, num_mels] (+ 'target_length'),
+    'language_vec', 'speaker_id' (dataloader.py:extract_meta).  -> dict of NumPy arrays in the batch contract.
+    s_quantum / t_quantum > 1 pad S / T up to a multiple (shape bucketing; lengths are untouched, the model masks by
+    length -- note that the reference's train-mode BatchNorm statistics include padded frames, so bucketing T is not
+    bit-neutral for the postnet, exactly like the reference's own batch-dependent padding)."""
+    S = _round_up(max(len(s["input"]) for s in samples), s_quantum)
+    B = len(samples)
+    out = {"inputs": np.zeros((B, S), dtype=np.int64), "input_lengths": np.zeros(B, dtype=np.int64)}
+    for b, s in enumerate(samples):
+        n = len(s["input"])
+        out["inputs"][b, :n] = s["input"]
+        out["input_lengths"][b] = n
+    if "mel_target" in samples[0]:
+        T = _round_up(max(len(s["mel_target"]) for s in samples), t_quantum)
+        mels = np.zeros((B, T, samples[0]["mel_target"].shape[1]), dtype=np.float32)
+        tl = np.zeros(B, dtype=np.int64)
+        for b, s in enumerate(samples):
+            n = len(s["mel_target"])
+            mels[b, :n] = s["mel_target"]
+            tl[b] = s.get("target_length", n)
+        out["mel_targets"], out["target_lengths"] = mels, tl
+    if hparams.multi_lingual:
+        out["input_language_vecs"] = np.asarray([s["language_vec"] for s in samples], dtype=np.float32)
+    if hparams.multi_speaker or hparams.multi_lingual:
+        out["input_spk_ids"] = np.asarray([s["speaker_id"] for s in samples], dtype=np.int64)
+    out["names"] = [s["name"] for s in samples]
+    return out
+
+
+def shard(items, rank, world_size):
+    """Every rank keeps every world_size-th item starting at its rank (dataloader.py:62-64)."""
+    return items[rank::world_size] if world_size > 1 else items
+
+
+def adapt_rate(global_step, hparams):
+    """Probability of drawing an adaptation sample at this step: 0 before adapt_start_step, a linear ramp to
+    final_adapt_rate at adapt_end_step (dataloader.py:196-204)."""
+    if global_step >= hparams.adapt_end_step:
+        r = 1.0
+    elif global_step < hparams.adapt_start_step:
+        r = 0.0
+    else:
+        r = (global_step - hparams.adapt_start_step) / float(hparams.adapt_end_step - hparams.adapt_start_step)
+    return r * hparams.final_adapt_rate
+
+
+class DeviceStager(object):
+    """Double-buffered H2D staging of batch dicts.
+
+        stager = DeviceStager(device)
+        stager.put(np_batch)                 # pinned copy + async H2D on the copy stream (returns immediately)
+        batch = stager.next()                # device tensors; the current stream now waits for their copy
+
+    Pinned buffers are kept per (key, shape, dtype) and reused; `depth` batches may be in flight."""
+
+    def __init__(self, device, depth=2):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("DeviceStager stages onto a HIP device (got %s)" % device)
+        self.depth = depth
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._pinned = {}
+        self._slot = 0
+        self._queue = []
+
+    def _pin(self, key, arr, slot):
+        k = (key, arr.shape, str(arr.dtype), slot)
+        buf = self._pinned.get(k)
+        if buf is None:
+            buf = torch.empty(arr.shape, dtype=torch.from_numpy(arr[:0] if arr.ndim else arr).dtype).pin_memory()
+            self._pinned[k] = buf
+        buf.numpy()[...] = arr
+        return buf
+
+    def put(self, np_batch):
+        if len(self._queue) >= self.depth:
+            raise RuntimeError("DeviceStager: %d batches already in flight" % self.depth)
+        slot = self._slot
+        self._slot = (self._slot + 1) % (self.depth + 1)
+        out = {}
+        with torch.cuda.stream(self.stream):
+            for k, v in np_batch.items():
+                if isinstance(v, np.ndarray):
+                    out[k] = self._pin(k, v, slot).to(self.device, non_blocking=True)
+                else:
+                    out[k] = v
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._queue.append((out, ev))
+
+    def next(self):
+        if not self._queue:
+            raise RuntimeError("DeviceStager: nothing staged")
+        out, ev = self._queue.pop(0)
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        for v in out.values():
+            if torch.is_tensor(v):
+                v.record_stream(torch.cuda.current_stream(self.device))
+        return out

@@ -8,7 +8,8 @@ oracle/synth.py (NumPy default_rng) so the fixtures hold outputs only.
     python tests/golden/make_goldens.py            # writes all groups
 
 Groups: G1 helpers, G2 tiny model fwd/loss/grads/Adam/eval-mode,
-G3 per-module, G4 autoregressive decode, G5 full-size spot checks, G6 LR schedule + packer.
+G3 per-module, G4 autoregressive decode, G5 full-size spot checks, G6 LR schedule + packer,
+G7 batch producer (packer caps, collate contract, adapt-rate ramp).
 """
 import json
 import os
@@ -288,8 +289,52 @@ def g6():
          n_params=np.asarray(sum(p.numel() for p in m.parameters())))
 
 
+# ------------------------------------------------------------------------------- G7
+def g7():
+    """Batch producer: packer on unsorted / capped inputs, collate contract, adapt rate, sharding."""
+    from types import SimpleNamespace
+    reset_hp()
+    rng = np.random.default_rng(11)
+    ex = []
+    for i in range(9):
+        L, T = int(rng.integers(5, 30)), int(rng.integers(20, 90))
+        lv = np.zeros([hp.max_num_language]); lv[int(rng.integers(0, 5))] = 1
+        ex.append({"name": "spk%d_utt%d" % (i % 3, i), "input": rng.integers(1, 255, size=L).astype(np.int32),
+                   "mel_target": rng.standard_normal((T, hp.num_mels)).astype(np.float32), "target_length": T,
+                   "language_vec": lv, "speaker_id": int(rng.integers(0, 50))})
+    b = rdata._prepare_batch(ex, hp)
+    proto = rdata.get_input_proto(hp)
+    tb = {k: proto[k](b[k]) for k in proto if k in b}                 # exactly what Feeder._enqueue_next_group enqueues
+    out = {"n": np.asarray(len(ex))}
+    for i, e in enumerate(ex):
+        out["ex%d_input" % i] = e["input"]; out["ex%d_mel" % i] = e["mel_target"]
+        out["ex%d_lang" % i] = e["language_vec"]; out["ex%d_spk" % i] = np.asarray(e["speaker_id"])
+    for k, v in tb.items():
+        if k == "names":
+            out["names"] = np.asarray(v)
+        else:
+            out["batch_" + k] = v.numpy(); out["dtype_" + k] = np.asarray(str(v.dtype))
+    # packer: unsorted examples, tight caps, `single`
+    tl = rng.integers(40, 400, size=60); il = rng.integers(8, 90, size=60)
+    exs = [{"input": np.zeros(int(i)), "mel_target": np.zeros((int(t), 1))} for i, t in zip(il, tl)]
+    caps = SimpleNamespace(batch_frame_limit=1200, batch_frame_quad_limit=400000)
+    out["pk_in"] = il; out["pk_tgt"] = tl
+    out["pk_sizes_tight"] = np.asarray([len(x) for x in rdata._pack_into_batches(exs, hparams=caps)])
+    out["pk_sizes_single"] = np.asarray([len(x) for x in rdata._pack_into_batches(exs, single=True, hparams=caps)])
+    noT = [{"input": np.zeros(int(i))} for i in il]                   # synthesis-time packing: target length = 1.5 x input
+    out["pk_sizes_notarget"] = np.asarray([len(x) for x in rdata._pack_into_batches(noT, hparams=caps)])
+    # adapt-rate ramp (Feeder._adapt_rate)
+    steps = [0, 999, 1000, 1500, 2000, 5000]
+    h2 = SimpleNamespace(adapt_start_step=1000, adapt_end_step=2000, final_adapt_rate=0.25)
+    out["adapt_steps"] = np.asarray(steps)
+    out["adapt_rates"] = np.asarray([rdata.Feeder._adapt_rate(SimpleNamespace(global_step=s_, _hparams=h2)) for s_ in steps])
+    h3 = SimpleNamespace(adapt_start_step=30000, adapt_end_step=30000, final_adapt_rate=0.25)      # reference default: a step
+    out["adapt_rates_default"] = np.asarray([rdata.Feeder._adapt_rate(SimpleNamespace(global_step=s_, _hparams=h3)) for s_ in (29999, 30000)])
+    save("g7_batching", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     torch.manual_seed(0)
     if "g1" in which: g1()
     if "g2" in which:
@@ -299,3 +344,4 @@ if __name__ == "__main__":
     if "g4" in which: g4()
     if "g5" in which: g5()
     if "g6" in which: g6()
+    if "g7" in which: g7()
