@@ -157,3 +157,42 @@ def synthetic_batch(cfg, B, S, T, seed=0, in_lens=None, tgt_lens=None, n_spk=Non
     return {"inputs": inputs, "input_lengths": in_lens, "mel_targets": mels,
             "target_lengths": tgt_lens, "input_spk_ids": spk, "input_language_vecs": lang,
             "names": ["utt%03d" % i for i in range(B)]}
+
+
+def synthetic_corpus(dirpath, seed=0, n=48):
+    """A tiny corpus in the reference's on-disk layout (corpora/process_corpus.py:296-348, dataloader.py:313-332,413-416):
+    mels.zip of <name>.npy float32 [T, 80] members, metadata.train.txt lines `name.npy|frames|text|lang`,
+    lang_id.json / spk_id.json.  Deterministic in (seed, n); used by the golden generator and by the tests that re-create
+    the same files on the GPU box.  Returns the paths."""
+    import io
+    import json
+    import os
+    import zipfile
+    rng = np.random.default_rng(seed)
+    langs = ["en-us", "de-de", "fr-fr"]
+    spks = ["spkA", "spkB", "spkC", "spkD"]
+    words = ["hello", "world", "grüße", "café", "byte", "speech", "über", "naïve", "tts", "模型"]
+    os.makedirs(dirpath, exist_ok=True)
+    zpath, mpath = os.path.join(dirpath, "mels.zip"), os.path.join(dirpath, "metadata.train.txt")
+    lines = []
+    with zipfile.ZipFile(zpath, "w") as zf:
+        for i in range(n):
+            spk = spks[int(rng.integers(0, len(spks)))]
+            lang = langs[int(rng.choice(3, p=[0.6, 0.25, 0.15]))]
+            T = int(rng.integers(20, 120))
+            mel = np.clip(rng.standard_normal((T, 80)), -4, 4).astype(np.float32)
+            name = "%s_%04d.npy" % (spk, i)
+            buf = io.BytesIO()
+            np.save(buf, mel)
+            zf.writestr(name, buf.getvalue())
+            text = " ".join(words[int(j)] for j in rng.integers(0, len(words), size=int(rng.integers(1, 6))))
+            lines.append("%s|%d|%s|%s" % (name, T, text, lang))
+    with open(mpath, "w", encoding="utf-8") as f:
+        f.write("\n".join(lines) + "\n")
+    lang_ids = {l: i for i, l in enumerate(langs)}
+    spk_ids = {s: i for i, s in enumerate(spks)}
+    with open(os.path.join(dirpath, "lang_id.json"), "w") as f:
+        json.dump(lang_ids, f)
+    with open(os.path.join(dirpath, "spk_id.json"), "w") as f:
+        json.dump(spk_ids, f)
+    return {"zip": zpath, "meta": mpath, "lang_ids": lang_ids, "spk_ids": spk_ids}

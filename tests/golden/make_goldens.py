@@ -333,8 +333,55 @@ def g7():
     save("g7_batching", **out)
 
 
+# ------------------------------------------------------------------------------- G8
+def g8():
+    """On-disk formats + feeders: the reference's Feeder / FeederEval run on the synthetic
+    corpus of oracle/synth.py; the fixture holds batch compositions (names) and checksums."""
+    import tempfile
+    out = {}
+    CFGS = {
+        "balanced": "bucket_size=16,batch_frame_limit=400,batch_frame_quad_limit=60000,data_warmup_steps=5,"
+                    "target_length_lower_bound=40,target_length_upper_bound=100",
+        "plain": "bucket_size=16,batch_frame_limit=400,batch_frame_quad_limit=60000,balanced_training=false,data_warmup_steps=0",
+        "adapt": "bucket_size=16,batch_frame_limit=400,batch_frame_quad_limit=60000,data_warmup_steps=0,"
+                 "adapt_start_step=0,adapt_end_step=0,final_adapt_rate=0.5",
+    }
+    with tempfile.TemporaryDirectory() as d:
+        c = synth.synthetic_corpus(d, seed=3, n=48)
+        for tag, over in CFGS.items():
+            for rank, world in ((0, 1), (1, 2)):
+                reset_hp(over)
+                rdata.zip_cache.clear()
+                kw = dict(adapt_lang=["fr-fr"]) if tag == "adapt" else {}
+                f = rdata.Feeder(c["zip"], c["meta"], hp, spk_to_id=c["spk_ids"], lang_to_id=c["lang_ids"], rank=rank, world_size=world, **kw)
+                seq = []
+                for _ in range(3):
+                    f._enqueue_next_group()
+                    while not f.queue.empty():
+                        b = f.queue.get()
+                        seq.append({"names": b["names"], "in_sum": int(b["inputs"].sum()), "mel_sum": float(b["mel_targets"].double().sum()),
+                                    "tl": b["target_lengths"].tolist(), "spk": b["input_spk_ids"].tolist(),
+                                    "lang": b["input_language_vecs"].argmax(1).tolist()})
+                out["train/%s/r%dw%d" % (tag, rank, world)] = seq
+        reset_hp("batch_frame_limit=400,batch_frame_quad_limit=60000")
+        rdata.zip_cache.clear()
+        fe = rdata.FeederEval(c["zip"], c["meta"], hp, spk_to_id=c["spk_ids"], lang_to_id=c["lang_ids"], shuffle=True, keep_order=True,
+                              pick_partial=True)
+        out["eval/partial"] = [{"names": b["names"], "tl": b["target_lengths"].tolist()} for b in fe.fetch_data()]
+        rdata.zip_cache.clear()
+        fe = rdata.FeederEval(c["zip"], c["meta"], hp, spk_to_id=c["spk_ids"], lang_to_id=c["lang_ids"], eval_lang=["de-de"], shuffle=False,
+                              target_spk="spkB")
+        out["eval/de_as_spkB"] = [{"names": b["names"], "spk": b["input_spk_ids"].tolist()} for b in fe.fetch_data()]
+        meta = rdata._read_meta(open(c["meta"], encoding="utf-8"), "nlti")
+        out["meta_head"] = meta[:3]
+    reset_hp()
+    with open(os.path.join(HERE, "g8_feeders.json"), "w") as f:
+        json.dump(out, f, indent=0, ensure_ascii=False)
+    print("wrote g8_feeders.json (%d sequences)" % len(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     torch.manual_seed(0)
     if "g1" in which: g1()
     if "g2" in which:
@@ -345,3 +392,4 @@ if __name__ == "__main__":
     if "g5" in which: g5()
     if "g6" in which: g6()
     if "g7" in which: g7()
+    if "g8" in which: g8()
