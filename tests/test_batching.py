@@ -105,7 +105,10 @@ def test_device_stager_round_trip_and_model_accepts_staged_batches():
                 assert dev[k].is_cuda and np.array_equal(dev[k].cpu().numpy(), v), k
             else:
                 assert dev[k] == v
-    # buffers are reused: staging the same shapes again allocates nothing new
+    # pinned buffers are reused: once every slot of the ring (depth + 1) has seen a shape, staging it again allocates nothing
+    for _ in range(3):
+        stager.put(b1); stager.next()
     n_pinned = len(stager._pinned)
-    stager.put(b1); stager.next()
+    for _ in range(4):
+        stager.put(b1); stager.next()
     assert len(stager._pinned) == n_pinned
