@@ -191,14 +191,20 @@ int join_aux(const b2s_model* m, hipStream_t st) {                           // 
     }
     return 0;
 }
-// weight-gradient GEMMs reduce over all B*L tokens into a small [out,in] matrix: split K over blocks so the
-// launch fills 256 CUs (>= ~1024 workgroups), partial sums combined with fp32 atomics into the zeroed gradient
+// weight-gradient GEMMs reduce over all B*L tokens into a small [out,in] matrix: split K over workgroups (fp32 slabs +
+// a reduce kernel).  bf16: the 256-row tile kernel runs one workgroup per CU, and these GEMMs share the chip with the
+// main stream's kernels (second stream) -- the split is chosen for B2S_DW_BLOCKS workgroups (default: measured best),
+// not for all 256 CUs, so that main-stream kernels always find free CUs.
 int pick_splitk(int Mo, int No, int K, int dtype) {
     const int bk = dtype ? 64 : 16;
-    const long tiles = (long)cdiv(Mo, 128) * cdiv(No, 128);
     const int nk = cdiv(K, bk);
-    // one full round of 2 workgroups per CU (512 slots), never spilling into a second, mostly empty round;
-    // fp32 atomics are the cost of splitting, so each split keeps >= 8 K tiles
+    if (dtype) {
+        static const int target = getenv("B2S_DW_BLOCKS") ? atoi(getenv("B2S_DW_BLOCKS")) : 256;
+        const long tiles = (long)cdiv(Mo, 256) * cdiv(No, 128);
+        int s = (int)std::min<long>(std::max<long>(1, target / tiles), std::max(1, nk / 4));
+        return std::max(1, std::min(s, 32));
+    }
+    const long tiles = (long)cdiv(Mo, 128) * cdiv(No, 128);
     int s = (int)std::min<long>(std::max<long>(1, 512 / tiles), std::max(1, nk / 4));
     return std::max(1, std::min(s, 32));
 }

@@ -11,6 +11,8 @@
 // K is walked in BK = 32 steps through an NSTAGE-deep LDS ring: NSTAGE-1 tiles are in flight, each wave waits only for
 // its own DMA of the tile it is about to use (counted s_waitcnt vmcnt, never 0 in steady state) and one raw s_barrier
 // per tile publishes it to the other waves and frees the oldest slot.
+// Lab switches (tools/gemm_lab.hip only, never defined in the library build): B2S_EXP_NODMA / NOWAIT / NOBAR / NOLDS /
+// DMAHOT / FULLLINE / REGLOAD ablate one pipeline component each; the results are in profiles/README.md.
 #include <algorithm>
 #include <cstdlib>
 #include "gemm.h"

@@ -19,6 +19,10 @@
 #include "gemm.h"
 #include "gemm_epi.h"
 
+#ifndef B2S_DMA_AUX
+#define B2S_DMA_AUX 0       // cache-policy bits of the LDS-DMA loads (sc0 = 1, nt = 2, sc1 = 16); measured: no policy beats the default
+#endif
+
 namespace t256 {
 
 constexpr int BM = 256, BK = 64, NSTAGE = 3;            // BN = 128 or 96 (template parameter NB = BN / 32)
@@ -141,7 +145,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
 #ifdef B2S_EXP_DMAHOT
             sa = zero + (lane & 15) * 8;
 #endif
-            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(sbase + idx * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(sbase + idx * 1024), 16, 0, B2S_DMA_AUX);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -157,7 +161,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
 #ifdef B2S_EXP_DMAHOT
             sb = zero + (lane & 15) * 8;
 #endif
-            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(sbase + A_BYTES + idx * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(sbase + A_BYTES + idx * 1024), 16, 0, B2S_DMA_AUX);
         }
     };
 
