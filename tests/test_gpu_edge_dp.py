@@ -167,3 +167,40 @@ def test_grouped_weight_gradient_option():
                         "-k", "bf16 or two_ranks or fused_trainer"], cwd=root, env=dict(os.environ, B2S_DW_GROUP="1"),
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("B,S,T", [(32, 50, 250), (9, 158, 808)])
+def test_training_step_at_packer_extreme_shapes(B, S, T):
+    """the two extremes of the reference's batch packer at full model size (many short / few long
+    utterances).  bf16 fused trainer vs the fp32-mode HIP path on the same weights and batch: the loss terms agree
+    within bf16 drift and three steps stay finite (the fp32 path itself is pinned to the oracle in test_gpu_model.py)."""
+    import hyperparams
+    from transformer.tacotron import Tacotron, compute_loss
+    from b2s_hip.trainer import HipTrainer
+    hp = hyperparams.hparams
+    cfg = make_config("")
+    st = synth.synthetic_state(cfg, 3)
+    nb = synth.synthetic_batch(cfg, B, S, T, seed=5, n_spk=1, n_lang=1)
+    batch = _dev(nb)
+    vals = {}
+    for mode in ("fp32", "bf16"):
+        hp.override_from_dict(hyperparams.DEFAULTS)
+        hp.parse("compute_dtype=%s,transformer_dropout_rate=0.0,decoder_dropout_rate=0.0" % mode)
+        m = Tacotron(hp)
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()})
+        m = m.to(DEV).train()
+        if mode == "fp32":
+            o = m(**batch)
+            vals[mode] = [float(x) for x in (lambda d: (d["loss"], d["bef_loss"], d["aft_loss"], d["stop_loss"]))(
+                compute_loss(m, batch["mel_targets"], batch["target_lengths"], o, hp))]
+        else:
+            tr = HipTrainer(m, hp)
+            v = tr.train_step(batch)
+            vals[mode] = [float(v[0]), float(v[1]), float(v[2]), float(v[5])]
+            for _ in range(2):
+                v = tr.train_step(batch)
+            assert torch.isfinite(v).all()
+        del m
+    for a, b in zip(vals["fp32"], vals["bf16"]):
+        assert abs(a - b) < 0.03 * abs(a) + 1e-3, vals
+    hp.override_from_dict(hyperparams.DEFAULTS)
