@@ -1,87 +1,63 @@
-"""Global hyper-parameters: same names and defaults as the reference's hyperparams.py:3-72.
+"""Global hyper-parameters of the drop-in surface.
 
-Build-side additions (default = reference behaviour): `compute_dtype` ("fp32" parity mode with exact
-fp32 MFMA, "bf16" performance mode), `guided_attention_weight` / `freeze_encoder` (north-star
-extensions that the reference does not have; OFF by default, parity unpinned).
+`hparams` carries the same names and default values as the reference's global HParams object (hyperparams.py:3-72) --
+drivers override it with `--hparams "a=1,b=2"` exactly as there -- organised here by what consumes each group.  Only the
+"model", "optimiser" and "batching" groups reach the HIP engine; the signal-processing and evaluation groups are read
+by the reference's CPU glue (utils/audio.py, eval.py) when this package is placed in front of a reference checkout.
+
+Build-side additions (defaults = reference behaviour): `compute_dtype` ("fp32" parity mode on exact fp32 MFMA, "bf16"
+performance mode), and the two north-star extensions the reference does not have, both OFF by default:
+`guided_attention_weight` / `guided_attention_sigma` and `freeze_encoder`.
 """
 from utils.hparams import HParams
 
-hparams = HParams(
-    num_mels=80,
-    frame_length_ms=50,
-    frame_shift_ms=12.5,
-    hop_length=int(16000 * 0.0125),  # samples.
-    win_length=int(16000 * 0.05),  # samples.
-    max_db=100,
-    ref_db=20,
-    preemphasis=0.97,
-    max_abs_value=4.0,
-    symmetric_mel=True,
-    sr=16000,
-    n_fft=2048,
+_SAMPLE_RATE = 16000
 
-    n_iter=60,
-    power=1.5,
+# Transformer-TTS model (transformer/tacotron.py, transformer/modules.py); decoder_hidden = encoder_hidden + speaker + language widths
+_MODEL = dict(
+    vocab_size=6000, embed_size=512, encoder_hidden=512, n_encoder_layer=6,
+    decoder_hidden=768, n_decoder_layer=6, n_attention_head=8,
+    prenet_hidden=256, postnet_hidden=512, n_postnet_layer=5, num_mels=80,
+    transformer_dropout_rate=0.1, decoder_dropout_rate=0.5,
+    multi_speaker=True, max_num_speaker=1000, speaker_embedding_size=128,
+    multi_lingual=True, max_num_language=100, language_embedding_size=128, language_net_hidden=128,
+    use_external_embed=False, external_embed_dim=1024,
     max_generation_frames=1100,
-    max_eval_batches=20,
-    max_eval_sample_length=1000,
-    eval_sample_per_speaker=4,
-
-    vocab_size=6000,
-    embed_size=512,
-    encoder_hidden=512,
-    decoder_hidden=768,
-    n_encoder_layer=6,
-    n_decoder_layer=6,
-    n_attention_head=8,
-    transformer_dropout_rate=0.1,
-    decoder_dropout_rate=0.5,
-    prenet_hidden=256,
-    postnet_hidden=512,
-    n_postnet_layer=5,
-
-    data_format="nlti",
-    use_sos=True,
-    bucket_size=512,
-    shuffle_training_data=True,
-    batch_frame_limit=8000,
-    batch_frame_quad_limit=7000000,
-    balanced_training=True,
-    lg_prob_scale=0.2,
-    adapt_start_step=30000,
-    adapt_end_step=30000,
-    final_adapt_rate=0.25,
-    data_warmup_steps=30000,
-    target_length_lower_bound=240,
-    target_length_upper_bound=800,
-
-    reg_weight=5e-9,
-
-    multi_speaker=True,
-    max_num_speaker=1000,
-    speaker_embedding_size=128,
-
-    multi_lingual=True,
-    max_num_language=100,
-    language_net_hidden=128,
-    language_embedding_size=128,
-
-    warmup_steps=50000,
-    max_lr=1e-3,
-    min_lr=1e-5,
-    lr_decay_step=550000,
-    lr_decay_rate=1e-2,
-    adam_eps=5e-8,
-
-    external_embed_dim=1024,
-    use_external_embed=False,
-
-    # ---- MI355X build additions (not in the reference) ----
-    compute_dtype="fp32",
-    guided_attention_weight=0.0,
-    guided_attention_sigma=0.2,
-    freeze_encoder=False,
 )
 
-# pristine copy of the defaults above (hparams is a mutable global that drivers override with --hparams)
+# loss / Adam / LambdaLR (transformer/tacotron.py:136-179, train.py:130-131)
+_OPTIMISER = dict(
+    reg_weight=5e-9, adam_eps=5e-8,
+    max_lr=1e-3, min_lr=1e-5, warmup_steps=50000, lr_decay_step=550000, lr_decay_rate=1e-2,
+)
+
+# feeders: sampling, curriculum and the two packing caps (dataloader.py)
+_BATCHING = dict(
+    data_format="nlti", use_sos=True, shuffle_training_data=True,
+    bucket_size=512, batch_frame_limit=8000, batch_frame_quad_limit=7000000,
+    balanced_training=True, lg_prob_scale=0.2,
+    adapt_start_step=30000, adapt_end_step=30000, final_adapt_rate=0.25,
+    data_warmup_steps=30000, target_length_lower_bound=240, target_length_upper_bound=800,
+)
+
+# evaluation driver
+_EVAL = dict(max_eval_batches=20, max_eval_sample_length=1000, eval_sample_per_speaker=4)
+
+# mel front end / Griffin-Lim vocoder of the reference's CPU glue (16 kHz, 50 ms windows every 12.5 ms)
+_SIGNAL = dict(
+    sr=_SAMPLE_RATE, n_fft=2048, frame_length_ms=50, frame_shift_ms=12.5,
+    win_length=int(_SAMPLE_RATE * 0.05), hop_length=int(_SAMPLE_RATE * 0.0125),
+    preemphasis=0.97, ref_db=20, max_db=100, max_abs_value=4.0, symmetric_mel=True,
+    n_iter=60, power=1.5,
+)
+
+# MI355X build additions (not in the reference)
+_BUILD = dict(compute_dtype="fp32", guided_attention_weight=0.0, guided_attention_sigma=0.2, freeze_encoder=False)
+
+_GROUPS = (_MODEL, _OPTIMISER, _BATCHING, _EVAL, _SIGNAL, _BUILD)
+assert sum(len(g) for g in _GROUPS) == len(set().union(*_GROUPS)), "a hyper-parameter is defined in two groups"
+
+hparams = HParams(**{k: v for g in _GROUPS for k, v in g.items()})
+
+# pristine copy of the defaults (hparams is a mutable global that drivers override; tests reset from this)
 DEFAULTS = dict(hparams.values())

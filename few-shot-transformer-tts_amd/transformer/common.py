@@ -66,19 +66,15 @@ def mask_reduce(loss, lengths, per_sample=False):
 
 
 def truncated_normal(tensor, mean=0, std=0.5):
-    """Best-of-8 resampling inside (-2 std, 2 std) (common.py:90-105)."""
-    with torch.no_grad():
-        tmp = tensor.new_empty(tuple(tensor.shape) + (8,)).normal_(mean=mean, std=std)
-        valid = (tmp < 2 * std) & (tmp > -2 * std)
-        ind = valid.max(-1, keepdim=True)[1]
-        return tmp.gather(-1, ind).squeeze(-1)
+    """A new tensor shaped like `tensor`, drawn from N(mean, std) truncated to two standard deviations (the distribution
+    the reference approximates with best-of-8 resampling, common.py:90-105; only the distribution is contractual)."""
+    out = torch.empty_like(tensor, dtype=torch.float32)
+    torch.nn.init.trunc_normal_(out, mean=float(mean), std=float(std), a=mean - 2.0 * std, b=mean + 2.0 * std)
+    return out
 
 
 def variance_scaling_initializer(tensor, factor=2.0):
-    """FAN_AVG truncated normal, std = sqrt(1.3 * factor / n) (common.py:108-124)."""
-    fan_in, fan_out = tensor.shape[1], tensor.shape[0]
-    for dim in tensor.shape[2:]:
-        fan_in *= dim
-        fan_out *= dim
-    n = (fan_in + fan_out) / 2
-    return truncated_normal(tensor, std=float(np.sqrt(1.3 * factor / n)))
+    """TF-style variance scaling, FAN_AVG mode: truncated normal with std = sqrt(1.3 * factor / ((fan_in + fan_out) / 2)),
+    fans counted over the receptive field for conv weights (common.py:108-124)."""
+    fan_in, fan_out = torch.nn.init._calculate_fan_in_and_fan_out(tensor)
+    return truncated_normal(tensor, std=(1.3 * factor * 2.0 / (fan_in + fan_out)) ** 0.5)

@@ -212,24 +212,29 @@ def compute_loss(model, mel_targets, target_lengths, outputs, hparams):
     return res
 
 
+# name rule -> initialiser, first match wins (tacotron.py:161-173): byte embedding ~ N(0, 1); speaker / language tables ~
+# truncated N(0, 0.5); every other weight matrix / conv kernel variance-scaled; biases zero; LayerNorm / BatchNorm affine
+# parameters keep torch's defaults
+_INIT_RULES = (
+    (lambda n: n == "encoder.embed.weight", lambda t: torch.randn(t.shape)),
+    (lambda n: n in ("encoder.speaker_embed.weight", "encoder.language_embed.weight"), lambda t: truncated_normal(t, 0, 0.5)),
+    (lambda n: "weight" in n and "layer_norm" not in n and "batchnorm" not in n, variance_scaling_initializer),
+    (lambda n: "bias" in n, torch.zeros_like),
+)
+
+
 def initialize_variables(model):
-    """TF-style init (tacotron.py:161-173); host-side, once."""
-    state_dict = model.state_dict()
-    updates = {}
-    for name, tensor in state_dict.items():
-        if name == 'encoder.embed.weight':
-            updates[name] = torch.normal(mean=0, std=1, size=tensor.shape).to(tensor.device)
-        elif name in ['encoder.speaker_embed.weight', 'encoder.language_embed.weight']:
-            updates[name] = truncated_normal(tensor, mean=0, std=0.5).to(tensor.device)
-        elif ('weight' in name) and ('layer_norm' not in name and 'batchnorm' not in name):
-            updates[name] = variance_scaling_initializer(tensor).to(tensor.device)
-        elif 'bias' in name:
-            updates[name] = torch.zeros_like(tensor)
-    model.load_state_dict(updates, strict=False)
+    """TF-style initialisation of a freshly constructed Tacotron, in place, once, on the host."""
+    with torch.no_grad():
+        for name, tensor in model.state_dict().items():
+            for applies, make in _INIT_RULES:
+                if applies(name):
+                    tensor.copy_(make(tensor).to(tensor.device, tensor.dtype))
+                    break
 
 
 def learning_rate_schedule(global_step, hp):
-    """tacotron.py:176-179."""
-    step = max(global_step - hp.warmup_steps, 0)
-    lr_rate = hp.lr_decay_rate ** (step / hp.lr_decay_step)
-    return max(hp.min_lr / hp.max_lr, lr_rate)
+    """LambdaLR multiplier (tacotron.py:176-179): 1 through the first warmup_steps, then an exponential decay that
+    reaches lr_decay_rate after lr_decay_step further steps, floored at min_lr / max_lr."""
+    past_warmup = max(global_step - hp.warmup_steps, 0)
+    return max(hp.lr_decay_rate ** (past_warmup / hp.lr_decay_step), hp.min_lr / hp.max_lr)
