@@ -46,54 +46,48 @@ def _no_standalone(name):
         "%s runs inside libb2s_hip as part of Encoder/Decoder (csrc/engine.hip); call model.encoder / model.decoder" % name)
 
 
-class TransformerEncoder(nn.Module):
+class _Stack(nn.Module):
+    """Parameter holder of a pre-LayerNorm Transformer stack.  The sub-layer lists are registered in `_LISTS` order, which
+    (together with the attribute names) IS the state_dict layout the HIP engine and published checkpoints rely on
+    (checked against the layout captured from the reference: tests/golden/state_layout_*.json)."""
+    _LISTS = ()
+    _NAME = ""
+
+    def __init__(self, input_size, width, n_layers, hparams, cross):
+        super(_Stack, self).__init__()
+        dtype = getattr(hparams, "compute_dtype", "fp32")
+        heads, p_drop = hparams.n_attention_head, hparams.transformer_dropout_rate
+        for name in self._LISTS:
+            setattr(self, name, nn.ModuleList())
+        self.pe_scale = nn.Parameter(torch.tensor(1.0))           # learnable scale of the sinusoid table
+        self.dropout = nn.Dropout(p_drop)
+        for i in range(n_layers):
+            w_in = input_size if i == 0 else width                 # layer 0 runs at the width it is fed (decoder: memory width)
+            self.attn_layer_norms.append(HipLayerNorm(w_in, eps=1e-6))
+            self.self_attentions.append(MultiheadAttention(w_in, w_in, True, heads, p_drop, dtype))
+            if cross:
+                self.encdec_layer_norms.append(HipLayerNorm(w_in, eps=1e-6))
+                self.encdec_attentions.append(MultiheadAttention(width, width, False, heads, p_drop, dtype))
+            self.ffn_layer_norms.append(HipLayerNorm(width, eps=1e-6))
+            self.ffn_layers.append(FFNLayer(width, 4 * width, width, p_drop, dtype))
+        self.output_layer_norm = HipLayerNorm(width, eps=1e-6)
+
+
+class TransformerEncoder(_Stack):
+    _LISTS = ("self_attentions", "attn_layer_norms", "ffn_layers", "ffn_layer_norms")
+
     def __init__(self, input_size, hparams):
-        super(TransformerEncoder, self).__init__()
-        cd = getattr(hparams, "compute_dtype", "fp32")
-        self.self_attentions = nn.ModuleList()
-        self.attn_layer_norms = nn.ModuleList()
-        self.ffn_layers = nn.ModuleList()
-        self.ffn_layer_norms = nn.ModuleList()
-        self.pe_scale = nn.Parameter(torch.tensor(1.0))
-        self.dropout = nn.Dropout(hparams.transformer_dropout_rate)
-        hidden_size = hparams.encoder_hidden
-        for layer in range(hparams.n_encoder_layer):
-            in_size = input_size if layer == 0 else hidden_size
-            self.attn_layer_norms.append(HipLayerNorm(in_size, eps=1e-6))
-            self.self_attentions.append(MultiheadAttention(in_size, in_size, True, hparams.n_attention_head,
-                                                           hparams.transformer_dropout_rate, cd))
-            self.ffn_layer_norms.append(HipLayerNorm(hidden_size, eps=1e-6))
-            self.ffn_layers.append(FFNLayer(hidden_size, hidden_size * 4, hidden_size, hparams.transformer_dropout_rate, cd))
-        self.output_layer_norm = HipLayerNorm(hidden_size, eps=1e-6)
+        super(TransformerEncoder, self).__init__(input_size, hparams.encoder_hidden, hparams.n_encoder_layer, hparams, cross=False)
 
     def forward(self, inputs, input_lengths):
         _no_standalone("TransformerEncoder")
 
 
-class TransformerDecoder(nn.Module):
+class TransformerDecoder(_Stack):
+    _LISTS = ("self_attentions", "attn_layer_norms", "encdec_attentions", "encdec_layer_norms", "ffn_layers", "ffn_layer_norms")
+
     def __init__(self, input_size, hparams):
-        super(TransformerDecoder, self).__init__()
-        cd = getattr(hparams, "compute_dtype", "fp32")
-        self.self_attentions = nn.ModuleList()
-        self.attn_layer_norms = nn.ModuleList()
-        self.encdec_attentions = nn.ModuleList()
-        self.encdec_layer_norms = nn.ModuleList()
-        self.ffn_layers = nn.ModuleList()
-        self.ffn_layer_norms = nn.ModuleList()
-        self.pe_scale = nn.Parameter(torch.tensor(1.0))
-        self.dropout = nn.Dropout(hparams.transformer_dropout_rate)
-        hidden_size = hparams.decoder_hidden
-        for layer in range(hparams.n_decoder_layer):
-            in_size = input_size if layer == 0 else hidden_size
-            self.attn_layer_norms.append(HipLayerNorm(in_size, eps=1e-6))
-            self.self_attentions.append(MultiheadAttention(in_size, in_size, True, hparams.n_attention_head,
-                                                           hparams.transformer_dropout_rate, cd))
-            self.encdec_layer_norms.append(HipLayerNorm(in_size, eps=1e-6))
-            self.encdec_attentions.append(MultiheadAttention(hidden_size, hidden_size, False, hparams.n_attention_head,
-                                                             hparams.transformer_dropout_rate, cd))
-            self.ffn_layer_norms.append(HipLayerNorm(hidden_size, eps=1e-6))
-            self.ffn_layers.append(FFNLayer(hidden_size, hidden_size * 4, hidden_size, hparams.transformer_dropout_rate, cd))
-        self.output_layer_norm = HipLayerNorm(hidden_size, eps=1e-6)
+        super(TransformerDecoder, self).__init__(input_size, hparams.decoder_hidden, hparams.n_decoder_layer, hparams, cross=True)
 
     def forward(self, inputs, targets, input_lengths, target_lengths):
         _no_standalone("TransformerDecoder")
