@@ -87,7 +87,8 @@ template <bool TA, bool TB, bool GATHER, int NB>
 __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, float* splitk_ws, int bx, int by, int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform -> SGPR: DMA destinations / branches on it are scalar
     const int li = lane & 15, lg = lane >> 4;
     constexpr int BN = NB * 32;                      // two waves along N, NB 16-column MFMA blocks each
     const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * (NB * 16);
@@ -116,6 +117,32 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
     }
     const long stepA = TA ? (long)BK * g.A.ld : BK, stepB = TB ? (long)BK * g.B.ld : BK;
     const int limA = TA ? g.A.R : g.A.C, limB = TB ? g.B.R : g.B.C;      // bound of the reduction index
+    // Fast DMA issue for K steps that lie completely inside the matrices (measured with s_memtime: the address arithmetic
+    // of the generic issue below -- 64-bit pointer math, bound checks, zero-page selects, ~10 VALU per instruction -- cost
+    // as much as a whole 32-deep half step of MFMAs on every wave).  A lane's source address is
+    //     (operand base + K step * stride)  [wave-uniform, SGPRs]  +  a 32-bit per-lane byte offset fixed for the launch,
+    // so a step costs no VALU work at all.  Rows / columns past the M / N edge are clamped to the last valid one: they only
+    // feed output rows / columns that are never stored.  Only a partial last K step needs zero fill -> generic path.
+    unsigned goffA[4], goffB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const LaneSrc s = lane_src<TA, true>(wave * 4 + i, lane);
+        if (TA) goffA[i] = 2u * (unsigned)((long)s.r * g.A.ld + min(m0 + s.c, max(g.A.C - 8, 0)));
+        else    goffA[i] = 2u * (unsigned)((long)min(m0 + s.r, g.A.R - 1) * g.A.ld + s.c);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const LaneSrc s = lane_src<TB, false>(wave * 2 + i, lane);
+        if (TB) goffB[i] = 2u * (unsigned)((long)s.r * g.B.ld + min(n0 + s.c, max(g.B.C - 8, 0)));
+        else    goffB[i] = 2u * (unsigned)((long)min(n0 + s.r, g.B.R - 1) * g.B.ld + s.c);
+    }
+    const int nfull = g.K / BK;                                          // K steps completely in bounds
+    const bool fast_ok = !GATHER && nfull > 0 && (TA ? (g.A.C >= 8 && (g.A.C & 7) == 0) : true) && (TB ? (g.B.C >= 8 && (g.B.C & 7) == 0) : true) &&
+                         (TA ? (long)g.A.R * g.A.ld : (long)g.A.R * g.A.ld) < (1L << 30) && (long)g.B.R * g.B.ld < (1L << 30);
+    // B instructions 12..15 of a 96-column tile would fill image rows no wave reads: waves 6, 7 skip them (4 DMAs per step)
+    // (K-contiguous B only: a reduction-major B instruction covers 4 k rows x all 128 columns, every one is needed)
+    const bool b_active0 = NB == 4 || TB || wave * 2 + 0 < 12, b_active1 = NB == 4 || TB || wave * 2 + 1 < 12;
+    const bool six = b_active0 && b_active1;                             // this wave issues 6 (else 4) DMA instructions per step
 
     const int nk_all = (g.K + BK - 1) / BK;
     const int per = (nk_all + g.splitk - 1) / g.splitk;
@@ -130,8 +157,19 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
 #ifdef B2S_EXP_NODMA
         return;
 #endif
-        const int kb = kt < kt_end ? kt * BK : (1 << 28);
         unsigned char* sbase = smem_raw + slot * STAGE_BYTES;
+        if (fast_ok && (kt < nfull || kt >= kt_end)) {                   // (steps past the end re-fetch the last full one: never consumed)
+            const long ks = min(kt, nfull - 1);
+            const char* sa = reinterpret_cast<const char*>(Ab) + ks * stepA * 2;
+            const char* sb = reinterpret_cast<const char*>(Bb) + ks * stepB * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(sa + goffA[i]), (lptr_t)(sbase + (wave * 4 + i) * 1024), 16, 0, B2S_DMA_AUX);
+            if (b_active0) __builtin_amdgcn_global_load_lds((gptr_t)(sb + goffB[0]), (lptr_t)(sbase + A_BYTES + (wave * 2 + 0) * 1024), 16, 0, B2S_DMA_AUX);
+            if (b_active1) __builtin_amdgcn_global_load_lds((gptr_t)(sb + goffB[1]), (lptr_t)(sbase + A_BYTES + (wave * 2 + 1) * 1024), 16, 0, B2S_DMA_AUX);
+            return;
+        }
+        const int kb = kt < kt_end ? kt * BK : (1 << 28);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = wave * 4 + i;
@@ -150,6 +188,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = wave * 2 + i;
+            if (!(i == 0 ? b_active0 : b_active1)) continue;
             const bf16_t* sb;
             if (GATHER) {
                 const LaneSrc s = lane_src<TB, false>(idx, lane);
@@ -221,7 +260,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
 #pragma unroll
     for (int p = 0; p < NSTAGE; ++p) issue(kt0 + p, p);
     bf16x8_t fa0[4], fb0[4], fa1[4], fb1[4];
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (NSTAGE - 1)) : "memory");
+    if (six) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     B2S_READ8(fa0, fb0, 0, 0)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -237,7 +276,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave no longer reads stage kt
         // stage kt+1 landed (own DMAs; the 6 of stage kt+2 stay in flight) ... for every wave, and slot `slot` is free
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (six) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // second half: first-half fragments of the next stage fly under the second-half MFMAs; the DMA issue of stage kt+3
         // (6 instructions + their address arithmetic) comes AFTER the MFMAs have been issued, so its VALU work runs while
