@@ -150,6 +150,7 @@ def main():
     for i in range(args.steps):
         vals = trainer.train_step(batches[i % len(batches)])
     ev1.record()
+    host_s = time.perf_counter() - t0                  # launch loop only: ~= elapsed means the step is host- (launch-) bound
     sync()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
@@ -177,7 +178,7 @@ def main():
                                       "dropout on, single speaker/language%s" % (B, S, T, ", frozen encoder, guided-attention weight 1.0, "
                                                                                  "batches drawn from a 30-utterance pool" if finetune else ""),
                           "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world},
-               "device_ms_per_step": round(dev_ms / args.steps, 3)}
+               "device_ms_per_step": round(dev_ms / args.steps, 3), "host_launch_ms_per_step": round(host_s / args.steps * 1e3, 3)}
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS
         ach = step_flops / (ms * 1e-3) / 1e12
         out["roofline_step"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",

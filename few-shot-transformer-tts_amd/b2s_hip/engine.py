@@ -85,6 +85,7 @@ class HipEngine(object):
         if mine != theirs:
             raise L.B2SError("module state_dict layout differs from the HIP model layout")
         self._sig = None
+        self._slots = None
         self._versions = None
         self._gflat = None
         self._gviews = {}
@@ -103,9 +104,18 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ binding
     def _tensors(self):
-        sd = dict(self.root.named_parameters())
-        sd.update(dict(self.root.named_buffers()))
-        return [sd[n] for n in self.names]
+        # (owning module's _parameters / _buffers dict, attribute) per bound tensor, resolved once: walking
+        # named_parameters() on every call cost ~0.8 ms x 4 calls per training step, a third of the host's launch time.
+        # Looking the attribute up each time still sees a Parameter object that was replaced on its module.
+        if self._slots is None:
+            mods = dict(self.root.named_modules())
+            slots = []
+            for n in self.names:
+                owner, _, attr = n.rpartition(".")
+                m = mods[owner]
+                slots.append((m._parameters if attr in m._parameters else m._buffers, attr))
+            self._slots = slots
+        return [d[a] for d, a in self._slots]
 
     def ensure_bound(self):
         ts = self._tensors()

@@ -49,6 +49,7 @@ __device__ inline void gemm_wave_epilogue(GemmArgs g, f32x4_t (&acc)[4][NB], flo
             for (int b = 0; b < NB; ++b) stg[row * 64 + ((b * 16 + li) ^ (((row >> 2) & 1) << 4))] = acc[a][b][r];
         }
     // (same-wave LDS hand-off: DS operations of one wave complete in order)
+    __builtin_amdgcn_sched_barrier(0);                     // the accumulators die here, before the operand prefetch below claims registers
     const long cbase = zo * g.cs_o + zi * g.cs_i;
     float* Cf = reinterpret_cast<float*>(g.C);
     bf16_t* Ct = reinterpret_cast<bf16_t*>(g.C);
@@ -62,8 +63,39 @@ __device__ inline void gemm_wave_epilogue(GemmArgs g, f32x4_t (&acc)[4][NB], flo
     float bv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bv[j] = (e.bias && n + j < g.N) ? e.bias[n + j] : 0.f;
+    // Global operands of the passes below (fp32 residual rows, the bf16 ReLU-mask rows, the C rows of an accumulate store)
+    // are fetched four passes at a time, ahead of those passes: C may alias the residual (in-place h += ...), so the
+    // compiler cannot lift a pass's loads above the previous pass's stores, and each pass would expose a full memory
+    // latency (measured, operands cold in HBM: 37 -> 24 us on the 8148x768x768 residual GEMM; no difference when they
+    // are cache-resident).  A lane reads and writes only its own addresses, so the early loads see the same data.
+    const bool full = n + 8 <= g.N;
+    const bool lane_ok = n < g.N && cchunk < NB * 2;
+    const bool pre_res = e.residual && full && (e.ldr & 3) == 0;
+    const bool pre_acc = !e.residual && vec_ok && full && g.c_fp32 && e.accumulate;
+    const bool pre_aux = aux && full && (e.ld_aux & 7) == 0;
+    constexpr int PG = 4;                                  // passes per prefetch group (8 at once does not fit the register budget)
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int pg = 0; pg < 8; pg += PG) {
+    float4 q0[PG], q1[PG];
+    uint4 qa[PG];
+#pragma unroll
+    for (int pp = 0; pp < PG; ++pp) {
+        const int m = mb + (pg + pp) * 8 + (lane >> 3);
+        q0[pp] = q1[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+        qa[pp] = make_uint4(0, 0, 0, 0);
+        if (m >= g.M || !lane_ok) continue;
+        if (pre_res) {
+            q0[pp] = *reinterpret_cast<const float4*>(e.residual + (long)m * e.ldr + n);
+            q1[pp] = *reinterpret_cast<const float4*>(e.residual + (long)m * e.ldr + n + 4);
+        } else if (pre_acc) {
+            q0[pp] = *reinterpret_cast<const float4*>(Cf + cbase + (long)m * g.ldc + n);
+            q1[pp] = *reinterpret_cast<const float4*>(Cf + cbase + (long)m * g.ldc + n + 4);
+        }
+        if (pre_aux) qa[pp] = *reinterpret_cast<const uint4*>(aux + (long)m * e.ld_aux + n);
+    }
+#pragma unroll
+    for (int pp = 0; pp < PG; ++pp) {
+        const int p = pg + pp;
         const int row = p * 8 + (lane >> 3);
         const int m = mb + row;
         const float4 v0 = *reinterpret_cast<const float4*>(stg + row * 64 + ((cchunk * 8) ^ (((row >> 2) & 1) << 4)));
@@ -76,10 +108,9 @@ __device__ inline void gemm_wave_epilogue(GemmArgs g, f32x4_t (&acc)[4][NB], flo
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        const bool full = n + 8 <= g.N;
         if (aux) {
-            if (full && (e.ld_aux & 7) == 0) {
-                const uint4 u = *reinterpret_cast<const uint4*>(aux + (long)m * e.ld_aux + n);
+            if (pre_aux) {
+                const uint4 u = qa[pp];
                 const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -98,9 +129,8 @@ __device__ inline void gemm_wave_epilogue(GemmArgs g, f32x4_t (&acc)[4][NB], flo
             for (int j = 0; j < 8; ++j) v[j] = b2s_keep(dcfg, idx + j) ? v[j] * dcfg.scale : 0.f;
         }
         if (e.residual) {
-            if (full && (e.ldr & 3) == 0) {
-                const float4 r0 = *reinterpret_cast<const float4*>(e.residual + (long)m * e.ldr + n);
-                const float4 r1 = *reinterpret_cast<const float4*>(e.residual + (long)m * e.ldr + n + 4);
+            if (pre_res) {
+                const float4 r0 = q0[pp], r1 = q1[pp];
                 v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
             } else {
 #pragma unroll
@@ -120,7 +150,7 @@ __device__ inline void gemm_wave_epilogue(GemmArgs g, f32x4_t (&acc)[4][NB], flo
                 float4* dst = reinterpret_cast<float4*>(Cf + off);
                 float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
                 if (e.accumulate) {
-                    const float4 c0 = dst[0], c1 = dst[1];
+                    const float4 c0 = pre_acc ? q0[pp] : dst[0], c1 = pre_acc ? q1[pp] : dst[1];
                     o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
                 }
                 dst[0] = o0; dst[1] = o1;
@@ -140,5 +170,6 @@ __device__ inline void gemm_wave_epilogue(GemmArgs g, f32x4_t (&acc)[4][NB], flo
                 else Ct[o] = f2bf(v[j]);
             }
         }
+    }
     }
 }

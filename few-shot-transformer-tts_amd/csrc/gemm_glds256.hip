@@ -6,8 +6,14 @@
 //   * 256x128 tiles move 25 % fewer operand bytes per FLOP, and
 //   * K-contiguous operands are fetched in whole 128-byte lines: BK = 64, one LDS-DMA instruction = 8 rows x 128 B
 //     (16 rows x 64 B half lines stream at ~28 B/clk/CU, whole lines at ~47).
-// One workgroup = 8 waves (4 along M x 2 along N, 64x64 accumulators each, the same 4x4 MFMA block as the 128x128 kernel),
-// one workgroup per CU, 3-stage LDS ring of 48 KB stages (two stages in flight), one s_barrier per 64-deep K step.
+// One workgroup = 8 MFMA waves (4 along M x 2 along N, 64x64 accumulators each, the same 4x4 MFMA block as the 128x128
+// kernel) + 4 producer waves (one per SIMD) that do nothing but issue the LDS-DMA loads; one workgroup per CU, 3-stage LDS
+// ring of 48 KB stages (two stages in flight), one s_barrier per 64-deep K step shared by both roles.
+// Why producer waves (s_memtime attribution, profiles/README.md): a wave that issues an LDS-DMA instruction blocks until
+// the texture path accepts it, ~400 clocks per K step for 6 instructions, and all 8 waves hit that phase together right
+// after the barrier, so the matrix pipe idled.  With the issue moved to waves that have nothing else to do the MFMA waves
+// never touch the vector-memory queue: 592 -> 660 TFLOP/s on the step's shape mix, 768 -> 965 on 8148x768x3072.
+// (12 waves = 3 per SIMD cap the kernel at 168 VGPRs: 148-166 used.)
 //
 // LDS images (the LDS-DMA writes lane-linearly, so every swizzle is applied on the SOURCE address):
 //   K-contiguous operand ("N layout"):  [rows][64 k], 128 B rows, physical 16-B chunk = chunk ^ ((row >> 1) & 7)
@@ -23,7 +29,16 @@
 #define B2S_DMA_AUX 0       // cache-policy bits of the LDS-DMA loads (sc0 = 1, nt = 2, sc1 = 16); measured: no policy beats the default
 #endif
 
+#ifndef B2S_NPROD
+#define B2S_NPROD 4         // >0: that many extra waves per workgroup do nothing but issue the LDS-DMA loads (producer / consumer split)
+#endif
+
 namespace t256 {
+
+constexpr int NPROD = B2S_NPROD;
+constexpr int nprod_of(bool gather) { return gather ? 0 : NPROD; }
+constexpr int nthreads_of(bool gather) { return 512 + 64 * nprod_of(gather); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 constexpr int BM = 256, BK = 64, NSTAGE = 3;            // BN = 128 or 96 (template parameter NB = BN / 32)
 constexpr int A_BYTES = BM * BK * 2, B_BYTES = 128 * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;     // 32 KB + 16 KB (12 KB used at BN = 96)
@@ -86,6 +101,9 @@ __device__ inline int xcd_tile_id(int orig, int nwg) {
 template <bool TA, bool TB, bool GATHER, int NB>
 __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, float* splitk_ws, int bx, int by, int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // conv-gather operands keep the DMA issue on the MFMA waves: their per-chunk address arithmetic (two divisions, a length
+    // lookup) serialised on 4 producer waves costs more than the blocking issue does (60 -> 84 us on the postnet GEMMs)
+    constexpr int NP = nprod_of(GATHER);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform -> SGPR: DMA destinations / branches on it are scalar
@@ -100,17 +118,22 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
 
     // DMA issue: wave w owns A instructions w*4 .. w*4+3 and B instructions w*2, w*2+1 of every stage (6 per wave).
     // Plain operands: the source address of a lane is affine in the stage index -> pointer at stage 0 + per-stage step.
-    const bf16_t* pa[4]; const bf16_t* pb[2];
-    int ka[4], kb_[2];            // reduction offset this lane's chunk covers inside a stage; -1 = never valid
+    // With producer waves (NP > 0) the 32 A + 16 (12 at BN = 96, K-contiguous B) instructions are dealt to waves 8.. instead.
+    constexpr int NBI = (NB == 4 || TB) ? 16 : 12;
+    constexpr int NPD = NP ? NP : 1, NIA = NP ? 32 / NPD : 4, NIB = NP ? NBI / NPD : 2, IPW = NIA + NIB;
+    const int iw = NP ? max(wave - 8, 0) : wave;
+    const int ia0 = iw * NIA, ib0 = iw * NIB;
+    const bf16_t* pa[NIA]; const bf16_t* pb[NIB];
+    int ka[NIA], kb_[NIB];        // reduction offset this lane's chunk covers inside a stage; -1 = never valid
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const LaneSrc s = lane_src<TA, true>(wave * 4 + i, lane);
+    for (int i = 0; i < NIA; ++i) {
+        const LaneSrc s = lane_src<TA, true>(ia0 + i, lane);
         if (TA) { ka[i] = (m0 + s.c) < g.A.C ? s.r : -1; pa[i] = Ab + (long)s.r * g.A.ld + m0 + s.c; }
         else    { ka[i] = (m0 + s.r) < g.A.R ? s.c : -1; pa[i] = Ab + (long)(m0 + s.r) * g.A.ld + s.c; }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const LaneSrc s = lane_src<TB, false>(wave * 2 + i, lane);
+    for (int i = 0; i < NIB; ++i) {
+        const LaneSrc s = lane_src<TB, false>(ib0 + i, lane);
         // (at BN = 96 the last quarter of the 128-wide B image belongs to no wave: it is filled from the zero page)
         if (TB) { kb_[i] = ((n0 + s.c) < g.B.C && s.c < BN) ? s.r : -1; pb[i] = Bb + (long)s.r * g.B.ld + n0 + s.c; }
         else    { kb_[i] = ((n0 + s.r) < g.B.R && s.r < BN) ? s.c : -1; pb[i] = Bb + (long)(n0 + s.r) * g.B.ld + s.c; }
@@ -123,16 +146,16 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
     //     (operand base + K step * stride)  [wave-uniform, SGPRs]  +  a 32-bit per-lane byte offset fixed for the launch,
     // so a step costs no VALU work at all.  Rows / columns past the M / N edge are clamped to the last valid one: they only
     // feed output rows / columns that are never stored.  Only a partial last K step needs zero fill -> generic path.
-    unsigned goffA[4], goffB[2];
+    unsigned goffA[NIA], goffB[NIB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const LaneSrc s = lane_src<TA, true>(wave * 4 + i, lane);
+    for (int i = 0; i < NIA; ++i) {
+        const LaneSrc s = lane_src<TA, true>(ia0 + i, lane);
         if (TA) goffA[i] = 2u * (unsigned)((long)s.r * g.A.ld + min(m0 + s.c, max(g.A.C - 8, 0)));
         else    goffA[i] = 2u * (unsigned)((long)min(m0 + s.r, g.A.R - 1) * g.A.ld + s.c);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const LaneSrc s = lane_src<TB, false>(wave * 2 + i, lane);
+    for (int i = 0; i < NIB; ++i) {
+        const LaneSrc s = lane_src<TB, false>(ib0 + i, lane);
         if (TB) goffB[i] = 2u * (unsigned)((long)s.r * g.B.ld + min(n0 + s.c, max(g.B.C - 8, 0)));
         else    goffB[i] = 2u * (unsigned)((long)min(n0 + s.r, g.B.R - 1) * g.B.ld + s.c);
     }
@@ -141,7 +164,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
                          (TA ? (long)g.A.R * g.A.ld : (long)g.A.R * g.A.ld) < (1L << 30) && (long)g.B.R * g.B.ld < (1L << 30);
     // B instructions 12..15 of a 96-column tile would fill image rows no wave reads: waves 6, 7 skip them (4 DMAs per step)
     // (K-contiguous B only: a reduction-major B instruction covers 4 k rows x all 128 columns, every one is needed)
-    const bool b_active0 = NB == 4 || TB || wave * 2 + 0 < 12, b_active1 = NB == 4 || TB || wave * 2 + 1 < 12;
+    const bool b_active0 = NP || NB == 4 || TB || wave * 2 + 0 < 12, b_active1 = NP || NB == 4 || TB || wave * 2 + 1 < 12;
     const bool six = b_active0 && b_active1;                             // this wave issues 6 (else 4) DMA instructions per step
 
     const int nk_all = (g.K + BK - 1) / BK;
@@ -163,16 +186,18 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
             const char* sa = reinterpret_cast<const char*>(Ab) + ks * stepA * 2;
             const char* sb = reinterpret_cast<const char*>(Bb) + ks * stepB * 2;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(sa + goffA[i]), (lptr_t)(sbase + (wave * 4 + i) * 1024), 16, 0, B2S_DMA_AUX);
-            if (b_active0) __builtin_amdgcn_global_load_lds((gptr_t)(sb + goffB[0]), (lptr_t)(sbase + A_BYTES + (wave * 2 + 0) * 1024), 16, 0, B2S_DMA_AUX);
-            if (b_active1) __builtin_amdgcn_global_load_lds((gptr_t)(sb + goffB[1]), (lptr_t)(sbase + A_BYTES + (wave * 2 + 1) * 1024), 16, 0, B2S_DMA_AUX);
+            for (int i = 0; i < NIA; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(sa + goffA[i]), (lptr_t)(sbase + (ia0 + i) * 1024), 16, 0, B2S_DMA_AUX);
+#pragma unroll
+            for (int i = 0; i < NIB; ++i)
+                if (NP || (i == 0 ? b_active0 : b_active1))
+                    __builtin_amdgcn_global_load_lds((gptr_t)(sb + goffB[i]), (lptr_t)(sbase + A_BYTES + (ib0 + i) * 1024), 16, 0, B2S_DMA_AUX);
             return;
         }
         const int kb = kt < kt_end ? kt * BK : (1 << 28);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = wave * 4 + i;
+        for (int i = 0; i < NIA; ++i) {
+            const int idx = ia0 + i;
             const bf16_t* sa;
             if (GATHER) {
                 const LaneSrc s = lane_src<TA, true>(idx, lane);
@@ -186,9 +211,9 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
             __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(sbase + idx * 1024), 16, 0, B2S_DMA_AUX);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = wave * 2 + i;
-            if (!(i == 0 ? b_active0 : b_active1)) continue;
+        for (int i = 0; i < NIB; ++i) {
+            const int idx = ib0 + i;
+            if (!NP && !(i == 0 ? b_active0 : b_active1)) continue;
             const bf16_t* sb;
             if (GATHER) {
                 const LaneSrc s = lane_src<TB, false>(idx, lane);
@@ -256,11 +281,32 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
         }                                                                                                          \
     }
 
-    // prologue: three stages in flight, stage 0 landed and published, its first-half fragments in registers
+    if (NP && wave >= 8) {
+        // Producer wave: keeps two stages in flight and never touches the matrix pipe.  Barrier k of the workgroup (k = 0 in
+        // the prologue) says "stage k has landed and every consumer is done with stage k - 1"; the freed slot is refilled
+        // right behind it.  The consumers run the same barrier sequence and never wait on a DMA issue.
 #pragma unroll
-    for (int p = 0; p < NSTAGE; ++p) issue(kt0 + p, p);
+        for (int p = 0; p < NSTAGE; ++p)
+            if (p < nk) issue(kt0 + p, p);
+        if (nk >= 3) wait_vm<2 * IPW>(); else if (nk == 2) wait_vm<IPW>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        int slot = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 2 < nk) wait_vm<IPW>(); else wait_vm<0>();          // stage kt + 1 landed (stage kt + 2 may still fly)
+            __builtin_amdgcn_s_barrier();
+            if (kt + NSTAGE < nk) issue(kt0 + kt + NSTAGE, slot);
+            slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+        }
+        return;
+    }
+
+    // prologue: three stages in flight, stage 0 landed and published, its first-half fragments in registers
+    if (!NP) {
+#pragma unroll
+        for (int p = 0; p < NSTAGE; ++p) issue(kt0 + p, p);
+    }
     bf16x8_t fa0[4], fb0[4], fa1[4], fb1[4];
-    if (six) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (!NP) { if (six) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     __builtin_amdgcn_s_barrier();
     B2S_READ8(fa0, fb0, 0, 0)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -276,7 +322,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave no longer reads stage kt
         // stage kt+1 landed (own DMAs; the 6 of stage kt+2 stay in flight) ... for every wave, and slot `slot` is free
-        if (six) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (!NP) { if (six) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();
         // second half: first-half fragments of the next stage fly under the second-half MFMAs; the DMA issue of stage kt+3
         // (6 instructions + their address arithmetic) comes AFTER the MFMAs have been issued, so its VALU work runs while
@@ -284,13 +330,13 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
         B2S_READ8(fa0, fb0, nslot, 0)
         __builtin_amdgcn_sched_barrier(0);
         B2S_MMA16(fa1, fb1)
-        issue(kt0 + kt + NSTAGE, slot);
+        if (!NP) issue(kt0 + kt + NSTAGE, slot);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         slot = nslot;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the trailing zero-page DMAs before the LDS is reused
+    if (!NP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the trailing zero-page DMAs before the LDS is reused
 #undef B2S_READ8
 #undef B2S_MMA16
 
@@ -299,7 +345,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
 }
 
 template <bool TA, bool TB, bool GATHER, int NB>
-__global__ __launch_bounds__(512, 1) void gemm_glds256_kernel(GemmArgs g, const bf16_t* zero, float* splitk_ws, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(nthreads_of(GATHER), 1) void gemm_glds256_kernel(GemmArgs g, const bf16_t* zero, float* splitk_ws, int tiles_m, int tiles_n) {
     const int wg = xcd_tile_id(blockIdx.x, gridDim.x);
     const int per_z = tiles_n * tiles_m;
     const int bz = wg / per_z, rem = wg - bz * per_z;
@@ -311,7 +357,7 @@ __global__ __launch_bounds__(512, 1) void gemm_glds256_kernel(GemmArgs g, const 
 // grid.  A training layer's weight gradients are 18 .. 72 tiles each -- far too few to fill 256 CUs one at a time, which
 // is what split-K + a slab-reduce kernel used to paper over; together they are ~290 tiles with the full 8148-deep K.
 template <int NB>
-__global__ __launch_bounds__(512, 1) void gemm_glds256_grouped_kernel(b2s_gemm_group grp, const bf16_t* zero) {
+__global__ __launch_bounds__(nthreads_of(false), 1) void gemm_glds256_grouped_kernel(b2s_gemm_group grp, const bf16_t* zero) {
     const int wg = xcd_tile_id(blockIdx.x, gridDim.x);
     int p = 0;
     while (p + 1 < grp.n && wg >= grp.tile0[p + 1]) ++p;
@@ -341,7 +387,7 @@ int launch256_nb(const GemmArgs& g_in, const bf16_t* zero, float* ws_all, size_t
     if (g.splitk > 1 && g.batch == 1 && g.c_fp32 && g.epi.accumulate && (g.N & 3) == 0 && (g.ldc & 3) == 0 &&
         (size_t)g.splitk * g.M * g.N <= ws_floats)
         ws = ws_all;
-    hipLaunchKernelGGL((gemm_glds256_kernel<TA, TB, GATHER, NB>), grid, dim3(512), smem, stream, g, zero, ws, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_glds256_kernel<TA, TB, GATHER, NB>), grid, dim3(nthreads_of(GATHER)), smem, stream, g, zero, ws, tiles_m, tiles_n);
     B2S_LAUNCH_CHECK();
     if (ws) B2S_TRY(b2s_splitk_reduce_launch(ws, (float*)g.C, g.M, g.N, g.ldc, g.splitk, g.epi.conv_dw_cin, stream));
     return 0;
@@ -384,7 +430,7 @@ int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((t256::gemm_glds256_grouped_kernel<4>), dim3(tiles), dim3(512), smem, stream, grp, zero);
+    hipLaunchKernelGGL((t256::gemm_glds256_grouped_kernel<4>), dim3(tiles), dim3(t256::nthreads_of(false)), smem, stream, grp, zero);
     B2S_LAUNCH_CHECK();
     return 0;
 }

@@ -50,12 +50,21 @@ int main(int argc, char** argv) {
         {8192, 8192, 8192, 0, 0, 1, "8192^3 NT"},
     };
     size_t maxel = (size_t)8192 * 8192;
+    // LAB_ROT=n: n placements of every operand, used round-robin by the timed launches (n * footprint > 256 MB defeats the
+    // memory-side cache, as inside the training step); LAB_EPI=1: fp32 output with bias + dropout + fp32 residual
+    const int rot = getenv("LAB_ROT") ? atoi(getenv("LAB_ROT")) : 1;
+    const bool epi = getenv("LAB_EPI") != nullptr;
     std::vector<bf16_t> hA(maxel), hB(maxel);
     for (size_t i = 0; i < maxel; ++i) { hA[i] = f2bf(frand()); hB[i] = f2bf(frand()); }
     bf16_t *dA, *dB; void* dC;
-    hipMalloc(&dA, maxel * 2); hipMalloc(&dB, maxel * 2); hipMalloc(&dC, maxel * 4);
-    hipMemcpy(dA, hA.data(), maxel * 2, hipMemcpyHostToDevice);
-    hipMemcpy(dB, hB.data(), maxel * 2, hipMemcpyHostToDevice);
+    float *dBias, *dRes;
+    hipMalloc(&dA, maxel * 2 * rot); hipMalloc(&dB, maxel * 2 * rot); hipMalloc(&dC, maxel * 4 * rot);
+    hipMalloc(&dBias, 8192 * 4); hipMalloc(&dRes, maxel * 4 * rot);
+    hipMemset(dBias, 0, 8192 * 4); hipMemset(dRes, 0, maxel * 4 * rot);
+    for (int r = 0; r < rot; ++r) {
+        hipMemcpy(dA + r * maxel, hA.data(), maxel * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dB + r * maxel, hB.data(), maxel * 2, hipMemcpyHostToDevice);
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<float> hC;
     double tot_us = 0, tot_fl = 0;
@@ -69,6 +78,11 @@ int main(int argc, char** argv) {
         if (s.tb) { g.B.ld = s.N; g.B.R = s.K; g.B.C = s.N; } else { g.B.ld = s.K; g.B.R = s.N; g.B.C = s.K; }
         g.C = dC; g.ldc = s.N; g.splitk = s.splitk;
         if (s.splitk > 1) { g.c_fp32 = 1; g.epi.accumulate = 1; } else g.c_fp32 = 0;
+        if (epi && s.splitk == 1) { g.c_fp32 = 1; g.epi.bias = dBias; g.epi.residual = dRes; g.epi.ldr = s.N; g.epi.drop = {0x1000000u, 1234u, 1.0f}; }
+        auto place = [&](int it) {
+            const int r = it % rot;
+            g.A.p = dA + r * maxel; g.B.p = dB + r * maxel; g.C = (char*)dC + r * maxel * 4; if (g.epi.residual) g.epi.residual = dRes + r * maxel;
+        };
         hipMemset(dC, 0, (size_t)s.M * s.N * 4);
         if (LAB_LAUNCH(g, s.ta, s.tb, 0)) return 1;
         hipDeviceSynchronize();
@@ -92,7 +106,8 @@ int main(int argc, char** argv) {
         }
         for (int w = 0; w < 5; ++w) LAB_LAUNCH(g, s.ta, s.tb, 0);
         hipEventRecord(e0, 0);
-        for (int it = 0; it < iters; ++it) LAB_LAUNCH(g, s.ta, s.tb, 0);
+        for (int it = 0; it < iters; ++it) { place(it); LAB_LAUNCH(g, s.ta, s.tb, 0); }
+        place(0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
