@@ -192,8 +192,8 @@ def main():
             trainer.train_step(batch)
         torch.cuda.synchronize()
         lib.b2s_prof_enable(0)
-        res = (C.c_double * 48)()
-        L.check(lib.b2s_prof_collect(res, 16))
+        res = (C.c_double * 51)()
+        L.check(lib.b2s_prof_collect(res, 17))
 
         def kname(v):               # the kernel names rocprofv3 reports (profiles/*kernel_stats.csv)
             dt, ta, tb, ga = v >> 3, (v >> 2) & 1, (v >> 1) & 1, v & 1
@@ -202,9 +202,10 @@ def main():
                 return "t256::gemm_glds256_kernel<%s, %s, %s, NB>" % (tf(ta), tf(tb), tf(ga))
             return "gemm_kernel<float, %s, %s>%s" % (tf(ta), tf(tb), " (conv gather)" if ga else "")
         names = {v: kname(v) for v in range(16)}
+        names[16] = "t256::gemm_glds256_grouped_kernel<4>"     # one launch = the weight gradients of one backward stage
         variants = []
         tot_f = tot_ms = 0.0
-        for v in range(16):
+        for v in range(17):
             f, msv, cnt = res[v * 3], res[v * 3 + 1], res[v * 3 + 2]
             if cnt:
                 variants.append({"kernel": names[v], "launches_per_step": cnt / nprof, "avg_us": round(msv * 1e3 / cnt, 2),
@@ -231,10 +232,10 @@ def main():
                            "all_gemm": {"tflops": round(tot_f / (tot_ms * 1e-3) / 1e12, 1), "ms_per_step": round(tot_ms / nprof, 3)},
                            "variants": variants,
                            "note": "algorithmic FLOPs (2MNK per launch) / HIP-event duration on the kernel's launch stream, separate "
-                                   "instrumented pass of the same steps; the <true, true, *> weight-gradient GEMMs run on a second stream "
-                                   "concurrently with the rest of the backward pass, so their event durations include time spent "
-                                   "sharing the CUs with main-stream kernels, and the split-K slab reduction that belongs to the launch "
-                                   "(rocprofv3 lists gemm_glds256_kernel and splitk_reduce_kernel separately, first wave to last)"}
+                                   "instrumented pass of the same steps; the weight-gradient GEMMs (grouped kernel, <true, true, *>) run on a "
+                                   "second stream concurrently with the rest of the backward pass, so their event durations -- and those "
+                                   "of the main-stream kernels they overlap -- include time spent sharing the CUs; <true, true, *> "
+                                   "durations also include the split-K slab reduction that belongs to the launch"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_train()
     if world > 1 or force_dp:

@@ -629,10 +629,11 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
         m->ev_pool.resize(256);
         for (auto& ev : m->ev_pool) B2S_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    // measured (MI355X, LJ-shaped step): the grouped launch is ~9 % cheaper in kernel time than split-K + slab reduce, but the
-    // many small split-K launches fill the tails of the main-stream kernels better -- the step is 0.1 ms faster without
-    // grouping.  Kept as an option (B2S_DW_GROUP=1) for shapes / parts where the balance differs.
-    m->dw_group = m->dtype == 1 && m->aux && getenv("B2S_DW_GROUP") != nullptr;
+    // measured (MI355X, LJ-shaped step): one grouped launch per backward stage (7 problems, ~290 tiles, full-depth K, no
+    // split-K slabs and no reduce kernels) against one split-K launch + slab reduce per weight gradient: 10.42 vs 10.73 ms
+    // per step with the producer-wave GEMM (it was 0.1 ms the other way round with the older kernel, whose long tiles
+    // left the main stream's kernels fewer idle CUs).  B2S_DW_GROUP=0 restores the per-GEMM launches.
+    m->dw_group = m->dtype == 1 && m->aux && !(getenv("B2S_DW_GROUP") && atoi(getenv("B2S_DW_GROUP")) == 0);
     B2S_TRY(ensure_pe(m, 2048));
     m->n_l2_chunks = 0; m->l2_chunks = nullptr; m->l2_fresh = false;
     B2S_TRY(build_chunks(m, true, false, &m->l2_chunks, &m->n_l2_chunks));

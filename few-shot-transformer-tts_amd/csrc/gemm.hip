@@ -266,7 +266,8 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
 extern "C" void b2s_prof_enable(int on) { g_prof_on = on != 0; }
-// out[v*3 + {0,1,2}] = total flops, total milliseconds, launches of GEMM variant v = dtype*8 + trans_a*4 + trans_b*2 + conv_gather
+// out[v*3 + {0,1,2}] = total flops, total milliseconds, launches of GEMM variant v = dtype*8 + trans_a*4 + trans_b*2 + conv_gather;
+// v = 16: grouped bf16 weight-gradient launches
 extern "C" int b2s_prof_collect(double* out, int n_variants) {
     for (int i = 0; i < n_variants * 3; ++i) out[i] = 0.0;
     FILE* dump = getenv("B2S_PROF_DUMP") ? fopen(getenv("B2S_PROF_DUMP"), "w") : nullptr;
@@ -297,12 +298,12 @@ int b2s_gemm_launch(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t 
     g_prof.push_back(r);
     return rc;
 }
-// grouped bf16 weight-gradient launch (gemm_glds256.hip), with the same optional timing record (variant 14 = bf16 TN)
+// grouped bf16 weight-gradient launch (gemm_glds256.hip), with the same optional timing record (variant 16)
 int b2s_gemm_grouped_launch(const GemmArgs* probs, int n, hipStream_t stream) {
     if (!g_prof_on) return b2s_gemm_glds256_grouped_launch(probs, n, b2s_gemm_zero_page(), stream);
     ProfRec r;
     B2S_HIP(hipEventCreate(&r.a)); B2S_HIP(hipEventCreate(&r.b));
-    r.variant = 14; r.flops = 0.0;
+    r.variant = 16; r.flops = 0.0;
     for (int i = 0; i < n; ++i) r.flops += 2.0 * probs[i].M * probs[i].N * (double)probs[i].K;
     r.M = probs[0].M; r.N = probs[0].N; r.K = probs[0].K; r.batch = n; r.splitk = 1;
     B2S_HIP(hipEventRecord(r.a, stream));

@@ -213,7 +213,8 @@ int b2s_cast_back(int dtype, const void* in, float* out, int64_t n, void* stream
 int b2s_dropout_mask(float p, uint64_t seed, uint32_t op_id, uint8_t* out, int64_t n, void* stream);
 
 /* ---- measurement: per-launch HIP-event timing of the MFMA GEMM kernel on its launch stream (bench.py).
- * variant v = dtype*8 + trans_a*4 + trans_b*2 + conv_gather (16 variants); out[v*3 + {0,1,2}] = flops, milliseconds, launches. */
+ * variant v = dtype*8 + trans_a*4 + trans_b*2 + conv_gather (16 variants), v = 16: grouped bf16 weight-gradient launches;
+ * out[v*3 + {0,1,2}] = flops, milliseconds, launches for v < n_variants. */
 void b2s_prof_enable(int on);
 int b2s_prof_collect(double* out, int n_variants);
 

@@ -155,16 +155,17 @@ def test_rccl_exchange_path_single_rank():
     assert abs(outs[0]["final_loss"] - outs[1]["final_loss"]) < 1e-2 * abs(outs[1]["final_loss"])
 
 
-def test_grouped_weight_gradient_option():
-    """B2S_DW_GROUP=1 (one grouped weight-gradient GEMM per backward stage, stage hooks delayed by one stage) is an
-    option, not the default: keep it correct -- fused trainer vs oracle and the 2-rank data-parallel run."""
+def test_ungrouped_weight_gradient_option():
+    """Default: one grouped weight-gradient GEMM per backward stage (stage hooks delayed by one stage).  B2S_DW_GROUP=0
+    -- one split-K launch + slab reduce per weight gradient -- is the option: keep it correct too (fused trainer vs
+    oracle and the 2-rank data-parallel run)."""
     import subprocess
     import sys
     if os.environ.get("B2S_DW_GROUP"):
         pytest.skip("inner run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_model.py", "tests/test_gpu_edge_dp.py",
-                        "-k", "bf16 or two_ranks or fused_trainer"], cwd=root, env=dict(os.environ, B2S_DW_GROUP="1"),
+                        "-k", "bf16 or two_ranks or fused_trainer"], cwd=root, env=dict(os.environ, B2S_DW_GROUP="0"),
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
