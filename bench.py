@@ -226,11 +226,46 @@ def main():
             if n:
                 traffic = round(sum(r["launches"] * (r["fetch_MB_per_launch_corrected_x2"] + (r["WRITE_SIZE_KB_per_launch"] or 0) / 1024)
                                     for r in rows) / n * 1e6)
+        # the same MFMA kernels with the GPU to themselves: the step's forward / dX shapes launched back-to-back through the
+        # C-ABI op (no second stream, operands cache-resident after the first launch) -- what the kernel does when it is
+        # not sharing CUs and not paying a fused residual epilogue; context for the in-step figure above, not a replacement
+        isolated = None
+        if args.dtype == "bf16":
+            Mt, Me = B * T, B * S
+            shapes = [("fwd qkv", Mt, 2304, 768, 0), ("fwd attn-out / q", Mt, 768, 768, 0), ("fwd ffn-in", Mt, 3072, 768, 0),
+                      ("fwd ffn-out", Mt, 768, 3072, 0), ("dX qkv", Mt, 768, 2304, 1), ("dX ffn-in", Mt, 768, 3072, 1),
+                      ("dX ffn-out", Mt, 3072, 768, 1), ("enc fwd ffn-out", Me, 512, 2048, 0)]
+            bufA = torch.randn(Mt * 3072, device=device).to(torch.bfloat16)
+            bufB = torch.randn(3072 * 3072, device=device).to(torch.bfloat16)
+            bufC = torch.empty(Mt * 3072, device=device, dtype=torch.bfloat16)
+            isolated, fl_sum, us_sum = [], 0.0, 0.0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for what, m_, n_, k_, tb in shapes:
+                d = L.GemmDesc()
+                d.dtype, d.trans_a, d.trans_b, d.M, d.N, d.K = 1, 0, tb, m_, n_, k_
+                d.lda, d.ldb, d.ldc, d.c_fp32, d.batch, d.batch_inner, d.alpha = k_, (n_ if tb else k_), n_, 0, 1, 1, 1.0
+                call = lambda: L.check(lib.b2s_gemm(C.byref(d), bufA.data_ptr(), bufB.data_ptr(), bufC.data_ptr(), None, None, None,
+                                                    None, L.stream()))
+                for _ in range(3):
+                    call()
+                e0.record()
+                for _ in range(30):
+                    call()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 30
+                fl = 2.0 * m_ * n_ * k_
+                isolated.append({"shape": "%s %dx%dx%d" % (what, m_, n_, k_), "us": round(us, 1), "tflops": round(fl / us / 1e6, 1)})
+                fl_sum += fl
+                us_sum += us
+            isolated.append({"shape": "all of the above", "us": round(us_sum, 1), "tflops": round(fl_sum / us_sum / 1e6, 1),
+                             "frac_of_peak": round(fl_sum / us_sum / 1e6 / peak, 4)})
+            del bufA, bufB, bufC
         out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
                            "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM side, PMC)",
                            "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                            "all_gemm": {"tflops": round(tot_f / (tot_ms * 1e-3) / 1e12, 1), "ms_per_step": round(tot_ms / nprof, 3)},
-                           "variants": variants,
+                           "variants": variants, "isolated": isolated,
                            "note": "algorithmic FLOPs (2MNK per launch) / HIP-event duration on the kernel's launch stream, separate "
                                    "instrumented pass of the same steps; the weight-gradient GEMMs (grouped kernel, <true, true, *>) run on a "
                                    "second stream concurrently with the rest of the backward pass, so their event durations -- and those "
