@@ -36,8 +36,11 @@
 namespace t256 {
 
 constexpr int NPROD = B2S_NPROD;
-constexpr int nprod_of(bool gather) { return gather ? 0 : NPROD; }
-constexpr int nthreads_of(bool gather) { return 512 + 64 * nprod_of(gather); }
+// GATHER: 0 = plain operands, 1 = conv gather with general addressing (issued by the MFMA waves), 2 = conv gather on a
+// K-contiguous A whose channel count is a multiple of BK (every K step lies inside one tap: wave-uniform tap / channel base,
+// a compare + select per lane; issued by the producer waves)
+constexpr int nprod_of(int gather) { return gather == 1 ? 0 : NPROD; }
+constexpr int nthreads_of(int gather) { return 512 + 64 * nprod_of(gather); }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 constexpr int BM = 256, BK = 64, NSTAGE = 3;            // BN = 128 or 96 (template parameter NB = BN / 32)
@@ -98,7 +101,7 @@ __device__ inline int xcd_tile_id(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-template <bool TA, bool TB, bool GATHER, int NB>
+template <bool TA, bool TB, int GATHER, int NB>
 __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, float* splitk_ws, int bx, int by, int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // conv-gather operands keep the DMA issue on the MFMA waves: their per-chunk address arithmetic (two divisions, a length
@@ -160,7 +163,22 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
         else    goffB[i] = 2u * (unsigned)((long)min(n0 + s.r, g.B.R - 1) * g.B.ld + s.c);
     }
     const int nfull = g.K / BK;                                          // K steps completely in bounds
-    const bool fast_ok = !GATHER && nfull > 0 && (TA ? (g.A.C >= 8 && (g.A.C & 7) == 0) : true) && (TB ? (g.B.C >= 8 && (g.B.C & 7) == 0) : true) &&
+    // aligned conv gather (GATHER == 2, conditions checked by the launcher): token position / valid length of every row
+    // this lane fetches; a K step then needs one unsigned compare per DMA instruction
+    constexpr bool GF = GATHER == 2;
+    int gt[GF ? NIA : 1], glim[GF ? NIA : 1];
+    if (GF) {
+        const float inv_T = __builtin_amdgcn_rcpf((float)g.A.g_T);
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const LaneSrc s = lane_src<false, true>(ia0 + i, lane);
+            const int r = min(m0 + s.r, g.A.R - 1), b = fast_div(r, g.A.g_T, inv_T);
+            gt[i] = r - b * g.A.g_T;
+            glim[i] = g.A.g_len ? min(g.A.g_len[b], g.A.g_T) : g.A.g_T;
+        }
+    }
+    const int g_spt = GF ? g.A.g_cin / BK : 1;                           // K steps per filter tap
+    const bool fast_ok = GATHER != 1 && nfull > 0 && (TA ? (g.A.C >= 8 && (g.A.C & 7) == 0) : true) && (TB ? (g.B.C >= 8 && (g.B.C & 7) == 0) : true) &&
                          (TA ? (long)g.A.R * g.A.ld : (long)g.A.R * g.A.ld) < (1L << 30) && (long)g.B.R * g.B.ld < (1L << 30);
     // B instructions 12..15 of a 96-column tile would fill image rows no wave reads: waves 6, 7 skip them (4 DMAs per step)
     // (K-contiguous B only: a reduction-major B instruction covers 4 k rows x all 128 columns, every one is needed)
@@ -185,21 +203,34 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
             const long ks = min(kt, nfull - 1);
             const char* sa = reinterpret_cast<const char*>(Ab) + ks * stepA * 2;
             const char* sb = reinterpret_cast<const char*>(Bb) + ks * stepB * 2;
+            if (GF) {
+                // virtual column ks*64 + c = tap j, channel ci0 + c  ->  x[row + j - 2][ci0 + c], zero outside the utterance
+                const int j = fast_div((int)ks, g_spt, __builtin_amdgcn_rcpf((float)g_spt)), ci0 = ((int)ks - j * g_spt) * BK;
+                sa = reinterpret_cast<const char*>(Ab) + ((long)(j - 2) * g.A.ld + ci0) * 2;
+#pragma unroll
+                for (int i = 0; i < NIA; ++i) {
+                    const bool ok = (unsigned)(gt[i] + j - 2) < (unsigned)glim[i];
+                    const char* src = ok ? sa + goffA[i] : reinterpret_cast<const char*>(zero);
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (ia0 + i) * 1024), 16, 0, B2S_DMA_AUX);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < NIA; ++i)
                 __builtin_amdgcn_global_load_lds((gptr_t)(sa + goffA[i]), (lptr_t)(sbase + (ia0 + i) * 1024), 16, 0, B2S_DMA_AUX);
+            }
 #pragma unroll
             for (int i = 0; i < NIB; ++i)
                 if (NP || (i == 0 ? b_active0 : b_active1))
                     __builtin_amdgcn_global_load_lds((gptr_t)(sb + goffB[i]), (lptr_t)(sbase + A_BYTES + (ib0 + i) * 1024), 16, 0, B2S_DMA_AUX);
             return;
         }
+        if (GF) return;                      // (the aligned gather has no partial K steps: nothing below is reachable, keep it out of the register budget)
         const int kb = kt < kt_end ? kt * BK : (1 << 28);
 #pragma unroll
         for (int i = 0; i < NIA; ++i) {
             const int idx = ia0 + i;
             const bf16_t* sa;
-            if (GATHER) {
+            if (GATHER == 1) {
                 const LaneSrc s = lane_src<TA, true>(idx, lane);
                 sa = TA ? chunk_src(g.A, Ab, kb + s.r, m0 + s.c, zero) : chunk_src(g.A, Ab, m0 + s.r, kb + s.c, zero);
             } else {
@@ -215,7 +246,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
             const int idx = ib0 + i;
             if (!NP && !(i == 0 ? b_active0 : b_active1)) continue;
             const bf16_t* sb;
-            if (GATHER) {
+            if (GATHER == 1) {
                 const LaneSrc s = lane_src<TB, false>(idx, lane);
                 sb = TB ? (s.c < BN ? chunk_src(g.B, Bb, kb + s.r, n0 + s.c, zero) : zero)
                         : (s.r < BN ? chunk_src(g.B, Bb, n0 + s.r, kb + s.c, zero) : zero);
@@ -344,7 +375,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
     gemm_wave_epilogue<NB>(g, acc, reinterpret_cast<float*>(smem_raw) + wave * (64 * 64), m0 + wrow, n0 + wcol, lane, z, zo, zi, ksplit, splitk_ws);
 }
 
-template <bool TA, bool TB, bool GATHER, int NB>
+template <bool TA, bool TB, int GATHER, int NB>
 __global__ __launch_bounds__(nthreads_of(GATHER), 1) void gemm_glds256_kernel(GemmArgs g, const bf16_t* zero, float* splitk_ws, int tiles_m, int tiles_n) {
     const int wg = xcd_tile_id(blockIdx.x, gridDim.x);
     const int per_z = tiles_n * tiles_m;
@@ -364,10 +395,10 @@ __global__ __launch_bounds__(nthreads_of(false), 1) void gemm_glds256_grouped_ke
     const int local = wg - grp.tile0[p];
     const int tiles_n = (grp.p[p].N + NB * 32 - 1) / (NB * 32);
     const int by = local / tiles_n, bx = local - by * tiles_n;
-    gemm256_body<true, true, false, NB>(grp.p[p], zero, nullptr, bx, by, 0);
+    gemm256_body<true, true, 0, NB>(grp.p[p], zero, nullptr, bx, by, 0);
 }
 
-template <bool TA, bool TB, bool GATHER, int NB>
+template <bool TA, bool TB, int GATHER, int NB>
 int launch256_nb(const GemmArgs& g_in, const bf16_t* zero, float* ws_all, size_t ws_floats, hipStream_t stream) {
     GemmArgs g = g_in;
     if (g.splitk > 1) {                     // every split must own at least one K step (empty splits would leave slabs unwritten)
@@ -402,7 +433,7 @@ inline int pick_nb(const GemmArgs& g) {
     const long r128 = (per * cdiv(g.N, 128) + 255) / 256 * 128, r96 = (per * cdiv(g.N, 96) + 255) / 256 * 101;   // 96 * 1.05
     return r96 < r128 ? 3 : 4;
 }
-template <bool TA, bool TB, bool GATHER>
+template <bool TA, bool TB, int GATHER>
 int launch256_t(const GemmArgs& g, const bf16_t* zero, float* ws_all, size_t ws_floats, hipStream_t stream) {
     return pick_nb(g) == 3 ? launch256_nb<TA, TB, GATHER, 3>(g, zero, ws_all, ws_floats, stream)
                            : launch256_nb<TA, TB, GATHER, 4>(g, zero, ws_all, ws_floats, stream);
@@ -441,12 +472,19 @@ long b2s_gemm_glds256_tiles(const GemmArgs& g) { return (long)cdiv(g.M, t256::BM
 int b2s_gemm_glds256_launch(const GemmArgs& g, bool ta, bool tb, const bf16_t* zero, float* ws, size_t ws_floats, hipStream_t stream) {
     const bool gather = g.A.g_cin > 0 || g.B.g_cin > 0;
     if (gather) {
-        if (!ta && !tb) return t256::launch256_t<false, false, true>(g, zero, ws, ws_floats, stream);
-        if (ta && tb) return t256::launch256_t<true, true, true>(g, zero, ws, ws_floats, stream);
+        if (!ta && !tb) {
+            // forward / backward-data convolution over >= 64-aligned channel counts: aligned gather on the producer waves
+            const bool aligned = g.A.g_cin > 0 && g.B.g_cin == 0 && g.A.g_cin % t256::BK == 0 && g.K % t256::BK == 0 && g.splitk == 1 &&
+                                 (long)g.A.R * g.A.ld < (1L << 29) && (long)g.B.R * g.B.ld < (1L << 30) && g.A.g_T > 0;
+            static const bool no_fast = getenv("B2S_CONV_GENERIC") != nullptr;      // A/B switch
+            if (aligned && !no_fast) return t256::launch256_t<false, false, 2>(g, zero, ws, ws_floats, stream);
+            return t256::launch256_t<false, false, 1>(g, zero, ws, ws_floats, stream);
+        }
+        if (ta && tb) return t256::launch256_t<true, true, 1>(g, zero, ws, ws_floats, stream);
         return b2s_fail(__FILE__, __LINE__, "conv gather is supported for the NT and TN forms only");
     }
-    if (!ta && !tb) return t256::launch256_t<false, false, false>(g, zero, ws, ws_floats, stream);
-    if (!ta && tb) return t256::launch256_t<false, true, false>(g, zero, ws, ws_floats, stream);
-    if (ta && !tb) return t256::launch256_t<true, false, false>(g, zero, ws, ws_floats, stream);
-    return t256::launch256_t<true, true, false>(g, zero, ws, ws_floats, stream);
+    if (!ta && !tb) return t256::launch256_t<false, false, 0>(g, zero, ws, ws_floats, stream);
+    if (!ta && tb) return t256::launch256_t<false, true, 0>(g, zero, ws, ws_floats, stream);
+    if (ta && !tb) return t256::launch256_t<true, false, 0>(g, zero, ws, ws_floats, stream);
+    return t256::launch256_t<true, true, 0>(g, zero, ws, ws_floats, stream);
 }

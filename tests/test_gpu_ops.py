@@ -79,6 +79,26 @@ def test_gemm_batched_heads_and_epilogue(dtype):
     assert relerr(C.cpu(), ref) < TOL[dtype], report("epilogue", C.cpu(), ref)
 
 
+@pytest.mark.parametrize("with_len", [True, False])
+def test_conv_gather_gemm_aligned_channels(with_len):
+    """The postnet's 512-channel layers: channel count a multiple of the GEMM's 64-deep K step and > 128 rows -> the
+    aligned gather of the 256-row tile kernel (producer waves, one compare per DMA instruction).  Ragged lengths with a
+    tile boundary inside an utterance; with_len=False is the backward-data form (no length mask on the gathered operand)."""
+    ops, lib = _ops()
+    g = torch.Generator().manual_seed(19)
+    B_, T, Cin, Cout = 3, 181, 128, 80
+    lens = torch.tensor([181, 97, 3], dtype=torch.int32)
+    x = bf16_round(torch.randn(B_, T, Cin, generator=g)); w = bf16_round(torch.randn(Cout, Cin, 5, generator=g) * 0.1)
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float() if with_len else torch.ones(B_, T)
+    ref = torch.nn.functional.conv1d((x * mask[..., None]).transpose(1, 2).double(), w.double(), None, 1, 2).transpose(1, 2)
+    wf = w.permute(0, 2, 1).reshape(Cout, 5 * Cin).contiguous()
+    y = ops.gemm(1, to_dev_compute(x.reshape(B_ * T, Cin), 1), to_dev_compute(wf, 1), B_ * T, Cout, 5 * Cin,
+                 lda=Cin, ldb=5 * Cin, conv_cin_a=Cin, conv_T=T, conv_len=lens.to(DEV) if with_len else None)
+    torch.cuda.synchronize()
+    got = y.cpu().view(B_, T, Cout)
+    assert relerr(got, ref) < TOL[1], report("conv aligned", got, ref)
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_conv_gather_gemm(dtype):
     """impute + Conv1d(k=5, pad=2) as an implicit GEMM (tacotron.py:84-85)."""
