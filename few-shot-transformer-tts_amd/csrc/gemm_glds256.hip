@@ -29,13 +29,16 @@
 #define B2S_DMA_AUX 0       // cache-policy bits of the LDS-DMA loads (sc0 = 1, nt = 2, sc1 = 16); measured: no policy beats the default
 #endif
 
+#ifndef B2S_GROUP_M
+#define B2S_GROUP_M 4
+#endif
 #ifndef B2S_NPROD
 #define B2S_NPROD 4         // >0: that many extra waves per workgroup do nothing but issue the LDS-DMA loads (producer / consumer split)
 #endif
 
 namespace t256 {
 
-constexpr int NPROD = B2S_NPROD;
+constexpr int NPROD = B2S_NPROD, GROUP_M = B2S_GROUP_M;
 // GATHER: 0 = plain operands, 1 = conv gather with general addressing (issued by the MFMA waves), 2 = conv gather on a
 // K-contiguous A whose channel count is a multiple of BK (every K step lies inside one tap: wave-uniform tap / channel base,
 // a compare + select per lane; issued by the producer waves)
@@ -380,7 +383,19 @@ __global__ __launch_bounds__(nthreads_of(GATHER), 1) void gemm_glds256_kernel(Ge
     const int wg = xcd_tile_id(blockIdx.x, gridDim.x);
     const int per_z = tiles_n * tiles_m;
     const int bz = wg / per_z, rem = wg - bz * per_z;
-    const int by = rem / tiles_n, bx = rem - by * tiles_n;
+    // Tile order inside the (XCD-contiguous) id range.  Wide outputs (>= 16 column panels): groups of GROUP_M row panels
+    // walked column by column, so the 32 workgroups an XCD runs at a time cover 4 row panels x 8 column panels -- equal A and
+    // B bytes per round, and the working set (3 MB at K = 768) fits the XCD's 4 MB L2.  Row-major order made every XCD
+    // re-fetch the whole weight matrix once per round (PMC: 126 MB fetched per forward ffn-in launch for 50 MB of
+    // per-XCD operands); measured 53.8 -> 50.2 us (N = 2304), 65.5 -> 59.3 (dX, N = 3072), 977 -> 927 (8192^3).  Narrow
+    // outputs keep the row-major order: an XCD's range is the same set of tiles either way, and the column-major walk
+    // measured 8-17 % slower on the K >= 2304 shapes.
+    int by, bx;
+    if (GROUP_M > 0 && tiles_n >= 16) {
+        const int gsz = GROUP_M * tiles_n, grp = rem / gsz, in = rem - grp * gsz;
+        const int rows = min(GROUP_M, tiles_m - grp * GROUP_M);
+        bx = in / rows; by = grp * GROUP_M + (in - bx * rows);
+    } else { by = rem / tiles_n; bx = rem - by * tiles_n; }
     gemm256_body<TA, TB, GATHER, NB>(g, zero, splitk_ws, bx, by, bz);
 }
 
