@@ -140,8 +140,15 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
         bool zero = false;
         if (row_len) { int b = row / rpb; zero = (row - b * rpb) >= row_len[b]; }
         const float mu = mean[row], rs = rstd[row];
-        float4 g[LN_MAXC], xh[LN_MAXC];
+        float4 g[LN_MAXC], xh[LN_MAXC], prev[LN_MAXC];
         float s1 = 0.f, s2 = 0.f;
+        // the accumulate operand (dx itself) is fetched with the row's other loads, not after the row reductions: one
+        // memory round trip per row instead of two (each wave walks its rows one at a time)
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            int ci = lane + 64 * i;
+            prev[i] = (accumulate && ci < nch) ? ld4(dx + (long)row * D + ci * 4) : make_float4(0, 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < LN_MAXC; ++i) {
             int ci = lane + 64 * i;
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
                 o.x = rs * (g[i].x - s1 - xh[i].x * s2); o.y = rs * (g[i].y - s1 - xh[i].y * s2);
                 o.z = rs * (g[i].z - s1 - xh[i].z * s2); o.w = rs * (g[i].w - s1 - xh[i].w * s2);
                 float* p = dx + (long)row * D + ci * 4;
-                if (accumulate) { float4 a = ld4(p); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+                o.x += prev[i].x; o.y += prev[i].y; o.z += prev[i].z; o.w += prev[i].w;
                 st4(p, o);
                 // the next backward op consumes bf16(dropout(dx)): write it here instead of a separate cast pass
                 if (dy2) st4(dy2 + (long)row * D + ci * 4, drop4(o, drop2, (uint32_t)((long)row * D + ci * 4)));
