@@ -99,27 +99,42 @@ __global__ __launch_bounds__(256) void k_dec_attn(const T* q, int ldq, const T* 
     const int part4 = tid & 3, kslot = tid >> 2;      // 64 keys per pass
     const int nch = CH / 4;                           // chunks per lane (dh is a multiple of 4*VE)
     float mx = -INFINITY;
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        const int j = j0 + kslot;
-        float s = 0.f;
-        if (j < n) {
-            const T* kr = Kb + (long)j * ldkv;
-            for (int i = 0; i < nch; ++i) {
+    // The loop is latency-bound (2 workgroups per CU, one dependent load -> reduce chain per 64 keys): the loads of SU passes
+    // (SU x nch 16-byte chunks per lane) are issued before the first is consumed.  Per-lane summation order is unchanged.
+    constexpr int SU = sizeof(T) == 2 ? 4 : 2, NCH_MAX = sizeof(T) == 2 ? 4 : 8;      // head width <= 128 (checked by the host)
+    for (int j0 = 0; j0 < n; j0 += 64 * SU) {
+        uint4 u[SU][NCH_MAX];
+#pragma unroll
+        for (int uu = 0; uu < SU; ++uu) {
+            const int j = j0 + uu * 64 + kslot;
+            const T* kr = Kb + (long)min(j, max(n - 1, 0)) * ldkv;       // (clamped rows are loaded but never used)
+#pragma unroll
+            for (int i = 0; i < NCH_MAX; ++i)
+                if (i < nch) u[uu][i] = *reinterpret_cast<const uint4*>(kr + (i * 4 + part4) * VE);
+        }
+#pragma unroll
+        for (int uu = 0; uu < SU; ++uu) {
+            const int j = j0 + uu * 64 + kslot;
+            if (j0 + uu * 64 >= n) break;              // (workgroup-uniform)
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH_MAX; ++i) {
+                if (i >= nch) continue;
                 const int c = (i * 4 + part4) * VE;
-                uint4 u = *reinterpret_cast<const uint4*>(kr + c);
                 if (sizeof(T) == 2) {
-                    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+                    const uint32_t w[4] = {u[uu][i].x, u[uu][i].y, u[uu][i].z, u[uu][i].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { s += sq[c + 2 * e] * bf2f(w[e] & 0xffff) + sq[c + 2 * e + 1] * bf2f(w[e] >> 16); }
                 } else {
-                    const float* f = reinterpret_cast<const float*>(&u);
+                    const float* f = reinterpret_cast<const float*>(&u[uu][i]);
                     s += sq[c] * f[0] + sq[c + 1] * f[1] + sq[c + 2] * f[2] + sq[c + 3] * f[3];
                 }
             }
+            if (j >= n) s = 0.f;
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            if (j < n && part4 == 0) { s *= scale; p[j] = s; mx = fmaxf(mx, s); }
         }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        if (j < n && part4 == 0) { s *= scale; p[j] = s; mx = fmaxf(mx, s); }
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
@@ -147,17 +162,29 @@ __global__ __launch_bounds__(256) void k_dec_attn(const T* q, int ldq, const T* 
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        for (int j = ty; j < n; j += R) {
-            const float w = p[j];
-            uint4 u = *reinterpret_cast<const uint4*>(Vb + (long)j * ldkv + tx * VE);
-            if (sizeof(T) == 2) {
-                const uint32_t ww[4] = {u.x, u.y, u.z, u.w};
+        constexpr int VU = 8;                       // V rows whose loads are in flight together (same accumulation order)
+        for (int j = ty; j < n; j += R * VU) {
+            uint4 uv[VU];
+            float wv[VU];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { acc[2 * e] += w * bf2f(ww[e] & 0xffff); acc[2 * e + 1] += w * bf2f(ww[e] >> 16); }
-            } else {
-                const float* f = reinterpret_cast<const float*>(&u);
+            for (int v = 0; v < VU; ++v) {
+                const int jj = j + v * R;
+                wv[v] = jj < n ? p[jj] : 0.f;
+                uv[v] = *reinterpret_cast<const uint4*>(Vb + (long)min(jj, max(n - 1, 0)) * ldkv + tx * VE);
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += w * f[e];
+            for (int v = 0; v < VU; ++v) {
+                if (j + v * R >= n) break;
+                const float w = wv[v];
+                if (sizeof(T) == 2) {
+                    const uint32_t ww[4] = {uv[v].x, uv[v].y, uv[v].z, uv[v].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[2 * e] += w * bf2f(ww[e] & 0xffff); acc[2 * e + 1] += w * bf2f(ww[e] >> 16); }
+                } else {
+                    const float* f = reinterpret_cast<const float*>(&uv[v]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += w * f[e];
+                }
             }
         }
 #pragma unroll
@@ -248,6 +275,7 @@ int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
     hipLaunchKernelGGL(k_dec_x0, dim3(B), dim3(256), 0, st, s->a3, s->lengths, m->pe_dec, m->P(p + "pe_scale"), s->t, s->x, D,
                        make_drop(pt, s->seed, 9003));
     const int ve = dt ? 8 : 4, Rr = 256 / (dh / ve);
+    B2S_CHECK(dh <= 128 && dh % (4 * ve) == 0, "decode attention: head width %d (needs a multiple of %d, at most 128)", dh, 4 * ve);
     const size_t sh_self = (size_t)(dh + maxT + Rr * dh + 8) * 4, sh_cross = (size_t)(dh + S + Rr * dh + 8) * 4;
     for (int l = 0; l < L; ++l) {
         const std::string lna = p + "attn_layer_norms." + std::to_string(l), lnx = p + "encdec_layer_norms." + std::to_string(l),

@@ -2,6 +2,7 @@
 // epilogues.  The step is HBM-bound on W (every weight is read once per frame), so the launch is shaped for
 // bandwidth, not MFMA occupancy: one workgroup per 16 output columns (N/16 workgroups stream disjoint 16-row
 // slabs of W), its 8 waves split K eight ways and meet in LDS, each issuing the loads of 4 K steps at a time; X (<= 64 rows) comes from L2.
+#include <cstdlib>
 #include "gemm.h"
 
 namespace {
@@ -26,8 +27,12 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(GemmArgs g) {
     const int n0 = blockIdx.x * 16;
     const T* X = reinterpret_cast<const T*>(g.A.p);
     const T* W = reinterpret_cast<const T*>(g.B.p);
-    const int nsteps = (g.K + KS - 1) / KS, per = (nsteps + NW - 1) / NW;
-    const int s0 = wave * per, s1 = min(nsteps, s0 + per);
+    // gridDim.y > 1: K is also split over workgroups (the 768 x 3072 ffn-out GEMM has only 48 column slabs and a 12-step
+    // K walk per wave); partial results are added atomically into the fp32 output, which already holds the residual
+    const int nsteps_all = (g.K + KS - 1) / KS, per_wg = (nsteps_all + gridDim.y - 1) / gridDim.y;
+    const int w0 = blockIdx.y * per_wg, nsteps = min(nsteps_all, w0 + per_wg);
+    const int per = (nsteps - w0 + NW - 1) / NW;
+    const int s0 = w0 + wave * per, s1 = min(nsteps, s0 + per);
     const T* wrow = W + (long)min(n0 + li, g.N - 1) * g.B.ld;
     const T* xrow[4];
 #pragma unroll
@@ -70,9 +75,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(GemmArgs g) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[w][m][nl];
         v *= e.alpha;
-        if (e.bias) v += e.bias[n];
+        if (e.bias && blockIdx.y == 0) v += e.bias[n];
         if (e.relu) v = fmaxf(v, 0.f);
         if (e.drop.thresh) v = b2s_keep(dcfg, (uint32_t)((long)m * g.N + n)) ? v * dcfg.scale : 0.f;
+        if (gridDim.y > 1) { atomicAdd(reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n, v); continue; }    // (launcher: C == residual, fp32, linear epilogue)
         if (e.residual) v += e.residual[(long)m * e.ldr + n];
         if (e.row_len) { int bb = m / e.rows_per_batch, t = m - bb * e.rows_per_batch; if (t >= e.row_len[bb]) v = 0.f; }
         const long off = (long)m * g.ldc + n;
@@ -94,7 +100,14 @@ int b2s_gemm_skinny_launch(const GemmArgs& g, int dtype, hipStream_t stream) {
     if (g.M > 64 || g.batch != 1 || g.splitk != 1 || g.A.g_cin || g.B.g_cin || g.epi.relu_aux || g.epi.conv_dw_cin || (g.K % ks) != 0)
         return -1;
     if (g.epi.kv_k && (!g.epi.kv_v || !g.epi.kv_t || g.N != 3 * g.epi.kv_D)) return -1;
-    dim3 grid(cdiv(g.N, 16));
+    // K split over workgroups for the few-column, deep-K problems of the bf16 decode step (fp32 keeps one deterministic
+    // summation order): the epilogue must be linear in the accumulator and the output must already hold the residual
+    int ksplit = 1;
+    static const bool no_split = getenv("B2S_SKINNY_NOSPLIT") != nullptr;
+    if (dtype && !no_split && g.K >= 2048 && g.N <= 1024 && g.c_fp32 && g.epi.residual == g.C && g.epi.ldr == g.ldc && !g.epi.relu &&
+        !g.epi.accumulate && !g.epi.row_len && !g.epi.kv_k)
+        ksplit = 4;
+    dim3 grid(cdiv(g.N, 16), ksplit);
     if (dtype) hipLaunchKernelGGL((skinny_kernel<bf16_t>), grid, dim3(NW * 64), 0, stream, g);
     else hipLaunchKernelGGL((skinny_kernel<float>), grid, dim3(NW * 64), 0, stream, g);
     B2S_LAUNCH_CHECK();

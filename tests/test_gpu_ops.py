@@ -79,6 +79,24 @@ def test_gemm_batched_heads_and_epilogue(dtype):
     assert relerr(C.cpu(), ref) < TOL[dtype], report("epilogue", C.cpu(), ref)
 
 
+@pytest.mark.parametrize("dtype,M,N,K", [(1, 64, 768, 3072), (1, 37, 520, 2048), (0, 64, 768, 3072), (1, 64, 768, 768)])
+def test_decode_step_gemm_in_place_residual(dtype, M, N, K):
+    """The decode step's ffn-out form: <= 64 rows, h += x W^T + b in place (fp32 h).  bf16 with K >= 2048 takes the
+    weight-streaming kernel's K-split-over-workgroups path (atomic adds into h); the other rows pin the single-pass path."""
+    ops, lib = _ops()
+    g = torch.Generator().manual_seed(M + N + K + dtype)
+    X = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.05
+    h = torch.randn(M, N, generator=g); bias = torch.randn(N, generator=g)
+    if dtype:
+        X, W = bf16_round(X), bf16_round(W)
+    ref = h.double() + X.double() @ W.double().t() + bias.double()[None, :]
+    hd = h.to(DEV).contiguous()
+    out = ops.gemm(dtype, to_dev_compute(X, dtype), to_dev_compute(W, dtype), M, N, K, out=hd, c_fp32=True, bias=bias.to(DEV), residual=hd)
+    torch.cuda.synchronize()
+    assert out.data_ptr() == hd.data_ptr()
+    assert relerr(hd.cpu(), ref) < TOL[dtype], report("in-place residual", hd.cpu(), ref)
+
+
 @pytest.mark.parametrize("with_len", [True, False])
 def test_conv_gather_gemm_aligned_channels(with_len):
     """The postnet's 512-channel layers: channel count a multiple of the GEMM's 64-deep K step and > 128 rows -> the
