@@ -91,27 +91,40 @@ __global__ __launch_bounds__(256) void k_dec_attn(const T* q, int ldq, const T* 
     const int CH = dh / VE, R = 256 / CH;
     float* part = p + nmax;
     float* red = part + R * dh;
-    for (int d = tid; d < dh; d += 256) sq[d] = TT<T>::ld(q + (long)b * ldq + h * dh + d);
-    __syncthreads();
     const T* Kb = Kc + b * kv_bstride + h * dh;
     const T* Vb = Vc + b * kv_bstride + h * dh;
-    // ---- scores
-    const int part4 = tid & 3, kslot = tid >> 2;      // 64 keys per pass
-    const int nch = CH / 4;                           // chunks per lane (dh is a multiple of 4*VE)
-    float mx = -INFINITY;
-    // The loop is latency-bound (2 workgroups per CU, one dependent load -> reduce chain per 64 keys): the loads of SU passes
-    // (SU x nch 16-byte chunks per lane) are issued before the first is consumed.  Per-lane summation order is unchanged.
+    const int part4 = tid & 3, kslot = tid >> 2;      // scores: 64 keys per pass, 4 lanes per key row
+    const int nch = CH / 4;                           // 16-byte chunks per lane (dh is a multiple of 4*VE)
+    const int tx = tid % CH, ty = tid / CH;           // value sum: one 16-byte column chunk per thread, R rows in parallel
+    // The kernel is a chain of dependent phases on 2 workgroups per CU, so memory latency is what it costs: the loads of SU key
+    // passes and of VU value rows are issued together, and the first group of both is in flight before the query is even
+    // staged (for the 160-key cross attention that is every load of the kernel in one round trip).  Summation order per
+    // lane is the plain sequential one.
     constexpr int SU = sizeof(T) == 2 ? 4 : 2, NCH_MAX = sizeof(T) == 2 ? 4 : 8;      // head width <= 128 (checked by the host)
-    for (int j0 = 0; j0 < n; j0 += 64 * SU) {
-        uint4 u[SU][NCH_MAX];
+    constexpr int VU = 8;
+    const int nlast = max(n - 1, 0);                  // (clamped rows are loaded but never used)
+    uint4 u[SU][NCH_MAX], uv[VU];
+    auto load_k = [&](int j0) {
 #pragma unroll
         for (int uu = 0; uu < SU; ++uu) {
-            const int j = j0 + uu * 64 + kslot;
-            const T* kr = Kb + (long)min(j, max(n - 1, 0)) * ldkv;       // (clamped rows are loaded but never used)
+            const T* kr = Kb + (long)min(j0 + uu * 64 + kslot, nlast) * ldkv;
 #pragma unroll
             for (int i = 0; i < NCH_MAX; ++i)
                 if (i < nch) u[uu][i] = *reinterpret_cast<const uint4*>(kr + (i * 4 + part4) * VE);
         }
+    };
+    auto load_v = [&](int j) {
+#pragma unroll
+        for (int v = 0; v < VU; ++v) uv[v] = *reinterpret_cast<const uint4*>(Vb + (long)min(j + v * R, nlast) * ldkv + tx * VE);
+    };
+    load_k(0);
+    if (ty < R) load_v(ty);
+    for (int d = tid; d < dh; d += 256) sq[d] = TT<T>::ld(q + (long)b * ldq + h * dh + d);
+    __syncthreads();
+    // ---- scores
+    float mx = -INFINITY;
+    for (int j0 = 0; j0 < n; j0 += 64 * SU) {
+        if (j0 > 0) load_k(j0);
 #pragma unroll
         for (int uu = 0; uu < SU; ++uu) {
             const int j = j0 + uu * 64 + kslot;
@@ -157,25 +170,16 @@ __global__ __launch_bounds__(256) void k_dec_attn(const T* q, int ldq, const T* 
     }
     __syncthreads();
     // ---- weighted sum of V rows
-    const int tx = tid % CH, ty = tid / CH;
     if (ty < R) {
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        constexpr int VU = 8;                       // V rows whose loads are in flight together (same accumulation order)
         for (int j = ty; j < n; j += R * VU) {
-            uint4 uv[VU];
-            float wv[VU];
-#pragma unroll
-            for (int v = 0; v < VU; ++v) {
-                const int jj = j + v * R;
-                wv[v] = jj < n ? p[jj] : 0.f;
-                uv[v] = *reinterpret_cast<const uint4*>(Vb + (long)min(jj, max(n - 1, 0)) * ldkv + tx * VE);
-            }
+            if (j > ty) load_v(j);
 #pragma unroll
             for (int v = 0; v < VU; ++v) {
                 if (j + v * R >= n) break;
-                const float w = wv[v];
+                const float w = p[j + v * R];
                 if (sizeof(T) == 2) {
                     const uint32_t ww[4] = {uv[v].x, uv[v].y, uv[v].z, uv[v].w};
 #pragma unroll

@@ -41,6 +41,16 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(GemmArgs g) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int mtiles = (g.M + 15) / 16;
+    // epilogue operands of this thread's (at most 2) output elements, fetched ahead of the K walk instead of after it
+    float rpre[2] = {0.f, 0.f}, bpre[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = tid + t * NW * 64, m = i >> 4, n = n0 + (i & 15);
+        if (i < 64 * 16 && m < g.M && n < g.N) {
+            if (g.epi.residual && gridDim.y == 1) rpre[t] = g.epi.residual[(long)m * g.epi.ldr + n];
+            if (g.epi.bias && blockIdx.y == 0) bpre[t] = g.epi.bias[n];
+        }
+    }
     for (int s = s0; s < s1; s += UN) {
         typename SK<T>::frag wb[UN], xa[UN][4];
 #pragma unroll
@@ -68,18 +78,20 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(GemmArgs g) {
     const GemmEpilogue& e = g.epi;
     DropCfg dcfg = e.drop;
     if (e.drop.thresh && e.drop_salt) dcfg.key ^= b2s_hash32((uint32_t)(*e.drop_salt) * 2246822519u + 3266489917u);
-    for (int i = tid; i < 64 * 16; i += NW * 64) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = tid + t * NW * 64;
         const int m = i >> 4, nl = i & 15, n = n0 + nl;
-        if (m >= g.M || n >= g.N) continue;
+        if (i >= 64 * 16 || m >= g.M || n >= g.N) continue;
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[w][m][nl];
         v *= e.alpha;
-        if (e.bias && blockIdx.y == 0) v += e.bias[n];
+        v += bpre[t];
         if (e.relu) v = fmaxf(v, 0.f);
         if (e.drop.thresh) v = b2s_keep(dcfg, (uint32_t)((long)m * g.N + n)) ? v * dcfg.scale : 0.f;
         if (gridDim.y > 1) { atomicAdd(reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n, v); continue; }    // (launcher: C == residual, fp32, linear epilogue)
-        if (e.residual) v += e.residual[(long)m * e.ldr + n];
+        v += rpre[t];
         if (e.row_len) { int bb = m / e.rows_per_batch, t = m - bb * e.rows_per_batch; if (t >= e.row_len[bb]) v = 0.f; }
         const long off = (long)m * g.ldc + n;
         if (g.c_fp32) { float* C = reinterpret_cast<float*>(g.C); if (e.accumulate) C[off] += v; else C[off] = v; }
