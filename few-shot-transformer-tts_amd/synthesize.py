@@ -14,6 +14,7 @@ are produced only with keep_self_alignments=True.
 import copy
 import ctypes as C
 import logging
+import os
 import time
 
 import torch
@@ -23,8 +24,25 @@ from b2s_hip import lib as L
 from b2s_hip.engine import _i32
 
 
+def _lane_bounds(B, lanes):
+    lanes = max(1, min(int(lanes), B))
+    base, extra = divmod(B, lanes)
+    out, lo = [], 0
+    for i in range(lanes):
+        hi = lo + base + (1 if i < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
 def eval_batch(model_eval, data, use_bar=True, bar_interval=10, use_graph=True, sync_interval=16,
-               keep_self_alignments=False):
+               keep_self_alignments=False, lanes=None):
+    """lanes > 1: the batch is decoded as that many independent sub-batches, each with its own KV cache, hipGraph and HIP
+    stream.  Utterances are independent (synthesize.py:23-47 never mixes batch rows), so the split changes no result; a
+    lane whose utterances have all stopped ends early and its remaining frames are the zeros the reference writes after a
+    stop.  Measured on MI355X (64 x 1000 frames): 1 / 2 / 4 lanes = 1.03 / 1.01 / 1.06 ms per frame step -- the frame loop
+    is bound by the ~5 us the command processor needs per kernel dispatch, which concurrent streams share, so the default
+    stays one lane (B2S_DECODE_LANES overrides); the option is for batches too large for one KV-cache allocation."""
     with torch.no_grad():
         tic = time.time()
         batch = copy.copy(data)
@@ -38,46 +56,89 @@ def eval_batch(model_eval, data, use_bar=True, bar_interval=10, use_graph=True, 
         S = enc_outputs.shape[1]
         max_frames = int(hp.max_generation_frames)
         train = bool(model_eval.decoder.training)          # the reference synthesises with decoder.train() (eval.py:116-117)
-        nbytes = lib.b2s_decode_ws_bytes(eng.handle, B, S, max_frames, int(keep_self_alignments))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        stream = torch.cuda.Stream(device=device)          # hipGraph capture needs a non-default stream
-        stream.wait_stream(torch.cuda.current_stream())
-        state = L.P()
-        frames, done = C.c_int(0), C.c_int(0)
-        with torch.cuda.stream(stream):
-            L.check(lib.b2s_decode_begin(eng.handle, L.ptr(enc_outputs), L.ptr(in32), B, S, max_frames, int(train), eng.next_seed(),
-                                         int(keep_self_alignments), L.ptr(ws), nbytes, stream.cuda_stream, C.byref(state)))
-            try:
-                shown = 0
-                while frames.value < max_frames and not done.value:
-                    n = min(sync_interval, max_frames - frames.value)
-                    L.check(lib.b2s_decode_run(eng.handle, state, n, int(use_graph), stream.cuda_stream))
-                    L.check(lib.b2s_decode_status(state, C.byref(frames), C.byref(done), stream.cuda_stream))
-                    if bar_interval != -1 and not use_bar and frames.value // bar_interval > shown:
-                        shown = frames.value // bar_interval
-                        print(frames.value)
-                lengths = torch.empty(B, dtype=torch.int32, device=device)
-                L.check(lib.b2s_decode_fetch(eng.handle, state, 0, L.ptr(torch.empty(1, device=device)), L.ptr(lengths), stream.cuda_stream))
-                stream.synchronize()
+        if lanes is None:
+            lanes = int(os.environ.get("B2S_DECODE_LANES", "1"))
+        H, NL, NM = eng.cfg.n_attention_head, eng.cfg.n_decoder_layer, hp.num_mels
+
+        class Lane(object):
+            pass
+        Ls = []
+        for lo, hi in _lane_bounds(B, lanes):
+            ln = Lane()
+            ln.lo, ln.hi, ln.B = lo, hi, hi - lo
+            ln.enc = enc_outputs[lo:hi].contiguous()
+            ln.in32 = in32[lo:hi].contiguous()
+            ln.nbytes = lib.b2s_decode_ws_bytes(eng.handle, ln.B, S, max_frames, int(keep_self_alignments))
+            ln.ws = torch.empty(ln.nbytes, dtype=torch.uint8, device=device)
+            ln.stream = torch.cuda.Stream(device=device)       # hipGraph capture needs a non-default stream
+            ln.stream.wait_stream(torch.cuda.current_stream())
+            ln.state, ln.frames, ln.done, ln.active = L.P(), C.c_int(0), C.c_int(0), True
+            Ls.append(ln)
+        try:
+            for ln in Ls:
+                L.check(lib.b2s_decode_begin(eng.handle, L.ptr(ln.enc), L.ptr(ln.in32), ln.B, S, max_frames, int(train), eng.next_seed(),
+                                             int(keep_self_alignments), L.ptr(ln.ws), ln.nbytes, ln.stream.cuda_stream, C.byref(ln.state)))
+            shown = 0
+            while any(ln.active for ln in Ls):
+                for ln in Ls:                                   # enqueue every lane's next frames before waiting on any of them
+                    if ln.active:
+                        n = min(sync_interval, max_frames - ln.frames.value)
+                        L.check(lib.b2s_decode_run(eng.handle, ln.state, n, int(use_graph), ln.stream.cuda_stream))
+                for ln in Ls:
+                    if ln.active:
+                        L.check(lib.b2s_decode_status(ln.state, C.byref(ln.frames), C.byref(ln.done), ln.stream.cuda_stream))
+                        ln.active = ln.frames.value < max_frames and not ln.done.value
+                f = max(ln.frames.value for ln in Ls)
+                if bar_interval != -1 and not use_bar and f // bar_interval > shown:
+                    shown = f // bar_interval
+                    print(f)
+            for ln in Ls:
+                ln.lengths = torch.empty(ln.B, dtype=torch.int32, device=device)
+                with torch.cuda.stream(ln.stream):
+                    L.check(lib.b2s_decode_fetch(eng.handle, ln.state, 0, L.ptr(torch.empty(1, device=device)), L.ptr(ln.lengths),
+                                                 ln.stream.cuda_stream))
+            for ln in Ls:
+                ln.stream.synchronize()
                 # the reference stops at the first frame count where every sample has stopped
-                t_gen = int(lengths.max().item()) if done.value else max_frames
-                t_gen = min(t_gen, frames.value)
-                mels = torch.empty(B, t_gen, hp.num_mels, dtype=torch.float32, device=device)
-                L.check(lib.b2s_decode_fetch(eng.handle, state, t_gen, L.ptr(mels), L.ptr(lengths), stream.cuda_stream))
-                H = eng.cfg.n_attention_head
-                alignments = {'self': [], 'encdec': []}
-                for layer in range(eng.cfg.n_decoder_layer):
-                    a = torch.empty(B, H, S, t_gen, dtype=torch.float32, device=device)
-                    L.check(lib.b2s_decode_alignment(eng.handle, state, 1, layer, t_gen, L.ptr(a), stream.cuda_stream))
-                    alignments['encdec'].append(a)
-                    if keep_self_alignments:
-                        a = torch.empty(B, H, t_gen, t_gen, dtype=torch.float32, device=device)
-                        L.check(lib.b2s_decode_alignment(eng.handle, state, 0, layer, t_gen, L.ptr(a), stream.cuda_stream))
-                        alignments['self'].append(a)
-                stream.synchronize()
-            finally:
-                lib.b2s_decode_end(state)
-        torch.cuda.current_stream().wait_stream(stream)
+                ln.t_gen = int(ln.lengths.max().item()) if ln.done.value else max_frames
+                ln.t_gen = min(ln.t_gen, ln.frames.value)
+            t_gen = max(ln.t_gen for ln in Ls)
+            one = len(Ls) == 1
+            mels = torch.empty(B, t_gen, NM, dtype=torch.float32, device=device) if one else \
+                torch.zeros(B, t_gen, NM, dtype=torch.float32, device=device)
+            lengths = torch.empty(B, dtype=torch.int32, device=device)
+            alignments = {'self': [], 'encdec': []}
+            for layer in range(NL):
+                alignments['encdec'].append((torch.empty if one else torch.zeros)(B, H, S, t_gen, dtype=torch.float32, device=device))
+                if keep_self_alignments:
+                    alignments['self'].append((torch.empty if one else torch.zeros)(B, H, t_gen, t_gen, dtype=torch.float32, device=device))
+            torch.cuda.synchronize(device)                      # the zero fills above ran on the caller's stream
+            for ln in Ls:
+                with torch.cuda.stream(ln.stream):
+                    st = ln.stream.cuda_stream
+                    m_l = mels if one else torch.empty(ln.B, ln.t_gen, NM, dtype=torch.float32, device=device)
+                    L.check(lib.b2s_decode_fetch(eng.handle, ln.state, ln.t_gen, L.ptr(m_l), L.ptr(ln.lengths), st))
+                    if not one:
+                        mels[ln.lo:ln.hi, :ln.t_gen].copy_(m_l)
+                    lengths[ln.lo:ln.hi].copy_(ln.lengths)
+                    for layer in range(NL):
+                        a = alignments['encdec'][layer] if one else torch.empty(ln.B, H, S, ln.t_gen, dtype=torch.float32, device=device)
+                        L.check(lib.b2s_decode_alignment(eng.handle, ln.state, 1, layer, ln.t_gen, L.ptr(a), st))
+                        if not one:
+                            alignments['encdec'][layer][ln.lo:ln.hi, :, :, :ln.t_gen].copy_(a)
+                        if keep_self_alignments:
+                            a = alignments['self'][layer] if one else torch.empty(ln.B, H, ln.t_gen, ln.t_gen, dtype=torch.float32, device=device)
+                            L.check(lib.b2s_decode_alignment(eng.handle, ln.state, 0, layer, ln.t_gen, L.ptr(a), st))
+                            if not one:
+                                alignments['self'][layer][ln.lo:ln.hi, :, :ln.t_gen, :ln.t_gen].copy_(a)
+            for ln in Ls:
+                ln.stream.synchronize()
+        finally:
+            for ln in Ls:
+                if ln.state:
+                    lib.b2s_decode_end(ln.state)
+        for ln in Ls:
+            torch.cuda.current_stream().wait_stream(ln.stream)
         mel_aft = model_eval.postnet(mels, lengths, _fuse_add=True)        # mels + postnet(mels), BN in eval mode
         for key in ('self', 'encdec'):
             alignments[key] = [a.cpu().numpy() for a in alignments[key]]

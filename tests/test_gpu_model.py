@@ -268,6 +268,34 @@ def test_decode_eval_batch(tag, over, case):
     assert np.array_equal(re_["mel_pre"], r["mel_pre"]) and np.array_equal(re_["mel_aft"], r["mel_aft"])
 
 
+@pytest.mark.parametrize("case", ["never", "mixed"])
+def test_decode_lanes_match_single_batch(case):
+    """eval_batch(lanes=k) decodes k independent sub-batches on their own streams / graphs / KV caches: same lengths,
+    same mels bit for bit (dropout off), same alignments over every utterance's generated frames; lanes that end early
+    leave the zeros the reference writes after a stop."""
+    import synthesize
+    g = load("g4_decode")
+    bias = -100.0 if case == "never" else float(g["tiny_mixed/stop_bias"])
+
+    def edit(st):
+        st["decoder.stop_net.bias"] = np.full((1,), bias, dtype=np.float32)
+    m, cfg, st, hp = build(TINY + ",max_generation_frames=40", state_edit=edit)
+    m.eval()
+    nb = synth.synthetic_batch(cfg, B=5, S=10, T=4, seed=11, in_lens=[10, 6, 8, 9, 3])
+    nb.pop("mel_targets"); nb.pop("target_lengths")
+    b = dev_batch(nb)
+    r1 = synthesize.eval_batch(m, b, use_bar=False, bar_interval=-1, sync_interval=7, lanes=1)
+    for k in (2, 3):
+        rk = synthesize.eval_batch(m, b, use_bar=False, bar_interval=-1, sync_interval=7, lanes=k)
+        assert [int(x) for x in rk["generated_lengths"]] == [int(x) for x in r1["generated_lengths"]]
+        assert rk["mel_pre"].shape == r1["mel_pre"].shape
+        assert np.array_equal(rk["mel_pre"], r1["mel_pre"]) and np.abs(rk["mel_aft"] - r1["mel_aft"]).max() < 1e-5
+        for i in range(cfg.n_decoder_layer):
+            for u, n in enumerate(r1["generated_lengths"]):
+                n = min(int(n), r1["mel_pre"].shape[1])
+                assert np.array_equal(rk["alignments"]["encdec"][i][u, :, :, :n], r1["alignments"]["encdec"][i][u, :, :, :n])
+
+
 def test_fullsize_spot_checks_fp32():
     """Default hparams (83.5 M parameters), B=4, S=100, T=600: slices, losses, stop indices, gradient norms (G5)."""
     from transformer.tacotron import compute_loss
