@@ -123,7 +123,9 @@ def main():
     model = Tacotron(hp)
     initialize_variables(model)
     model = model.to(device).train()
-    trainer = HipTrainer(model, hp)
+    # B2S_ADAM_OVERLAP=1: optimizer step on the second stream under the next forward pass (measured: no gain -- the GEMM
+    # workgroups fill a CU's registers and LDS, so nothing co-resides with them)
+    trainer = HipTrainer(model, hp, overlap_adam=bool(os.environ.get("B2S_ADAM_OVERLAP")))
     cfg = make_config("")
     B, S, T = args.batch, args.S, args.T
     batch = make_batch(cfg, B, S, T, seed=rank, device=device)     # same shape on every rank, different data

@@ -41,9 +41,13 @@ class _SchedView(object):
 
 
 class HipTrainer(object):
-    def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0):
+    def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0, overlap_adam=False):
         from transformer.tacotron import learning_rate_schedule
         self.model, self.hp = model, hp
+        # overlap_adam: the optimizer step runs on the engine's second stream while the next step's forward pass starts
+        # (every engine entry point waits for the parameter groups it reads).  Code that reads parameters or optimizer state
+        # with plain torch ops between steps must call sync() first; state_dict() / load_state_dict() / utils.checkpoint do.
+        self.overlap_adam = bool(overlap_adam)
         self.eng = model.engine()
         self.eng.ensure_bound()
         self.lib = self.eng.lib
@@ -83,10 +87,15 @@ class HipTrainer(object):
     def _param_names(self):
         return [n for n, _ in self.model.named_parameters()]           # = torch.optim.Adam(m.parameters()) index order
 
+    def sync(self):
+        """Make the current torch stream wait for an overlapped optimizer step (no-op otherwise)."""
+        L.check(self.lib.b2s_adam_wait(self.eng.handle, L.stream()))
+
     def state_dict(self):
         """Optimizer state in torch.optim.Adam.state_dict() layout (what train.py:130 + checkpoint.py:27 write), so a
         checkpoint written from the fused trainer resumes under the reference loop and vice versa.  Parameters that
         were never updated (no step yet, frozen encoder) have no entry, as in torch."""
+        self.sync()
         names = self._param_names()
         state = {}
         if self.global_step > 0:
@@ -105,6 +114,7 @@ class HipTrainer(object):
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        self.sync()
         names = self._param_names()
         groups = sd["param_groups"]
         order = [i for g in groups for i in g["params"]]
@@ -170,8 +180,8 @@ class HipTrainer(object):
             self.bucketer.finish()
         lr = self.hp.max_lr * self.lr_lambda(self.global_step)
         self.global_step += 1
-        L.check(lib.b2s_adam_step(eng.handle, lr, self.global_step, self.beta1, self.beta2, self.hp.adam_eps,
-                                  self.hp.reg_weight, 1.0 / self.world, L.stream()))
+        L.check(lib.b2s_adam_step_ex(eng.handle, lr, self.global_step, self.beta1, self.beta2, self.hp.adam_eps,
+                                     self.hp.reg_weight, 1.0 / self.world, int(self.overlap_adam), L.stream()))
         eng._needs_zero = True
         self.last_aft_losses = per
         return vals

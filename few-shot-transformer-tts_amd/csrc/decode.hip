@@ -346,6 +346,7 @@ extern "C" int b2s_decode_begin(b2s_model* m, const float* memory, const int32_t
     B2S_CHECK(m && m->bound, "model parameters are not bound");
     B2S_CHECK(memory && input_lengths && ws && out && B > 0 && S > 0 && max_frames > 0, "bad argument");
     hipStream_t st = S_(stream);
+    B2S_TRY(b2s_adam_wait(m, stream));                         // an overlapped optimizer step may still be writing the weights
     b2s_decode_state* s = new b2s_decode_state();
     s->B = B; s->S = S; s->maxT = max_frames; s->train = train; s->seed = seed; s->in_len = input_lengths;
     s->keep_self = keep_self_alignments != 0;

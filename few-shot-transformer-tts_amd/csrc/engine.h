@@ -120,6 +120,12 @@ struct b2s_model {
     // the main stream on the group it has just launched.
     mutable bool dw_group = false;
     mutable std::vector<GemmArgs> dw_pending;
+    // Optimizer step overlapped with the next forward pass (b2s_adam_step_ex, overlap = 1): the fused Adam runs on the aux
+    // stream in three groups -- postnet, encoder, decoder parameters (the order the next step first needs them) -- and
+    // every entry point waits on its caller's stream for the groups it reads before it touches a weight.
+    int adam_grp[4] = {0, 0, 0, 0};                            // chunk ranges [grp[g], grp[g+1]) of encoder / decoder / postnet
+    mutable hipEvent_t adam_ev[3] = {nullptr, nullptr, nullptr};
+    mutable bool adam_pending[3] = {false, false, false};
     mutable int pending_stage = -1;
     mutable hipEvent_t pending_ev = nullptr;
     void (*stage_hook)(int, void*) = nullptr;       // called on the host after each backward stage is enqueued

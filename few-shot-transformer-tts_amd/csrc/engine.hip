@@ -570,9 +570,15 @@ namespace {
 int build_chunks(b2s_model* m, bool l2only, bool with_state, MtChunk** out, int* nout) {
     std::vector<MtChunk> h;
     const int CH = 16384;
+    int grp_first[3] = {-1, -1, -1}, last_grp = 0;
+    bool grouped = true;                      // parameters come in encoder, decoder, postnet order (state_dict order)
     for (size_t i = 0; i < m->tinfo.size(); ++i) {
         const TensorInfo& t = m->tinfo[i];
         if (t.kind != 1 || (l2only && !t.l2)) continue;
+        const int gi = t.name.compare(0, 8, "encoder.") == 0 ? 0 : t.name.compare(0, 8, "postnet.") == 0 ? 2 : 1;
+        if (gi < last_grp) grouped = false;
+        last_grp = gi;
+        if (grp_first[gi] < 0) grp_first[gi] = (int)h.size();
         if (!m->grad[i] && with_state) continue;
         if (with_state && m->cfg.freeze_encoder && t.name.compare(0, 8, "encoder.") == 0) continue;   // frozen: never updated
         for (long o = 0; o < t.numel; o += CH) {
@@ -592,6 +598,26 @@ int build_chunks(b2s_model* m, bool l2only, bool with_state, MtChunk** out, int*
         m->owned.push_back(d);
     }
     *out = d; *nout = (int)h.size();
+    if (with_state) {
+        // chunk ranges per group; a table that is not in group order is treated as one (decoder) group
+        const int n = (int)h.size();
+        if (!grouped) { m->adam_grp[0] = 0; m->adam_grp[1] = 0; m->adam_grp[2] = n; m->adam_grp[3] = n; }
+        else {
+            m->adam_grp[3] = n;
+            m->adam_grp[2] = grp_first[2] >= 0 ? grp_first[2] : n;
+            m->adam_grp[1] = grp_first[1] >= 0 ? grp_first[1] : m->adam_grp[2];
+            m->adam_grp[0] = 0;
+        }
+    }
+    return 0;
+}
+// the caller's stream waits for the overlapped optimizer groups in `mask` (bit 0 encoder, 1 decoder, 2 postnet)
+int wait_adam(const b2s_model* m, hipStream_t st, int mask) {
+    for (int g = 0; g < 3; ++g)
+        if ((mask >> g & 1) && m->adam_pending[g]) {
+            B2S_HIP(hipStreamWaitEvent(st, m->adam_ev[g], 0));
+            m->adam_pending[g] = false;
+        }
     return 0;
 }
 }  // namespace
@@ -645,6 +671,7 @@ extern "C" int b2s_model_sync_weights(b2s_model* m, void* stream) { return b2s_m
 extern "C" int b2s_model_sync_weights_ex(b2s_model* m, void* stream, int shadows_fresh) {
     B2S_TRY(check_bound(m));
     hipStream_t st = S_(stream);
+    B2S_TRY(wait_adam(m, st, shadows_fresh ? 4 : 7));
     if (!shadows_fresh) m->l2_fresh = false;
     if (m->dtype && !shadows_fresh)
         for (size_t i = 0; i < m->tinfo.size(); ++i)
@@ -679,6 +706,7 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
                                    uint64_t seed, void* ws, size_t ws_bytes, float* memory_out, void* stream,
                                    b2s_ctx** ctx_out) {
     B2S_TRY(check_bound(m));
+    B2S_TRY(wait_adam(m, S_(stream), 1));
     const b2s_config& cf = m->cfg;
     B2S_CHECK(inputs && input_lengths && memory_out && ws, "null argument");
     B2S_CHECK(B > 0 && S > 0, "bad shape B=%d S=%d", B, S);
@@ -839,6 +867,7 @@ int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, 
 
 extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_memory, void* stream) {
     B2S_TRY(check_bound(m));
+    B2S_TRY(wait_adam(m, S_(stream), 7));
     B2S_CHECK(c && c->kind == 1 && d_memory, "bad encoder context");
     const b2s_config& cf = m->cfg;
     hipStream_t st = S_(stream);
@@ -898,6 +927,7 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
                                    const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
                                    size_t ws_bytes, float* mels_out, float* stop_out, void* stream, b2s_ctx** ctx_out) {
     B2S_TRY(check_bound(m));
+    B2S_TRY(wait_adam(m, S_(stream), 7));
     const b2s_config& cf = m->cfg;
     B2S_CHECK(memory && input_lengths && targets && target_lengths && mels_out && stop_out && ws, "null argument");
     B2S_CHECK(B > 0 && S > 0 && T > 0, "bad shape B=%d S=%d T=%d", B, S, T);
@@ -1013,6 +1043,7 @@ extern "C" int b2s_decoder_guided_loss(b2s_model* m, b2s_ctx* c, float* out, flo
 extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_mels, const float* d_stop, const float* d_guided,
                                        int flags, float* d_memory_out, void* stream) {
     B2S_TRY(check_bound(m));
+    B2S_TRY(wait_adam(m, S_(stream), 7));
     const bool want_dmem = !(flags & B2S_DEC_BWD_NO_DMEMORY);
     B2S_CHECK(c && c->kind == 2 && d_mels && (d_memory_out || !want_dmem), "bad decoder context");
     const b2s_config& cf = m->cfg;
@@ -1131,6 +1162,7 @@ extern "C" int b2s_postnet_forward(b2s_model* m, const float* inputs, const int3
                                    int train, uint64_t seed, void* ws, size_t ws_bytes, float* out, void* stream,
                                    b2s_ctx** ctx_out) {
     B2S_TRY(check_bound(m));
+    B2S_TRY(wait_adam(m, S_(stream), 7));
     const b2s_config& cf = m->cfg;
     B2S_CHECK(inputs && lengths && out && ws && B > 0 && T > 0, "bad argument");
     hipStream_t st = S_(stream);
@@ -1177,6 +1209,7 @@ extern "C" int b2s_postnet_forward(b2s_model* m, const float* inputs, const int3
 
 extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out, float* d_inputs_out, void* stream) {
     B2S_TRY(check_bound(m));
+    B2S_TRY(wait_adam(m, S_(stream), 7));
     B2S_CHECK(c && c->kind == 3 && d_out && d_inputs_out, "bad postnet context");
     B2S_CHECK(c->train, "postnet backward requires a train-mode forward (batch statistics)");
     const b2s_config& cf = m->cfg;
@@ -1225,6 +1258,7 @@ extern "C" int b2s_loss_forward(b2s_model* m, const float* mel_bef, const float*
                                 const float* mel_targets, const int32_t* target_lengths, int B, int T, float* losses_out,
                                 float* aft_losses_out, float* scratch, void* stream) {
     B2S_TRY(check_bound(m));
+    B2S_TRY(wait_adam(m, S_(stream), 7));
     B2S_CHECK(mel_bef && mel_aft && stop_logits && mel_targets && target_lengths && losses_out && aft_losses_out && scratch, "null argument");
     hipStream_t st = S_(stream);
     float* l2 = scratch;                      // scratch[0] = l2, scratch[1..] partial sums
@@ -1246,6 +1280,7 @@ extern "C" int b2s_loss_backward(b2s_model* m, const float* mel_bef, const float
 }
 extern "C" int b2s_l2_backward(b2s_model* m, const float* grad_scale, void* stream) {
     B2S_TRY(check_bound(m));
+    B2S_TRY(wait_adam(m, S_(stream), 7));
     for (size_t i = 0; i < m->tinfo.size(); ++i)
         B2S_CHECK(!m->tinfo[i].l2 || m->grad[i], "gradient of %s is not bound", m->tinfo[i].name.c_str());
     return ro_mt_axpy(m->l2_chunks, m->n_l2_chunks, m->cfg.reg_weight, grad_scale, S_(stream));
@@ -1264,9 +1299,39 @@ extern "C" int b2s_adam_bind(b2s_model* m, void* const* exp_avg_host, void* cons
 }
 extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
                              void* stream) {
+    return b2s_adam_step_ex(m, lr, step, beta1, beta2, eps, l2, grad_scale, 0, stream);
+}
+extern "C" int b2s_adam_wait(b2s_model* m, void* stream) {
+    B2S_CHECK(m, "null model");
+    return wait_adam(m, S_(stream), 7);
+}
+extern "C" int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
+                                int overlap, void* stream) {
     B2S_TRY(check_bound(m));
     B2S_CHECK(m->adam_chunks && step >= 1, "Adam state not bound or bad step");
     hipStream_t st = S_(stream);
+    B2S_TRY(wait_adam(m, st, 7));
+    if (overlap && m->aux) {
+        float hp[3] = {lr, (float)(1.0 - std::pow((double)beta1, step)), (float)std::sqrt(1.0 - std::pow((double)beta2, step))};
+        float* dhp = m->small + 16 + (step % 8) * 4;
+        B2S_HIP(hipMemcpyAsync(dhp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
+        const bool cover = !m->cfg.freeze_encoder;
+        B2S_TRY(join_aux(m, st));                              // (normally a no-op: the backward entry points drain the aux stream)
+        hipEvent_t ready = m->next_event();
+        B2S_HIP(hipEventRecord(ready, st));                    // gradients (and their all-reduce) are complete here
+        B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
+        static const int order[3] = {2, 0, 1};                 // postnet (conv re-layout at the top of the step), encoder, decoder
+        for (int k = 0; k < 3; ++k) {
+            const int g = order[k], lo = m->adam_grp[g], n = m->adam_grp[g + 1] - lo;
+            if (n <= 0) continue;
+            B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, m->aux));
+            if (!m->adam_ev[g]) B2S_HIP(hipEventCreateWithFlags(&m->adam_ev[g], hipEventDisableTiming));
+            B2S_HIP(hipEventRecord(m->adam_ev[g], m->aux));
+            m->adam_pending[g] = true;
+        }
+        m->l2_fresh = cover;
+        return 0;
+    }
     float hp[3] = {lr, (float)(1.0 - std::pow((double)beta1, step)), (float)std::sqrt(1.0 - std::pow((double)beta2, step))};
     float* dhp = m->small + 16 + (step % 8) * 4;         // rotate slots: earlier steps may still be in flight
     B2S_HIP(hipMemcpyAsync(dhp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
@@ -1279,6 +1344,7 @@ extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, floa
 }
 extern "C" int b2s_zero_grads(b2s_model* m, void* stream) {
     B2S_TRY(check_bound(m));
+    B2S_TRY(wait_adam(m, S_(stream), 7));
     // coalesce adjacent gradient buffers (the host normally binds one flat buffer) into few memsets
     std::vector<std::pair<char*, size_t>> r;
     for (size_t i = 0; i < m->tinfo.size(); ++i)

@@ -45,6 +45,8 @@ def save_model(model_dir, model=None, optim=None, sched=None, step=None):
     """Write {'model', 'optim', 'sched', 'step'} (whichever are given).  With a step the file is
     <model_dir>/model.ckpt-<step>; without one `model_dir` itself is the file name (reference behaviour)."""
     objs = {"model": _bare(model) if model is not None else None, "optim": optim, "sched": sched}
+    if hasattr(optim, "sync"):        # fused HIP trainer: an overlapped optimizer step may still be writing the parameters
+        optim.sync()
     payload = {k: objs[k].state_dict() for k in _PARTS if objs[k] is not None}
     target = model_dir
     if step:
@@ -58,6 +60,8 @@ def load_model(model_path, model=None, optim=None, sched=None, map_location={}):
     """Restore whichever of model / optim / sched are both in the file and passed in; returns the step (taken from
     the scheduler when the file has none)."""
     payload = torch.load(model_path, map_location=map_location)
+    if hasattr(optim, "sync"):
+        optim.sync()
     if model is not None and "model" in payload:
         _bare(model).load_state_dict(_strip_prefix(payload["model"]))
     if optim is not None and "optim" in payload:

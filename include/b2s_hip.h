@@ -155,6 +155,13 @@ void b2s_decode_end(b2s_decode_state* s);
 int b2s_adam_bind(b2s_model* m, void* const* exp_avg_host, void* const* exp_avg_sq_host, int n);
 int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
                   void* stream);
+/* overlap = 1: the update runs on the model's second stream in three groups (postnet, encoder, decoder parameters) and
+ * the call returns with `stream` free to go on; every entry point that reads weights makes ITS stream wait for the groups
+ * it needs (b2s_encoder_forward: encoder only), so the next step's forward overlaps the tail of the update.  Anything that
+ * reads the bound parameter / Adam-state tensors outside this library must call b2s_adam_wait on its stream first. */
+int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
+                     int overlap, void* stream);
+int b2s_adam_wait(b2s_model* m, void* stream);
 /* Zero every bound parameter gradient.  Every *_backward entry point ACCUMULATES into the bound gradient
  * buffers (several use atomics), so the host calls this once at the start of each backward pass. */
 int b2s_zero_grads(b2s_model* m, void* stream);
