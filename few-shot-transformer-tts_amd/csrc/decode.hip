@@ -65,20 +65,23 @@ __global__ void k_dec_x0(const float* a3, const int* lengths, const float* pe, c
         x[(long)b * D + c] = v;
     }
 }
-// append this frame's k, v (from qkv [B,3D]) to the caches [B,maxT,D] at position t
+// append this frame's k, v (from qkv [B,3D]) to the head-major caches [B,H,maxT,dh] at position t (every head's rows are
+// contiguous, so the per-head attention below streams whole cache lines instead of 2*dh-byte segments at a 2*D-byte stride)
 template <typename T>
-__global__ void k_dec_append(const T* qkv, const int* tptr, T* Kc, T* Vc, int maxT, int D) {
-    const int b = blockIdx.x, t = *tptr;
+__global__ void k_dec_append(const T* qkv, const int* tptr, T* Kc, T* Vc, int maxT, int D, int dh) {
+    const int b = blockIdx.x, t = *tptr, H = D / dh;
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
-        Kc[((long)b * maxT + t) * D + c] = qkv[(long)b * 3 * D + D + c];
-        Vc[((long)b * maxT + t) * D + c] = qkv[(long)b * 3 * D + 2 * D + c];
+        const int h = c / dh, d = c - h * dh;
+        const long o = (((long)b * H + h) * maxT + t) * dh + d;
+        Kc[o] = qkv[(long)b * 3 * D + D + c];
+        Vc[o] = qkv[(long)b * 3 * D + 2 * D + c];
     }
 }
 // single-query attention for one (b, h) per 256-thread workgroup: keys [0, n), n = t+1 (self) or klen[b] (cross).
 // Scores: 4 lanes share one key row (each 16-byte load instruction covers 64 contiguous bytes of a row), softmax
 // through LDS, weighted V sum with one 16-byte column chunk per thread and a cross-row LDS reduction.
 template <typename T>
-__global__ __launch_bounds__(256) void k_dec_attn(const T* q, int ldq, const T* Kc, const T* Vc, int ldkv, long kv_bstride, T* out,
+__global__ __launch_bounds__(256) void k_dec_attn(const T* q, int ldq, const T* Kc, const T* Vc, int ldkv, long kv_bstride, long kv_hstride, T* out,
                                                   int ldo, float* probs, int probs_rows, int probs_ld, const int* tptr,
                                                   const int* klen, int self, int H, int dh, int nmax, float scale, DropCfg drop) {
     constexpr int VE = TT<T>::VE;
@@ -91,8 +94,8 @@ __global__ __launch_bounds__(256) void k_dec_attn(const T* q, int ldq, const T* 
     const int CH = dh / VE, R = 256 / CH;
     float* part = p + nmax;
     float* red = part + R * dh;
-    const T* Kb = Kc + b * kv_bstride + h * dh;
-    const T* Vb = Vc + b * kv_bstride + h * dh;
+    const T* Kb = Kc + b * kv_bstride + h * kv_hstride;      // head stride: dh (heads interleaved in a row) or maxT*dh (head-major cache)
+    const T* Vb = Vc + b * kv_bstride + h * kv_hstride;
     const int part4 = tid & 3, kslot = tid >> 2;      // scores: 64 keys per pass, 4 lanes per key row
     const int nch = CH / 4;                           // 16-byte chunks per lane (dh is a multiple of 4*VE)
     const int tx = tid % CH, ty = tid / CH;           // value sum: one 16-byte column chunk per thread, R rows in parallel
@@ -292,12 +295,12 @@ int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
         // in the streaming loop cost more than the saved node.)
         const bool fuse_kv = B <= 64 && D % 32 == 0;
         GemmEpilogue eq;
-        if (fuse_kv) { eq.kv_k = s->selfK[l]; eq.kv_v = s->selfV[l]; eq.kv_t = s->t; eq.kv_maxT = maxT; eq.kv_D = D; }
+        if (fuse_kv) { eq.kv_k = s->selfK[l]; eq.kv_v = s->selfV[l]; eq.kv_t = s->t; eq.kv_maxT = maxT; eq.kv_D = D; eq.kv_dh = dh; }
         B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "self_attentions", l, "qkv_transform.weight")), B, 3 * D, D, s->qkv, 0, 3 * D, eq));
         if (!fuse_kv)
-            hipLaunchKernelGGL((k_dec_append<T>), dim3(B), dim3(256), 0, st, (const T*)s->qkv, s->t, (T*)s->selfK[l], (T*)s->selfV[l], maxT, D);
+            hipLaunchKernelGGL((k_dec_append<T>), dim3(B), dim3(256), 0, st, (const T*)s->qkv, s->t, (T*)s->selfK[l], (T*)s->selfV[l], maxT, D, dh);
         hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(256), sh_self, st, (const T*)s->qkv, 3 * D, (const T*)s->selfK[l],
-                           (const T*)s->selfV[l], D, (long)maxT * D, (T*)s->ctx, D, s->selfP[l], maxT, maxT, s->t, (const int*)nullptr, 1, H, dh,
+                           (const T*)s->selfV[l], dh, (long)maxT * D, (long)maxT * dh, (T*)s->ctx, D, s->selfP[l], maxT, maxT, s->t, (const int*)nullptr, 1, H, dh,
                            maxT, scale, make_drop(pt, s->seed, 9010 + l));
         GemmEpilogue ea; ea.drop = make_drop(pt, s->seed, 9020 + l); ea.drop_salt = s->t; ea.residual = s->x; ea.ldr = D;
         B2S_TRY(lin(m, st, s->ctx, D, m->W(nm2(p, "self_attentions", l, "output_transform.weight")), B, D, D, s->x, 1, D, ea));
@@ -306,7 +309,7 @@ int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
                                  nullptr, 1, st));
         B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "encdec_attentions", l, "q_transform.weight")), B, D, D, s->qkv, 0, D, GemmEpilogue()));
         hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(256), sh_cross, st, (const T*)s->qkv, D, (const T*)s->crossKV[l],
-                           (const T*)s->crossKV[l] + D, 2 * D, (long)S * 2 * D, (T*)s->ctx, D, s->crossP[l], maxT, S, s->t, s->in_len, 0, H, dh,
+                           (const T*)s->crossKV[l] + D, 2 * D, (long)S * 2 * D, (long)dh, (T*)s->ctx, D, s->crossP[l], maxT, S, s->t, s->in_len, 0, H, dh,
                            S, scale, make_drop(pt, s->seed, 9030 + l));
         GemmEpilogue ex; ex.drop = make_drop(pt, s->seed, 9040 + l); ex.drop_salt = s->t; ex.residual = s->x; ex.ldr = D;
         B2S_TRY(lin(m, st, s->ctx, D, m->W(nm2(p, "encdec_attentions", l, "output_transform.weight")), B, D, D, s->x, 1, D, ex));

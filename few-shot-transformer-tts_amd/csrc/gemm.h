@@ -32,10 +32,10 @@ struct GemmEpilogue {
     int conv_dw_cin = 0;                  // >0: output column n = j*cin+ci is stored at ci*5 + j
     int accumulate = 0;                   // fp32 output only: C += v
     // decode-step fusion, honoured by the weight-streaming kernel only (gemm_skinny.hip; the tiled kernels reject it): output
-    // columns [kv_D, 2 kv_D) / [2 kv_D, 3 kv_D) are also appended to the caches kv_k / kv_v [M][kv_maxT][kv_D] at position *kv_t
+    // columns [kv_D, 2 kv_D) / [2 kv_D, 3 kv_D) are also appended to the head-major caches kv_k / kv_v [M][kv_D/kv_dh][kv_maxT][kv_dh] at position *kv_t
     void *kv_k = nullptr, *kv_v = nullptr;
     const int* kv_t = nullptr;
-    int kv_maxT = 0, kv_D = 0;
+    int kv_maxT = 0, kv_D = 0, kv_dh = 0;
 };
 
 struct GemmArgs {

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(GemmArgs g) {
         if (e.kv_k && n >= e.kv_D) {          // this frame's k / v columns also go to the caches at position *kv_t
             const int which = n >= 2 * e.kv_D, c = n - (1 + which) * e.kv_D;
             T* cache = reinterpret_cast<T*>(which ? e.kv_v : e.kv_k);
-            TT<T>::st(cache + ((long)m * e.kv_maxT + *e.kv_t) * e.kv_D + c, v);
+            const int hh = c / e.kv_dh, d = c - hh * e.kv_dh;
+            TT<T>::st(cache + (((long)m * (e.kv_D / e.kv_dh) + hh) * e.kv_maxT + *e.kv_t) * e.kv_dh + d, v);
         }
     }
 }
@@ -111,7 +112,7 @@ int b2s_gemm_skinny_launch(const GemmArgs& g, int dtype, hipStream_t stream) {
     const int ks = dtype ? 32 : 4;
     if (g.M > 64 || g.batch != 1 || g.splitk != 1 || g.A.g_cin || g.B.g_cin || g.epi.relu_aux || g.epi.conv_dw_cin || (g.K % ks) != 0)
         return -1;
-    if (g.epi.kv_k && (!g.epi.kv_v || !g.epi.kv_t || g.N != 3 * g.epi.kv_D)) return -1;
+    if (g.epi.kv_k && (!g.epi.kv_v || !g.epi.kv_t || g.N != 3 * g.epi.kv_D || g.epi.kv_dh <= 0 || g.epi.kv_D % g.epi.kv_dh)) return -1;
     // K split over workgroups for the few-column, deep-K problems of the bf16 decode step (fp32 keeps one deterministic
     // summation order): the epilogue must be linear in the accumulator and the output must already hold the residual
     int ksplit = 1;
