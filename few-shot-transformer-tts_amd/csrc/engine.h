@@ -126,6 +126,7 @@ struct b2s_model {
     int adam_grp[4] = {0, 0, 0, 0};                            // chunk ranges [grp[g], grp[g+1]) of encoder / decoder / postnet
     mutable hipEvent_t adam_ev[3] = {nullptr, nullptr, nullptr};
     mutable bool adam_pending[3] = {false, false, false};
+    mutable LnReduceBatch ln_jobs = {};                       // LayerNorm parameter-gradient reductions queued for the stage's single launch
     mutable int pending_stage = -1;
     mutable hipEvent_t pending_ev = nullptr;
     void (*stage_hook)(int, void*) = nullptr;       // called on the host after each backward stage is enqueued

@@ -257,7 +257,9 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
 }
 // end of backward stage `stage`: its parameter gradients are complete once the aux stream has drained.  drain: last stage
 // of this C entry point -- the main stream rejoins the aux stream and every outstanding hook fires.
+int flush_ln_jobs(const b2s_model* m, hipStream_t st);
 int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain) {
+    B2S_TRY(flush_ln_jobs(m, st));                     // the stage's LayerNorm parameter gradients
     if (!m->dw_group) {
         B2S_TRY(join_aux(m, st));
         m->stage_done(stage);
@@ -387,6 +389,7 @@ struct Scratch {
     float *S = nullptr, *dP = nullptr; void* dS = nullptr;
     void *dyT = nullptr, *dz = nullptr, *dqkv = nullptr, *dctx = nullptr, *dh = nullptr, *dkv = nullptr;
     float *dx = nullptr, *a3 = nullptr, *dmem = nullptr, *dstop_m = nullptr, *lnws = nullptr;
+    float* r_lnws[RO_LN_BATCH] = {nullptr, nullptr, nullptr, nullptr};      // one partial buffer per LayerNorm whose reduction is pending
     void *dmelT = nullptr, *doutT = nullptr, *da3 = nullptr, *dz1 = nullptr, *dz2 = nullptr;
 };
 
@@ -444,6 +447,7 @@ void plan_encoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     sc.dyT = sc.r_dyT[0]; sc.dz = sc.r_dz[0]; sc.dqkv = sc.r_dqkv[0];
     sc.dctx = a.T(M * D, esz); sc.dh = a.T(M * D, esz); sc.dx = a.f32(M * D);
     sc.lnws = a.f32((long)RO_LN_WS_ROWS * 2 * D);
+    for (int i = 0; i < RO_LN_BATCH; ++i) sc.r_lnws[i] = a.f32((long)RO_LN_WS_ROWS * 2 * D);
 }
 
 void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::vector<float*>& xs) {
@@ -488,6 +492,7 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     sc.dz1 = a.T(M * cf.prenet_hidden, esz); sc.dz2 = a.T(M * cf.prenet_hidden, esz);
     sc.dstop_m = a.f32(M);
     sc.lnws = a.f32((long)RO_LN_WS_ROWS * 2 * D);
+    for (int i = 0; i < RO_LN_BATCH; ++i) sc.r_lnws[i] = a.f32((long)RO_LN_WS_ROWS * 2 * D);
 }
 
 struct PostScratch { std::vector<void*> du; float* stat; };
@@ -811,6 +816,10 @@ int take_dy(b2s_model* m, hipStream_t st, Scratch& sc, long M, int D, const Drop
     if (m->dtype || dres.thresh) { B2S_TRY(ro_cast_drop(m->dtype, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); *dy = sc.dyT; }
     return 0;
 }
+int flush_ln_jobs(const b2s_model* m, hipStream_t st) {
+    if (m->ln_jobs.n > 0) { B2S_TRY(ro_ln_param_reduce_batch(m->ln_jobs, st)); m->ln_jobs.n = 0; }
+    return 0;
+}
 // LayerNorm backward at the exit of a sublayer (dx += ...), optionally also emitting the NEXT sublayer's dY operand
 int ln_bwd_exit(b2s_model* m, hipStream_t st, Scratch& sc, const void* dh, int dh_fp32, int lddh, const float* x_in,
                 const std::string& lnp, const float* mean, const float* rstd, int accumulate, long M, int D,
@@ -823,8 +832,13 @@ int ln_bwd_exit(b2s_model* m, hipStream_t st, Scratch& sc, const void* dh, int d
         dy2 = sc.dyT; nd = *next;
     }
     B2S_TRY(guard_write(m, sc.dx, st));
+    // the parameter-gradient partials of up to RO_LN_BATCH LayerNorms are reduced by one launch (flush_ln_jobs: end of the stage)
+    if (m->ln_jobs.n == RO_LN_BATCH) B2S_TRY(flush_ln_jobs(m, st));
+    LnReduceJob& jb = m->ln_jobs.j[m->ln_jobs.n];
+    jb.ws = sc.r_lnws[m->ln_jobs.n]; jb.D = D; jb.dgamma = m->G(lnp + ".weight"); jb.dbeta = m->G(lnp + ".bias");
     B2S_TRY(ro_layernorm_bwd(m->dtype, dh, dh_fp32, lddh, x_in, m->P(lnp + ".weight"), mean, rstd, sc.dx, accumulate,
-                             m->G(lnp + ".weight"), m->G(lnp + ".bias"), (int)M, D, row_len, rpb, st, sc.lnws, dy2, nd));
+                             jb.dgamma, jb.dbeta, (int)M, D, row_len, rpb, st, const_cast<float*>(jb.ws), dy2, nd, &jb.nblk));
+    ++m->ln_jobs.n;
     sc.dy_ready = dy2 != nullptr;
     return 0;
 }

@@ -19,9 +19,15 @@ int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float*
 int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const float* x, const float* gamma,
                      const float* mean, const float* rstd, float* dx, int accumulate, float* dgamma, float* dbeta,
                      int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws = nullptr,
-                     void* dy2 = nullptr, DropCfg drop2 = DropCfg{0, 0, 1.f});
+                     void* dy2 = nullptr, DropCfg drop2 = DropCfg{0, 0, 1.f}, int* defer_nblk = nullptr);
 // ws (optional): RO_LN_WS_ROWS * 2 * D floats of scratch for the parameter-gradient partials (avoids global atomics)
+// defer_nblk (with ws): the partial-sum reduction into dgamma / dbeta is NOT launched; *defer_nblk receives the number of
+// partial rows and the caller reduces several LayerNorms' partials in one launch (ro_ln_param_reduce_batch)
 constexpr int RO_LN_WS_ROWS = 768;
+struct LnReduceJob { const float* ws; int nblk, D; float* dgamma; float* dbeta; };
+constexpr int RO_LN_BATCH = 4;
+struct LnReduceBatch { int n; LnReduceJob j[RO_LN_BATCH]; };
+int ro_ln_param_reduce_batch(const LnReduceBatch& b, hipStream_t st);
 
 // P = softmax(scale*S + mask) per row; rows [Z=B*H][Lq][ldp].  mask_mode bit0: keys >= klen[b] masked,
 // bit1: causal (key > query masked); bias: optional dense additive fp32 bias [bias_sb*b + bias_sq*q + k].

@@ -210,6 +210,24 @@ __global__ __launch_bounds__(256) void k_ln_param_reduce(const float* ws, int nb
     }
 }
 
+// the same reduction for up to RO_LN_BATCH LayerNorms in one launch (blockIdx.z = job): a backward stage's 2-3 LayerNorms
+// cost one ~5 us dispatch instead of one each
+__global__ __launch_bounds__(256) void k_ln_param_reduce_batch(LnReduceBatch bt) {
+    __shared__ float sh[4][64];
+    const LnReduceJob jb = bt.j[blockIdx.z];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float acc = 0.f;
+    if (c < 2 * jb.D)
+        for (int b = blockIdx.y * 4 + ry; b < jb.nblk; b += gridDim.y * 4) acc += jb.ws[(long)b * 2 * jb.D + c];
+    sh[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && c < 2 * jb.D) {
+        const float s = sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx];
+        atomicAdd(c < jb.D ? jb.dgamma + c : jb.dbeta + (c - jb.D), s);
+    }
+}
+
 // ---------------------------------------------------------------------------------- softmax
 template <typename T>
 __global__ __launch_bounds__(256) void k_softmax_fwd(const float* S, T* P, T* Pd, int H, int Lq, int Lk, int ldp,
@@ -707,7 +725,8 @@ int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float*
 }
 int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const float* x, const float* gamma,
                      const float* mean, const float* rstd, float* dx, int accumulate, float* dgamma, float* dbeta,
-                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws, void* dy2, DropCfg drop2) {
+                     int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws, void* dy2, DropCfg drop2,
+                     int* defer_nblk) {
     B2S_CHECK(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
     int grid = cdiv(M, 4); if (grid > (ws ? RO_LN_WS_ROWS : 512)) grid = ws ? RO_LN_WS_ROWS : 512;
     if (dy_fp32 || !dtype)
@@ -716,10 +735,19 @@ int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const flo
     else
         hipLaunchKernelGGL((k_ln_bwd<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, lddy, x, gamma, mean,
                            rstd, dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch, ws, (bf16_t*)dy2, drop2);
-    if (ws) {
+    if (ws && defer_nblk) *defer_nblk = grid;
+    else if (ws) {
         int gy = cdiv(grid, 32); if (gy < 1) gy = 1;
         hipLaunchKernelGGL(k_ln_param_reduce, dim3(cdiv(2 * D, 64), gy), dim3(256), 0, st, (const float*)ws, grid, D, dgamma, dbeta);
     }
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_ln_param_reduce_batch(const LnReduceBatch& b, hipStream_t st) {
+    if (b.n <= 0) return 0;
+    int dmax = 0, nmax = 0;
+    for (int i = 0; i < b.n; ++i) { dmax = std::max(dmax, b.j[i].D); nmax = std::max(nmax, b.j[i].nblk); }
+    int gy = cdiv(nmax, 32); if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(k_ln_param_reduce_batch, dim3(cdiv(2 * dmax, 64), gy, b.n), dim3(256), 0, st, b);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_softmax_fwd(int dtype, const float* S, void* P, void* Pd, int B, int H, int Lq, int Lk, int ldp, float scale,
