@@ -37,7 +37,8 @@ struct AttnSave {            // one attention sub-layer
     float *mean = nullptr, *rstd = nullptr;
     void* h = nullptr;       // LN output (T)
     void* qkv = nullptr;     // self: [M,3D] ; cross: q [M,D]
-    void* kv = nullptr;      // cross: [B*S,2D]
+    void* kv = nullptr;      // cross: [B*S,2D] (row stride ldkv: 2D, or L*2D when the layers' K/V live in one projection output)
+    int ldkv = 0;
     void *P = nullptr, *Pd = nullptr;   // softmax weights (T) [B,H,Lq,ldp] ; Pd == P when no dropout
     void* ctx = nullptr;     // [M,D] (T)
     float* lse = nullptr;    // fused path: log-sum-exp [B*H, Lq]
@@ -68,6 +69,7 @@ struct b2s_ctx {
     const float* lang_vecs = nullptr;
     // encoder
     std::vector<AttnSave> self_attn, cross_attn;
+    void* kvcat = nullptr;      // decoder: [B*S][L*2D] K/V of every layer (when the model has a kv_cat weight slab)
     std::vector<FfnSave> ffn;
     float* x_final = nullptr;           // input of the output LayerNorm
     float *mean_f = nullptr, *rstd_f = nullptr;
@@ -126,6 +128,10 @@ struct b2s_model {
     int adam_grp[4] = {0, 0, 0, 0};                            // chunk ranges [grp[g], grp[g+1]) of encoder / decoder / postnet
     mutable hipEvent_t adam_ev[3] = {nullptr, nullptr, nullptr};
     mutable bool adam_pending[3] = {false, false, false};
+    // bf16 mode: the compute-dtype copies of the L encoder-decoder kv_transform weights are one slab [L*2D][D], so that the
+    // memory K/V of all layers come from ONE GEMM (N = L*2D) and d(memory) from ONE GEMM over the concatenated dK/dV
+    // (K = L*2D) instead of L launches of 56-112 tiles each
+    void* kv_cat = nullptr;
     mutable LnReduceBatch ln_jobs = {};                       // LayerNorm parameter-gradient reductions queued for the stage's single launch
     mutable int pending_stage = -1;
     mutable hipEvent_t pending_ev = nullptr;

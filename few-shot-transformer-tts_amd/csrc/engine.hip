@@ -391,6 +391,7 @@ struct Scratch {
     float *dx = nullptr, *a3 = nullptr, *dmem = nullptr, *dstop_m = nullptr, *lnws = nullptr;
     float* r_lnws[RO_LN_BATCH] = {nullptr, nullptr, nullptr, nullptr};      // one partial buffer per LayerNorm whose reduction is pending
     void *dmelT = nullptr, *doutT = nullptr, *da3 = nullptr, *dz1 = nullptr, *dz2 = nullptr;
+    void* dkvcat = nullptr;          // [Mk][L*2D]: dK / dV of every decoder layer (models with a kv_cat weight slab)
 };
 
 void plan_attn(Arena& a, AttnSave& s, int esz, long M, int D, int B, int H, int Lq, int Lk, bool cross, long Mk,
@@ -399,7 +400,7 @@ void plan_attn(Arena& a, AttnSave& s, int esz, long M, int D, int B, int H, int 
     s.mean = a.f32(M); s.rstd = a.f32(M);
     s.h = a.T(M * D, esz);
     s.qkv = a.T(M * (cross ? D : 3 * D), esz);
-    if (cross) s.kv = a.T(Mk * 2 * D, esz);
+    if (cross) { s.kv = a.T(Mk * 2 * D, esz); s.ldkv = 2 * D; }        // (re-pointed into the ctx-wide K/V buffer by plan_decoder when there is one)
     const long pn = (long)B * H * Lq * s.ldp;
     if (use_flash(D / H)) {
         s.lse = a.f32((long)B * H * Lq);
@@ -475,6 +476,11 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
         plan_ffn(a, c.ffn[l], esz, M, D);
         xs.push_back(a.f32(M * D));
     }
+    if (m->kv_cat) {
+        const int L = cf.n_decoder_layer;
+        c.kvcat = a.T(Mk * L * 2 * D, esz);
+        for (int l = 0; l < L; ++l) { c.cross_attn[l].kv = (char*)c.kvcat + (size_t)l * 2 * D * esz; c.cross_attn[l].ldkv = L * 2 * D; }
+    }
     c.x_final = xs.back();
     c.mean_f = a.f32(M); c.rstd_f = a.f32(M);
     c.outT = a.T(M * D, esz);
@@ -491,6 +497,7 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     sc.dmelT = a.T(M * cf.num_mels, esz); sc.doutT = a.T(M * D, esz); sc.da3 = a.T(M * D, esz);
     sc.dz1 = a.T(M * cf.prenet_hidden, esz); sc.dz2 = a.T(M * cf.prenet_hidden, esz);
     sc.dstop_m = a.f32(M);
+    if (m->kv_cat) sc.dkvcat = a.T(Mk * cf.n_decoder_layer * 2 * D, esz);
     sc.lnws = a.f32((long)RO_LN_WS_ROWS * 2 * D);
     for (int i = 0; i < RO_LN_BATCH; ++i) sc.r_lnws[i] = a.f32((long)RO_LN_WS_ROWS * 2 * D);
 }
@@ -636,6 +643,14 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
         m->grad[i] = grad_host ? grad_host[i] : nullptr;
     }
     // compute-dtype shadows
+    if (m->dtype == 1 && !m->kv_cat && m->cfg.n_decoder_layer > 0 && !getenv("B2S_NO_KVCAT")) {
+        const int L = m->cfg.n_decoder_layer, D = m->cfg.decoder_hidden;
+        B2S_HIP(hipMalloc(&m->kv_cat, (size_t)L * 2 * D * D * 2));
+        m->owned.push_back(m->kv_cat);
+        for (int l = 0; l < L; ++l)
+            m->shadow[m->id("decoder.decoder.encdec_attentions." + std::to_string(l) + ".kv_transform.weight")] =
+                (char*)m->kv_cat + (size_t)l * 2 * D * D * 2;
+    }
     for (int i = 0; i < n; ++i) {
         const TensorInfo& t = m->tinfo[i];
         if (!t.gemm_weight) continue;
@@ -962,6 +977,9 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
     const std::string p = "decoder.decoder.";
     auto run = [&]() -> int {
         B2S_TRY(ro_cast(dt, memory, c->memT, Mk * D, st));
+        if (c->kvcat)       // memory K/V of every layer in one projection: [Mk, D] x [L*2D, D]^T
+            B2S_TRY(linear(m, st, c->memT, D, m->kv_cat, (int)Mk, cf.n_decoder_layer * 2 * D, D, c->kvcat, 0, cf.n_decoder_layer * 2 * D,
+                           GemmEpilogue()));
         B2S_TRY(ro_cast(dt, targets, c->tgtT, M * NM, st));
         // prenet (tacotron.py:55-65)
         GemmEpilogue e0; e0.bias = m->P("decoder.prenet.dense0.bias"); e0.relu = 1; e0.drop = make_drop(pd, seed, opid(2, 0, 1));
@@ -996,8 +1014,9 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
             B2S_TRY(ro_layernorm_fwd(dt, x1, m->P(lnx + ".weight"), m->P(lnx + ".bias"), x.h, D, nullptr, 0, x.mean, x.rstd, (int)M, D,
                                      1e-6f, nullptr, 1, st));
             B2S_TRY(linear(m, st, x.h, D, m->W(nm(p, "encdec_attentions", l, "q_transform.weight")), (int)M, D, D, x.qkv, 0, D, GemmEpilogue()));
-            B2S_TRY(linear(m, st, c->memT, D, m->W(nm(p, "encdec_attentions", l, "kv_transform.weight")), (int)Mk, 2 * D, D, x.kv, 0, 2 * D,
-                           GemmEpilogue()));
+            if (!c->kvcat)
+                B2S_TRY(linear(m, st, c->memT, D, m->W(nm(p, "encdec_attentions", l, "kv_transform.weight")), (int)Mk, 2 * D, D, x.kv, 0, 2 * D,
+                               GemmEpilogue()));
             x.op_attn = opid(2, l, 6); x.op_res = opid(2, l, 7);
             const char* kv = (const char*)x.kv;
             GuidedArgs ga;
@@ -1005,7 +1024,7 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
                 ga.rows = c->ga_rows + (long)l * B * H * T; ga.qlen = target_lengths;
                 ga.inv2s2 = 1.f / (2.f * cf.guided_attention_sigma * cf.guided_attention_sigma);
             }
-            B2S_TRY(attn_core_fwd(dt, st, x.qkv, D, kv, 2 * D, kv + (size_t)D * esz, 2 * D, x.ctx, D, B, H, T, S, dh, 1, input_lengths,
+            B2S_TRY(attn_core_fwd(dt, st, x.qkv, D, kv, x.ldkv, kv + (size_t)D * esz, x.ldkv, x.ctx, D, B, H, T, S, dh, 1, input_lengths,
                                   nullptr, 0, 0, make_drop(pt, seed, x.op_attn), sc.S, x.P, x.Pd, x.lse, guided ? &ga : nullptr));
             x.mask_mode = 1;
             GemmEpilogue ex; ex.drop = make_drop(pt, seed, x.op_res); ex.residual = x1; ex.ldr = D;
@@ -1104,21 +1123,24 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
             B2S_TRY(take_dy(m, st, sc, M, D, dres, &dy));
             B2S_TRY(linear_dw(m, st, dy, D, x.ctx, D, (int)M, D, D, m->G(wo)));
             B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, sc.dctx, 0, D, GemmEpilogue()));
-            sc.dqkv = Scratch::rot(sc.r_dqkv, sc.i_dqkv); sc.dkv = Scratch::rot(sc.r_dkv, sc.i_dkv);
-            B2S_TRY(guard_write(m, sc.dqkv, st)); B2S_TRY(guard_write(m, sc.dkv, st));
+            sc.dqkv = Scratch::rot(sc.r_dqkv, sc.i_dqkv);
+            B2S_TRY(guard_write(m, sc.dqkv, st));
+            int lddkv = 2 * D;
+            if (sc.dkvcat) { sc.dkv = (char*)sc.dkvcat + (size_t)l * 2 * D * esz; lddkv = cf.n_decoder_layer * 2 * D; }     // own columns per layer: no reuse hazard
+            else { sc.dkv = Scratch::rot(sc.r_dkv, sc.i_dkv); B2S_TRY(guard_write(m, sc.dkv, st)); }
             const char* kv = (const char*)x.kv; char* dkv = (char*)sc.dkv;
             GuidedArgs ga;
             if (guided) {
                 ga.rows = c->ga_rows + (long)l * B * H * T; ga.qlen = c->tgt_len; ga.scale = c->ga_small + 2;
                 ga.inv2s2 = 1.f / (2.f * cf.guided_attention_sigma * cf.guided_attention_sigma);
             }
-            B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, x.qkv, D, kv, 2 * D, kv + (size_t)D * esz, 2 * D, x.P, x.Pd, sc.dqkv, D, dkv, 2 * D,
-                                  dkv + (size_t)D * esz, 2 * D, B, H, T, S, dh, datt, sc.dP, sc.dS, x.lse, x.ctx, x.mask_mode, c->in_len,
+            B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, x.qkv, D, kv, x.ldkv, kv + (size_t)D * esz, x.ldkv, x.P, x.Pd, sc.dqkv, D, dkv, lddkv,
+                                  dkv + (size_t)D * esz, lddkv, B, H, T, S, dh, datt, sc.dP, sc.dS, x.lse, x.ctx, x.mask_mode, c->in_len,
                                   guided ? &ga : nullptr));
             B2S_TRY(linear_dw(m, st, sc.dqkv, D, x.h, D, (int)M, D, D, m->G(wq)));
             B2S_TRY(linear_dx(m, st, sc.dqkv, D, m->W(wq), (int)M, D, D, sc.dh, 0, D, GemmEpilogue()));
-            B2S_TRY(linear_dw(m, st, sc.dkv, 2 * D, c->memT, D, (int)Mk, 2 * D, D, m->G(wkv)));
-            if (want_dmem) {
+            B2S_TRY(linear_dw(m, st, sc.dkv, lddkv, c->memT, D, (int)Mk, 2 * D, D, m->G(wkv)));
+            if (want_dmem && !sc.dkvcat) {
                 GemmEpilogue em; em.accumulate = first_mem ? 0 : 1;
                 B2S_TRY(linear_dx(m, st, sc.dkv, 2 * D, m->W(wkv), (int)Mk, D, 2 * D, d_memory_out, 1, D, em));
                 first_mem = false;
@@ -1131,7 +1153,21 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
                               nm(p, "self_attentions", l, "output_transform.weight"), lna, nullptr, l > 0 ? &nd : nullptr));
         B2S_TRY(end_stage(m, st, 2 + (cf.n_decoder_layer - 1 - l), false));
     }
-    if (first_mem && want_dmem) B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
+    if (want_dmem && sc.dkvcat && cf.n_decoder_layer > 0) {
+        // d(memory) = [dKV_0 .. dKV_{L-1}] [Mk, L*2D] x Wcat [L*2D, D]: one GEMM with K = L*2D instead of L accumulating launches.
+        // 56 output tiles only -> K split over 4 workgroups each (slab workspace; free here: with grouped weight gradients
+        // nothing on the second stream uses it)
+        const int Kc = cf.n_decoder_layer * 2 * D;
+        GemmArgs g;
+        g.A.p = sc.dkvcat; g.A.ld = Kc; g.A.R = (int)Mk; g.A.C = Kc;
+        g.B.p = m->kv_cat; g.B.ld = D; g.B.R = Kc; g.B.C = D;
+        g.M = (int)Mk; g.N = D; g.K = Kc; g.C = d_memory_out; g.c_fp32 = 1; g.ldc = D;
+        if (m->dw_group) {
+            B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
+            g.epi.accumulate = 1; g.splitk = 4;
+        }
+        B2S_TRY(b2s_gemm_launch(g, dt, false, true, st));
+    } else if (first_mem && want_dmem) B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
     B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, opid(2, 0, 3)), st));
     // prenet backward
     DropCfg d1 = make_drop(pd, c->seed, opid(2, 0, 1)), d2 = make_drop(pd, c->seed, opid(2, 0, 2));
@@ -1156,7 +1192,7 @@ extern "C" int b2s_decoder_alignment(b2s_model* m, b2s_ctx* c, int which, int la
     if (s.lse) {
         const int D = m->cfg.decoder_hidden, H = m->cfg.n_attention_head, dh = D / H, esz = m->esz;
         AttnArgs a;
-        if (which) a = flash_args(s.qkv, D, s.kv, 2 * D, nullptr, 0, c->B, H, s.Lq, s.Lk, dh, 1, c->in_len, DropCfg{0, 0, 1.f}, s.lse);
+        if (which) a = flash_args(s.qkv, D, s.kv, s.ldkv, nullptr, 0, c->B, H, s.Lq, s.Lk, dh, 1, c->in_len, DropCfg{0, 0, 1.f}, s.lse);
         else a = flash_args(s.qkv, 3 * D, (const char*)s.qkv + (size_t)D * esz, 3 * D, nullptr, 0, c->B, H, s.Lq, s.Lk, dh, 2, nullptr, DropCfg{0, 0, 1.f}, s.lse);
         return b2s_flash_align(m->dtype, a, dh, out, S_(stream));
     }
