@@ -245,6 +245,17 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
     hipEvent_t ready = m->next_event();
     B2S_HIP(hipEventRecord(ready, st));
     B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
+    // a stage with only a few output tiles (prenet: 9, mel / stop heads: 6) would walk the whole token dimension inside
+    // each of them (127 K steps, > 100 us on a handful of CUs, and the drain at the end of the entry point waits for it):
+    // those go through the split-K launch instead
+    long tiles = 0;
+    for (const GemmArgs& g : q) tiles += b2s_gemm_glds256_tiles(g);
+    if (tiles < 32) {
+        for (GemmArgs g : q) {
+            g.splitk = pick_splitk(g.M, g.N, g.K, m->dtype);
+            B2S_TRY(b2s_gemm_launch(g, m->dtype, true, true, m->aux));
+        }
+    } else
     for (size_t i = 0; i < q.size(); i += B2S_MAX_GROUP)
         B2S_TRY(b2s_gemm_grouped_launch(q.data() + i, (int)std::min<size_t>(B2S_MAX_GROUP, q.size() - i), m->aux));
     hipEvent_t done = m->next_event();
