@@ -42,8 +42,10 @@ constexpr int NPROD = B2S_NPROD, GROUP_M = B2S_GROUP_M;
 // GATHER: 0 = plain operands, 1 = conv gather with general addressing (issued by the MFMA waves), 2 = conv gather on a
 // K-contiguous A whose channel count is a multiple of BK (every K step lies inside one tap: wave-uniform tap / channel base,
 // a compare + select per lane; issued by the producer waves)
-constexpr int nprod_of(int gather) { return gather == 1 ? 0 : NPROD; }
-constexpr int nthreads_of(int gather) { return 512 + 64 * nprod_of(gather); }
+// MW: rows of MFMA waves.  4 -> 256-row tiles (8 MFMA + 4 producer waves), 2 -> 128-row tiles (4 + 2 waves, 96 KB ring) for
+// problems whose 256-row tiling leaves most CUs without a workgroup (the 1596-row encoder GEMMs: 42 tiles on 256 CUs).
+constexpr int nprod_of(int gather, int mw = 4) { return gather == 1 ? 0 : NPROD * mw / 4; }
+constexpr int nthreads_of(int gather, int mw = 4) { return 64 * (2 * mw + nprod_of(gather, mw)); }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 constexpr int BM = 256, BK = 64, NSTAGE = 3;            // BN = 128 or 96 (template parameter NB = BN / 32)
@@ -104,19 +106,21 @@ __device__ inline int xcd_tile_id(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-template <bool TA, bool TB, int GATHER, int NB>
+template <bool TA, bool TB, int GATHER, int NB, int MW = 4>
 __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, float* splitk_ws, int bx, int by, int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // conv-gather operands keep the DMA issue on the MFMA waves: their per-chunk address arithmetic (two divisions, a length
     // lookup) serialised on 4 producer waves costs more than the blocking issue does (60 -> 84 us on the postnet GEMMs)
-    constexpr int NP = nprod_of(GATHER);
+    static_assert(MW == 4 || (MW == 2 && !TA && GATHER == 0), "128-row tiles: plain K-contiguous A only");
+    constexpr int NP = nprod_of(GATHER, MW), NC = 2 * MW;                       // producer / MFMA waves
+    constexpr int BMt = MW * 64, A_B = BMt * BK * 2, STG = A_B + B_BYTES;       // tile rows, A image and stage bytes of this variant
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform -> SGPR: DMA destinations / branches on it are scalar
     const int li = lane & 15, lg = lane >> 4;
     constexpr int BN = NB * 32;                      // two waves along N, NB 16-column MFMA blocks each
     const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * (NB * 16);
-    const int m0 = by * BM, n0 = bx * BN;
+    const int m0 = by * BMt, n0 = bx * BN;
     const int z = bz / g.splitk, ksplit = bz - z * g.splitk;
     const int zo = z / g.batch_inner, zi = z - zo * g.batch_inner;
     const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A.p) + zo * g.A.bs_o + zi * g.A.bs_i;
@@ -126,8 +130,8 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
     // Plain operands: the source address of a lane is affine in the stage index -> pointer at stage 0 + per-stage step.
     // With producer waves (NP > 0) the 32 A + 16 (12 at BN = 96, K-contiguous B) instructions are dealt to waves 8.. instead.
     constexpr int NBI = (NB == 4 || TB) ? 16 : 12;
-    constexpr int NPD = NP ? NP : 1, NIA = NP ? 32 / NPD : 4, NIB = NP ? NBI / NPD : 2, IPW = NIA + NIB;
-    const int iw = NP ? max(wave - 8, 0) : wave;
+    constexpr int NPD = NP ? NP : 1, NIA = NP ? (BMt / 8) / NPD : (BMt / 8) / NC, NIB = NP ? NBI / NPD : 2, IPW = NIA + NIB;
+    const int iw = NP ? max(wave - NC, 0) : wave;
     const int ia0 = iw * NIA, ib0 = iw * NIB;
     const bf16_t* pa[NIA]; const bf16_t* pb[NIB];
     int ka[NIA], kb_[NIB];        // reduction offset this lane's chunk covers inside a stage; -1 = never valid
@@ -201,7 +205,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
 #ifdef B2S_EXP_NODMA
         return;
 #endif
-        unsigned char* sbase = smem_raw + slot * STAGE_BYTES;
+        unsigned char* sbase = smem_raw + slot * STG;
         if (fast_ok && (kt < nfull || kt >= kt_end)) {                   // (steps past the end re-fetch the last full one: never consumed)
             const long ks = min(kt, nfull - 1);
             const char* sa = reinterpret_cast<const char*>(Ab) + ks * stepA * 2;
@@ -224,7 +228,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
 #pragma unroll
             for (int i = 0; i < NIB; ++i)
                 if (NP || (i == 0 ? b_active0 : b_active1))
-                    __builtin_amdgcn_global_load_lds((gptr_t)(sb + goffB[i]), (lptr_t)(sbase + A_BYTES + (ib0 + i) * 1024), 16, 0, B2S_DMA_AUX);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(sb + goffB[i]), (lptr_t)(sbase + A_B + (ib0 + i) * 1024), 16, 0, B2S_DMA_AUX);
             return;
         }
         if (GF) return;                      // (the aligned gather has no partial K steps: nothing below is reachable, keep it out of the register budget)
@@ -259,7 +263,7 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
 #ifdef B2S_EXP_DMAHOT
             sb = zero + (lane & 15) * 8;
 #endif
-            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(sbase + A_BYTES + idx * 1024), 16, 0, B2S_DMA_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(sbase + A_B + idx * 1024), 16, 0, B2S_DMA_AUX);
         }
     };
 
@@ -277,11 +281,11 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
         }
         if (TB) {
             const int k = lg * 8 + (li >> 2), col = wcol + t * 16 + (li & 3) * 4, sw = ((li >> 2) | ((lg & 1) << 2)) << 1;
-            const unsigned o = (unsigned)A_BYTES + 2u * (k * 128 + (((col >> 3) ^ sw) << 3) + (col & 7));
+            const unsigned o = (unsigned)A_B + 2u * (k * 128 + (((col >> 3) ^ sw) << 3) + (col & 7));
             offB[0][t] = o; offB[1][t] = o + UNIT;
         } else {
             const int r = wcol + t * 16 + li;
-            offB[0][t] = (unsigned)(A_BYTES + r * 128 + ((lg ^ swz_n(r)) << 4)); offB[1][t] = offB[0][t] ^ 64u;
+            offB[0][t] = (unsigned)(A_B + r * 128 + ((lg ^ swz_n(r)) << 4)); offB[1][t] = offB[0][t] ^ 64u;
         }
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem_raw;
@@ -308,14 +312,14 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CA[a], CB[b], acc[a][b], 0, 0, 0);
 #define B2S_READ8(FA, FB, SLOT, H)                                                                                \
     {                                                                                                              \
-        const unsigned sb_ = lds_base + (unsigned)((SLOT) * STAGE_BYTES);                                          \
+        const unsigned sb_ = lds_base + (unsigned)((SLOT) * STG);                                          \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                            \
             frag_issue(FA[t], TA, sb_ + offA[H][t]);                                                               \
             if (t < NB) frag_issue(FB[t], TB, sb_ + offB[H][t]);                                                   \
         }                                                                                                          \
     }
 
-    if (NP && wave >= 8) {
+    if (NP && wave >= NC) {
         // Producer wave: keeps two stages in flight and never touches the matrix pipe.  Barrier k of the workgroup (k = 0 in
         // the prologue) says "stage k has landed and every consumer is done with stage k - 1"; the freed slot is refilled
         // right behind it.  The consumers run the same barrier sequence and never wait on a DMA issue.
@@ -378,8 +382,8 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
     gemm_wave_epilogue<NB>(g, acc, reinterpret_cast<float*>(smem_raw) + wave * (64 * 64), m0 + wrow, n0 + wcol, lane, z, zo, zi, ksplit, splitk_ws);
 }
 
-template <bool TA, bool TB, int GATHER, int NB>
-__global__ __launch_bounds__(nthreads_of(GATHER), 1) void gemm_glds256_kernel(GemmArgs g, const bf16_t* zero, float* splitk_ws, int tiles_m, int tiles_n) {
+template <bool TA, bool TB, int GATHER, int NB, int MW = 4>
+__global__ __launch_bounds__(nthreads_of(GATHER, MW), 1) void gemm_glds256_kernel(GemmArgs g, const bf16_t* zero, float* splitk_ws, int tiles_m, int tiles_n) {
     const int wg = xcd_tile_id(blockIdx.x, gridDim.x);
     const int per_z = tiles_n * tiles_m;
     const int bz = wg / per_z, rem = wg - bz * per_z;
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(nthreads_of(GATHER), 1) void gemm_glds256_kernel(Ge
         const int rows = min(GROUP_M, tiles_m - grp * GROUP_M);
         bx = in / rows; by = grp * GROUP_M + (in - bx * rows);
     } else { by = rem / tiles_n; bx = rem - by * tiles_n; }
-    gemm256_body<TA, TB, GATHER, NB>(g, zero, splitk_ws, bx, by, bz);
+    gemm256_body<TA, TB, GATHER, NB, MW>(g, zero, splitk_ws, bx, by, bz);
 }
 
 // Grouped weight-gradient launch: up to B2S_MAX_GROUP independent dW = dY^T X problems (TN form, fp32 accumulate) in one
@@ -413,27 +417,27 @@ __global__ __launch_bounds__(nthreads_of(false), 1) void gemm_glds256_grouped_ke
     gemm256_body<true, true, 0, NB>(grp.p[p], zero, nullptr, bx, by, 0);
 }
 
-template <bool TA, bool TB, int GATHER, int NB>
+template <bool TA, bool TB, int GATHER, int NB, int MW = 4>
 int launch256_nb(const GemmArgs& g_in, const bf16_t* zero, float* ws_all, size_t ws_floats, hipStream_t stream) {
     GemmArgs g = g_in;
     if (g.splitk > 1) {                     // every split must own at least one K step (empty splits would leave slabs unwritten)
         const int nk_all = cdiv(g.K, BK), per = cdiv(nk_all, g.splitk);
         g.splitk = cdiv(nk_all, per);
     }
-    constexpr size_t smem = (size_t)NSTAGE * STAGE_BYTES;           // 144 KB
+    constexpr size_t smem = (size_t)NSTAGE * (MW * 64 * BK * 2 + B_BYTES);           // 144 KB (96 KB with 128-row tiles)
     static bool attr_set = false;
     if (!attr_set) {
-        B2S_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<TA, TB, GATHER, NB>),
+        B2S_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<TA, TB, GATHER, NB, MW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, NB * 32);
+    const int tiles_m = cdiv(g.M, MW * 64), tiles_n = cdiv(g.N, NB * 32);
     dim3 grid(tiles_m * tiles_n * g.batch * g.splitk);               // 1-D: the kernel maps linear ids to tiles (XCD-aware)
     float* ws = nullptr;
     if (g.splitk > 1 && g.batch == 1 && g.c_fp32 && g.epi.accumulate && (g.N & 3) == 0 && (g.ldc & 3) == 0 &&
         (size_t)g.splitk * g.M * g.N <= ws_floats)
         ws = ws_all;
-    hipLaunchKernelGGL((gemm_glds256_kernel<TA, TB, GATHER, NB>), grid, dim3(nthreads_of(GATHER)), smem, stream, g, zero, ws, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_glds256_kernel<TA, TB, GATHER, NB, MW>), grid, dim3(nthreads_of(GATHER, MW)), smem, stream, g, zero, ws, tiles_m, tiles_n);
     B2S_LAUNCH_CHECK();
     if (ws) B2S_TRY(b2s_splitk_reduce_launch(ws, (float*)g.C, g.M, g.N, g.ldc, g.splitk, g.epi.conv_dw_cin, stream));
     return 0;
@@ -450,6 +454,17 @@ inline int pick_nb(const GemmArgs& g) {
 }
 template <bool TA, bool TB, int GATHER>
 int launch256_t(const GemmArgs& g, const bf16_t* zero, float* ws_all, size_t ws_floats, hipStream_t stream) {
+    if (!TA && GATHER == 0) {
+        // 128-row tiles when 256-row tiles would occupy at most half of the CUs
+        static const int small_tiles = getenv("B2S_GEMM128_MAX_TILES") ? atoi(getenv("B2S_GEMM128_MAX_TILES")) : 128;
+        const int nb = pick_nb(g);
+        const long t256n = (long)cdiv(g.M, BM) * cdiv(g.N, nb * 32) * g.batch * std::max(1, g.splitk);
+        if (t256n <= small_tiles && g.M > 128) {
+            constexpr bool ta = false;          // (the 128-row variant is instantiated for K-contiguous A only)
+            return nb == 3 ? launch256_nb<ta, TB, 0, 3, 2>(g, zero, ws_all, ws_floats, stream)
+                           : launch256_nb<ta, TB, 0, 4, 2>(g, zero, ws_all, ws_floats, stream);
+        }
+    }
     return pick_nb(g) == 3 ? launch256_nb<TA, TB, GATHER, 3>(g, zero, ws_all, ws_floats, stream)
                            : launch256_nb<TA, TB, GATHER, 4>(g, zero, ws_all, ws_floats, stream);
 }

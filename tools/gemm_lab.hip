@@ -38,6 +38,10 @@ int main(int argc, char** argv) {
         {8148, 3072, 768, 0, 0, 1, "fwd ffn in"},
         {8148, 768, 3072, 0, 0, 1, "fwd ffn out"},
         {1596, 2048, 512, 0, 0, 1, "fwd enc ffn in"},
+        {1596, 1536, 512, 0, 0, 1, "fwd enc qkv"},
+        {1596, 512, 512, 0, 0, 1, "fwd enc attn out"},
+        {1596, 512, 1536, 0, 1, 1, "dX enc qkv"},
+        {1596, 768, 1536, 0, 1, 1, "dX cross kv (old)"},
         {1596, 512, 2048, 0, 0, 1, "fwd enc ffn out"},
         {8148, 768, 768, 0, 1, 1, "dX attn out"},
         {8148, 768, 2304, 0, 1, 1, "dX qkv"},
@@ -114,7 +118,7 @@ int main(int argc, char** argv) {
         const double us = ms * 1e3 / iters, fl = 2.0 * s.M * s.N * s.K;
         printf("%2zu %-22s M=%5d N=%5d K=%5d %s%s sk=%2d  %8.2f us  %7.1f TF  err=%.2f%s\n", si, s.what, s.M, s.N, s.K, s.ta ? "T" : "N",
                s.tb ? "T" : "N", s.splitk, us, fl / us / 1e6, worst, worst > 1.0 ? "  <-- MISMATCH" : "");
-        if (si < 13) { tot_us += us; tot_fl += fl; }
+        if (si < 17) { tot_us += us; tot_fl += fl; }
     }
     printf("step-shape mix: %.1f us total, %.1f TF/s\n", tot_us, tot_fl / tot_us / 1e6);
     return 0;
