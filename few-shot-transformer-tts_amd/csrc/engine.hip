@@ -611,6 +611,13 @@ int build_chunks(b2s_model* m, bool l2only, bool with_state, MtChunk** out, int*
             c.d = with_state ? (float*)m->exp_avg_sq[i] + o : nullptr;
             c.n = (int)std::min<long>(CH, t.numel - o); c.pad = t.l2 ? 1 : 0;
             c.s = (with_state && m->dtype == 1 && t.gemm_weight && m->shadow[i] && m->shadow[i] != m->data[i]) ? (bf16_t*)m->shadow[i] + o : nullptr;
+            c.s2 = nullptr; c.cin = 0; c.cout = 0; c.off = o;
+            if (with_state && m->dtype == 1 && t.name.compare(0, 20, "postnet.conv_layers.") == 0 && t.shape.size() == 3) {
+                const int l = atoi(t.name.c_str() + 20);
+                if (l >= 0 && l < m->cfg.n_postnet_layer && m->conv_wf[l] && m->conv_wb[l]) {
+                    c.s = (bf16_t*)m->conv_wf[l]; c.s2 = (bf16_t*)m->conv_wb[l]; c.cout = (int)t.shape[0]; c.cin = (int)t.shape[1];
+                }
+            }
             h.push_back(c);
         }
     }
@@ -707,10 +714,12 @@ extern "C" int b2s_model_sync_weights_ex(b2s_model* m, void* stream, int shadows
     if (m->dtype && !shadows_fresh)
         for (size_t i = 0; i < m->tinfo.size(); ++i)
             if (m->tinfo[i].gemm_weight) B2S_TRY(ro_cast(1, (const float*)m->data[i], m->shadow[i], m->tinfo[i].numel, st));
-    for (int l = 0; l < m->cfg.n_postnet_layer; ++l) {
-        const TensorInfo& t = m->tinfo[m->id("postnet.conv_layers." + std::to_string(l) + ".weight")];
-        B2S_TRY(ro_conv_w_relayout(m->dtype, m->P(t.name), m->conv_wf[l], m->conv_wb[l], (int)t.shape[0], (int)t.shape[1], st));
-    }
+    // (bf16 mode after a fused optimizer step: the Adam kernel has written both conv weight images itself)
+    if (!(shadows_fresh && m->dtype == 1 && m->adam_chunks))
+        for (int l = 0; l < m->cfg.n_postnet_layer; ++l) {
+            const TensorInfo& t = m->tinfo[m->id("postnet.conv_layers." + std::to_string(l) + ".weight")];
+            B2S_TRY(ro_conv_w_relayout(m->dtype, m->P(t.name), m->conv_wf[l], m->conv_wb[l], (int)t.shape[0], (int)t.shape[1], st));
+        }
     return 0;
 }
 

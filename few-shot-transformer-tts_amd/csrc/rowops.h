@@ -98,7 +98,12 @@ int ro_loss_bwd(const float* bef, const float* aft, const float* stop, const flo
                 hipStream_t st);
 
 // multi-tensor ops over a chunk table (device array of MtChunk)
-struct MtChunk { float* a; float* b; float* c; float* d; bf16_t* s; int n; int pad; };   // pad: 1 = member of the L2 set; s: bf16 shadow (or null)
+struct MtChunk {            // pad: 1 = member of the L2 set; s: bf16 shadow (or null)
+    float* a; float* b; float* c; float* d; bf16_t* s; int n; int pad;
+    // conv weights (cin > 0): the shadows are the two re-laid-out bf16 images of the whole tensor (see ro_conv_w_relayout),
+    // s = forward image, s2 = backward-data image; off = index of the chunk's first element in the [Cout][Cin][5] master
+    bf16_t* s2; int cin, cout; long off;
+};
 int ro_mt_sumsq(const MtChunk* chunks, int nchunks, float* out, float scale, hipStream_t st);         // out += scale*sum a^2
 int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gscale, hipStream_t st);  // b += alpha*gscale*a
 // Adam: a=param b=grad c=m d=v ; lr and step read from device (hp[0]=lr, hp[1]=bias_corr1, hp[2]=bias_corr2)

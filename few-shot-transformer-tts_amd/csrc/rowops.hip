@@ -665,7 +665,13 @@ __global__ __launch_bounds__(256) void k_mt_adam(const MtChunk* ch, const float*
         c.c[i] = m; c.d[i] = v;
         p -= (lr / bc1) * m / (sqrtf(v) / sbc2 + eps);
         c.a[i] = p;
-        if (c.s) c.s[i] = f2bf(p);                       // refresh the compute-dtype shadow in the same pass
+        if (c.cin) {                                     // conv weight: both re-laid-out images, no separate relayout pass
+            const long gi = c.off + i, r = gi / 5;
+            const int j = (int)(gi - r * 5), co = (int)(r / c.cin), ci = (int)(r - (long)co * c.cin);
+            const bf16_t pb = f2bf(p);
+            c.s[(long)co * 5 * c.cin + (long)j * c.cin + ci] = pb;
+            c.s2[(long)ci * 5 * c.cout + (long)(4 - j) * c.cout + co] = pb;
+        } else if (c.s) c.s[i] = f2bf(p);                // refresh the compute-dtype shadow in the same pass
         ss += p * p;
     }
     if (sumsq_part) {            // sum of squares of the UPDATED L2 members: the next step's regulariser value for free
