@@ -201,7 +201,8 @@ def main():
             dt, ta, tb, ga = v >> 3, (v >> 2) & 1, (v >> 1) & 1, v & 1
             tf = lambda x: "true" if x else "false"
             if dt:                  # 256-row tile kernel, 128- or 96-column variant chosen per shape (NB = 4 | 3)
-                return "t256::gemm_glds256_kernel<%s, %s, %s, NB>" % (tf(ta), tf(tb), "G" if ga else "0")      # G = 1 | 2 (conv gather)
+                # NB = 3 | 4 (96- / 128-column tiles), MW = 4 | 2 (256- / 128-row tiles), G = 1 | 2 (conv gather)
+                return "t256::gemm_glds256_kernel<%s, %s, %s, NB, MW>" % (tf(ta), tf(tb), "G" if ga else "0")
             return "gemm_kernel<float, %s, %s>%s" % (tf(ta), tf(tb), " (conv gather)" if ga else "")
         names = {v: kname(v) for v in range(16)}
         names[16] = "t256::gemm_glds256_grouped_kernel<4>"     # one launch = the weight gradients of one backward stage
@@ -222,7 +223,7 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_train_bf16_pmc_hbm_traffic.json")
         if os.path.exists(pmc) and args.dtype == "bf16" and args.mode == "train" and (B, S, T) == (14, 114, 582):
-            pre = dom["kernel"].split(", NB>")[0].replace(", G", ", ")
+            pre = dom["kernel"].split(", NB, MW>")[0].replace(", G", ", ")
             rows = [r for r in json.load(open(pmc)) if r["kernel"].startswith(pre)]
             n = sum(r["launches"] for r in rows)
             if n:
