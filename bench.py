@@ -17,6 +17,10 @@ import os
 import sys
 import time
 
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  With RCCL's streams in the process the engine's
+# second stream landed on the main stream's hardware queue and the two serialised (single-rank RCCL run: 10.9 ms per step
+# against 9.98 with 8 queues; no effect without RCCL).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "few-shot-transformer-tts_amd")
 for p in (ROOT, PKG):

@@ -6,7 +6,13 @@ a HIP device, the calls raise.  PyTorch is used only for device memory, streams 
 import ctypes as C
 import os
 
-import torch
+# The engine runs its weight-gradient GEMMs on a second HIP stream.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4); with RCCL's streams in the process the second stream shared the main stream's queue and the two serialised
+# (+10 % step time).  Effective only if the HIP runtime has not initialised yet -- importing this package before the first
+# torch.cuda call is enough; launchers can also export it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libb2s_hip.so")

@@ -30,6 +30,15 @@ batch = make_batch(make_config(""), 14, 114, 582, seed=0, device="cuda")
 for _ in range(5):
     tr.train_step(batch)
 torch.cuda.synchronize()
+# one step at a time with an empty queue: pure host cost of enqueueing a step (no back-pressure from the GPU)
+single = []
+for _ in range(6):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train_step(batch)
+    single.append((time.perf_counter() - t0) * 1e3)
+torch.cuda.synchronize()
+print("host time to enqueue one step on an idle queue (ms):", " ".join("%.2f" % x for x in single))
 n = 20
 pr = cProfile.Profile()
 t0 = time.perf_counter()
