@@ -21,6 +21,7 @@
 //   reduction-major operand ("T layout"): units of [32 k][128 cols] exactly as in gemm_glds.hip (ds_read_b64_tr_b16),
 //        A: 4 units (k half, column half), B: 2 units (k half).
 #include <algorithm>
+#include <vector>
 #include <cstdlib>
 #include "gemm.h"
 #include "gemm_epi.h"
@@ -408,10 +409,21 @@ __global__ __launch_bounds__(nthreads_of(GATHER, MW), 1) void gemm_glds256_kerne
 // is what split-K + a slab-reduce kernel used to paper over; together they are ~290 tiles with the full 8148-deep K.
 template <int NB>
 __global__ __launch_bounds__(nthreads_of(false), 1) void gemm_glds256_grouped_kernel(b2s_gemm_group grp, const bf16_t* zero) {
-    const int wg = xcd_tile_id(blockIdx.x, gridDim.x);
+    // Workgroup i runs on XCD i % 8.  The list is walked in launch order (problem ranges tile0[]), so every XCD gets an equal
+    // share of every problem -- a globally XCD-contiguous order handed all 36 short tiles of a decoder layer to one XCD and
+    // 36 long tiles to each of the other seven (32 CUs each): a second round of 8148-deep tiles, 213 us instead of ~120.
+    // Inside a problem the ids that land on one XCD are mapped to a contiguous piece of its row-major tile list (shared
+    // A / B panels stay in that XCD's L2).
+    const int i = blockIdx.x;
     int p = 0;
-    while (p + 1 < grp.n && wg >= grp.tile0[p + 1]) ++p;
-    const int local = wg - grp.tile0[p];
+    while (p + 1 < grp.n && i >= grp.tile0[p + 1]) ++p;
+    const int s0 = grp.tile0[p], cnt = grp.tile0[p + 1] - s0, xcd = i & 7;
+    int before = 0;                                     // tiles of this problem on lower-numbered XCDs
+    for (int x = 0; x < xcd; ++x) {
+        const int first = s0 + ((x - s0) & 7);          // smallest id >= s0 on XCD x
+        before += first < s0 + cnt ? (s0 + cnt - 1 - first) / 8 + 1 : 0;
+    }
+    const int local = before + (i - (s0 + ((xcd - s0) & 7))) / 8;
     const int tiles_n = (grp.p[p].N + NB * 32 - 1) / (NB * 32);
     const int by = local / tiles_n, bx = local - by * tiles_n;
     gemm256_body<true, true, 0, NB>(grp.p[p], zero, nullptr, bx, by, 0);
@@ -475,12 +487,36 @@ int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* 
     B2S_CHECK(n >= 1 && n <= B2S_MAX_GROUP, "grouped GEMM: %d problems (max %d)", n, B2S_MAX_GROUP);
     b2s_gemm_group grp;
     grp.n = n;
+    // Launch order = dispatch order.  Tiles cost ~K; with one workgroup per CU the makespan of "deepest first" against
+    // "shallowest first" is decided by list scheduling on the CU count (288 tiles of a decoder layer: 252 deep + 36 shallow --
+    // shallow first lets the 36 early finishers take the last 32 deep tiles, deep first leaves 32 shallow tiles to 4 CUs)
+    int order[B2S_MAX_GROUP];
+    auto makespan = [&](bool deep_first) {
+        for (int i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order, order + n, [&](int a, int b) { return deep_first ? probs[a].K > probs[b].K : probs[a].K < probs[b].K; });
+        std::vector<long> cu(256, 0);                 // min-heap of CU finish times
+        auto cmp = [](long a, long b) { return a > b; };
+        long end = 0;
+        for (int k = 0; k < n; ++k) {
+            const GemmArgs& g = probs[order[k]];
+            const int t = cdiv(g.M, t256::BM) * cdiv(g.N, 128);
+            for (int j = 0; j < t; ++j) {
+                std::pop_heap(cu.begin(), cu.end(), cmp);
+                cu.back() += g.K + 1024;               // K steps + fixed per-tile cost, in units of one K element
+                end = std::max(end, cu.back());
+                std::push_heap(cu.begin(), cu.end(), cmp);
+            }
+        }
+        return end;
+    };
+    const long deep = makespan(true), shallow = makespan(false);
+    if (deep <= shallow) makespan(true);               // (leaves `order` as chosen)
     int tiles = 0;
-    for (int i = 0; i < n; ++i) {
-        const GemmArgs& g = probs[i];
-        B2S_CHECK(g.batch == 1 && g.c_fp32 && g.epi.accumulate && g.A.g_cin == 0 && g.B.g_cin == 0, "grouped GEMM: problem %d is not a plain fp32-accumulate dW", i);
-        grp.p[i] = g; grp.p[i].splitk = 1;
-        grp.tile0[i] = tiles;
+    for (int k = 0; k < n; ++k) {
+        const GemmArgs& g = probs[order[k]];
+        B2S_CHECK(g.batch == 1 && g.c_fp32 && g.epi.accumulate && g.A.g_cin == 0 && g.B.g_cin == 0, "grouped GEMM: problem %d is not a plain fp32-accumulate dW", order[k]);
+        grp.p[k] = g; grp.p[k].splitk = 1;
+        grp.tile0[k] = tiles;
         tiles += cdiv(g.M, t256::BM) * cdiv(g.N, 128);
     }
     grp.tile0[n] = tiles;

@@ -52,6 +52,9 @@ int main(int argc, char** argv) {
         {768, 3072, 8148, 1, 1, 3, "dW ffn out"},
         {4096, 4096, 4096, 0, 0, 1, "4096^3 NT"},
         {8192, 8192, 8192, 0, 0, 1, "8192^3 NT"},
+        {4096, 4096, 4096, 1, 1, 1, "4096^3 TT"},
+        {4096, 4096, 4096, 0, 1, 1, "4096^3 NT(b T)"},
+        {4096, 4096, 4096, 1, 0, 1, "4096^3 TN(a T)"},
     };
     size_t maxel = (size_t)8192 * 8192;
     // LAB_ROT=n: n placements of every operand, used round-robin by the timed launches (n * footprint > 256 MB defeats the
@@ -121,5 +124,67 @@ int main(int argc, char** argv) {
         if (si < 17) { tot_us += us; tot_fl += fl; }
     }
     printf("step-shape mix: %.1f us total, %.1f TF/s\n", tot_us, tot_fl / tot_us / 1e6);
+    if (getenv("LAB_GROUPED")) {
+        // the weight gradients of one decoder layer as the engine launches them: one grouped launch, 7 problems, full-depth K
+        struct P { int M, N, K; };
+        const P ps[7] = {{3072, 768, 8148}, {768, 3072, 8148}, {2304, 768, 8148}, {768, 768, 8148}, {768, 768, 8148}, {768, 768, 8148}, {1536, 768, 1596}};
+        GemmArgs probs[7];
+        size_t offA = 0, offB = 0, offC = 0;
+        double fl = 0;
+        for (int i = 0; i < 7; ++i) {
+            GemmArgs& g = probs[i];
+            g.M = ps[i].M; g.N = ps[i].N; g.K = ps[i].K;
+            g.A.p = dA + offA; g.A.ld = g.M; g.A.R = g.K; g.A.C = g.M;
+            g.B.p = dB + offB; g.B.ld = g.N; g.B.R = g.K; g.B.C = g.N;
+            g.C = (float*)dC + offC; g.ldc = g.N; g.c_fp32 = 1; g.epi.accumulate = 1; g.splitk = 1;
+            offA += (size_t)g.K * g.M; offB += (size_t)g.K * g.N; offC += (size_t)g.M * g.N;
+            fl += 2.0 * g.M * g.N * g.K;
+        }
+        for (int w = 0; w < 3; ++w) b2s_gemm_glds256_grouped_launch(probs, 7, b2s_gemm_zero_page(), 0);
+        hipEventRecord(e0, 0);
+        for (int it = 0; it < iters; ++it) b2s_gemm_glds256_grouped_launch(probs, 7, b2s_gemm_zero_page(), 0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("grouped decoder-layer dW (7 problems, 288 tiles): %.1f us  %.1f TF\n", ms * 1e3 / iters, fl / (ms * 1e3 / iters) / 1e6);
+        // the same problems one by one with the engine's split-K choice
+        const int sk[7] = {3, 3, 4, 14, 14, 14, 6};
+        hipEventRecord(e0, 0);
+        for (int it = 0; it < iters; ++it)
+            for (int i = 0; i < 7; ++i) { GemmArgs g = probs[i]; g.splitk = sk[i]; LAB_LAUNCH(g, 1, 1, 0); }
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("same 7 problems, split-K launches + slab reduce: %.1f us  %.1f TF\n", ms * 1e3 / iters, fl / (ms * 1e3 / iters) / 1e6);
+        // sensitivity: subsets of the group, and the same problems with a padded leading dimension (ld = 4096)
+        auto time_group = [&](const char* what, GemmArgs* pp, int n) {
+            double f = 0; for (int i = 0; i < n; ++i) f += 2.0 * pp[i].M * pp[i].N * pp[i].K;
+            for (int w = 0; w < 2; ++w) b2s_gemm_glds256_grouped_launch(pp, n, b2s_gemm_zero_page(), 0);
+            hipEventRecord(e0, 0);
+            for (int it = 0; it < iters; ++it) b2s_gemm_glds256_grouped_launch(pp, n, b2s_gemm_zero_page(), 0);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float t; hipEventElapsedTime(&t, e0, e1);
+            printf("  %-44s %7.1f us  %6.1f TF\n", what, t * 1e3 / iters, f / (t * 1e3 / iters) / 1e6);
+        };
+        time_group("problems 0-1 (144 tiles)", probs, 2);
+        time_group("problems 0-2 (198 tiles)", probs, 3);
+        time_group("problems 0-5 (252 tiles, all long)", probs, 6);
+        {
+            GemmArgs padded[7]; size_t oa = 0, ob = 0;
+            for (int i = 0; i < 7; ++i) {
+                padded[i] = probs[i];
+                padded[i].A.p = dA + oa; padded[i].A.ld = 4096; padded[i].B.p = dB + ob; padded[i].B.ld = 4096;
+                oa += (size_t)padded[i].K * 4096; ob += (size_t)padded[i].K * 4096;
+            }
+            if (oa <= maxel * rot && ob <= maxel * rot) time_group("all 7, operands with ld = 4096", padded, 7);
+            else printf("  (padded test needs LAB_ROT >= %zu)\n", oa / maxel + 1);
+        }
+        for (int i = 0; i < 3; ++i) {
+            GemmArgs g = probs[i]; g.splitk = 1;
+            hipEventRecord(e0, 0);
+            for (int it = 0; it < iters; ++it) LAB_LAUNCH(g, 1, 1, 0);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("  problem %d alone, sk=1 (%d tiles): %.1f us\n", i, (g.M / 256) * ((g.N + 127) / 128), ms * 1e3 / iters);
+        }
+    }
     return 0;
 }
