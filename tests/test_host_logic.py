@@ -193,3 +193,48 @@ def test_stage_order_covers_all_parameters():
     assert eng.stage_of("decoder.decoder.self_attentions.0.qkv_transform.weight") == 3
     assert eng.stage_of("encoder.embed.weight") == eng.n_stages() - 1
     fresh_hp()
+
+
+def test_gemm_tile_maps_are_bijections():
+    """The block-id -> tile maps of the bf16 GEMM kernels (csrc/gemm_glds256.hip), restated in Python: the XCD-aware id map,
+    the grouped-row-panel order of wide outputs and the per-problem XCD map of the grouped weight-gradient launch must each
+    visit every tile exactly once, for tile counts that are not multiples of 8 / 4 too."""
+    def xcd_tile_id(orig, nwg):
+        xcd, q, r = orig & 7, nwg >> 3, nwg & 7
+        return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + (orig >> 3)
+
+    def wide_order(rem, tiles_m, tiles_n, G=4):
+        gsz = G * tiles_n
+        grp, inn = divmod(rem, gsz)
+        rows = min(G, tiles_m - grp * G)
+        bx, r = divmod(inn, rows)
+        return grp * G + r, bx
+
+    for tiles_m, tiles_n in [(32, 24), (7, 16), (29, 32), (6, 16), (1, 17), (5, 64)]:
+        n = tiles_m * tiles_n
+        ids = sorted(xcd_tile_id(i, n) for i in range(n))
+        assert ids == list(range(n))
+        seen = {wide_order(xcd_tile_id(i, n), tiles_m, tiles_n) for i in range(n)}
+        assert seen == {(by, bx) for by in range(tiles_m) for bx in range(tiles_n)}
+
+    def grouped(i, tile0):
+        p = 0
+        while p + 1 < len(tile0) - 1 and i >= tile0[p + 1]:
+            p += 1
+        s0, cnt, xcd = tile0[p], tile0[p + 1] - tile0[p], i & 7
+        before = 0
+        for x in range(xcd):
+            first = s0 + ((x - s0) & 7)
+            before += (s0 + cnt - 1 - first) // 8 + 1 if first < s0 + cnt else 0
+        return p, before + (i - (s0 + ((xcd - s0) & 7))) // 8
+
+    for counts in [(72, 72, 54, 18, 18, 18), (36,), (24, 8, 32, 32), (1, 2, 3, 5, 7, 11, 13, 17), (9,), (18, 18, 18, 54, 72, 72, 36)]:
+        tile0 = [0]
+        for c in counts:
+            tile0.append(tile0[-1] + c)
+        got = sorted(grouped(i, tile0) for i in range(tile0[-1]))
+        assert got == [(p, t) for p, c in enumerate(counts) for t in range(c)], counts
+        # every XCD gets within one tile of an equal share of every problem
+        for p, c in enumerate(counts):
+            share = [sum(1 for i in range(tile0[p], tile0[p + 1]) if i % 8 == x) for x in range(8)]
+            assert max(share) - min(share) <= 1
