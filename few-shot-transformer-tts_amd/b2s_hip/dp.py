@@ -44,9 +44,30 @@ class GradBucketer(object):
                                           stage == self.n_stages - 1):
             self._launch()
 
-    def finish(self):
+    def finish(self, expect_all=True):
+        """Launch what is still pending, wait for every all-reduce and (expect_all) check that the launched ranges tile the
+        whole flat gradient buffer exactly once -- a stage that never reported would otherwise leave its gradients un-averaged
+        and the replicas would drift apart silently."""
         if self._pending is not None:
             self._launch()
         for w in self._works:
             w.wait()
         self._works = []
+        if expect_all:
+            pos = 0
+            for lo, hi in self.launched:
+                if lo != pos:
+                    break
+                pos = hi
+            if pos != self.flat.numel():
+                raise RuntimeError("gradient exchange covered [0, %d) of %d elements (ranges %s): a backward stage did not report"
+                                   % (pos, self.flat.numel(), self.launched[:4]))
+
+    def abort(self):
+        """Wait for what was launched and drop the rest (a stage hook failed; the step is being abandoned)."""
+        for w in self._works:
+            try:
+                w.wait()
+            except Exception:
+                pass
+        self._works, self._pending = [], None

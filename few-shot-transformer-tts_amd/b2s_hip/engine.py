@@ -90,6 +90,8 @@ class HipEngine(object):
         self._gflat = None
         self._gviews = {}
         self._needs_zero = True
+        self._bwd_seen = set()            # segment kinds back-propagated since the gradient buffer was last zeroed (autograd path)
+        self._trainer = None              # weakref to an attached HipTrainer (its Adam moments mirror the flat gradient layout)
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
         self._calls = 0
         self.index = {n_: i for i, n_ in enumerate(self.names)}
@@ -131,6 +133,10 @@ class HipEngine(object):
                     raise L.B2SError("tensor %s must be contiguous %s on %s" % (n, want, dev))
             total = sum(t.numel() for t, k in zip(ts, self.kinds) if k == 1)
             if self._gflat is None or self._gflat.device != dev:
+                if self._gflat is not None and self._trainer is not None and self._trainer() is not None:
+                    raise L.B2SError("the model moved from %s to %s under an attached HipTrainer: its optimizer state lives on "
+                                     "the old device; build a new HipTrainer (load_state_dict carries the state over)"
+                                     % (self._gflat.device, dev))
                 self._gflat = torch.zeros(total, dtype=torch.float32, device=dev)
             self._gviews = {}
             data = (L.P * len(ts))(*[t.data_ptr() for t in ts])
@@ -197,6 +203,18 @@ class HipEngine(object):
         if self._needs_zero:
             L.check(self.lib.b2s_zero_grads(self.handle, L.stream()))
             self._needs_zero = False
+            self._bwd_seen = set()
+
+    def _claim_backward(self, kind):
+        """Autograd path: the segment functions hand autograd VIEWS of the one flat gradient buffer, which is zeroed once per
+        backward pass (first backward call after a forward).  Two forward passes back-propagated in one pass --
+        (lossA + lossB).backward() -- would accumulate both into the same range and return it twice (2 x (A + B)), and
+        backward(retain_graph=True) twice likewise: refuse instead of returning wrong gradients.  The reference loop
+        (train.py:171-174: one forward, one backward, one step) never does either."""
+        if kind in self._bwd_seen:
+            raise L.B2SError("second backward of the %s segment into the same gradient buffer: back-propagate each forward pass "
+                             "on its own (one forward per backward; retain_graph re-use is not supported)" % kind)
+        self._bwd_seen.add(kind)
 
     def grad_view(self, name):
         return self._gviews[name]
@@ -331,6 +349,8 @@ class EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dmem):
         eng = ctx.eng
+        eng.begin_backward()
+        eng._claim_backward("encoder")
         eng.encoder_backward(ctx.c, dmem)
         ctx.c.free()
         grads = tuple(eng.grad_view(ctx.prefix + n) if r else None for n, r in zip(ctx.names, ctx.req))
@@ -352,6 +372,8 @@ class DecoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dmels, dstop, dguided):
         eng = ctx.eng
+        eng.begin_backward()
+        eng._claim_backward("decoder")
         if dmels is None:
             dmels = torch.zeros(ctx.mem_shape[0], ctx.c.keep[3].shape[1], ctx.c.keep[3].shape[2], device=ctx.c.keep[0].device)
         dmem = eng.decoder_backward(ctx.c, dmels, dstop, ctx.mem_shape, dguided.reshape(1) if dguided is not None else None,
@@ -372,6 +394,8 @@ class PostnetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         eng = ctx.eng
+        eng.begin_backward()
+        eng._claim_backward("postnet")
         din = eng.postnet_backward(ctx.c, dout)
         if ctx.fuse:
             din = eng.add(din, dout)

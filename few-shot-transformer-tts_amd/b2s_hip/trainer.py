@@ -10,6 +10,7 @@ across ranks, LambdaLR schedule `learning_rate_schedule`.
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -64,6 +65,10 @@ class HipTrainer(object):
                 m_ptrs[i] = self.exp_avg.data_ptr() + 4 * off
                 v_ptrs[i] = self.exp_avg_sq.data_ptr() + 4 * off
         L.check(self.lib.b2s_adam_bind(self.eng.handle, m_ptrs, v_ptrs, n))
+        # parameters replaced later (.to(), load_state_dict(assign=True), .data swaps) re-bind the engine; the C side rebuilds
+        # the fused optimizer's pointer table against the new tensors (b2s_model_bind), the moments stay these buffers
+        self.eng._trainer = weakref.ref(self)
+        self._hook_error = None
         self.global_step = 0
         self.freeze_encoder = bool(self.eng.cfg.freeze_encoder)
         self._one = torch.ones(1, dtype=torch.float32, device=g.device)
@@ -145,8 +150,13 @@ class HipTrainer(object):
 
     # ------------------------------------------------------------------ gradient exchange
     def _on_stage(self, stage, _user):
-        if self.bucketer is not None:
-            self.bucketer.stage_done(stage)
+        # called from C through ctypes: an exception escaping here would be printed and swallowed, the bucket never reduced
+        # and the step applied to un-averaged gradients -- keep it and re-raise from train_step before the optimizer runs
+        try:
+            if self.bucketer is not None and self._hook_error is None:
+                self.bucketer.stage_done(stage)
+        except BaseException as e:          # noqa: B902 (must not propagate into ctypes)
+            self._hook_error = e
 
     # ------------------------------------------------------------------ one step
     def train_step(self, batch):
@@ -167,6 +177,7 @@ class HipTrainer(object):
         eng._needs_zero = False
         if self.bucketer is not None:
             self.bucketer.begin_step()
+        self._hook_error = None
         dbef, daft, dstop = eng.loss_backward(mels, aft, stop, batch["mel_targets"], tgt32, None)
         din = eng.postnet_backward(c_post, daft)
         dmel = eng.add(eng.add(din, daft), dbef)
@@ -176,8 +187,13 @@ class HipTrainer(object):
         for c in (c_post, c_dec, c_enc):
             if c is not None:
                 c.free()
+        if self._hook_error is not None:
+            err, self._hook_error = self._hook_error, None
+            if self.bucketer is not None:
+                self.bucketer.abort()
+            raise RuntimeError("gradient exchange failed in the backward stage hook; the optimizer step was NOT applied") from err
         if self.bucketer is not None:
-            self.bucketer.finish()
+            self.bucketer.finish(expect_all=not self.freeze_encoder)
         lr = self.hp.max_lr * self.lr_lambda(self.global_step)
         self.global_step += 1
         L.check(lib.b2s_adam_step_ex(eng.handle, lr, self.global_step, self.beta1, self.beta2, self.hp.adam_eps,

@@ -636,6 +636,11 @@ int build_chunks(b2s_model* m, bool l2only, bool with_state, MtChunk** out, int*
         B2S_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(MtChunk), hipMemcpyHostToDevice));
         m->owned.push_back(d);
     }
+    if (*out) {                                 // re-bind: the table being replaced (hipFree waits for kernels still reading it)
+        auto it = std::find(m->owned.begin(), m->owned.end(), (void*)*out);
+        if (it != m->owned.end()) m->owned.erase(it);
+        (void)hipFree(*out);
+    }
     *out = d; *nout = (int)h.size();
     if (with_state) {
         // chunk ranges per group; a table that is not in group order is treated as one (decoder) group
@@ -647,6 +652,29 @@ int build_chunks(b2s_model* m, bool l2only, bool with_state, MtChunk** out, int*
             m->adam_grp[1] = grp_first[1] >= 0 ? grp_first[1] : m->adam_grp[2];
             m->adam_grp[0] = 0;
         }
+    }
+    return 0;
+}
+int rebuild_adam_chunks(b2s_model* m) {
+    const int before = m->n_adam_chunks;
+    B2S_TRY(build_chunks(m, false, true, &m->adam_chunks, &m->n_adam_chunks));
+    m->l2_fresh = false;
+    if (m->n_adam_chunks != before || !m->l2_part) {
+        if (m->l2_part) {
+            auto it = std::find(m->owned.begin(), m->owned.end(), (void*)m->l2_part);
+            if (it != m->owned.end()) m->owned.erase(it);
+            (void)hipFree(m->l2_part);
+            m->l2_part = nullptr;
+        }
+        if (m->n_adam_chunks) { B2S_HIP(hipMalloc(&m->l2_part, (size_t)m->n_adam_chunks * sizeof(float))); m->owned.push_back(m->l2_part); }
+    }
+    return 0;
+}
+// postnet conv weights -> the two GEMM images [Cout][5*Cin] / [Cin][5*Cout] (flipped) in the compute dtype
+int relayout_convs(b2s_model* m, hipStream_t st) {
+    for (int l = 0; l < m->cfg.n_postnet_layer; ++l) {
+        const TensorInfo& t = m->tinfo[m->id("postnet.conv_layers." + std::to_string(l) + ".weight")];
+        B2S_TRY(ro_conv_w_relayout(m->dtype, m->P(t.name), m->conv_wf[l], m->conv_wb[l], (int)t.shape[0], (int)t.shape[1], st));
     }
     return 0;
 }
@@ -708,9 +736,13 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
     // left the main stream's kernels fewer idle CUs).  B2S_DW_GROUP=0 restores the per-GEMM launches.
     m->dw_group = m->dtype == 1 && m->aux && !(getenv("B2S_DW_GROUP") && atoi(getenv("B2S_DW_GROUP")) == 0);
     B2S_TRY(ensure_pe(m, 2048));
-    m->n_l2_chunks = 0; m->l2_chunks = nullptr; m->l2_fresh = false;
+    m->l2_fresh = false;
     B2S_TRY(build_chunks(m, true, false, &m->l2_chunks, &m->n_l2_chunks));
     m->bound = true;
+    // A fused optimizer bound earlier (b2s_adam_bind) holds the OLD parameter / gradient pointers in its chunk table: rebuild
+    // it against the new ones (the moment buffers belong to the caller and are still the ones it registered), so the step
+    // never writes through stale pointers after .to() / load_state_dict(assign=True) replaced a parameter.
+    if (m->adam_chunks) B2S_TRY(rebuild_adam_chunks(m));
     return 0;
 }
 
@@ -724,11 +756,9 @@ extern "C" int b2s_model_sync_weights_ex(b2s_model* m, void* stream, int shadows
         for (size_t i = 0; i < m->tinfo.size(); ++i)
             if (m->tinfo[i].gemm_weight) B2S_TRY(ro_cast(1, (const float*)m->data[i], m->shadow[i], m->tinfo[i].numel, st));
     // (bf16 mode after a fused optimizer step: the Adam kernel has written both conv weight images itself)
-    if (!(shadows_fresh && m->dtype == 1 && m->adam_chunks))
-        for (int l = 0; l < m->cfg.n_postnet_layer; ++l) {
-            const TensorInfo& t = m->tinfo[m->id("postnet.conv_layers." + std::to_string(l) + ".weight")];
-            B2S_TRY(ro_conv_w_relayout(m->dtype, m->P(t.name), m->conv_wf[l], m->conv_wb[l], (int)t.shape[0], (int)t.shape[1], st));
-        }
+    // (after a fused optimizer step the conv images are current: bf16 -- the Adam kernel writes them itself; fp32 -- the step
+    // re-lays them out behind the update, b2s_adam_step_ex)
+    if (!(shadows_fresh && m->adam_chunks)) B2S_TRY(relayout_convs(m, st));
     return 0;
 }
 
@@ -1371,10 +1401,7 @@ extern "C" int b2s_adam_bind(b2s_model* m, void* const* exp_avg_host, void* cons
         m->exp_avg[i] = exp_avg_host[i]; m->exp_avg_sq[i] = exp_avg_sq_host[i];
         B2S_CHECK(m->tinfo[i].kind != 1 || !m->grad[i] || (m->exp_avg[i] && m->exp_avg_sq[i]), "missing Adam state for %s", m->tinfo[i].name.c_str());
     }
-    B2S_TRY(build_chunks(m, false, true, &m->adam_chunks, &m->n_adam_chunks));
-    m->l2_fresh = false; m->l2_part = nullptr;
-    if (m->n_adam_chunks) { B2S_HIP(hipMalloc(&m->l2_part, (size_t)m->n_adam_chunks * sizeof(float))); m->owned.push_back(m->l2_part); }
-    return 0;
+    return rebuild_adam_chunks(m);
 }
 extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
                              void* stream) {
@@ -1404,6 +1431,7 @@ extern "C" int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, f
             const int g = order[k], lo = m->adam_grp[g], n = m->adam_grp[g + 1] - lo;
             if (n <= 0) continue;
             B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, m->aux));
+            if (g == 2 && m->dtype == 0) B2S_TRY(relayout_convs(m, m->aux));     // fp32: the conv GEMM images follow the masters
             if (!m->adam_ev[g]) B2S_HIP(hipEventCreateWithFlags(&m->adam_ev[g], hipEventDisableTiming));
             B2S_HIP(hipEventRecord(m->adam_ev[g], m->aux));
             m->adam_pending[g] = true;
@@ -1418,6 +1446,9 @@ extern "C" int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, f
     // the partial sums cover the L2 regulariser only if every member is in the chunk table (not with a frozen encoder)
     const bool cover = !m->cfg.freeze_encoder;
     B2S_TRY(ro_mt_adam(m->adam_chunks, m->n_adam_chunks, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part : nullptr, st));
+    // fp32 (parity) mode: the Adam kernel does not write the conv GEMM images (in bf16 mode it does); refresh them here so that
+    // an eval / synthesis forward between two training steps sees the weights the step just produced
+    if (m->dtype == 0) B2S_TRY(relayout_convs(m, st));
     m->l2_fresh = cover;
     return 0;
 }

@@ -174,3 +174,50 @@ def eval_batch_recompute(model_eval, data):
         return {'mel_pre': mels.cpu().numpy(), 'mel_aft': mel_aft.cpu().numpy(),
                 'alignments': {k: [a.cpu().numpy() for a in align[k]] for k in ('self', 'encdec')},
                 'generated_lengths': list(target_lengths.cpu().numpy())}
+
+
+def save_eval_results(names, mel_pre, mel_aft, alignments, input_lengths, generated_lengths,
+                      output_dir, save_trimmed_wave=False, n_plot_alignment=None):
+    """Write the results of eval_batch to `output_dir` (reference synthesize.py:75-106, same signature and file names):
+    `<name>.npy` = mel_aft[i][:generated_lengths[i]] always; `<name>.wav` (+ `<name>_trim.wav`), `<name>_mel.png` and
+    `<name>_align.png` when the reference's vocoder / plotting helpers (`utils.audio`, `utils.infolog`: out of this
+    package's scope) are importable, i.e. when a reference checkout follows this package on sys.path.  A failing sample
+    is logged and skipped, as in the reference; samples are written by a small thread pool."""
+    import threading
+    import traceback
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+    try:
+        from utils.audio import mel2wav, save_wav, trim_silence_intervals
+    except Exception:                       # librosa / soundfile / the reference checkout are optional
+        mel2wav = save_wav = trim_silence_intervals = None
+    try:
+        from utils.infolog import plot_attn, plot_mel
+    except Exception:                       # matplotlib / fastdtw are optional
+        plot_attn = plot_mel = None
+    os.makedirs(output_dir, exist_ok=True)
+
+    def save_one(i):
+        try:
+            name, n = names[i], int(generated_lengths[i])
+            mel = np.asarray(mel_aft[i])[:n]
+            np.save(os.path.join(output_dir, '%s.npy' % name), mel)
+            if mel2wav is not None:
+                wav = mel2wav(mel)
+                save_wav(wav, os.path.join(output_dir, '%s.wav' % name))
+                if save_trimmed_wave:
+                    save_wav(trim_silence_intervals(wav), os.path.join(output_dir, '%s_trim.wav' % name))
+            if plot_mel is not None:
+                plot_mel(os.path.join(output_dir, '%s_mel.png' % name), mel)
+                if n_plot_alignment is None or i < n_plot_alignment:
+                    aligns = [np.asarray(a[i]).transpose([0, 2, 1]) for a in alignments["encdec"]]
+                    plot_attn(aligns, os.path.join(output_dir, '%s_align.png' % name), enc_length=input_lengths[i], dec_length=n)
+        except Exception:
+            logging.error('Fail to produce eval output: ' + str(names[i]))
+            logging.error(traceback.format_exc())
+
+    tic = time.time()
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        list(pool.map(save_one, range(len(names))))
+    logging.info('[%s] Finished saving evals in %.2f secs: ' % (threading.current_thread().name, time.time() - tic) + str(names))

@@ -1,6 +1,15 @@
-"""Small host utilities of the drop-in surface (the reference's `utils` package keeps its other modules -- audio, infolog --
-when this package is placed in front of a reference checkout)."""
+"""Small host utilities of the drop-in surface.
+
+Placed in front of a reference checkout (PYTHONPATH=<this package>:<reference>) this package supplies `dict_send_to`,
+`utils.checkpoint`, `utils.hparams` and `utils.text`; the reference's other `utils` modules (infolog, audio, transcribe:
+logging / plotting / vocoder / cloud-STT glue, out of scope here) stay importable because the package path is extended
+with every other `utils` directory on sys.path (tests/test_dropin_imports.py executes the import blocks of the
+reference's train.py and eval.py against this layout)."""
+import pkgutil
+
 import torch
+
+__path__ = pkgutil.extend_path(__path__, __name__)
 
 
 def dict_send_to(data, device, detach=False, as_numpy=False):

@@ -1,0 +1,137 @@
+"""Fused-trainer state hazards (round-1 advisor findings): parameter re-binding under an attached trainer, fp32 conv GEMM
+images after the fused optimizer step, exceptions raised inside the backward stage hook, and the one-forward-per-backward
+contract of the autograd path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import b2s_oracle as O                     # checker only
+from oracle import synth, TINY, TINY96
+from gpu_util import DEV
+from test_gpu_model import build, dev_batch
+
+
+def _batch(cfg):
+    nb = synth.synthetic_batch(cfg, B=3, S=11, T=23, seed=7, in_lens=[11, 7, 4], tgt_lens=[23, 15, 9])
+    return nb, dev_batch(nb)
+
+
+@pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
+def test_rebind_under_trainer_updates_live_parameters(compute_dtype):
+    """Parameters replaced after HipTrainer was built (here: every .data swapped for a fresh allocation, what
+    load_state_dict(assign=True) / .to() do) must keep being updated by the fused Adam step: the run equals an undisturbed
+    one, and the abandoned storage is never written again."""
+    from b2s_hip.trainer import HipTrainer
+    ma, cfg, _, hp = build(TINY96, compute_dtype=compute_dtype)
+    nb, b = _batch(cfg)
+    ma.train()
+    ta = HipTrainer(ma, hp)
+    ta.eng._seed = 99; ta.eng._calls = 0
+    for _ in range(3):
+        ta.train_step(b)
+    ref = {k: v.detach().clone() for k, v in ma.state_dict().items()}
+    mb, _, _, hp = build(TINY96, compute_dtype=compute_dtype)
+    mb.train()
+    tb = HipTrainer(mb, hp)
+    tb.eng._seed = 99; tb.eng._calls = 0
+    tb.train_step(b)
+    torch.cuda.synchronize()
+    old = {n: p.data for n, p in mb.named_parameters()}
+    snap = {n: t.clone() for n, t in old.items()}
+    with torch.no_grad():
+        for n, p in mb.named_parameters():
+            p.data = p.data.clone()                     # new storage, same values: data_ptr changes -> the engine re-binds
+    for _ in range(2):
+        tb.train_step(b)
+    torch.cuda.synchronize()
+    for n, t in old.items():
+        assert torch.equal(t, snap[n]), "stale storage of %s was written after the re-bind" % n
+    tol = 1e-6 if compute_dtype == "fp32" else 2e-2
+    for k, v in mb.state_dict().items():
+        d = float((v.double() - ref[k].double()).abs().max())
+        assert d <= tol * (1.0 + float(ref[k].double().abs().max())), (k, d)
+    moved = max(float((p.data - snap[n]).abs().max()) for n, p in mb.named_parameters())
+    assert moved > 1e-4, "live parameters did not move after the re-bind"
+
+
+def test_fp32_step_then_eval_forward_uses_updated_conv_weights():
+    """fp32 (parity) mode: after one fused step an eval-mode forward (postnet conv GEMM images included) must see the weights
+    the step produced -- compared with the oracle evaluated on the oracle's own updated parameters."""
+    from b2s_hip.trainer import HipTrainer
+    m, cfg, st, hp = build(TINY96)
+    nb, b = _batch(cfg)
+    m.train()
+    tr = HipTrainer(m, hp)
+    P = O.to_torch_state(st, requires_grad=True)
+    ob = O.to_torch_batch(nb)
+    opt = {}
+    for step in range(2):
+        tr.train_step(b)
+        O.train_step(P, cfg, ob, opt, step, train=True)
+    m.eval()
+    with torch.no_grad():
+        o = m(**b)
+        ref = O.tacotron_forward({k: v.detach() for k, v in P.items()}, cfg, ob, train=False)
+    for k in ("mel_bef", "mel_aft"):
+        d = float((o[k].cpu() - ref[k]).abs().max())
+        assert d < 2e-4, (k, d)
+    # the postnet on its own (the segment eval_batch calls) agrees too
+    with torch.no_grad():
+        res = m.postnet(b["mel_targets"], b["target_lengths"]).cpu()
+        rres = O.postnet_forward({k: v.detach() for k, v in P.items()}, cfg, ob["mel_targets"], ob["target_lengths"], train=False)
+    rres = rres[0] if isinstance(rres, tuple) else rres
+    assert float((res - rres).abs().max()) < 2e-4
+
+
+def test_stage_hook_exception_is_raised_before_the_optimizer_step():
+    from b2s_hip.trainer import HipTrainer
+    import ctypes as C
+    from b2s_hip import lib as L
+    m, cfg, _, hp = build(TINY)
+    _, b = _batch(cfg)
+    m.train()
+    tr = HipTrainer(m, hp)
+
+    class Boom(object):
+        launched = []
+        def begin_step(self): pass
+        def stage_done(self, stage): raise ValueError("boom at stage %d" % stage)
+        def finish(self, expect_all=True): raise AssertionError("finish must not run after a failed hook")
+        def abort(self): self.aborted = True
+    tr.bucketer = Boom()
+    L.check(tr.lib.b2s_model_set_stage_hook(tr.eng.handle, C.cast(tr._hook, L.P), None))
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    with pytest.raises(RuntimeError, match="optimizer step was NOT applied") as ei:
+        tr.train_step(b)
+    assert isinstance(ei.value.__cause__, ValueError) and tr.bucketer.aborted
+    torch.cuda.synchronize()
+    assert tr.global_step == 0
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+
+
+def test_autograd_path_refuses_two_forwards_in_one_backward():
+    """(lossA + lossB).backward() over two forward passes would return 2 x (A + B) through the shared flat gradient buffer:
+    the engine raises instead; one forward per backward keeps working and matches the oracle gradient."""
+    from transformer.tacotron import compute_loss
+    from b2s_hip import lib as L
+    m, cfg, st, hp = build(TINY)
+    nb, b = _batch(cfg)
+    m.train()
+    la = compute_loss(m, b["mel_targets"], b["target_lengths"], m(**b), hp)["loss"]
+    lb = compute_loss(m, b["mel_targets"], b["target_lengths"], m(**b), hp)["loss"]
+    with pytest.raises((L.B2SError, RuntimeError), match="one forward per backward"):
+        (la + lb).backward()
+    for p in m.parameters():
+        p.grad = None
+    lc = compute_loss(m, b["mel_targets"], b["target_lengths"], m(**b), hp)["loss"]
+    lc.backward()
+    P = O.to_torch_state(st, requires_grad=True)
+    ob = O.to_torch_batch(nb)
+    rl = O.compute_loss(P, cfg, ob["mel_targets"], ob["target_lengths"], O.tacotron_forward(P, cfg, ob, train=True))["loss"]
+    rl.backward()
+    for n, p in m.named_parameters():
+        ref = P[n].grad
+        assert abs(float(p.grad.double().norm()) - float(ref.double().norm())) <= 2e-3 * float(ref.double().norm()) + 1e-6, n

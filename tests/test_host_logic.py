@@ -238,3 +238,35 @@ def test_gemm_tile_maps_are_bijections():
         for p, c in enumerate(counts):
             share = [sum(1 for i in range(tile0[p], tile0[p + 1]) if i % 8 == x) for x in range(8)]
             assert max(share) - min(share) <= 1
+
+
+def test_grad_bucketer_reports_missing_stage():
+    """finish() verifies that the launched all-reduce ranges tile the flat gradient buffer: a backward stage that never
+    reported (e.g. its hook raised) must not pass silently as 'reduced'."""
+    from b2s_hip.dp import GradBucketer
+
+    class Work(object):
+        def wait(self): pass
+
+    class FakeDist(object):
+        def __init__(self): self.calls = []
+        def all_reduce(self, t, group=None, async_op=False):
+            self.calls.append(t.numel()); return Work()
+    flat = torch.zeros(100)
+    ranges = {0: (0, 30), 1: (30, 30), 2: (30, 70), 3: (70, 100)}
+    d = FakeDist()
+    bk = GradBucketer(flat, ranges, 4, bucket_elems=35, dist=d)
+    bk.begin_step()
+    for s in range(4):
+        bk.stage_done(s)
+    bk.finish()
+    assert bk.launched == [(0, 70), (70, 100)] and d.calls == [70, 30]
+    bk.begin_step()
+    for s in (0, 1, 2):                                   # stage 3 never reports
+        bk.stage_done(s)
+    with pytest.raises(RuntimeError, match="did not report"):
+        bk.finish()
+    bk.begin_step()
+    for s in (0, 1, 2):
+        bk.stage_done(s)
+    bk.finish(expect_all=False)                           # frozen encoder: the tail of the buffer is never exchanged
