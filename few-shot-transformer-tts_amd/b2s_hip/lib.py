@@ -76,6 +76,7 @@ _PROTOS = {
     "b2s_adam_step": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, P]),
     "b2s_zero_grads": (C.c_int, [P, P]),
     "b2s_gemm": (C.c_int, [C.POINTER(GemmDesc), P, P, P, P, P, P, P, P]),
+    "b2s_gemm_splitk": (C.c_int, [C.POINTER(GemmDesc), C.c_int, P, P, P, P, C.c_size_t, P]),
     "b2s_layernorm_forward": (C.c_int, [C.c_int, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, P]),
     "b2s_layernorm_backward": (C.c_int, [C.c_int, P, P, P, P, P, P, P, P, C.c_int, C.c_int, P]),
     "b2s_attention_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

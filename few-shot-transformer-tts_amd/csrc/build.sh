@@ -4,6 +4,8 @@ set -e
 cd "$(dirname "$0")"
 OUT=../libb2s_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+# --clean: recompile every source (what __graft_entry__.build() runs); default: only what changed
+if [ "$1" = "--clean" ]; then rm -rf obj; fi
 mkdir -p obj
 pids=()
 for f in gemm gemm_glds gemm_glds256 gemm_skinny attention rowops engine capi_ops decode; do

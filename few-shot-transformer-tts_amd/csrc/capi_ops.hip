@@ -41,6 +41,21 @@ extern "C" int b2s_gemm(const b2s_gemm_desc* d, const void* A, const void* B, vo
     g.epi.conv_dw_cin = d->conv_dw_cin;
     return b2s_gemm_launch(g, d->dtype, d->trans_a != 0, d->trans_b != 0, S_(stream));
 }
+extern "C" int b2s_gemm_splitk(const b2s_gemm_desc* d, int splitk, const void* A, const void* B, float* C, float* ws, size_t ws_floats,
+                               void* stream) {
+    B2S_CHECK(d && A && B && C && splitk >= 1, "null argument / bad split");
+    B2S_CHECK(d->c_fp32 && d->accumulate && !d->relu && d->drop_p == 0.f && d->conv_cin_a == 0, "split-K needs a linear fp32 accumulate epilogue");
+    GemmArgs g;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.batch = d->batch > 0 ? d->batch : 1; g.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
+    g.A.p = A; g.A.ld = d->lda; g.A.bs_o = d->a_bs_o; g.A.bs_i = d->a_bs_i;
+    g.B.p = B; g.B.ld = d->ldb; g.B.bs_o = d->b_bs_o; g.B.bs_i = d->b_bs_i;
+    if (d->trans_a) { g.A.R = d->K; g.A.C = d->M; } else { g.A.R = d->M; g.A.C = d->K; }
+    if (d->trans_b) { g.B.R = d->K; g.B.C = d->N; } else { g.B.R = d->N; g.B.C = d->K; }
+    g.C = C; g.c_fp32 = 1; g.ldc = d->ldc; g.cs_o = d->c_bs_o; g.cs_i = d->c_bs_i;
+    g.epi.alpha = d->alpha; g.epi.accumulate = 1; g.epi.conv_dw_cin = d->conv_dw_cin;
+    g.splitk = splitk; g.ws = ws; g.ws_floats = ws ? ws_floats : 0;
+    return b2s_gemm_launch(g, d->dtype, d->trans_a != 0, d->trans_b != 0, S_(stream));
+}
 extern "C" int b2s_layernorm_forward(int dtype, const float* x, const float* gamma, const float* beta, void* y, float* mean,
                                      float* rstd, int M, int D, float eps, void* stream) {
     B2S_CHECK(x && gamma && beta && y && mean && rstd, "null argument");

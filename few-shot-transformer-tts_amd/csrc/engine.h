@@ -107,6 +107,11 @@ struct b2s_model {
     float* l2_part = nullptr;
     bool l2_fresh = false;
     std::vector<void*> owned;                       // hipMalloc'ed buffers
+    // split-K slab workspaces, one per stream this model launches split-K GEMMs on ([0] caller's stream, [1] aux stream):
+    // launches of one stream are ordered, the two streams never share a slab
+    float* sk_ws[2] = {nullptr, nullptr};
+    size_t sk_ws_floats = 0;
+    void set_ws(GemmArgs& g, hipStream_t st) const { g.ws = sk_ws[(aux && st == aux) ? 1 : 0]; g.ws_floats = g.ws ? sk_ws_floats : 0; }
     // second HIP stream for the weight-gradient GEMMs: they depend only on (dY, X) and feed nothing in the backward chain,
     // so they run concurrently with the dX / attention / LayerNorm kernels of the same layer (the 128x128-tile GEMMs leave
     // CUs idle in their last, partial wave of workgroups).  Hazards on re-used scratch buffers are tracked per buffer.

@@ -218,6 +218,7 @@ int linear_dw(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
     g.epi.accumulate = 1;          // parameter gradients accumulate; the host zeroes them once per backward pass
     if (m->dw_group) { m->dw_pending.push_back(g); return 0; }      // launched by end_stage() as part of the stage's group
     g.splitk = pick_splitk(Nout, Kin, M, m->dtype);
+    m->set_ws(g, m->aux ? m->aux : st);
     if (!m->aux) return b2s_gemm_launch(g, m->dtype, true, true, st);
     hipEvent_t ready = m->next_event();
     B2S_HIP(hipEventRecord(ready, st));                    // dY (and X) are complete at this point of the main stream
@@ -253,6 +254,7 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
     if (tiles < 32) {
         for (GemmArgs g : q) {
             g.splitk = pick_splitk(g.M, g.N, g.K, m->dtype);
+            m->set_ws(g, m->aux);
             B2S_TRY(b2s_gemm_launch(g, m->dtype, true, true, m->aux));
         }
     } else {
@@ -725,6 +727,14 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
         m->conv_wf[l] = a; m->conv_wb[l] = b;
     }
     if (!m->small) { B2S_HIP(hipMalloc(&m->small, 64 * sizeof(float))); m->owned.push_back(m->small); }
+    if (m->dtype == 1 && !m->sk_ws[0]) {
+        // largest split-K user: a postnet conv weight gradient, splitk * Cout * 5 Cin floats (6 x 512 x 2560 = 31 MB at the
+        // default sizes); sized generously, HBM is 288 GB
+        m->sk_ws_floats = (size_t)24 << 20;
+        for (int i = 0; i < 2; ++i)
+            if (hipMalloc(&m->sk_ws[i], m->sk_ws_floats * sizeof(float)) == hipSuccess) m->owned.push_back(m->sk_ws[i]);
+            else { m->sk_ws[i] = nullptr; (void)hipGetLastError(); }      // (no slab: that stream's split-K launches use atomics)
+    }
     if (!m->aux && !getenv("B2S_NO_AUX")) {
         B2S_HIP(hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking));
         m->ev_pool.resize(256);
@@ -1224,6 +1234,7 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
         if (m->dw_group) {
             B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
             g.epi.accumulate = 1; g.splitk = 4;
+            m->set_ws(g, st);
         }
         B2S_TRY(b2s_gemm_launch(g, dt, false, true, st));
     } else if (first_mem && want_dmem) B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
@@ -1345,6 +1356,7 @@ extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out
             g.M = cout; g.N = 5 * cin; g.K = (int)M;
             g.C = m->G("postnet.conv_layers." + std::to_string(i) + ".weight"); g.c_fp32 = 1; g.ldc = 5 * cin;
             g.epi.conv_dw_cin = cin; g.epi.accumulate = 1; g.splitk = pick_splitk(cout, 5 * cin, (int)M, dt);
+            m->set_ws(g, st);
             B2S_TRY(b2s_gemm_launch(g, dt, true, true, st));
         }
         {   // dx[m, ci] = mask(m) * sum_{j', co} dy[m + j' - 2, co] * w[co, ci, 4 - j']

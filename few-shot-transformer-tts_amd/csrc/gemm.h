@@ -48,6 +48,10 @@ struct GemmArgs {
     int ldc = 0;
     long cs_o = 0, cs_i = 0;
     GemmEpilogue epi;
+    // split-K slab workspace ([splitk][M][N] fp32) owned by the CALLER (the model keeps one per stream it launches on; there
+    // is no process-wide slab).  Null / too small: the partial tiles are accumulated with fp32 atomics instead.
+    float* ws = nullptr;
+    size_t ws_floats = 0;
 };
 
 // dtype: 0 = fp32 (mfma_f32_16x16x4f32), 1 = bf16 (mfma_f32_16x16x32_bf16, fp32 accumulate)
@@ -58,12 +62,13 @@ int b2s_gemm_glds_launch(const GemmArgs& g, bool ta, bool tb, hipStream_t stream
 int b2s_gemm_skinny_launch(const GemmArgs& g, int dtype, hipStream_t stream);
 // 256x128-tile variant for the large-M forms (gemm_glds256.hip) and the split-K slab reduction shared by both
 long b2s_gemm_glds256_tiles(const GemmArgs& g);
-int b2s_gemm_glds256_launch(const GemmArgs& g, bool ta, bool tb, const bf16_t* zero, float* ws, size_t ws_floats, hipStream_t stream);
+int b2s_gemm_glds256_launch(const GemmArgs& g, bool ta, bool tb, const bf16_t* zero, hipStream_t stream);
 int b2s_splitk_reduce_launch(const float* ws, float* dst, int M, int N, int ldc, int splitk, int conv_dw_cin, hipStream_t stream);
 // up to B2S_MAX_GROUP weight-gradient problems (TN form, fp32 accumulate, no split-K) in one launch
 #define B2S_MAX_GROUP 8
 struct b2s_gemm_group { int n; int tile0[B2S_MAX_GROUP + 1]; GemmArgs p[B2S_MAX_GROUP]; };
 int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* zero, hipStream_t stream);
-// (zero page / split-K workspace owned by gemm_glds.hip)
+// 256 zero bytes in device memory, written once at first use and immutable afterwards (source of the out-of-bounds chunks of
+// the LDS-DMA loads); the only process-wide device object of the GEMM layer
 const bf16_t* b2s_gemm_zero_page();
 int b2s_gemm_grouped_launch(const GemmArgs* probs, int n, hipStream_t stream);      // gemm.hip: + optional timing record

@@ -13,6 +13,7 @@
 //     ds_read_b32 (fp32); an operand whose reduction index is the slow dimension (the "NN"/"TN"
 //     backward forms) is kept [BK][rows+pad] and read with ds_read_b64_tr_b16 (bf16), so no
 //     transposed copy of any activation or weight is ever written to HBM.
+#include <mutex>
 #include "gemm.h"
 
 namespace {
@@ -235,12 +236,13 @@ int launch_t(const GemmArgs& g, hipStream_t stream) {
     constexpr int TILE_A = TA ? BK * LDT : BM * LDN;
     constexpr int TILE_B = TB ? BK * LDT : BN * LDN;
     constexpr size_t smem = 2 * (size_t)(TILE_A + TILE_B) * sizeof(T);
-    static bool attr_set = false;
-    if (!attr_set) {
-        B2S_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, TA, TB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, TA, TB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    B2S_HIP(attr_err);
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch * g.splitk);
     hipLaunchKernelGGL((gemm_kernel<T, TA, TB>), grid, dim3(256), smem, stream, g);
     B2S_LAUNCH_CHECK();
@@ -258,11 +260,14 @@ int launch_d(const GemmArgs& g, bool ta, bool tb, hipStream_t s) {
 }  // namespace
 
 // ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
+#include <atomic>
 #include <vector>
 #include <cstdlib>
 namespace {
 struct ProfRec { hipEvent_t a, b; int variant; double flops; int M, N, K, batch, splitk; };
-bool g_prof_on = false;
+// measurement state (b2s_prof_*): process-wide by design -- one timing log for every model in the process -- and guarded
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 }  // namespace
 extern "C" void b2s_prof_enable(int on) { g_prof_on = on != 0; }
@@ -271,6 +276,7 @@ extern "C" void b2s_prof_enable(int on) { g_prof_on = on != 0; }
 extern "C" int b2s_prof_collect(double* out, int n_variants) {
     for (int i = 0; i < n_variants * 3; ++i) out[i] = 0.0;
     FILE* dump = getenv("B2S_PROF_DUMP") ? fopen(getenv("B2S_PROF_DUMP"), "w") : nullptr;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& r : g_prof) {
         B2S_HIP(hipEventSynchronize(r.b));
         float ms = 0.f;
@@ -295,7 +301,7 @@ int b2s_gemm_launch(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t 
     B2S_HIP(hipEventRecord(r.a, stream));
     int rc = gemm_launch_inner(g, dtype, ta, tb, stream);
     B2S_HIP(hipEventRecord(r.b, stream));
-    g_prof.push_back(r);
+    { std::lock_guard<std::mutex> lock(g_prof_mu); g_prof.push_back(r); }
     return rc;
 }
 // grouped bf16 weight-gradient launch (gemm_glds256.hip), with the same optional timing record (variant 16)
@@ -309,7 +315,7 @@ int b2s_gemm_grouped_launch(const GemmArgs* probs, int n, hipStream_t stream) {
     B2S_HIP(hipEventRecord(r.a, stream));
     int rc = b2s_gemm_glds256_grouped_launch(probs, n, b2s_gemm_zero_page(), stream);
     B2S_HIP(hipEventRecord(r.b, stream));
-    g_prof.push_back(r);
+    { std::lock_guard<std::mutex> lock(g_prof_mu); g_prof.push_back(r); }
     return rc;
 }
 static int gemm_launch_inner(const GemmArgs& g, int dtype, bool ta, bool tb, hipStream_t stream) {

@@ -11,10 +11,12 @@
 // K is walked in BK = 32 steps through an NSTAGE-deep LDS ring: NSTAGE-1 tiles are in flight, each wave waits only for
 // its own DMA of the tile it is about to use (counted s_waitcnt vmcnt, never 0 in steady state) and one raw s_barrier
 // per tile publishes it to the other waves and frees the oldest slot.
-// Lab switches (tools/gemm_lab.hip only, never defined in the library build): B2S_EXP_NODMA / NOWAIT / NOBAR / NOLDS /
-// DMAHOT / FULLLINE / REGLOAD ablate one pipeline component each; the results are in profiles/README.md.
+// (The round-1 ablation switches that attributed the main loop's time -- no DMA / no wait / no barrier / no LDS reads / L1-hot
+// DMA / whole-line fetch / register loads, results in profiles/README.md -- lived here as #ifdefs; they were removed from the
+// production kernel and can be re-created from commit a6102c4 with tools/gemm_lab.hip.)
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include "gemm.h"
 #include "gemm_epi.h"
 
@@ -89,9 +91,6 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
     // Always issues exactly 4 DMA instructions per wave (tiles past the end fetch the zero page into a slot nobody
     // reads again), so the in-flight count is a compile-time constant and the waits below never drain the queue.
     auto issue = [&](int kt, int buf) {
-#ifdef B2S_EXP_NODMA
-        return;
-#endif
         const int kb = kt < kt_end ? kt * BK : (1 << 28);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -106,20 +105,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
                 sa = (ka[i] >= 0 && kb + ka[i] < limA) ? pa[i] + kt * stepA : zero;
                 sb = (kb_[i] >= 0 && kb + kb_[i] < limB) ? pb[i] + kt * stepB : zero;
             }
-#ifdef B2S_EXP_FULLLINE
-            // traffic-pattern experiment (results are garbage): K-contiguous operands fetched as 8 rows x 128 B per instruction
-            if (!TA) { int r = (q & 7) * 8 + (lane >> 3) + ((kt & 1) ? 64 : 0); sa = (m0 + r < g.A.R && kt < kt_end) ? Ab + (long)(m0 + r) * g.A.ld + (kt >> 1) * 64 + (lane & 7) * 8 : zero; }
-            if (!TB) { int r = (q & 7) * 8 + (lane >> 3) + ((kt & 1) ? 64 : 0); sb = (n0 + r < g.B.R && kt < kt_end) ? Bb + (long)(n0 + r) * g.B.ld + (kt >> 1) * 64 + (lane & 7) * 8 : zero; }
-#endif
-#ifdef B2S_EXP_DMAHOT
-            sa = zero + (lane & 15) * 8; sb = zero + (lane & 15) * 8;
-#endif
-#ifdef B2S_EXP_REGLOAD
-            { uint4 t0, t1; asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off" : "=&v"(t0), "=&v"(t1) : "v"(sa), "v"(sb) : "memory"); }
-#else
             __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(smem + buf * 2 * TILE + q * 512), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(smem + buf * 2 * TILE + TILE + q * 512), 16, 0, 0);
-#endif
         }
     };
     // Fragment reads are issued as inline-asm DS instructions so that the compiler cannot sink them next to their
@@ -156,33 +143,18 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
 
     // Software pipeline: the DMA ring keeps NSTAGE-1 tiles in flight; the fragments of tile kt+1 are read from LDS while
     // the 16 MFMAs of tile kt execute (register double buffer), so neither HBM nor LDS latency is exposed.
-#if defined(B2S_EXP_NOWAIT) || defined(B2S_EXP_NODMA)
-#define B2S_EXP_WAIT
-#else
-#define B2S_EXP_WAIT asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTAGE - 3)) : "memory");
-#endif
-#ifdef B2S_EXP_NOBAR
-#define B2S_EXP_BAR
-#else
-#define B2S_EXP_BAR __builtin_amdgcn_s_barrier();
-#endif
-#ifdef B2S_EXP_NOLDS
-#define B2S_EXP_FRAG(d, t, a) asm volatile("" : "+v"(d))
-#else
-#define B2S_EXP_FRAG(d, t, a) frag_issue(d, t, a)
-#endif
 #define B2S_MMA16(CA, CB)                                                                                         \
     _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < 4; ++b)                   \
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CA[a], CB[b], acc[a][b], 0, 0, 0);
 #define B2S_STEP(KT, CA, CB, NA, NB)                                                                              \
     {                                                                                                              \
-        B2S_EXP_WAIT /* tile KT+1 landed (own DMAs) */    \
-        B2S_EXP_BAR             /* ... for every wave; tile KT-1 is fully consumed */             \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTAGE - 3)) : "memory");   /* tile KT+1 landed (own DMAs) */    \
+        __builtin_amdgcn_s_barrier();             /* ... for every wave; tile KT-1 is fully consumed */             \
         issue(kt0 + (KT) + NSTAGE - 1, ((KT) + NSTAGE - 1) % NSTAGE);                                              \
         const unsigned sb_ = lds_base + (unsigned)((((KT) + 1) % NSTAGE) * 2 * TILE * 2);                         \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                            \
-            B2S_EXP_FRAG(NA[t], TA, sb_ + offA[t]);                                                                  \
-            B2S_EXP_FRAG(NB[t], TB, sb_ + offB[t]);                                                                  \
+            frag_issue(NA[t], TA, sb_ + offA[t]);                                                                  \
+            frag_issue(NB[t], TB, sb_ + offB[t]);                                                                  \
         }                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         B2S_MMA16(CA, CB)                                                                                          \
@@ -218,9 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, const bf1
     gemm_wave_epilogue<4>(g, acc, reinterpret_cast<float*>(smem_raw) + wave * (64 * 64), m0 + wrow, n0 + wcol, lane, z, zo, zi, ksplit, splitk_ws);
 }
 
-bf16_t* g_zero_page = nullptr;
-float* g_splitk_ws = nullptr;
-size_t g_splitk_ws_floats = 0;
+bf16_t* g_zero_page = nullptr;         // immutable after ensure_globals(): see b2s_gemm_zero_page()
 
 // dst[m*ldc + col(n)] += alpha-scaled sum over splits of ws[s][m][n]
 __global__ void splitk_reduce_kernel(const float* ws, float* dst, int M, int N, int ldc, int splitk, int conv_dw_cin) {
@@ -253,17 +223,18 @@ int launch_t(const GemmArgs& g_in, hipStream_t stream) {
         g.splitk = cdiv(nk_all, per);
     }
     constexpr size_t smem = NSTAGE * 2 * (size_t)TILE * sizeof(bf16_t);     // 16 KB per stage
-    static bool attr_set = false;
-    if (!attr_set) {
-        B2S_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<TA, TB, GATHER>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<TA, TB, GATHER>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    B2S_HIP(attr_err);
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch * g.splitk);
     float* ws = nullptr;
     if (g.splitk > 1 && g.batch == 1 && g.c_fp32 && g.epi.accumulate && (g.N & 3) == 0 && (g.ldc & 3) == 0 &&
-        (size_t)g.splitk * g.M * g.N <= g_splitk_ws_floats)
-        ws = g_splitk_ws;
+        g.ws && (size_t)g.splitk * g.M * g.N <= g.ws_floats)
+        ws = g.ws;
     hipLaunchKernelGGL((gemm_glds_kernel<TA, TB, GATHER>), grid, dim3(256), smem, stream, g, (const bf16_t*)g_zero_page, ws);
     B2S_LAUNCH_CHECK();
     if (ws) B2S_TRY(b2s_splitk_reduce_launch(ws, (float*)g.C, g.M, g.N, g.ldc, g.splitk, g.epi.conv_dw_cin, stream));
@@ -281,12 +252,13 @@ int b2s_splitk_reduce_launch(const float* ws, float* dst, int M, int N, int ldc,
 }
 
 static int ensure_globals() {
-    if (!g_zero_page) {
-        B2S_HIP(hipMalloc(&g_zero_page, 256));
-        B2S_HIP(hipMemset(g_zero_page, 0, 256));
-        g_splitk_ws_floats = (size_t)24 << 20;                       // 96 MB of split-K slabs
-        if (hipMalloc(&g_splitk_ws, g_splitk_ws_floats * sizeof(float)) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_ws_floats = 0; }
-    }
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+        err = hipMalloc(&g_zero_page, 256);
+        if (err == hipSuccess) err = hipMemset(g_zero_page, 0, 256);
+    });
+    B2S_HIP(err);
     return 0;
 }
 const bf16_t* b2s_gemm_zero_page() { return ensure_globals() ? nullptr : g_zero_page; }
@@ -298,7 +270,7 @@ int b2s_gemm_glds_launch(const GemmArgs& g, bool ta, bool tb, hipStream_t stream
     // FLOP); the 128x128 kernel keeps the batched (per-head) and short problems.  B2S_GEMM256_MIN_M overrides.
     static const long min_m = getenv("B2S_GEMM256_MIN_M") ? atol(getenv("B2S_GEMM256_MIN_M")) : 129;
     if (g.batch == 1 && g.M >= min_m)
-        return b2s_gemm_glds256_launch(g, ta, tb, g_zero_page, g_splitk_ws, g_splitk_ws_floats, stream);
+        return b2s_gemm_glds256_launch(g, ta, tb, g_zero_page, stream);
     const bool gather = g.A.g_cin > 0 || g.B.g_cin > 0;
     if (gather) {       // conv1d forms: forward / backward-data (NT, gather on A) and weight gradient (TN, gather on B)
         if (!ta && !tb) return launch_t<false, false, true>(g, stream);

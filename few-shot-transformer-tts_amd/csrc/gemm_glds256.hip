@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <vector>
 #include <cstdlib>
+#include <mutex>
 #include "gemm.h"
 #include "gemm_epi.h"
 
@@ -203,9 +204,6 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
     // Always exactly 6 DMA instructions per wave and stage (stages past the end fetch the zero page into a slot nobody
     // reads again): the in-flight count is a compile-time constant and the counted waits below never drain the queue.
     auto issue = [&](int kt, int slot) {
-#ifdef B2S_EXP_NODMA
-        return;
-#endif
         unsigned char* sbase = smem_raw + slot * STG;
         if (fast_ok && (kt < nfull || kt >= kt_end)) {                   // (steps past the end re-fetch the last full one: never consumed)
             const long ks = min(kt, nfull - 1);
@@ -244,9 +242,6 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
             } else {
                 sa = (ka[i] >= 0 && kb + ka[i] < limA) ? pa[i] + kt * stepA : zero;
             }
-#ifdef B2S_EXP_DMAHOT
-            sa = zero + (lane & 15) * 8;
-#endif
             __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(sbase + idx * 1024), 16, 0, B2S_DMA_AUX);
         }
 #pragma unroll
@@ -261,9 +256,6 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
             } else {
                 sb = (kb_[i] >= 0 && kb + kb_[i] < limB) ? pb[i] + kt * stepB : zero;
             }
-#ifdef B2S_EXP_DMAHOT
-            sb = zero + (lane & 15) * 8;
-#endif
             __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(sbase + A_B + idx * 1024), 16, 0, B2S_DMA_AUX);
         }
     };
@@ -430,25 +422,26 @@ __global__ __launch_bounds__(nthreads_of(false), 1) void gemm_glds256_grouped_ke
 }
 
 template <bool TA, bool TB, int GATHER, int NB, int MW = 4>
-int launch256_nb(const GemmArgs& g_in, const bf16_t* zero, float* ws_all, size_t ws_floats, hipStream_t stream) {
+int launch256_nb(const GemmArgs& g_in, const bf16_t* zero, hipStream_t stream) {
     GemmArgs g = g_in;
     if (g.splitk > 1) {                     // every split must own at least one K step (empty splits would leave slabs unwritten)
         const int nk_all = cdiv(g.K, BK), per = cdiv(nk_all, g.splitk);
         g.splitk = cdiv(nk_all, per);
     }
     constexpr size_t smem = (size_t)NSTAGE * (MW * 64 * BK * 2 + B_BYTES);           // 144 KB (96 KB with 128-row tiles)
-    static bool attr_set = false;
-    if (!attr_set) {
-        B2S_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<TA, TB, GATHER, NB, MW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_kernel<TA, TB, GATHER, NB, MW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    B2S_HIP(attr_err);
     const int tiles_m = cdiv(g.M, MW * 64), tiles_n = cdiv(g.N, NB * 32);
     dim3 grid(tiles_m * tiles_n * g.batch * g.splitk);               // 1-D: the kernel maps linear ids to tiles (XCD-aware)
     float* ws = nullptr;
     if (g.splitk > 1 && g.batch == 1 && g.c_fp32 && g.epi.accumulate && (g.N & 3) == 0 && (g.ldc & 3) == 0 &&
-        (size_t)g.splitk * g.M * g.N <= ws_floats)
-        ws = ws_all;
+        g.ws && (size_t)g.splitk * g.M * g.N <= g.ws_floats)
+        ws = g.ws;
     hipLaunchKernelGGL((gemm_glds256_kernel<TA, TB, GATHER, NB, MW>), grid, dim3(nthreads_of(GATHER, MW)), smem, stream, g, zero, ws, tiles_m, tiles_n);
     B2S_LAUNCH_CHECK();
     if (ws) B2S_TRY(b2s_splitk_reduce_launch(ws, (float*)g.C, g.M, g.N, g.ldc, g.splitk, g.epi.conv_dw_cin, stream));
@@ -465,7 +458,7 @@ inline int pick_nb(const GemmArgs& g) {
     return r96 < r128 ? 3 : 4;
 }
 template <bool TA, bool TB, int GATHER>
-int launch256_t(const GemmArgs& g, const bf16_t* zero, float* ws_all, size_t ws_floats, hipStream_t stream) {
+int launch256_t(const GemmArgs& g, const bf16_t* zero, hipStream_t stream) {
     if (!TA && GATHER == 0) {
         // 128-row tiles when 256-row tiles would occupy at most half of the CUs
         static const int small_tiles = getenv("B2S_GEMM128_MAX_TILES") ? atoi(getenv("B2S_GEMM128_MAX_TILES")) : 128;
@@ -473,12 +466,12 @@ int launch256_t(const GemmArgs& g, const bf16_t* zero, float* ws_all, size_t ws_
         const long t256n = (long)cdiv(g.M, BM) * cdiv(g.N, nb * 32) * g.batch * std::max(1, g.splitk);
         if (t256n <= small_tiles && g.M > 128) {
             constexpr bool ta = false;          // (the 128-row variant is instantiated for K-contiguous A only)
-            return nb == 3 ? launch256_nb<ta, TB, 0, 3, 2>(g, zero, ws_all, ws_floats, stream)
-                           : launch256_nb<ta, TB, 0, 4, 2>(g, zero, ws_all, ws_floats, stream);
+            return nb == 3 ? launch256_nb<ta, TB, 0, 3, 2>(g, zero, stream)
+                           : launch256_nb<ta, TB, 0, 4, 2>(g, zero, stream);
         }
     }
-    return pick_nb(g) == 3 ? launch256_nb<TA, TB, GATHER, 3>(g, zero, ws_all, ws_floats, stream)
-                           : launch256_nb<TA, TB, GATHER, 4>(g, zero, ws_all, ws_floats, stream);
+    return pick_nb(g) == 3 ? launch256_nb<TA, TB, GATHER, 3>(g, zero, stream)
+                           : launch256_nb<TA, TB, GATHER, 4>(g, zero, stream);
 }
 
 }  // namespace t256
@@ -521,12 +514,13 @@ int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* 
     }
     grp.tile0[n] = tiles;
     constexpr size_t smem = (size_t)t256::NSTAGE * t256::STAGE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        B2S_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t256::gemm_glds256_grouped_kernel<4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(t256::gemm_glds256_grouped_kernel<4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    B2S_HIP(attr_err);
     hipLaunchKernelGGL((t256::gemm_glds256_grouped_kernel<4>), dim3(tiles), dim3(t256::nthreads_of(false)), smem, stream, grp, zero);
     B2S_LAUNCH_CHECK();
     return 0;
@@ -535,7 +529,7 @@ int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* 
 // number of 256x128 tiles a problem decomposes into (the dispatcher in gemm_glds.hip uses it to pick the tile shape)
 long b2s_gemm_glds256_tiles(const GemmArgs& g) { return (long)cdiv(g.M, t256::BM) * cdiv(g.N, 128) * g.batch * std::max(1, g.splitk); }
 
-int b2s_gemm_glds256_launch(const GemmArgs& g, bool ta, bool tb, const bf16_t* zero, float* ws, size_t ws_floats, hipStream_t stream) {
+int b2s_gemm_glds256_launch(const GemmArgs& g, bool ta, bool tb, const bf16_t* zero, hipStream_t stream) {
     const bool gather = g.A.g_cin > 0 || g.B.g_cin > 0;
     if (gather) {
         if (!ta && !tb) {
@@ -543,14 +537,14 @@ int b2s_gemm_glds256_launch(const GemmArgs& g, bool ta, bool tb, const bf16_t* z
             const bool aligned = g.A.g_cin > 0 && g.B.g_cin == 0 && g.A.g_cin % t256::BK == 0 && g.K % t256::BK == 0 && g.splitk == 1 &&
                                  (long)g.A.R * g.A.ld < (1L << 29) && (long)g.B.R * g.B.ld < (1L << 30) && g.A.g_T > 0;
             static const bool no_fast = getenv("B2S_CONV_GENERIC") != nullptr;      // A/B switch
-            if (aligned && !no_fast) return t256::launch256_t<false, false, 2>(g, zero, ws, ws_floats, stream);
-            return t256::launch256_t<false, false, 1>(g, zero, ws, ws_floats, stream);
+            if (aligned && !no_fast) return t256::launch256_t<false, false, 2>(g, zero, stream);
+            return t256::launch256_t<false, false, 1>(g, zero, stream);
         }
-        if (ta && tb) return t256::launch256_t<true, true, 1>(g, zero, ws, ws_floats, stream);
+        if (ta && tb) return t256::launch256_t<true, true, 1>(g, zero, stream);
         return b2s_fail(__FILE__, __LINE__, "conv gather is supported for the NT and TN forms only");
     }
-    if (!ta && !tb) return t256::launch256_t<false, false, 0>(g, zero, ws, ws_floats, stream);
-    if (!ta && tb) return t256::launch256_t<false, true, 0>(g, zero, ws, ws_floats, stream);
-    if (ta && !tb) return t256::launch256_t<true, false, 0>(g, zero, ws, ws_floats, stream);
-    return t256::launch256_t<true, true, 0>(g, zero, ws, ws_floats, stream);
+    if (!ta && !tb) return t256::launch256_t<false, false, 0>(g, zero, stream);
+    if (!ta && tb) return t256::launch256_t<false, true, 0>(g, zero, stream);
+    if (ta && !tb) return t256::launch256_t<true, false, 0>(g, zero, stream);
+    return t256::launch256_t<true, true, 0>(g, zero, stream);
 }

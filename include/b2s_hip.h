@@ -181,6 +181,13 @@ typedef struct b2s_gemm_desc {
 } b2s_gemm_desc;
 int b2s_gemm(const b2s_gemm_desc* d, const void* A, const void* B, void* C, const float* bias, const float* residual,
              const int32_t* row_len, const int32_t* conv_len, void* stream);
+/* The same GEMM with the reduction split over `splitk` workgroup groups (weight-gradient shapes: small M x N, long K).
+ * Requires c_fp32 = 1, accumulate = 1 and a linear epilogue.  ws: caller-owned slab workspace of ws_floats >= splitk*M*N
+ * floats that must not be shared by launches on different streams (partial tiles are written there and summed into C
+ * by a second kernel on the same stream); ws = NULL: partial tiles are added into C with fp32 atomics.  The library holds
+ * no slab of its own (csrc/gemm.h: GemmArgs::ws). */
+int b2s_gemm_splitk(const b2s_gemm_desc* d, int splitk, const void* A, const void* B, float* C, float* ws, size_t ws_floats,
+                    void* stream);
 int b2s_layernorm_forward(int dtype, const float* x, const float* gamma, const float* beta, void* y, float* mean,
                           float* rstd, int M, int D, float eps, void* stream);
 int b2s_layernorm_backward(int dtype, const void* dy, const float* x, const float* gamma, const float* mean,

@@ -279,3 +279,39 @@ def test_gemm_256_tile_kernel_all_forms(nb):
                         "-k", "test_gemm_forms or test_gemm_batched or test_conv_gather or bf16 or test_decode"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("slabs", [True, False])
+def test_splitk_weight_gradient_gemms_on_two_streams(slabs):
+    """Split-K slab workspaces belong to the caller, one per stream (GemmArgs::ws; the library owns none): two different
+    weight-gradient GEMMs (TN form, K = 8192 split 8 ways) issued back to back on two streams, many rounds, both results
+    right every round.  slabs=False: the fp32-atomic accumulation path."""
+    import ctypes as C
+    ops, lib = _ops()
+    L = lib
+    l = L.load()
+    g = torch.Generator().manual_seed(11)
+    K = 8192
+    shapes = [(768, 640), (512, 768)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    probs = []
+    for i, (M, N) in enumerate(shapes):
+        A = bf16_round(torch.randn(K, M, generator=g) * 0.5 + i)         # A^T stored [K][M]
+        B = bf16_round(torch.randn(K, N, generator=g) * 0.5 - i)
+        ref = (A.double().t() @ B.double())
+        d = L.GemmDesc()
+        d.dtype, d.trans_a, d.trans_b, d.M, d.N, d.K = 1, 1, 1, M, N, K
+        d.lda, d.ldb, d.ldc, d.c_fp32, d.batch, d.batch_inner, d.alpha, d.accumulate = M, N, N, 1, 1, 1, 1.0, 1
+        ws = torch.empty(8 * M * N, dtype=torch.float32, device=DEV) if slabs else None
+        probs.append((d, to_dev_compute(A, 1), to_dev_compute(B, 1), torch.zeros(M, N, device=DEV), ws, ref))
+    torch.cuda.synchronize()
+    rounds = 12
+    for r in range(rounds):
+        for (d, A, B, Cd, ws, ref), st in zip(probs, streams):
+            with torch.cuda.stream(st):
+                Cd.zero_()
+                L.check(l.b2s_gemm_splitk(C.byref(d), 8, A.data_ptr(), B.data_ptr(), Cd.data_ptr(), ws.data_ptr() if ws is not None else None,
+                                          ws.numel() if ws is not None else 0, st.cuda_stream))
+        torch.cuda.synchronize()
+        for d, A, B, Cd, ws, ref in probs:
+            assert relerr(Cd.cpu(), ref) < 2e-3, (r, report("splitk", Cd.cpu(), ref))

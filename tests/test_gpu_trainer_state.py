@@ -48,7 +48,7 @@ def test_rebind_under_trainer_updates_live_parameters(compute_dtype):
     torch.cuda.synchronize()
     for n, t in old.items():
         assert torch.equal(t, snap[n]), "stale storage of %s was written after the re-bind" % n
-    tol = 1e-6 if compute_dtype == "fp32" else 2e-2
+    tol = 1e-4 if compute_dtype == "fp32" else 2e-2     # (split-K atomics reorder sums: runs differ by ~2e-5 after 3 Adam steps)
     for k, v in mb.state_dict().items():
         d = float((v.double() - ref[k].double()).abs().max())
         assert d <= tol * (1.0 + float(ref[k].double().abs().max())), (k, d)
