@@ -75,6 +75,22 @@ def cpu_baseline_train(budget_s=25.0):
             "seconds_per_step": round(best, 3)}
 
 
+def _sub_bench(extra):
+    """Run another bench mode in a child process and return the fields of its JSON line that matter on the parent's line."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1"] + extra, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    d = json.loads(lines[-1])
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "final_loss", "config", "roofline", "roofline_step",
+            "cpu_baseline")
+    d = {k: d[k] for k in keep if k in d}
+    if isinstance(d.get("roofline"), dict):
+        d["roofline"] = {k: v for k, v in d["roofline"].items() if k not in ("variants", "isolated", "note")}
+    return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,7 +106,21 @@ def main():
     ap.add_argument("--hparams", default="", help="extra hparams overrides (experiments), e.g. transformer_dropout_rate=0.0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="train mode, 1 GPU: skip the decode / finetune / fp32_mode sub-benchmarks added to the JSON line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N ranks ourselves (one process per GPU, RCCL rendezvous on
+        # 127.0.0.1) -- the same command line the driver uses
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -280,6 +310,21 @@ def main():
                                    "durations also include the split-K slab reduction that belongs to the launch"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_train()
+    if world > 1 or force_dp:
+        out_n = torch.distributed.get_world_size()
+        if rank == 0:
+            out["rccl_ranks"] = out_n                  # what the RCCL group itself reports (== n_gpus)
+    if rank == 0 and world == 1 and args.mode == "train" and args.dtype == "bf16" and not args.no_extras:
+        # the other BASELINE.json configs on the same JSON line (each in its own process: the hparams object is global):
+        #   decode     configs[3]  64 utterances x 1000 frames, hipGraph-captured KV-cached loop
+        #   finetune   configs[4]  frozen encoder + guided-attention loss, batches from a 30-utterance pool
+        #   fp32_mode  the parity-proven arithmetic (exact-fp32 MFMA) on the headline batch
+        del trainer, model
+        torch.cuda.empty_cache()
+        out["decode"] = _sub_bench(["--mode", "decode", "--steps", "10", "--warmup", "1"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
+        out["finetune"] = _sub_bench(["--mode", "finetune", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
+                                      "--no-roofline-pass"])
+        out["fp32_mode"] = _sub_bench(["--dtype", "fp32", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-roofline-pass"])
     if world > 1 or force_dp:
         torch.distributed.destroy_process_group()
     if rank == 0:

@@ -9,7 +9,7 @@ oracle/synth.py (NumPy default_rng) so the fixtures hold outputs only.
 
 Groups: G1 helpers, G2 tiny model fwd/loss/grads/Adam/eval-mode,
 G3 per-module, G4 autoregressive decode, G5 full-size spot checks, G6 LR schedule + packer,
-G7 batch producer (packer caps, collate contract, adapt-rate ramp).
+G7 batch producer (packer caps, collate contract, adapt-rate ramp), G8 feeders, G9 full-size autoregressive decode.
 """
 import json
 import os
@@ -202,6 +202,58 @@ def g3():
     save("g3_modules", **arrs)
 
 
+def pick_staggered_bias(raw, lo, hi):
+    """raw [B, T]: stop logits without the bias, from a run that never stops (batch rows are independent and a row's
+    logits up to its stop do not depend on the bias).  Returns a bias b such that the first frames with raw + b > 0 are
+    pairwise different and lie in [lo, hi) (one row may never stop when no bias separates all of them): the staggered-stop /
+    zero-tail logic then runs for several frames."""
+    cands = np.unique(-raw[:, lo:hi].ravel())
+    cands = np.concatenate([(cands[:-1] + cands[1:]) * 0.5, cands[-1:] + 1.0])
+    best = None
+    for b in cands:
+        hit = raw + b > 0
+        first = np.where(hit.any(1), hit.argmax(1), raw.shape[1])
+        finite = first[first < raw.shape[1]]
+        # pairwise different stop frames, all >= lo; at most one row may never stop (that row reports frames + 1)
+        if len(set(first.tolist())) == raw.shape[0] and first.min() >= lo and len(finite) >= raw.shape[0] - 1 and finite.max() < hi:
+            spread = (len(finite), np.diff(np.sort(first)).min())
+            if best is None or spread > best[0]:
+                best = (spread, float(b), first)
+    assert best is not None, "no bias staggers the stops"
+    print("   staggered stops at frames", best[2].tolist(), "bias %.5f" % best[1])
+    return best[1]
+
+
+# ------------------------------------------------------------------------------- G9
+def g9():
+    """Full-size autoregressive decode (BASELINE configs[3] at a CPU-feasible size): default hparams, dropout rates 0 (so
+    that decoder.train() synthesis is deterministic), B=3, S=40, max_generation_frames=48,
+    stop bias chosen so the three utterances stop at three different frames >= 8."""
+    over = "transformer_dropout_rate=0.0,decoder_dropout_rate=0.0,max_generation_frames=48"
+    m, cfg = build_model(over, seed=77)
+    nb = synth.synthetic_batch(cfg, B=3, S=40, T=4, seed=21, in_lens=[40, 31, 36], n_spk=572, n_lang=38)
+    b = tbatch(nb)
+    b.pop("mel_targets"); b.pop("target_lengths")
+    m.eval()
+    m.decoder.stop_net.bias.data.fill_(-100.0)
+    r = rsynth.eval_batch(m, b, use_bar=False, bar_interval=-1)
+    with torch.no_grad():
+        enc = m.encoder(b["inputs"], b["input_lengths"], b["input_spk_ids"], b["input_language_vecs"])
+        _, sl, _ = m.decoder(enc, b["input_lengths"], torch.from_numpy(r["mel_pre"]), torch.full([3], 48, dtype=torch.int32))
+    bias = pick_staggered_bias((sl + 100.0).numpy(), lo=8, hi=46)
+    m.decoder.stop_net.bias.data.fill_(bias)
+    r = rsynth.eval_batch(m, b, use_bar=False, bar_interval=-1)
+    arrs = {"stop_bias": np.float32(bias), "mel_pre": r["mel_pre"], "mel_aft": r["mel_aft"],
+            "generated_lengths": np.asarray(r["generated_lengths"])}
+    for i in range(cfg.n_decoder_layer):
+        a = r["alignments"]["encdec"][i]                             # [B,H,S,T]
+        arrs["align_argmax_%d" % i] = a.argmax(axis=2).astype(np.int32)
+        top2 = np.sort(a, axis=2)[:, :, -2:, :]
+        arrs["align_margin_%d" % i] = (top2[:, :, 1] - top2[:, :, 0]).astype(np.float32)      # arg-max margin (ties are not comparable)
+    print("g9 generated_lengths", r["generated_lengths"])
+    save("g9_decode_fullsize", **arrs)
+
+
 # ------------------------------------------------------------------------------- G4
 def g4():
     arrs = {}
@@ -226,10 +278,9 @@ def g4():
                     _, sl, _ = m.decoder(enc, b["input_lengths"], dec_in,
                                          torch.full([3], 40, dtype=torch.int32))
                 raw = sl + 100.0                                    # logits without the bias
-                # choose bias so that sample i first crosses zero at a different step
-                med = raw[:, 5:35].median()
-                m.decoder.stop_net.bias.data.fill_(float(-med))
-                arrs["%s_%s/stop_bias" % (tag, case)] = np.float32(-med)
+                bias = pick_staggered_bias(raw.numpy(), lo=8, hi=38)
+                m.decoder.stop_net.bias.data.fill_(bias)
+                arrs["%s_%s/stop_bias" % (tag, case)] = np.float32(bias)
             r = rsynth.eval_batch(m, b, use_bar=False, bar_interval=-1)
             arrs["%s_%s/mel_pre" % (tag, case)] = r["mel_pre"]
             arrs["%s_%s/mel_aft" % (tag, case)] = r["mel_aft"]
@@ -381,7 +432,7 @@ def g8():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     torch.manual_seed(0)
     if "g1" in which: g1()
     if "g2" in which:
@@ -393,3 +444,4 @@ if __name__ == "__main__":
     if "g6" in which: g6()
     if "g7" in which: g7()
     if "g8" in which: g8()
+    if "g9" in which: g9()

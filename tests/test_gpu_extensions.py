@@ -159,3 +159,58 @@ def test_guided_bf16_dropout_on_full_heads():
     assert abs(direct - float(losses["ga_loss"])) < 2e-3 * direct, (direct, float(losses["ga_loss"]))
     for n, p in m.named_parameters():
         assert torch.isfinite(p.grad).all(), n
+
+
+def test_dropout_on_decode_statistics_vs_recompute_loop():
+    """The reference synthesises with decoder.train() (eval.py:116-117): prenet dropout 0.5 and transformer dropout 0.1 are
+    live and, because its loop recomputes the whole prefix every frame (synthesize.py:35-45), every earlier position gets
+    fresh masks at every step.  The KV-cached loop draws each position's masks once (when that frame is generated) and
+    keeps its K / V.  RNG streams differ anyway, so the comparison is statistical: 256 copies of ONE utterance (the only
+    randomness is dropout) through the HIP hipGraph loop and through the oracle's recompute-every-frame loop on the same
+    weights; the distributions of generated length and of the per-frame mel mean / spread must agree within sampling
+    noise + the bounds below (the measured numbers are printed and quoted in INTEGRATION.md section 3)."""
+    import synthesize
+    from test_gpu_model import build, dev_batch, load
+    g = load("g4_decode")
+    over = TINY96.replace("transformer_dropout_rate=0.0,decoder_dropout_rate=0.0", "transformer_dropout_rate=0.1,decoder_dropout_rate=0.5")
+    assert over != TINY96
+    bias = float(g["tiny96_mixed/stop_bias"]) + 0.6
+
+    def edit(st):
+        st["decoder.stop_net.bias"] = np.full((1,), bias, dtype=np.float32)
+    m, cfg, st, hp = build(over + ",max_generation_frames=40", state_edit=edit)
+    m.eval()
+    m.decoder.train()
+    B = 256
+    one = synth.synthetic_batch(cfg, B=1, S=10, T=4, seed=11, in_lens=[10])
+    nb = {k: (np.repeat(np.asarray(v), B, axis=0) if not isinstance(v, list) else v * B) for k, v in one.items()}
+    nb.pop("mel_targets"); nb.pop("target_lengths")
+    r = synthesize.eval_batch(m, dev_batch(nb), use_bar=False, bar_interval=-1)
+    P = O.to_torch_state(st)
+    torch.manual_seed(0)
+    ro = O.eval_batch(P, cfg, O.to_torch_batch(nb), decoder_train=True)
+    lh = np.minimum(np.asarray(r["generated_lengths"], dtype=np.float64), 41)
+    lo = np.minimum(ro["generated_lengths"].numpy().astype(np.float64), 41)
+    # per-frame statistics over utterances still running at that frame
+    def frame_stats(mel, lens, t):
+        alive = lens > t
+        x = mel[alive, t, :]
+        return alive.mean(), x.mean(), x.std()
+    mh, mo = r["mel_pre"], ro["mel_pre"].numpy()
+    T = min(mh.shape[1], mo.shape[1])
+    rows = []
+    for t in range(0, T, 4):
+        ah, uh, sh = frame_stats(mh, lh, t)
+        ao, uo, so = frame_stats(mo, lo, t)
+        rows.append((t, ah, ao, uh, uo, sh, so))
+    print("dropout-on decode, 256 x one utterance: generated length HIP %.2f +- %.2f | oracle (recompute loop) %.2f +- %.2f"
+          % (lh.mean(), lh.std(), lo.mean(), lo.std()))
+    for t, ah, ao, uh, uo, sh, so in rows:
+        print("  frame %2d: alive %.2f / %.2f  mel mean %+.4f / %+.4f  mel std %.4f / %.4f" % (t, ah, ao, uh, uo, sh, so))
+    se = np.sqrt(lh.var() / B + lo.var() / B)
+    assert abs(lh.mean() - lo.mean()) < 4 * se + 0.1 * lo.mean(), (lh.mean(), lo.mean())
+    assert 0.6 < (lh.std() + 0.5) / (lo.std() + 0.5) < 1.67
+    for t, ah, ao, uh, uo, sh, so in rows:
+        if min(ah, ao) > 0.3:
+            assert abs(uh - uo) < 0.25 * max(so, sh) + 0.02, (t, uh, uo)
+            assert 0.7 < sh / so < 1.43, (t, sh, so)

@@ -184,6 +184,37 @@ def test_g4_decode(tag, over, case):
         assert (am == g[pre + "align_argmax_%d" % i]).all()
 
 
+# ------------------------------------------------------------------ G9 full-size decode (BASELINE configs[3] at CPU size)
+G9_OVER = "transformer_dropout_rate=0.0,decoder_dropout_rate=0.0,max_generation_frames=48"
+
+
+def g9_inputs(g):
+    cfg = make_config(G9_OVER)
+    st = synth.synthetic_state(cfg, 77)
+    st["decoder.stop_net.bias"] = np.full((1,), float(g["stop_bias"]), dtype=np.float32)
+    nb = synth.synthetic_batch(cfg, B=3, S=40, T=4, seed=21, in_lens=[40, 31, 36], n_spk=572, n_lang=38)
+    nb.pop("mel_targets"); nb.pop("target_lengths")
+    return cfg, st, nb
+
+
+def check_align_argmax(aligns, g, n_layers, min_margin=1e-4):
+    """encoder-decoder alignment arg-max equals the reference's wherever the reference's own top-2 margin exceeds min_margin
+    (at random init some frames attend almost uniformly; a tie-break there is not a property of either implementation)."""
+    for i in range(n_layers):
+        am = np.asarray(aligns[i]).argmax(axis=2)
+        ok = (am == g["align_argmax_%d" % i]) | (g["align_margin_%d" % i] < min_margin)
+        assert ok.all(), "layer %d: %d arg-max positions differ" % (i, int((~ok).sum()))
+
+
+def test_g9_decode_fullsize():
+    g = load("g9_decode_fullsize")
+    cfg, st, nb = g9_inputs(g)
+    r = O.eval_batch(O.to_torch_state(st), cfg, O.to_torch_batch(nb))
+    assert r["generated_lengths"].tolist() == g["generated_lengths"].tolist() and len(set(g["generated_lengths"].tolist())) == 3
+    close(r["mel_pre"], g["mel_pre"], atol=5e-5); close(r["mel_aft"], g["mel_aft"], atol=5e-5)
+    check_align_argmax([a.numpy() for a in r["alignments"]["encdec"]], g, cfg.n_decoder_layer)
+
+
 # ------------------------------------------------------------------ G5 full size (slow-ish: ~10 s)
 def test_g5_fullsize():
     g = load("g5_fullsize")

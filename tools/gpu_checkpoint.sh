@@ -11,7 +11,7 @@ python bench.py --mode finetune --no-cpu-baseline > $out/${tag}_bench_finetune.j
 export TMPDIR=/tmp
 repo=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_train -o train -- python $repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass > $out/${tag}_prof_train.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_train -o train -- python $repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass --no-extras > $out/${tag}_prof_train.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof_decode -o decode -- python $repo/bench.py --mode decode --no-cpu-baseline > $out/${tag}_prof_decode.log 2>&1
 cd $repo
 find $out/${tag}_prof_train $out/${tag}_prof_decode -name "*kernel_stats.csv" | head

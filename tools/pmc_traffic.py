@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes) into per-kernel per-launch HBM traffic.
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [skip_launches_per_kernel]
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [mfma_counter_collection.csv]
+The optional third pass (--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE) adds mfma_util = MFMA-busy cycles summed over the
+chip's 1024 SIMDs / (1024 x GRBM_GUI_ACTIVE), i.e. the fraction of matrix-pipe cycles a kernel keeps busy.
 FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts 128-byte requests at 64 bytes, so it is doubled
 (MI355X_MICROARCH.md, section HBM); WRITE_SIZE is reported as is (uncalibrated per that guide).
 """
@@ -29,6 +31,7 @@ def load(path, counter):
 def main():
     fetch, write, out = sys.argv[1:4]
     f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
+    mb, ga = (load(sys.argv[4], "SQ_VALU_MFMA_BUSY_CYCLES"), load(sys.argv[4], "GRBM_GUI_ACTIVE")) if len(sys.argv) > 4 else ({}, {})
     rows = []
     for k in f:
         fv, wv = f[k], w.get(k, [])
@@ -36,12 +39,13 @@ def main():
                      "FETCH_SIZE_KB_per_launch": round(sum(fv) / len(fv), 1),
                      "fetch_MB_per_launch_corrected_x2": round(2 * sum(fv) / len(fv) / 1024, 2),
                      "WRITE_SIZE_KB_per_launch": round(sum(wv) / len(wv), 1) if wv else None,
-                     "total_fetch_MB_corrected": round(2 * sum(fv) / 1024, 1)})
+                     "total_fetch_MB_corrected": round(2 * sum(fv) / 1024, 1),
+                     "mfma_util": round(sum(mb[k]) / (1024.0 * sum(ga[k])), 4) if k in mb and k in ga and sum(ga[k]) > 0 else None})
     rows.sort(key=lambda r: -r["total_fetch_MB_corrected"])
     json.dump(rows, open(out, "w"), indent=1)
     for r in rows[:12]:
-        print("%-60s launches %5d  fetch %9.2f MB/launch  write %9.2f MB/launch" % (
-            r["kernel"][:60], r["launches"], r["fetch_MB_per_launch_corrected_x2"], (r["WRITE_SIZE_KB_per_launch"] or 0) / 1024))
+        print("%-60s launches %5d  fetch %9.2f MB/launch  write %9.2f MB/launch  mfma_util %s" % (
+            r["kernel"][:60], r["launches"], r["fetch_MB_per_launch_corrected_x2"], (r["WRITE_SIZE_KB_per_launch"] or 0) / 1024, r["mfma_util"]))
 
 
 if __name__ == "__main__":
