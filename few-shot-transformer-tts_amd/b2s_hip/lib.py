@@ -106,6 +106,7 @@ _PROTOS = {
     "b2s_prof_enable": (None, [C.c_int]),
     "b2s_adam_step_ex": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, P]),
     "b2s_adam_wait": (C.c_int, [P, P]),
+    "b2s_adam_step_groups": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, P]),
     "b2s_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "b2s_dropout_mask": (C.c_int, [C.c_float, C.c_uint64, C.c_uint32, P, C.c_int64, P]),
 }

@@ -49,6 +49,12 @@ class HipTrainer(object):
         # (every engine entry point waits for the parameter groups it reads).  Code that reads parameters or optimizer state
         # with plain torch ops between steps must call sync() first; state_dict() / load_state_dict() / utils.checkpoint do.
         self.overlap_adam = bool(overlap_adam)
+        # split_adam: decoder / postnet parameters are updated on the second stream while the encoder backward still runs
+        # (b2s_adam_step_groups).  Measured on MI355X (profiles/README.md, round 2): no gain -- a wide Adam launch puts waves
+        # on every CU and the backward's GEMM workgroups (a whole CU each) starve; a narrow launch (64 workgroups) leaves
+        # them CUs but its HBM stream raises memory latency and the latency-bound encoder kernels run 1.6x slower while it
+        # lasts; a CU-masked stream serialised the two queues.  Off by default, kept as an option (B2S_SPLIT_ADAM=1).
+        self.split_adam = os.environ.get("B2S_SPLIT_ADAM", "0") == "1"
         self.eng = model.engine()
         self.eng.ensure_bound()
         self.lib = self.eng.lib
@@ -182,6 +188,16 @@ class HipTrainer(object):
         din = eng.postnet_backward(c_post, daft)
         dmel = eng.add(eng.add(din, daft), dbef)
         dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape, self._one if guided else None, not self.freeze_encoder)
+        lr = self.hp.max_lr * self.lr_lambda(self.global_step)
+        step_no = self.global_step + 1
+        adam = (lr, step_no, self.beta1, self.beta2, self.hp.adam_eps, self.hp.reg_weight, 1.0 / self.world)
+        # The decoder / postnet gradients (78 % of the parameters) are final here.  Their optimizer update (HBM-bound, no LDS)
+        # goes to the engine's second stream and runs under the encoder backward, whose GEMMs are 78..208 workgroups on
+        # 256 CUs; the encoder group follows on this stream.  Data parallel: those gradients' all-reduce must be complete
+        # first, so the split is used only without a process group (the exchange itself overlaps the encoder backward there).
+        split = self.split_adam and self.bucketer is None and not self.freeze_encoder and not self.overlap_adam
+        if split:
+            L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 1, L.stream()))
         if not self.freeze_encoder:
             eng.encoder_backward(c_enc, dmem)
         for c in (c_post, c_dec, c_enc):
@@ -194,10 +210,14 @@ class HipTrainer(object):
             raise RuntimeError("gradient exchange failed in the backward stage hook; the optimizer step was NOT applied") from err
         if self.bucketer is not None:
             self.bucketer.finish(expect_all=not self.freeze_encoder)
-        lr = self.hp.max_lr * self.lr_lambda(self.global_step)
-        self.global_step += 1
-        L.check(lib.b2s_adam_step_ex(eng.handle, lr, self.global_step, self.beta1, self.beta2, self.hp.adam_eps,
-                                     self.hp.reg_weight, 1.0 / self.world, int(self.overlap_adam), L.stream()))
+        self.global_step = step_no
+        if split:
+            L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 1, 0, L.stream()))
+            # order this stream behind the second-stream update (done long before the encoder backward ends): plain torch
+            # code that reads parameters right after train_step needs no explicit sync()
+            L.check(lib.b2s_adam_wait(eng.handle, L.stream()))
+        else:
+            L.check(lib.b2s_adam_step_ex(eng.handle, *adam, int(self.overlap_adam), L.stream()))
         eng._needs_zero = True
         self.last_aft_losses = per
         return vals

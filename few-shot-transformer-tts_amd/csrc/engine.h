@@ -133,6 +133,7 @@ struct b2s_model {
     int adam_grp[4] = {0, 0, 0, 0};                            // chunk ranges [grp[g], grp[g+1]) of encoder / decoder / postnet
     mutable hipEvent_t adam_ev[3] = {nullptr, nullptr, nullptr};
     mutable bool adam_pending[3] = {false, false, false};
+    int adam_step_no = 0, adam_step_mask = 0;                  // b2s_adam_step_groups: groups already updated in step adam_step_no
     // bf16 mode: the compute-dtype copies of the L encoder-decoder kv_transform weights are one slab [L*2D][D], so that the
     // memory K/V of all layers come from ONE GEMM (N = L*2D) and d(memory) from ONE GEMM over the concatenated dK/dV
     // (K = L*2D) instead of L launches of 56-112 tiles each

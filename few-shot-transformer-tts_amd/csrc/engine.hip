@@ -585,6 +585,10 @@ extern "C" int b2s_model_create(const b2s_config* cfg, b2s_model** out) {
 }
 extern "C" void b2s_model_destroy(b2s_model* m) {
     if (!m) return;
+    (void)hipDeviceSynchronize();                 // nothing of this model is in flight any more
+    if (m->aux) (void)hipStreamDestroy(m->aux);
+    for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+    for (int g = 0; g < 3; ++g) if (m->adam_ev[g]) (void)hipEventDestroy(m->adam_ev[g]);
     for (void* p : m->owned) (void)hipFree(p);
     delete m;
 }
@@ -965,7 +969,7 @@ int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, 
 
 extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_memory, void* stream) {
     B2S_TRY(check_bound(m));
-    B2S_TRY(wait_adam(m, S_(stream), 7));
+    B2S_TRY(wait_adam(m, S_(stream), 1));       // reads encoder weights only (b2s_adam_step_groups may be updating the other groups)
     B2S_CHECK(c && c->kind == 1 && d_memory, "bad encoder context");
     const b2s_config& cf = m->cfg;
     hipStream_t st = S_(stream);
@@ -1462,6 +1466,49 @@ extern "C" int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, f
     // an eval / synthesis forward between two training steps sees the weights the step just produced
     if (m->dtype == 0) B2S_TRY(relayout_convs(m, st));
     m->l2_fresh = cover;
+    return 0;
+}
+extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
+                                    int groups, int on_aux, void* stream) {
+    B2S_TRY(check_bound(m));
+    B2S_CHECK(m->adam_chunks && step >= 1 && groups > 0 && groups < 8, "Adam state not bound, bad step or bad group mask");
+    if (step != m->adam_step_no) { m->adam_step_no = step; m->adam_step_mask = 0; }
+    B2S_CHECK((m->adam_step_mask & groups) == 0, "parameter group mask %d was already updated in step %d", groups & m->adam_step_mask, step);
+    hipStream_t st = S_(stream);
+    B2S_TRY(wait_adam(m, st, groups));
+    float hp[3] = {lr, (float)(1.0 - std::pow((double)beta1, step)), (float)std::sqrt(1.0 - std::pow((double)beta2, step))};
+    float* dhp = m->small + 16 + (step % 8) * 4;               // (every piece of one step uploads the same three values)
+    B2S_HIP(hipMemcpyAsync(dhp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
+    const bool cover = !m->cfg.freeze_encoder;
+    hipStream_t run = st;
+    if (on_aux && m->aux) {
+        hipEvent_t ready = m->next_event();
+        B2S_HIP(hipEventRecord(ready, st));                    // gradients of `groups` (and their all-reduce) are complete here
+        B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
+        run = m->aux;
+    }
+    // beside the backward pass: a narrow launch (see k_mt_adam_narrow); B2S_ADAM_CUS = number of its workgroups, 0 = wide launch
+    // (measured, MI355X: a CU-masked stream made the two queues run one after the other instead of side by side)
+    static const int narrow = getenv("B2S_ADAM_CUS") ? atoi(getenv("B2S_ADAM_CUS")) : 64;
+    static const int order[3] = {1, 2, 0};                     // decoder, postnet, encoder
+    for (int k = 0; k < 3; ++k) {
+        const int g = order[k], lo = m->adam_grp[g], n = m->adam_grp[g + 1] - lo;
+        if (!(groups >> g & 1) || n <= 0) continue;
+        if (run != st && narrow > 0)
+            B2S_TRY(ro_mt_adam_narrow(m->adam_chunks + lo, n, narrow, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, run));
+        else
+            B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, run));
+        if (g == 2 && m->dtype == 0) B2S_TRY(relayout_convs(m, run));
+        if (run != st) {
+            if (!m->adam_ev[g]) B2S_HIP(hipEventCreateWithFlags(&m->adam_ev[g], hipEventDisableTiming));
+            B2S_HIP(hipEventRecord(m->adam_ev[g], run));
+            m->adam_pending[g] = true;
+        }
+    }
+    m->adam_step_mask |= groups;
+    // the per-chunk sums of squares cover the regulariser once every group has been stepped (groups whose chunk range is
+    // empty -- a frozen encoder -- never are: `cover` is false then)
+    m->l2_fresh = cover && m->adam_step_mask == 7;
     return 0;
 }
 extern "C" int b2s_zero_grads(b2s_model* m, void* stream) {

@@ -109,6 +109,8 @@ int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gsc
 // Adam: a=param b=grad c=m d=v ; lr and step read from device (hp[0]=lr, hp[1]=bias_corr1, hp[2]=bias_corr2)
 int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1, float beta2, float eps, float l2,
                float grad_scale, float* sumsq_part, hipStream_t st);
+int ro_mt_adam_narrow(const MtChunk* chunks, int nchunks, int nwg, const float* hp, float beta1, float beta2, float eps, float l2,
+                      float grad_scale, float* sumsq_part, hipStream_t st);
 int ro_sum_scaled(const float* part, int n, float scale, float* out, hipStream_t st);
 
 // conv weight relayouts (fp32 master [Cout][Cin][5] -> T):  fwd[co][j*Cin+ci] ; bwd[ci][j*Cout+co] = w[co][ci][4-j]

@@ -679,6 +679,46 @@ __global__ __launch_bounds__(256) void k_mt_adam(const MtChunk* ch, const float*
         if (threadIdx.x == 0) sumsq_part[blockIdx.x] = c.pad ? ss : 0.f;
     }
 }
+// The same update from a NARROW grid: gridDim.x workgroups of 1024 threads walk the chunk list.  For the optimizer update that
+// runs beside the encoder backward: a few dozen 16-wave workgroups settle on as many CUs and stay there, the other CUs remain
+// completely free for the backward's GEMM workgroups (which need a whole CU's LDS and registers and cannot start on a CU
+// that holds any other wave -- the one-workgroup-per-chunk launch above puts waves on every CU and starved them).
+__global__ __launch_bounds__(1024) void k_mt_adam_narrow(const MtChunk* ch, int nchunks, const float* hp, float b1, float b2, float eps,
+                                                         float l2, float gs, float* sumsq_part) {
+    __shared__ float sh[16];
+    const float lr = hp[0], bc1 = hp[1], sbc2 = hp[2];
+    for (int ci_ = blockIdx.x; ci_ < nchunks; ci_ += gridDim.x) {
+        const MtChunk c = ch[ci_];
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < c.n; i += 1024) {
+            float p = c.a[i], g = c.b[i] * gs + (c.pad ? l2 : 0.f) * p, m = c.c[i], v = c.d[i];
+            m = b1 * m + (1.f - b1) * g;
+            v = b2 * v + (1.f - b2) * g * g;
+            c.c[i] = m; c.d[i] = v;
+            p -= (lr / bc1) * m / (sqrtf(v) / sbc2 + eps);
+            c.a[i] = p;
+            if (c.cin) {
+                const long gi = c.off + i, r = gi / 5;
+                const int j = (int)(gi - r * 5), co = (int)(r / c.cin), ci = (int)(r - (long)co * c.cin);
+                const bf16_t pb = f2bf(p);
+                c.s[(long)co * 5 * c.cin + (long)j * c.cin + ci] = pb;
+                c.s2[(long)ci * 5 * c.cout + (long)(4 - j) * c.cout + co] = pb;
+            } else if (c.s) c.s[i] = f2bf(p);
+            ss += p * p;
+        }
+        if (sumsq_part) {
+            ss = wave_sum(ss);
+            __syncthreads();                                   // (sh is reused by the next chunk)
+            if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                float t = threadIdx.x < 16 ? sh[threadIdx.x] : 0.f;
+                t = wave_sum(t);
+                if (threadIdx.x == 0) sumsq_part[ci_] = c.pad ? t : 0.f;
+            }
+        }
+    }
+}
 // out[0] = scale * sum(part[0..n))
 __global__ __launch_bounds__(1024) void k_sum_scaled(const float* part, int n, float scale, float* out) {
     __shared__ float sh[16];
@@ -937,6 +977,13 @@ int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1,
                float grad_scale, float* sumsq_part, hipStream_t st) {
     if (nchunks > 0)
         hipLaunchKernelGGL(k_mt_adam, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_mt_adam_narrow(const MtChunk* chunks, int nchunks, int nwg, const float* hp, float beta1, float beta2, float eps, float l2,
+                      float grad_scale, float* sumsq_part, hipStream_t st) {
+    if (nchunks > 0)
+        hipLaunchKernelGGL(k_mt_adam_narrow, dim3(std::min(nwg, nchunks)), dim3(1024), 0, st, chunks, nchunks, hp, beta1, beta2, eps, l2,
+                           grad_scale, sumsq_part);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_sum_scaled(const float* part, int n, float scale, float* out, hipStream_t st) {

@@ -162,6 +162,17 @@ int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, fl
 int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
                      int overlap, void* stream);
 int b2s_adam_wait(b2s_model* m, void* stream);
+/* One optimizer step applied in pieces: `groups` is a mask of parameter groups (B2S_ADAM_ENCODER | _DECODER | _POSTNET)
+ * whose gradients are final.  on_aux = 1: those groups are updated on the model's second stream, ordered after everything
+ * already enqueued on `stream`, and the call returns with `stream` free to go on -- the fused trainer updates the decoder
+ * and postnet parameters this way while the encoder backward (small kernels that leave most CUs idle) still runs, then the
+ * encoder group on `stream` itself.  Every group must be stepped exactly once per `step`; entry points wait for the groups
+ * they read (as with b2s_adam_step_ex). */
+#define B2S_ADAM_ENCODER 1
+#define B2S_ADAM_DECODER 2
+#define B2S_ADAM_POSTNET 4
+int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
+                         int groups, int on_aux, void* stream);
 /* Zero every bound parameter gradient.  Every *_backward entry point ACCUMULATES into the bound gradient
  * buffers (several use atomics), so the host calls this once at the start of each backward pass. */
 int b2s_zero_grads(b2s_model* m, void* stream);

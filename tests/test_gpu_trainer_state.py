@@ -135,3 +135,24 @@ def test_autograd_path_refuses_two_forwards_in_one_backward():
     for n, p in m.named_parameters():
         ref = P[n].grad
         assert abs(float(p.grad.double().norm()) - float(ref.double().norm())) <= 2e-3 * float(ref.double().norm()) + 1e-6, n
+
+
+def test_split_optimizer_step_matches_single_launch(monkeypatch):
+    """b2s_adam_step_groups (decoder + postnet parameters updated on the second stream under the encoder backward, encoder
+    group afterwards) is the same arithmetic as the single-launch step: identical parameters after three steps."""
+    from b2s_hip.trainer import HipTrainer
+    res = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("B2S_SPLIT_ADAM", split)
+        m, cfg, _, hp = build(TINY96, compute_dtype="bf16")
+        _, b = _batch(cfg)
+        m.train()
+        tr = HipTrainer(m, hp)
+        assert tr.split_adam == (split == "1")
+        for _ in range(3):
+            v = tr.train_step(b)
+        res.append(({k: t.detach().clone() for k, t in m.state_dict().items()}, v.cpu().numpy()))
+    for k, t in res[0][0].items():
+        d = float((t.double() - res[1][0][k].double()).abs().max())
+        assert d <= 2e-2 * (1.0 + float(t.double().abs().max())), (k, d)           # bf16 + atomics: runs are not bit-reproducible
+    assert abs(res[0][1][0] - res[1][1][0]) < 2e-2 * abs(res[0][1][0])

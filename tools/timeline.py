@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timeline of ONE training step from a rocprofv3 --kernel-trace CSV: kernels in start order with duration, the gap to the
-previous kernel's end on the same queue, and a per-category summary.  The step boundary is the fused Adam kernel.
+previous kernel's end on the same queue, and a per-category summary.  A step runs from one k_embed_prep_fwd launch to the next.
 usage: timeline.py t_kernel_trace.csv [--step N] [--list]"""
 import csv
 import re
@@ -25,8 +25,9 @@ def short(n):
     return (m.group(1) if m else n)[:64]
 
 
-adam = [i for i, r in enumerate(rows) if 'k_mt_adam' in r['Kernel_Name']]
-lo, hi = adam[step - 1] + 1, adam[step] + 1
+# a step starts at the encoder's embedding kernel (the first kernel of the forward pass)
+adam = [i for i, r in enumerate(rows) if 'k_embed_prep_fwd' in r['Kernel_Name']]
+lo, hi = adam[step - 1], adam[step]
 seg = rows[lo:hi]
 t0 = int(seg[0]['Start_Timestamp'])
 t_end = max(int(r['End_Timestamp']) for r in seg)
