@@ -3,6 +3,9 @@
 #pragma once
 #include "gemm.h"
 
+// 16-byte global store.  (Measured: write-through `sc1` stores, meant to spare the end-of-kernel L2 write-back, gain 1 us on
+// the bf16-output GEMMs and lose 5 us on the fp32 residual ones -- plain stores stay.)
+__device__ __forceinline__ void epi_store16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
 template <int NB>     // the wave's block is 64 rows x NB*16 columns
 __device__ inline void gemm_wave_epilogue(GemmArgs g, f32x4_t (&acc)[4][NB], float* stg, int mb, int nb, int lane, int z, int zo, int zi,
                                           int ksplit, float* splitk_ws) {
@@ -153,11 +156,12 @@ __device__ inline void gemm_wave_epilogue(GemmArgs g, f32x4_t (&acc)[4][NB], flo
                     const float4 c0 = pre_acc ? q0[pp] : dst[0], c1 = pre_acc ? q1[pp] : dst[1];
                     o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
                 }
-                dst[0] = o0; dst[1] = o1;
+                epi_store16(dst, make_uint4(__float_as_uint(o0.x), __float_as_uint(o0.y), __float_as_uint(o0.z), __float_as_uint(o0.w)));
+                epi_store16(dst + 1, make_uint4(__float_as_uint(o1.x), __float_as_uint(o1.y), __float_as_uint(o1.z), __float_as_uint(o1.w)));
             } else {
                 uint4 o;
                 o.x = f2bf2(v[0], v[1]); o.y = f2bf2(v[2], v[3]); o.z = f2bf2(v[4], v[5]); o.w = f2bf2(v[6], v[7]);
-                *reinterpret_cast<uint4*>(Ct + off) = o;
+                epi_store16(Ct + off, o);
             }
         } else {
 #pragma unroll

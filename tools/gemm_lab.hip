@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <vector>
+#include <string>
 #ifndef LAB_KERNEL
 #define LAB_KERNEL "../few-shot-transformer-tts_amd/csrc/gemm_glds.hip"
 #endif
@@ -56,6 +57,17 @@ int main(int argc, char** argv) {
         {4096, 4096, 4096, 0, 1, 1, "4096^3 NT(b T)"},
         {4096, 4096, 4096, 1, 0, 1, "4096^3 TN(a T)"},
     };
+    if (const char* sp = getenv("LAB_SHAPES")) {          // "M,N,K,ta,tb;M,N,K,ta,tb;..." replaces the built-in list
+        shapes.clear();
+        std::string all(sp);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(';', pos); if (end == std::string::npos) end = all.size();
+            Shape sh{0, 0, 0, 0, 0, 1, "custom"};
+            if (sscanf(all.substr(pos, end - pos).c_str(), "%d,%d,%d,%d,%d", &sh.M, &sh.N, &sh.K, &sh.ta, &sh.tb) == 5) shapes.push_back(sh);
+            pos = end + 1;
+        }
+    }
     size_t maxel = (size_t)8192 * 8192;
     // LAB_ROT=n: n placements of every operand, used round-robin by the timed launches (n * footprint > 256 MB defeats the
     // memory-side cache, as inside the training step); LAB_EPI=1: fp32 output with bias + dropout + fp32 residual
@@ -121,7 +133,7 @@ int main(int argc, char** argv) {
         const double us = ms * 1e3 / iters, fl = 2.0 * s.M * s.N * s.K;
         printf("%2zu %-22s M=%5d N=%5d K=%5d %s%s sk=%2d  %8.2f us  %7.1f TF  err=%.2f%s\n", si, s.what, s.M, s.N, s.K, s.ta ? "T" : "N",
                s.tb ? "T" : "N", s.splitk, us, fl / us / 1e6, worst, worst > 1.0 ? "  <-- MISMATCH" : "");
-        if (si < 17) { tot_us += us; tot_fl += fl; }
+        if (si < 17 || getenv("LAB_SHAPES")) { tot_us += us; tot_fl += fl; }
     }
     printf("step-shape mix: %.1f us total, %.1f TF/s\n", tot_us, tot_fl / tot_us / 1e6);
     if (getenv("LAB_GROUPED")) {
