@@ -15,7 +15,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libb2s_hip.so")
+LIB_PATH = os.environ.get("B2S_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libb2s_hip.so")      # (override: instrumented development builds)
 
 _lib = None
 

@@ -11,6 +11,7 @@
 // Per-step HBM traffic (the roofline that bounds this path): decoder-stack weights once (49.9 M params) +
 // self K/V cache read (Ld*2*B*t*Dd) + cross K/V read (Ld*2*B*S*Dd) + cache append.
 #include "engine.h"
+#include "decode_fused.h"
 
 struct b2s_decode_state {
     int B = 0, S = 0, maxT = 0, train = 0;
@@ -28,6 +29,13 @@ struct b2s_decode_state {
     std::vector<float*> crossP, selfP;   // attention rows of every step: [B,H,maxT,S] / [B,H,maxT,maxT]
     void *tgt = nullptr, *a1 = nullptr, *a2 = nullptr, *h = nullptr, *qkv = nullptr, *ctx = nullptr, *f = nullptr, *outT = nullptr;
     float *a3 = nullptr, *x = nullptr, *mean = nullptr, *rstd = nullptr, *mel_step = nullptr, *stop_step = nullptr;
+    // fused step (decode_fused.hip): residual stream ping-pong [2][B][D], partial output slabs ping-pong [2][NS][B][D], and the
+    // arrival counter of the last kernel of a frame
+    float* Xpp[2] = {nullptr, nullptr};
+    float* Ppp[2] = {nullptr, nullptr};
+    int* done_cnt = nullptr;
+    int ns_ffn = 0;
+    bool fused = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipStream_t graph_stream = nullptr;
@@ -249,6 +257,14 @@ void plan_decode(const b2s_model* m, b2s_decode_state& s, Arena& a) {
     s.a3 = a.f32((long)B * D); s.x = a.f32((long)B * D); s.mean = a.f32(B); s.rstd = a.f32(B);
     s.h = a.T((long)B * D, esz); s.qkv = a.T((long)B * 3 * D, esz); s.ctx = a.T((long)B * D, esz); s.f = a.T((long)B * 4 * D, esz);
     s.outT = a.T((long)B * D, esz); s.mel_step = a.f32((long)B * cf.num_mels); s.stop_step = a.f32(B);
+    static const bool no_fused = getenv("B2S_DECODE_UNFUSED") != nullptr;          // A/B switch: one kernel per op (round-1 path)
+    s.ns_ffn = b2s_df_ffn_slices(m->dtype, 4 * D);
+    s.fused = !no_fused && b2s_df_supported(m->dtype, D, H, 4 * D, cf.num_mels, cf.prenet_hidden, std::max(T, S));
+    if (s.fused) {
+        const int ns = std::max(H, s.ns_ffn);
+        for (int i = 0; i < 2; ++i) { s.Xpp[i] = a.f32((long)B * D); s.Ppp[i] = a.f32((long)ns * B * D); }
+        s.done_cnt = (int*)a.take(256);
+    }
 }
 
 int lin(const b2s_model* m, hipStream_t st, const void* X, int ldx, const void* W, int M, int N, int K, void* out, int out_fp32, int ldo,
@@ -264,6 +280,64 @@ int lin(const b2s_model* m, hipStream_t st, const void* X, int ldx, const void* 
     return b2s_gemm_launch(g, m->dtype, false, false, st);
 }
 std::string nm2(const std::string& p, const char* list, int i, const char* leaf) { return p + list + "." + std::to_string(i) + "." + leaf; }
+
+// One frame with one kernel per sublayer (decode_fused.hip): prenet + input, 3 kernels per decoder layer, heads + stop logic.
+int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
+    const b2s_config& cf = m->cfg;
+    const int B = s->B, S = s->S, maxT = s->maxT, D = cf.decoder_hidden, H = cf.n_attention_head, dh = D / H, L = cf.n_decoder_layer;
+    const int NM = cf.num_mels, HP = cf.prenet_hidden, dt = m->dtype;
+    const float pt = s->train ? cf.transformer_dropout_rate : 0.f, pd = s->train ? cf.decoder_dropout_rate : 0.f;
+    const float scale = 1.f / sqrtf((float)dh);
+    const std::string p = "decoder.decoder.";
+    DfPrenet pn;
+    pn.mels = s->mels; pn.maxT = maxT; pn.NM = NM; pn.HP = HP; pn.D = D; pn.B = B;
+    pn.W0 = m->W("decoder.prenet.dense0.weight"); pn.W1 = m->W("decoder.prenet.dense1.weight"); pn.Wf = m->W("decoder.prenet.dense_final.weight");
+    pn.b0 = m->P("decoder.prenet.dense0.bias"); pn.b1 = m->P("decoder.prenet.dense1.bias");
+    pn.pe = m->pe_dec; pn.pe_scale = m->P(p + "pe_scale"); pn.lengths = s->lengths; pn.t = s->t; pn.X = s->Xpp[0];
+    pn.drop0 = make_drop(pd, s->seed, 9001); pn.drop1 = make_drop(pd, s->seed, 9002); pn.drop_x = make_drop(pt, s->seed, 9003);
+    B2S_TRY(b2s_df_prenet(dt, pn, st));
+    int k = 0, np = 0;                           // sublayer index within the frame, slabs written by the previous kernel
+    auto common = [&](const std::string& ln, DropCfg dres) {
+        DfCommon c;
+        c.X_in = s->Xpp[k & 1]; c.X_out = s->Xpp[(k + 1) & 1]; c.P_prev = s->Ppp[(k + 1) & 1]; c.np_prev = np; c.P_out = s->Ppp[k & 1];
+        c.B = B; c.D = D; c.ln_g = m->P(ln + ".weight"); c.ln_b = m->P(ln + ".bias"); c.eps = 1e-6f; c.t = s->t; c.drop_res = dres;
+        return c;
+    };
+    for (int l = 0; l < L; ++l) {
+        const std::string lna = p + "attn_layer_norms." + std::to_string(l), lnx = p + "encdec_layer_norms." + std::to_string(l),
+                          lnf = p + "ffn_layer_norms." + std::to_string(l);
+        DfAttn sa;
+        sa.c = common(lna, make_drop(pt, s->seed, 9020 + l));
+        sa.H = H; sa.dh = dh; sa.Wqkv = m->W(nm2(p, "self_attentions", l, "qkv_transform.weight"));
+        sa.Wo = m->W(nm2(p, "self_attentions", l, "output_transform.weight"));
+        sa.Kc = s->selfK[l]; sa.Vc = s->selfV[l]; sa.ldkv = dh; sa.kv_bstride = (long)maxT * D; sa.kv_hstride = (long)maxT * dh; sa.maxT = maxT;
+        sa.probs = s->selfP[l]; sa.probs_rows = maxT; sa.probs_ld = maxT; sa.klen = nullptr; sa.nmax = maxT; sa.scale = scale;
+        sa.drop_attn = make_drop(pt, s->seed, 9010 + l);
+        B2S_TRY(b2s_df_attn(dt, true, sa, st));
+        ++k; np = H;
+        DfAttn xa;
+        xa.c = common(lnx, make_drop(pt, s->seed, 9040 + l));
+        xa.H = H; xa.dh = dh; xa.Wqkv = m->W(nm2(p, "encdec_attentions", l, "q_transform.weight"));
+        xa.Wo = m->W(nm2(p, "encdec_attentions", l, "output_transform.weight"));
+        xa.Kc = s->crossKV[l]; xa.Vc = (char*)s->crossKV[l] + (size_t)D * m->esz; xa.ldkv = 2 * D; xa.kv_bstride = (long)S * 2 * D; xa.kv_hstride = dh;
+        xa.maxT = maxT; xa.probs = s->crossP[l]; xa.probs_rows = maxT; xa.probs_ld = S; xa.klen = s->in_len; xa.nmax = S; xa.scale = scale;
+        xa.drop_attn = make_drop(pt, s->seed, 9030 + l);
+        B2S_TRY(b2s_df_attn(dt, false, xa, st));
+        ++k; np = H;
+        DfFfn ff;
+        ff.c = common(lnf, make_drop(pt, s->seed, 9060 + l));
+        ff.F = 4 * D; ff.ns = s->ns_ffn; ff.W1 = m->W(nm2(p, "ffn_layers", l, "input_layer.weight")); ff.W2 = m->W(nm2(p, "ffn_layers", l, "output_layer.weight"));
+        ff.drop_hid = make_drop(pt, s->seed, 9050 + l);
+        B2S_TRY(b2s_df_ffn(dt, ff, st));
+        ++k; np = s->ns_ffn;
+    }
+    DfFinal fn;
+    fn.X_in = s->Xpp[k & 1]; fn.P_prev = s->Ppp[(k + 1) & 1]; fn.np_prev = np; fn.B = B; fn.D = D; fn.NM = NM; fn.maxT = maxT;
+    fn.ln_g = m->P(p + "output_layer_norm.weight"); fn.ln_b = m->P(p + "output_layer_norm.bias"); fn.eps = 1e-6f;
+    fn.Wmel = m->W("decoder.mel_net.weight"); fn.wstop = m->P("decoder.stop_net.weight"); fn.bstop = m->P("decoder.stop_net.bias");
+    fn.mels = s->mels; fn.t = s->t; fn.finished = s->finished; fn.lengths = s->lengths; fn.status = s->status; fn.done_cnt = s->done_cnt;
+    return b2s_df_final(dt, fn, st);
+}
 
 template <typename T>
 int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
@@ -331,6 +405,7 @@ int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
     return 0;
 }
 int step(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
+    if (s->fused) return step_fused(m, s, st);
     return m->dtype ? step_t<bf16_t>(m, s, st) : step_t<float>(m, s, st);
 }
 }  // namespace
@@ -362,6 +437,12 @@ extern "C" int b2s_decode_begin(b2s_model* m, const float* memory, const int32_t
     int rc = b2s_ensure_pe_export(m, max_frames + 1);
     if (rc) { delete s; return rc; }
     hipLaunchKernelGGL(k_dec_begin, dim3(cdiv(B, 64)), dim3(64), 0, st, s->t, s->finished, s->lengths, s->status, B);
+    if (s->done_cnt && hipMemsetAsync(s->done_cnt, 0, sizeof(int), st) != hipSuccess) { delete s; return b2s_fail(__FILE__, __LINE__, "memset failed"); }
+    if (s->fused) {     // the first sublayer of the first frame loads (and ignores) a partial slab: it must hold finite values
+        const size_t pb = (size_t)std::max(m->cfg.n_attention_head, s->ns_ffn) * B * m->cfg.decoder_hidden * 4;
+        for (int i = 0; i < 2; ++i)
+            if (hipMemsetAsync(s->Ppp[i], 0, pb, st) != hipSuccess) { delete s; return b2s_fail(__FILE__, __LINE__, "memset failed"); }
+    }
     rc = ro_cast(m->dtype, memory, s->memT, (long)B * S * D, st);
     for (int l = 0; l < cf.n_decoder_layer && !rc; ++l) {
         rc = lin(m, st, s->memT, D, m->W(nm2("decoder.decoder.", "encdec_attentions", l, "kv_transform.weight")), B * S, 2 * D, D, s->crossKV[l], 0,

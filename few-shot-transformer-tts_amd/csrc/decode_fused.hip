@@ -1,0 +1,803 @@
+// Autoregressive decode step, fused: ONE kernel per decoder sublayer and frame (20 kernel nodes per frame instead of 76).
+// Reference loop: synthesize.py:35-45 (one decoder pass per frame); modules.py:123-145 (the sublayers).
+//
+// Why: a frame is a chain of small dependent phases (LayerNorm -> projection -> attention -> projection ...), and with one
+// kernel per phase the frame cost was the number of kernel boundaries (76 x ~9 us, profiles/r01_*), not the 0.9 GB it has to
+// stream.  Here the work of a sublayer is cut so that no phase inside it needs another workgroup's result:
+//   * the batch is cut into groups of UB utterances and the sublayer into NS slices -- a head for the attention sublayers,
+//     1/NS of the hidden units for the FFN -- one workgroup per (slice, group), slice = blockIdx % NS so that with NS = 8
+//     every XCD works on one slice and that slice's weights are fetched into one L2 only (HBM reads every weight once);
+//   * a workgroup recomputes what is cheap (x = X + previous partial slabs, LayerNorm of its UB rows), runs its slice of the
+//     input projection, the attention of its (utterance, head) pairs over the KV cache, and its slice's SHARE of the output
+//     projection (K = dh or F/NS), which it stores as partial slab `slice`;
+//   * the sum over slices is taken by the next kernel's workgroups in a fixed order (no atomics: frames are bit-reproducible,
+//     eager == graph replay), the residual-dropout mask depends on (utterance, column, frame) only and is applied per slab.
+// With UB rows per workgroup the projections are GEMVs: VALU dot products (v_dot2c_f32_bf16 in bf16 mode), 4 lanes per weight
+// row so that every load instruction covers 64 contiguous bytes of 16 rows; the loads of a row's whole K walk are in flight
+// together.  Bound: the L2 -> CU stream of the slice's weights (every group re-reads them) and the HBM stream of the KV cache.
+#include <algorithm>
+#include "decode_fused.h"
+
+namespace {
+
+template <typename T> struct DV;
+template <> struct DV<float>  { static constexpr int VE = 4; };
+template <> struct DV<bf16_t> { static constexpr int VE = 8; };
+
+constexpr int UBA = 2;                   // utterances per workgroup: attention sublayers, prenet, heads
+constexpr int UBF = 8;                   //                           FFN sublayer (twice the slices: every group re-reads a slice's weights
+                                         //                           from L2, and that L2 -> CU traffic is what bounds the FFN kernel)
+constexpr int HT = 256;                  // threads that work on one utterance's attention
+constexpr int NT = UBA * HT;             // threads per workgroup (8 waves: 256 VGPRs each, enough to keep a whole K walk of loads in flight)
+
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+
+// Widths.  FAST instantiation: exactly the reference's default sizes (hyperparams.py:24-35 -- every released checkpoint): the step
+// counts of the GEMV are compile-time and its load / consume sequences contain no control flow at all (hipcc waits vmcnt(0) at the
+// join of every conditional block, even a workgroup-uniform one, which serialises the loads).  Generic instantiation: anything up
+// to the maxima below, uniform conditions per step (correct, slower); wider models run the unfused path (b2s_df_supported).
+constexpr int FD_D = 768, FD_DH = 96, FD_FS = 96, FD_HP = 256, FD_NM = 80;
+constexpr int DF_MAX_D = 768, DF_MAX_DH = 128, DF_MAX_FS = 256, DF_MAX_HP = 256, DF_MAX_NM = 128;
+template <typename T, bool FAST> constexpr int KD_STEPS = (FAST ? FD_D : DF_MAX_D) / (8 * DV<T>::VE);       // K = D, 8 lanes per row
+template <typename T, bool FAST> constexpr int FS_STEPS = (FAST ? FD_FS : DF_MAX_FS) / (8 * DV<T>::VE);     // K = F / NS, 8 lanes per row
+template <typename T, bool FAST> constexpr int HP_STEPS = (FAST ? FD_HP : DF_MAX_HP) / (4 * DV<T>::VE);     // K = prenet width, 4 lanes per row
+template <typename T, bool FAST> constexpr int DH_STEPS = (FAST ? FD_DH : DF_MAX_DH) / (4 * DV<T>::VE);     // K = head width, 4 lanes per row
+template <typename T> constexpr int NM_LPR = 16 / DV<T>::VE;                                                // K = num_mels: 16 elements per step
+template <bool FAST> constexpr int NM_STEPS = (FAST ? FD_NM : DF_MAX_NM) / 16;
+
+template <typename T> __device__ __forceinline__ float dotv(const uint4& w, const uint4& a, float acc);
+template <> __device__ __forceinline__ float dotv<float>(const uint4& w, const uint4& a, float acc) {
+    acc = fmaf(__uint_as_float(w.x), __uint_as_float(a.x), acc);
+    acc = fmaf(__uint_as_float(w.y), __uint_as_float(a.y), acc);
+    acc = fmaf(__uint_as_float(w.z), __uint_as_float(a.z), acc);
+    acc = fmaf(__uint_as_float(w.w), __uint_as_float(a.w), acc);
+    return acc;
+}
+template <> __device__ __forceinline__ float dotv<bf16_t>(const uint4& w, const uint4& a, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w.x), __builtin_bit_cast(bf2_t, a.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w.y), __builtin_bit_cast(bf2_t, a.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w.z), __builtin_bit_cast(bf2_t, a.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w.w), __builtin_bit_cast(bf2_t, a.w), acc, false);
+    return acc;
+}
+// value as the compute dtype would store it (bf16 mode: rounded to bf16, as the unfused path's intermediate tensors are)
+template <typename T> __device__ __forceinline__ float rnd(float v);
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+template <> __device__ __forceinline__ float rnd<bf16_t>(float v) { return bf2f(f2bf(v)); }
+
+__device__ __forceinline__ DropCfg salted(DropCfg d, int t) {      // same per-frame key as the GEMM epilogues (gemm_epi.h: drop_salt)
+    if (d.thresh) d.key ^= b2s_hash32((uint32_t)t * 2246822519u + 3266489917u);
+    return d;
+}
+
+// out[r][j] = sum_k a[r][k] * W[row(j)][k]  for j < ncols, r < UB.  W: global, row stride ldw elements, K contiguous (16-byte aligned
+// rows), row(j) = (j / blk_rows) * blk_stride + j % blk_rows (blk_rows >= ncols: plain); a: LDS, [UB][lda] in T; out: LDS [UB][ldo] fp32.
+// LPR lanes share a weight row (LPR * 16 contiguous bytes per row and load instruction: LPR = 8 fetches whole 128-byte lines),
+// NT / LPR rows per pass, a lane walks its share of K in nsteps = K / (LPR * VE) <= U steps (K must be a multiple of LPR * VE: every
+// lane of a step is in bounds, so the only conditions are workgroup-uniform -- a load under a per-lane condition makes hipcc branch
+// around it and drain the queue).  The kernel is a chain of dependent phases on one workgroup per CU, so what it costs is memory
+// round trips: the loads of JU rows (JU * nsteps 16-byte loads per lane) form one set, and the next set is issued before the current
+// one is consumed -- two sets, ~200 KB per CU, are in flight for the whole walk.
+template <typename T, bool FAST, int UB, int LPR, int U, int JU>
+__device__ __forceinline__ void gemv_lds(const T* __restrict__ W, long ldw, int ncols, int K, const T* a, int lda, float* out, int ldo, int tid,
+                                         int blk_rows = 1 << 30, long blk_stride = 0) {
+    constexpr int VE = DV<T>::VE, STEP = LPR * VE, RG = NT / LPR;
+    const int p = tid % LPR, rg = tid / LPR;
+    const int nset = (ncols + RG * JU - 1) / (RG * JU);
+    const int nsteps = FAST ? U : K / STEP;            // (uniform; FAST: compile-time)
+    uint4 wA[JU][U], wB[JU][U];
+    auto issue = [&](uint4 (&w)[JU][U], int set) {
+#pragma unroll
+        for (int q = 0; q < JU; ++q) {
+            const int j = min((set * JU + q) * RG + rg, ncols - 1), blk = j / blk_rows;
+            const T* wr = W + ((long)blk * blk_stride + (j - blk * blk_rows)) * ldw + p * VE;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (FAST || u < nsteps) w[q][u] = *reinterpret_cast<const uint4*>(wr + u * STEP);
+        }
+    };
+    auto consume = [&](const uint4 (&w)[JU][U], int set) {
+        float acc[JU][UB];
+#pragma unroll
+        for (int q = 0; q < JU; ++q)
+#pragma unroll
+            for (int r = 0; r < UB; ++r) acc[q][r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (FAST || u < nsteps) {
+                const int k = u * STEP + p * VE;
+                uint4 av[UB];
+#pragma unroll
+                for (int r = 0; r < UB; ++r) av[r] = *reinterpret_cast<const uint4*>(a + r * lda + k);
+#pragma unroll
+                for (int q = 0; q < JU; ++q)
+#pragma unroll
+                    for (int r = 0; r < UB; ++r) acc[q][r] = dotv<T>(w[q][u], av[r], acc[q][r]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < JU; ++q) {
+            const int j = (set * JU + q) * RG + rg;
+#pragma unroll
+            for (int r = 0; r < UB; ++r) {
+                float v = acc[q][r];
+#pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+                if (j < ncols && p == 0) out[r * ldo + j] = v;
+            }
+        }
+    };
+    if (sizeof(T) == 4) {           // fp32 (parity mode): one set at a time
+        for (int q = 0; q < nset; ++q) { issue(wA, q); consume(wA, q); }
+        return;
+    }
+    issue(wA, 0);
+    for (int q = 0; q < nset; q += 2) {
+        if (q + 1 < nset) issue(wB, q + 1);
+        consume(wA, q);
+        if (q + 2 < nset) issue(wA, q + 2);
+        if (q + 1 < nset) consume(wB, q + 1);
+    }
+}
+
+// The same product on the matrix pipe (bf16, compile-time K): out[r][j] = sum_k a[r][k] * W[row(j)][k].  With a handful of rows the
+// VALU version above spends as long on v_dot2c as on the loads; one v_mfma_f32_16x16x32_bf16 takes 16 weight rows x 32 k straight from
+// the loaded registers (lane l holds W[row l&15][k = (l>>4)*8 .. +8]: the 16-byte load IS the A fragment) against the activations of
+// up to 16 utterances (B fragment from LDS, columns >= UB repeat the last row and are never stored), accumulates over K in the
+// accumulator and needs no cross-lane reduction.  A wave owns row blocks wave, wave + 8, ...; a set is JB row blocks x CU k-steps
+// (K = 32 * CU * CPR; CPR = 2: the two halves of a row block's K walk are the two alternating sets), two sets in flight.
+template <int UB, int CU, int JB, int CPR>
+__device__ __forceinline__ void gemv_mfma(const bf16_t* __restrict__ W, long ldw, int ncols, const bf16_t* a, int lda, float* out, int ldo, int tid,
+                                          int blk_rows = 1 << 30, long blk_stride = 0) {
+    static_assert(CPR == 1 || (CPR == 2 && JB == 1), "a row block's K walk is one set or two");
+    constexpr int NW = NT / 64;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int nrb = (ncols + 15) >> 4;
+    const int my_nrb = nrb > wave ? (nrb - wave + NW - 1) / NW : 0;
+    const bf16_t* arow = a + min(li, UB - 1) * lda + lg * 8;
+    bf16x8_t wA[JB][CU], wB[JB][CU];
+    auto issue = [&](bf16x8_t (&w)[JB][CU], int i, int kc) {          // row blocks i*JB .. of this wave, K part kc
+#pragma unroll
+        for (int q = 0; q < JB; ++q) {
+            const int rb = wave + min(i * JB + q, my_nrb - 1) * NW;
+            const int j = min(rb * 16 + li, ncols - 1), blk = j / blk_rows;
+            const bf16_t* wr = W + ((long)blk * blk_stride + (j - blk * blk_rows)) * ldw + kc * CU * 32 + lg * 8;
+#pragma unroll
+            for (int u = 0; u < CU; ++u) w[q][u] = *reinterpret_cast<const bf16x8_t*>(wr + u * 32);
+        }
+    };
+    f32x4_t acc[JB];
+    auto mma = [&](const bf16x8_t (&w)[JB][CU], int kc, bool first) {
+#pragma unroll
+        for (int q = 0; q < JB; ++q) if (first) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const bf16x8_t bv = *reinterpret_cast<const bf16x8_t*>(arow + (kc * CU + u) * 32);
+#pragma unroll
+            for (int q = 0; q < JB; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[q][u], bv, acc[q], 0, 0, 0);
+        }
+    };
+    auto store = [&](int i) {                                          // D layout: row (= weight row) (lane>>4)*4 + r, column (= utterance) lane & 15
+#pragma unroll
+        for (int q = 0; q < JB; ++q) {
+            if (i * JB + q >= my_nrb || li >= UB) continue;
+            const int j0 = (wave + (i * JB + q) * NW) * 16 + lg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (j0 + r < ncols) out[li * ldo + j0 + r] = acc[q][r];
+        }
+    };
+    const int nset = (my_nrb + JB - 1) / JB;
+    if (nset == 0) return;
+    if (CPR == 2) {                 // A = first half of a row block's K, B = second half
+        issue(wA, 0, 0);
+        for (int i = 0; i < nset; ++i) {
+            issue(wB, i, 1);
+            mma(wA, 0, true);
+            if (i + 1 < nset) issue(wA, i + 1, 0);
+            mma(wB, 1, false);
+            store(i);
+        }
+    } else {
+        issue(wA, 0, 0);
+        for (int i = 0; i < nset; i += 2) {
+            if (i + 1 < nset) issue(wB, i + 1, 0);
+            mma(wA, 0, true); store(i);
+            if (i + 2 < nset) issue(wA, i + 2, 0);
+            if (i + 1 < nset) { mma(wB, 0, true); store(i + 1); }
+        }
+    }
+}
+
+// Dispatch: bf16 at the default widths -> matrix pipe; anything else -> the VALU walk (fp32: one set at a time -- it is the parity
+// mode, registers matter more than overlap there).
+template <typename T, bool FAST, int UB, int LPR, int U, int JU, int M_CU, int M_JB, int M_CPR>
+__device__ __forceinline__ void gemv(const T* __restrict__ W, long ldw, int ncols, int K, const T* a, int lda, float* out, int ldo, int tid,
+                                     int blk_rows = 1 << 30, long blk_stride = 0) {
+    if constexpr (FAST && sizeof(T) == 2) gemv_mfma<UB, M_CU, M_JB, M_CPR>(reinterpret_cast<const bf16_t*>(W), ldw, ncols, reinterpret_cast<const bf16_t*>(a), lda, out, ldo, tid, blk_rows, blk_stride);
+    else gemv_lds<T, FAST, UB, LPR, U, JU>(W, ldw, ncols, K, a, lda, out, ldo, tid, blk_rows, blk_stride);
+}
+
+// xs[u][:] = X_in[b_u] + sum_s P_prev[s][b_u]  (fixed order), published to X_out by the slice-0 workgroups; hs[u][:] = T(LayerNorm(xs[u]))
+template <typename T, int UB, int NPS>          // NPS > 0: np_prev is NPS (or 0) -- all slab loads of a row chunk are issued together
+__device__ __forceinline__ void load_x_ln(const DfCommon& c, int b0, bool publish, float* xs, T* hs, float* red, int tid) {
+    const int D = c.D;
+    for (int i = tid; i < UB * (D >> 2); i += NT) {
+        const int u = i / (D >> 2), c4 = (i - u * (D >> 2)) * 4, b = min(b0 + u, c.B - 1);
+        float4 v = *reinterpret_cast<const float4*>(c.X_in + (long)b * D + c4);
+        if (NPS > 0) {
+            if (c.np_prev > 0) {                                      // (uniform; fixed summation order s = 0, 1, ...)
+                float4 q[NPS > 0 ? NPS : 1];
+#pragma unroll
+                for (int s = 0; s < NPS; ++s) q[s] = *reinterpret_cast<const float4*>(c.P_prev + ((long)s * c.B + b) * D + c4);
+#pragma unroll
+                for (int s = 0; s < NPS; ++s) { v.x += q[s].x; v.y += q[s].y; v.z += q[s].z; v.w += q[s].w; }
+            }
+        } else {
+            for (int s = 0; s < c.np_prev; ++s) {
+                const float4 q = *reinterpret_cast<const float4*>(c.P_prev + ((long)s * c.B + b) * D + c4);
+                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+        }
+        *reinterpret_cast<float4*>(xs + u * D + c4) = v;
+        if (publish && b0 + u < c.B) *reinterpret_cast<float4*>(c.X_out + (long)b * D + c4) = v;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < UB) {                           // one wave per row: mean, then variance around it (two passes, as k_ln_fwd)
+        float s = 0.f;
+        for (int k = lane; k < D; k += 64) s += xs[wave * D + k];
+        const float mu = wave_sum(s) / D;
+        float q = 0.f;
+        for (int k = lane; k < D; k += 64) { const float d = xs[wave * D + k] - mu; q += d * d; }
+        const float rs = 1.f / sqrtf(wave_sum(q) / D + c.eps);
+        if (lane == 0) { red[2 * wave] = mu; red[2 * wave + 1] = rs; }
+    }
+    __syncthreads();
+    for (int i = tid; i < UB * D; i += NT) {
+        const int u = i / D, k = i - u * D;
+        TT<T>::st(hs + i, (xs[i] - red[2 * u]) * red[2 * u + 1] * c.ln_g[k] + c.ln_b[k]);
+    }
+    __syncthreads();
+}
+
+// The same in two steps for the default-size kernels: every load of a workgroup's residual rows and partial slabs is issued at once
+// (XIT iterations x (1 + NPS) 16-byte loads per thread), BEFORE the weight prefetch -- the loads of a wave complete in issue order, and
+// the LayerNorm that waits for these rows heads the kernel's dependency chain, the weights are needed later.
+template <int UB, int NPS, int XIT>
+struct XRegs { float4 x[XIT]; float4 p[XIT][NPS > 0 ? NPS : 1]; float4 g[XIT], be[XIT]; };
+template <int UB, int NPS, int XIT>
+__device__ __forceinline__ void issue_x(const DfCommon& c, int b0, XRegs<UB, NPS, XIT>& r, int tid) {
+    const int D = c.D, n4 = UB * (D >> 2);
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+        const int i = min(tid + it * NT, n4 - 1);
+        const int u = i / (D >> 2), c4 = (i - u * (D >> 2)) * 4, b = min(b0 + u, c.B - 1);
+        r.x[it] = *reinterpret_cast<const float4*>(c.X_in + (long)b * D + c4);
+        r.g[it] = *reinterpret_cast<const float4*>(c.ln_g + c4);          // (LayerNorm scale / shift of the same columns: no round trip of their own later)
+        r.be[it] = *reinterpret_cast<const float4*>(c.ln_b + c4);
+#pragma unroll
+        for (int s = 0; s < NPS; ++s) r.p[it][s] = *reinterpret_cast<const float4*>(c.P_prev + ((long)min(s, max(c.np_prev, 1) - 1) * c.B + b) * D + c4);
+    }
+}
+template <typename T, int UB, int NPS, int XIT>
+__device__ __forceinline__ void finish_x_ln(const DfCommon& c, int b0, bool publish, const XRegs<UB, NPS, XIT>& r, float* xs, T* hs, float* red, int tid) {
+    const int D = c.D, n4 = UB * (D >> 2);
+    const float use = c.np_prev > 0 ? 1.f : 0.f;         // (first sublayer of a frame: no previous partial outputs; the slab loads re-read slab 0)
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+        const int i = tid + it * NT;
+        if (i >= n4) continue;
+        const int u = i / (D >> 2), c4 = (i - u * (D >> 2)) * 4, b = b0 + u;
+        float4 v = r.x[it];
+#pragma unroll
+        for (int s = 0; s < NPS; ++s) { v.x += use * r.p[it][s].x; v.y += use * r.p[it][s].y; v.z += use * r.p[it][s].z; v.w += use * r.p[it][s].w; }
+        *reinterpret_cast<float4*>(xs + u * D + c4) = v;
+        if (publish && b < c.B) *reinterpret_cast<float4*>(c.X_out + (long)b * D + c4) = v;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < UB) {
+        float s = 0.f;
+        for (int k = lane; k < D; k += 64) s += xs[wave * D + k];
+        const float mu = wave_sum(s) / D;
+        float q = 0.f;
+        for (int k = lane; k < D; k += 64) { const float d = xs[wave * D + k] - mu; q += d * d; }
+        const float rs = 1.f / sqrtf(wave_sum(q) / D + c.eps);
+        if (lane == 0) { red[2 * wave] = mu; red[2 * wave + 1] = rs; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+        const int i = tid + it * NT;
+        if (i >= n4) continue;
+        const int u = i / (D >> 2), c4 = (i - u * (D >> 2)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(xs + u * D + c4);
+        const float mu = red[2 * u], rs = red[2 * u + 1];
+        TT<T>::st(hs + u * D + c4 + 0, (v.x - mu) * rs * r.g[it].x + r.be[it].x);
+        TT<T>::st(hs + u * D + c4 + 1, (v.y - mu) * rs * r.g[it].y + r.be[it].y);
+        TT<T>::st(hs + u * D + c4 + 2, (v.z - mu) * rs * r.g[it].z + r.be[it].z);
+        TT<T>::st(hs + u * D + c4 + 3, (v.w - mu) * rs * r.g[it].w + r.be[it].w);
+    }
+    __syncthreads();
+}
+
+// partial slab: P_out[slice][b_u][:] = dropout(of[u][:])
+template <int UB>
+__device__ __forceinline__ void store_partial(const DfCommon& c, int slice, int b0, const float* of, int t, int tid) {
+    const DropCfg d = salted(c.drop_res, t);
+    const int D = c.D;
+    for (int i = tid; i < UB * (D >> 2); i += NT) {
+        const int u = i / (D >> 2), k = (i - u * (D >> 2)) * 4, b = b0 + u;
+        if (b >= c.B) continue;
+        float4 v = *reinterpret_cast<const float4*>(of + u * D + k);
+        if (d.thresh) {
+            const uint32_t idx = (uint32_t)((long)b * D + k);
+            v.x = b2s_keep(d, idx) ? v.x * d.scale : 0.f; v.y = b2s_keep(d, idx + 1) ? v.y * d.scale : 0.f;
+            v.z = b2s_keep(d, idx + 2) ? v.z * d.scale : 0.f; v.w = b2s_keep(d, idx + 3) ? v.w * d.scale : 0.f;
+        }
+        *reinterpret_cast<float4*>(c.P_out + ((long)slice * c.B + b) * D + k) = v;
+    }
+}
+
+// Single-query attention of one (utterance, head) by HT threads (one half of the workgroup per utterance; both halves run the same
+// phases, the barriers are workgroup-wide): keys [0, n).  sq: the query (fp32, LDS, dh values);
+// result in ctx (LDS, dh values).  Scores: 4 lanes share one key row; softmax through LDS; weighted V sum with one 16-byte column
+// chunk per thread and a cross-row LDS reduction (the structure of the unfused k_dec_attn, decode.hip).
+template <typename T>
+__device__ __forceinline__ void attend(const float* sq, const T* Kb, const T* Vb, int ldkv, int n, int dh, float scale, float* p, float* part,
+                                       float* red, float* prow, DropCfg dc, uint32_t drop_row, float* ctx, int tid) {
+    constexpr int VE = DV<T>::VE;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int CH = dh / VE, R = HT / CH;
+    const int part4 = tid & 3, kslot = tid >> 2;
+    const int nch = (CH + 3) / 4;                      // 16-byte chunks per lane
+    const int tx = tid % CH, ty = tid / CH;
+    constexpr int SU = sizeof(T) == 2 ? 4 : 2, NCH_MAX = sizeof(T) == 2 ? 4 : 8;      // head width <= 128
+    constexpr int VU = 8;
+    const int nlast = max(n - 1, 0);
+    uint4 u[SU][NCH_MAX], uv[VU];
+    auto load_k = [&](int j0) {
+#pragma unroll
+        for (int uu = 0; uu < SU; ++uu) {
+            const T* kr = Kb + (long)min(j0 + uu * 64 + kslot, nlast) * ldkv;
+#pragma unroll
+            for (int i = 0; i < NCH_MAX; ++i)
+                if (i < nch && i * 4 + part4 < CH) u[uu][i] = *reinterpret_cast<const uint4*>(kr + (i * 4 + part4) * VE);
+        }
+    };
+    auto load_v = [&](int j) {
+#pragma unroll
+        for (int v = 0; v < VU; ++v) uv[v] = *reinterpret_cast<const uint4*>(Vb + (long)min(j + v * R, nlast) * ldkv + tx * VE);
+    };
+    load_k(0);
+    if (ty < R) load_v(ty);
+    float mx = -INFINITY;
+    for (int j0 = 0; j0 < n; j0 += 64 * SU) {
+        if (j0 > 0) load_k(j0);
+#pragma unroll
+        for (int uu = 0; uu < SU; ++uu) {
+            const int j = j0 + uu * 64 + kslot;
+            if (j0 + uu * 64 >= n) break;              // (workgroup-uniform)
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH_MAX; ++i) {
+                if (i >= nch || i * 4 + part4 >= CH) continue;
+                const int c = (i * 4 + part4) * VE;
+                if (sizeof(T) == 2) {
+                    const uint32_t w[4] = {u[uu][i].x, u[uu][i].y, u[uu][i].z, u[uu][i].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s += sq[c + 2 * e] * bf2f(w[e] & 0xffff) + sq[c + 2 * e + 1] * bf2f(w[e] >> 16); }
+                } else {
+                    const float* f = reinterpret_cast<const float*>(&u[uu][i]);
+                    s += sq[c] * f[0] + sq[c + 1] * f[1] + sq[c + 2] * f[2] + sq[c + 3] * f[3];
+                }
+            }
+            if (j >= n) s = 0.f;
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            if (j < n && part4 == 0) { s *= scale; p[j] = s; mx = fmaxf(mx, s); }
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < n; j += HT) { const float e = __expf(p[j] - mx); p[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    for (int j = tid; j < n; j += HT) {
+        float w = p[j] * inv;
+        if (prow) prow[j] = w;
+        if (dc.thresh) w = b2s_keep(dc, drop_row + (uint32_t)j) ? w * dc.scale : 0.f;
+        p[j] = w;
+    }
+    __syncthreads();
+    if (ty < R) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int j = ty; j < n; j += R * VU) {
+            if (j > ty) load_v(j);
+#pragma unroll
+            for (int v = 0; v < VU; ++v) {
+                if (j + v * R >= n) break;
+                const float w = p[j + v * R];
+                if (sizeof(T) == 2) {
+                    const uint32_t ww[4] = {uv[v].x, uv[v].y, uv[v].z, uv[v].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[2 * e] += w * bf2f(ww[e] & 0xffff); acc[2 * e + 1] += w * bf2f(ww[e] >> 16); }
+                } else {
+                    const float* f = reinterpret_cast<const float*>(&uv[v]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += w * f[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) part[ty * dh + tx * VE + e] = acc[e];
+    }
+    __syncthreads();
+    for (int d = tid; d < dh; d += HT) {
+        float o = 0.f;
+        for (int r = 0; r < R; ++r) o += part[r * dh + d];
+        ctx[d] = o;
+    }
+    __syncthreads();
+}
+
+inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// ------------------------------------------------------------------------------------------------ attention sublayer
+template <typename T, bool SELF, bool FAST>
+__global__ __launch_bounds__(NT) void k_df_attn(DfAttn a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int VE = DV<T>::VE, UB = UBA;
+    const DfCommon& c = a.c;
+    const int tid = threadIdx.x, D = c.D, dh = a.dh, H = a.H;
+    const int h = blockIdx.x % H, b0 = (blockIdx.x / H) * UB, t = *c.t;
+    const int CH = dh / VE, R = HT / CH;
+    // LDS carve-up (must match b2s_df_attn_lds)
+    float* xs = reinterpret_cast<float*>(lds);                         // [UB][D]   residual rows; later the output projection
+    T* hs = reinterpret_cast<T*>(xs + UB * D);                         // [UB][D]   LayerNorm output
+    float* qf = reinterpret_cast<float*>(hs + UB * D);                 // [3][UB][dh] q / k / v of this head
+    T* cs = reinterpret_cast<T*>(qf + 3 * UB * dh);                    // [UB][dh]  attention context
+    float* red0 = reinterpret_cast<float*>(cs + UB * dh);              // [8]       LayerNorm statistics
+    float* scr = red0 + 8;                                             // per utterance: ctx [dh] | p [nmax] | part [R][dh] | red [8]
+    const int scr_n = dh + a.nmax + R * dh + 8;
+    if constexpr (FAST) {                   // default sizes: every row / slab / LayerNorm-parameter load of the workgroup in one go
+        constexpr int NPS = SELF ? 32 : 8, XIT = (UB * FD_D / 4 + NT - 1) / NT;
+        XRegs<UB, NPS, XIT> xr;
+        issue_x<UB, NPS, XIT>(c, b0, xr, tid);
+        finish_x_ln<T, UB, NPS, XIT>(c, b0, h == 0, xr, xs, hs, red0, tid);
+    } else {
+        load_x_ln<T, UB, 0>(c, b0, h == 0, xs, hs, red0, tid);
+    }
+    const T* Wq = reinterpret_cast<const T*>(a.Wqkv);
+    // q (and k, v) of this head: rows [h*dh, (h+1)*dh) of each D-row block of the projection weight; the result is [UB][NQ*dh]
+    constexpr int NQ = SELF ? 3 : 1;
+    gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(Wq + (long)h * dh * D, D, NQ * dh, D, hs, D, qf, NQ * dh, tid, dh, D);
+    __syncthreads();
+    T* Kc = reinterpret_cast<T*>(a.Kc);
+    T* Vc = reinterpret_cast<T*>(a.Vc);
+    for (int i = tid; i < UB * dh; i += NT) {
+        const int u = i / dh, d = i - u * dh, b = b0 + u;
+        float* row = qf + u * NQ * dh;
+        row[d] = rnd<T>(row[d]);                                       // the query as the compute dtype holds it
+        if (SELF && b < c.B) {                                          // this frame's key / value row goes to the caches at position t
+            const long o = (long)b * a.kv_bstride + (long)h * a.kv_hstride + (long)t * a.ldkv + d;
+            TT<T>::st(Kc + o, row[dh + d]);
+            TT<T>::st(Vc + o, row[2 * dh + d]);
+        }
+    }
+    __syncthreads();                                                   // (workgroup scope: the cache rows just written are visible to the loads below)
+    DropCfg dc = a.drop_attn;
+    dc.key ^= b2s_hash32((uint32_t)t * 2654435761u + 77u);
+    {   // one half of the workgroup per utterance
+        const int u = tid / HT, ht = tid - u * HT;
+        const int b = min(b0 + u, c.B - 1);
+        const int n = SELF ? t + 1 : a.klen[b];
+        const T* Kb = Kc + (long)b * a.kv_bstride + (long)h * a.kv_hstride;
+        const T* Vb = Vc + (long)b * a.kv_bstride + (long)h * a.kv_hstride;
+        float* my = scr + (long)u * scr_n;
+        float* prow = (a.probs && b0 + u < c.B) ? a.probs + (((long)b * H + h) * a.probs_rows + t) * a.probs_ld : nullptr;
+        attend<T>(qf + u * NQ * dh, Kb, Vb, a.ldkv, n, dh, a.scale, my + dh, my + dh + a.nmax, my + dh + a.nmax + R * dh, prow, dc,
+                  (uint32_t)((b * H + h) * 4096), my, ht);
+        for (int d = ht; d < dh; d += HT) TT<T>::st(cs + u * dh + d, my[d]);
+    }
+    __syncthreads();
+    // this head's share of the output projection: of[u][n] = sum_d ctx[u][d] * Wo[n][h*dh + d]   (K = dh: every row of a pass set in flight)
+    gemv<T, FAST, UB, 4, DH_STEPS<T, FAST>, 3, FD_DH / 32, 3, 1>(reinterpret_cast<const T*>(a.Wo) + (long)h * dh, D, D, dh, cs, dh, xs, D, tid);
+    __syncthreads();
+    store_partial<UB>(c, h, b0, xs, t, tid);
+}
+
+// ------------------------------------------------------------------------------------------------ FFN sublayer
+template <typename T, bool FAST>
+__global__ __launch_bounds__(NT) void k_df_ffn(DfFfn a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int UB = UBF;
+    const DfCommon& c = a.c;
+    const int tid = threadIdx.x, D = c.D, FS = a.F / a.ns;
+    const int sl = blockIdx.x % a.ns, b0 = (blockIdx.x / a.ns) * UB, t = *c.t;
+    float* xs = reinterpret_cast<float*>(lds);                         // [UB][D]
+    T* hs = reinterpret_cast<T*>(xs + UB * D);                         // [UB][D]
+    float* ff = reinterpret_cast<float*>(hs + UB * D);                 // [UB][FS]
+    T* fs = reinterpret_cast<T*>(ff + UB * FS);                        // [UB][FS]
+    float* red = reinterpret_cast<float*>(fs + UB * FS);               // [8]
+    if constexpr (FAST && sizeof(T) == 2) {
+        // Default sizes, bf16: the slice's weights are 96 x 768 (W1) + 768 x 96 (W2) = 42 16-byte loads per lane -- all of them are
+        // issued before anything else, so the kernel is ONE memory round trip (weights, residual rows and partial slabs together)
+        // instead of a chain of four.  MFMA fragments as in gemv_mfma.
+        constexpr int KS1 = FD_D / 32, RB1 = FD_FS / 16, KS2 = FD_FS / 32, NW = NT / 64, RB2W = FD_D / 16 / NW;
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+        const bf16_t* W1 = reinterpret_cast<const bf16_t*>(a.W1);
+        const bf16_t* W2 = reinterpret_cast<const bf16_t*>(a.W2);
+        constexpr int XIT = (UB * FD_D / 4 + NT - 1) / NT;
+        XRegs<UB, 8, XIT> xr;
+        issue_x<UB, 8, XIT>(c, b0, xr, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8_t w1[KS1], w2[RB2W][KS2];
+        {
+            const bf16_t* wr = W1 + ((long)sl * FS + min(wave, RB1 - 1) * 16 + li) * D + lg * 8;
+#pragma unroll
+            for (int u = 0; u < KS1; ++u) w1[u] = *reinterpret_cast<const bf16x8_t*>(wr + u * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        finish_x_ln<T, UB, 8, XIT>(c, b0, sl == 0, xr, xs, hs, red, tid);
+#pragma unroll
+        for (int q = 0; q < RB2W; ++q) {                 // (streams in under the first projection and the ReLU)
+            const bf16_t* w2r = W2 + (long)((wave + q * NW) * 16 + li) * a.F + sl * FS + lg * 8;
+#pragma unroll
+            for (int u = 0; u < KS2; ++u) w2[q][u] = *reinterpret_cast<const bf16x8_t*>(w2r + u * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave < RB1) {
+            const bf16_t* arow = reinterpret_cast<const bf16_t*>(hs) + min(li, UB - 1) * D + lg * 8;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < KS1; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[u], *reinterpret_cast<const bf16x8_t*>(arow + u * 32), acc, 0, 0, 0);
+            if (li < UB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ff[li * FS + wave * 16 + lg * 4 + r] = acc[r];
+            }
+        }
+        __syncthreads();
+        const DropCfg dh_ = salted(a.drop_hid, t);
+        for (int i = tid; i < UB * FS; i += NT) {
+            const int u = i / FS, k = i - u * FS, b = min(b0 + u, c.B - 1);
+            float v = fmaxf(ff[i], 0.f);
+            if (dh_.thresh) v = b2s_keep(dh_, (uint32_t)((long)b * a.F + sl * FS + k)) ? v * dh_.scale : 0.f;
+            TT<T>::st(fs + i, v);
+        }
+        __syncthreads();
+        {
+            const bf16_t* arow = reinterpret_cast<const bf16_t*>(fs) + min(li, UB - 1) * FS + lg * 8;
+            bf16x8_t bv[KS2];
+#pragma unroll
+            for (int u = 0; u < KS2; ++u) bv[u] = *reinterpret_cast<const bf16x8_t*>(arow + u * 32);
+#pragma unroll
+            for (int q = 0; q < RB2W; ++q) {
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < KS2; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q][u], bv[u], acc, 0, 0, 0);
+                if (li < UB) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xs[li * D + (wave + q * NW) * 16 + lg * 4 + r] = acc[r];
+                }
+            }
+        }
+        __syncthreads();
+        store_partial<UB>(c, sl, b0, xs, t, tid);
+    } else {
+    load_x_ln<T, UB, FAST ? 8 : 0>(c, b0, sl == 0, xs, hs, red, tid);
+    gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(reinterpret_cast<const T*>(a.W1) + (long)sl * FS * D, D, FS, D, hs, D, ff, FS, tid);
+    __syncthreads();
+    const DropCfg dh_ = salted(a.drop_hid, t);
+    for (int i = tid; i < UB * FS; i += NT) {
+        const int u = i / FS, k = i - u * FS, b = min(b0 + u, c.B - 1);
+        float v = fmaxf(ff[i], 0.f);
+        if (dh_.thresh) v = b2s_keep(dh_, (uint32_t)((long)b * a.F + sl * FS + k)) ? v * dh_.scale : 0.f;
+        TT<T>::st(fs + i, v);
+    }
+    __syncthreads();
+    gemv<T, FAST, UB, 8, FS_STEPS<T, FAST>, 3, FD_FS / 32, 3, 1>(reinterpret_cast<const T*>(a.W2) + (long)sl * FS, a.F, D, FS, fs, FS, xs, D, tid);
+    __syncthreads();
+    store_partial<UB>(c, sl, b0, xs, t, tid);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ prenet + decoder input
+// tacotron.py:55-65 at one position + modules.py:113-120: x = (t > 0 and t-1 < len ? prenet(mel[t-1]) : 0) + PE[t] * pe_scale, dropout
+template <typename T, bool FAST>
+__global__ __launch_bounds__(NT) void k_df_prenet(DfPrenet a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int UB = UBA;
+    const int tid = threadIdx.x, b0 = blockIdx.x * UB, t = *a.t;
+    const int NMp = (a.NM + 31) & ~31, HP = a.HP, D = a.D;
+    T* tg = reinterpret_cast<T*>(lds);                                 // [UB][NMp]
+    T* a1 = tg + UB * NMp;                                             // [UB][HP]
+    T* a2 = a1 + UB * HP;                                              // [UB][HP]
+    float* o = reinterpret_cast<float*>(a2 + UB * HP);                 // [UB][max(HP, D)]
+    const int ldo = max(HP, D);
+    for (int i = tid; i < UB * NMp; i += NT) {
+        const int u = i / NMp, k = i - u * NMp, b = min(b0 + u, a.B - 1);
+        TT<T>::st(tg + i, (t > 0 && k < a.NM) ? a.mels[((long)b * a.maxT + (t - 1)) * a.NM + k] : 0.f);
+    }
+    __syncthreads();
+    gemv_lds<T, FAST, UB, NM_LPR<T>, NM_STEPS<FAST>, 1>(reinterpret_cast<const T*>(a.W0), a.NM, HP, a.NM, tg, NMp, o, ldo, tid);
+    __syncthreads();
+    const DropCfg d0 = salted(a.drop0, t), d1 = salted(a.drop1, t);
+    for (int i = tid; i < UB * HP; i += NT) {
+        const int u = i / HP, k = i - u * HP, b = min(b0 + u, a.B - 1);
+        float v = fmaxf(o[u * ldo + k] + a.b0[k], 0.f);
+        if (d0.thresh) v = b2s_keep(d0, (uint32_t)(b * HP + k)) ? v * d0.scale : 0.f;
+        TT<T>::st(a1 + i, v);
+    }
+    __syncthreads();
+    gemv<T, FAST, UB, 4, HP_STEPS<T, FAST>, 1, FD_HP / 32, 1, 1>(reinterpret_cast<const T*>(a.W1), HP, HP, HP, a1, HP, o, ldo, tid);
+    __syncthreads();
+    for (int i = tid; i < UB * HP; i += NT) {
+        const int u = i / HP, k = i - u * HP, b = min(b0 + u, a.B - 1);
+        float v = fmaxf(o[u * ldo + k] + a.b1[k], 0.f);
+        if (d1.thresh) v = b2s_keep(d1, (uint32_t)(b * HP + k)) ? v * d1.scale : 0.f;
+        TT<T>::st(a2 + i, v);
+    }
+    __syncthreads();
+    gemv<T, FAST, UB, 4, HP_STEPS<T, FAST>, 1, FD_HP / 32, 1, 1>(reinterpret_cast<const T*>(a.Wf), HP, D, HP, a2, HP, o, ldo, tid);
+    __syncthreads();
+    DropCfg dx = a.drop_x;
+    dx.key ^= b2s_hash32((uint32_t)t + 0x9e3779b9u);
+    const float sc = *a.pe_scale;
+    for (int i = tid; i < UB * D; i += NT) {
+        const int u = i / D, k = i - u * D, b = b0 + u;
+        if (b >= a.B) continue;
+        const bool have = t > 0 && (t - 1) < a.lengths[b];
+        float v = (have ? o[u * ldo + k] : 0.f) + a.pe[(long)t * D + k] * sc;
+        if (dx.thresh) v = b2s_keep(dx, (uint32_t)(b * D + k)) ? v * dx.scale : 0.f;
+        a.X[(long)b * D + k] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ heads + stop logic
+// output LayerNorm, mel_net, stop_net (tacotron.py:112-115 at one position), then synthesize.py:42-45; the last workgroup to
+// finish advances the frame counter and publishes {frames, all finished}.
+template <typename T, bool FAST>
+__global__ __launch_bounds__(NT) void k_df_final(DfFinal a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int last;
+    constexpr int UB = UBA;
+    const int tid = threadIdx.x, D = a.D, b0 = blockIdx.x * UB, t = *a.t;
+    float* xs = reinterpret_cast<float*>(lds);                         // [UB][D]
+    T* hs = reinterpret_cast<T*>(xs + UB * D);                         // [UB][D]
+    float* mo = reinterpret_cast<float*>(hs + UB * D);                 // [UB][NM]
+    float* red = mo + UB * a.NM;                                       // [8 + UB]
+    DfCommon c;
+    c.X_in = a.X_in; c.X_out = nullptr; c.P_prev = a.P_prev; c.np_prev = a.np_prev; c.P_out = nullptr; c.B = a.B; c.D = D;
+    c.ln_g = a.ln_g; c.ln_b = a.ln_b; c.eps = a.eps; c.t = a.t; c.drop_res = DropCfg{0, 0, 1.f};
+    if constexpr (FAST) {
+        constexpr int XIT = (UB * FD_D / 4 + NT - 1) / NT;
+        XRegs<UB, 32, XIT> xr;
+        issue_x<UB, 32, XIT>(c, b0, xr, tid);
+        finish_x_ln<T, UB, 32, XIT>(c, b0, false, xr, xs, hs, red, tid);
+    } else {
+        load_x_ln<T, UB, 0>(c, b0, false, xs, hs, red, tid);
+    }
+    gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(reinterpret_cast<const T*>(a.Wmel), D, a.NM, D, hs, D, mo, a.NM, tid);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < UB) {                           // stop logit: fp32 weights against the compute-dtype activations (ro_rowdot_fwd)
+        float s = 0.f;
+        for (int k = lane; k < D; k += 64) s += TT<T>::ld(hs + wave * D + k) * a.wstop[k];
+        s = wave_sum(s);
+        if (lane == 0) red[8 + wave] = s + a.bstop[0];
+    }
+    __syncthreads();
+    for (int i = tid; i < UB * a.NM; i += NT) {
+        const int u = i / a.NM, k = i - u * a.NM, b = b0 + u;
+        if (b >= a.B) continue;
+        const bool active = t < a.lengths[b];
+        a.mels[((long)b * a.maxT + t) * a.NM + k] = active ? mo[i] : 0.f;
+    }
+    __syncthreads();
+    if (tid < UB && b0 + tid < a.B) {
+        const int b = b0 + tid;
+        const bool active = t < a.lengths[b];
+        const bool stop = active && red[8 + tid] > 0.f;
+        const int fin = a.finished[b] | (stop ? 1 : 0);
+        a.finished[b] = fin;
+        if (!fin) a.lengths[b] += 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();                                               // publish finished[] / lengths[] before the ticket
+        last = atomicAdd(a.done_cnt, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last) {                                                        // (L2-served loads: every workgroup's finished[] is visible)
+        int mine = 1;
+        for (int b = tid; b < a.B; b += NT) mine &= __hip_atomic_load(a.finished + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int all = __syncthreads_and(mine);
+        if (tid == 0) {
+            *a.done_cnt = 0;
+            *a.t = t + 1;
+            a.status[0] = t + 1; a.status[1] = all;
+        }
+    }
+}
+
+template <typename K, typename A>
+int launch(K kern, int grid, size_t lds, const A& a, hipStream_t st) {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+size_t b2s_df_attn_lds(int dtype, int D, int dh, int nmax) {
+    const size_t e = dtype ? 2 : 4, ve = dtype ? 8 : 4;
+    const size_t R = HT / (dh / ve);
+    constexpr size_t UB = UBA;
+    return al16((size_t)UB * D * 4 + UB * D * e + 3 * UB * dh * 4 + UB * dh * e + 8 * 4 + (size_t)UB * (dh + nmax + R * dh + 8) * 4 + 64);
+}
+size_t b2s_df_ffn_lds(int dtype, int D, int F, int ns) {
+    const size_t e = dtype ? 2 : 4, FS = F / ns;
+    constexpr size_t UB = UBF;
+    return al16((size_t)UB * D * 4 + UB * D * e + UB * FS * 4 + UB * FS * e + 2 * UB * 4 + 64);
+}
+int b2s_df_ffn_slices(int dtype, int F) {
+    if (F == 32 * FD_FS) return 32;                    // the default sizes: 32 slices of FD_FS hidden units (FAST instantiation)
+    const int step = 8 * (dtype ? 8 : 4);              // generic: the slice is a K walk of 8 lanes per row
+    for (int ns = 16; ns >= 1; --ns)
+        if (F % ns == 0 && (F / ns) % step == 0 && F / ns <= DF_MAX_FS) return ns;
+    return 0;
+}
+bool b2s_df_supported(int dtype, int D, int H, int F, int NM, int HP, int nmax) {
+    const int ve = dtype ? 8 : 4;
+    if (H <= 0 || D % H) return false;
+    const int dh = D / H;
+    if (D > DF_MAX_D || dh > DF_MAX_DH || HP > DF_MAX_HP || NM > DF_MAX_NM || b2s_df_ffn_slices(dtype, F) == 0) return false;
+    // every GEMV walks K in whole steps of (lanes per row) x (16 bytes)
+    return D % (8 * ve) == 0 && dh % (4 * ve) == 0 && HP % (4 * ve) == 0 && NM % 16 == 0 &&
+           b2s_df_attn_lds(dtype, D, dh, nmax) <= 64 * 1024 && b2s_df_ffn_lds(dtype, D, F, b2s_df_ffn_slices(dtype, F)) <= 64 * 1024;
+}
+// the FAST instantiations serve exactly the default sizes (see the top of the file)
+int b2s_df_prenet(int dtype, const DfPrenet& a, hipStream_t st) {
+    const size_t e = dtype ? 2 : 4;
+    constexpr int UB = UBA;
+    const size_t lds = al16((size_t)UB * ((a.NM + 31) & ~31) * e + 2 * UB * a.HP * e + (size_t)UB * std::max(a.HP, a.D) * 4 + 64);
+    const int grid = (a.B + UB - 1) / UB;
+    const bool fast = a.HP == FD_HP && a.NM == FD_NM;
+    if (dtype) return fast ? launch(k_df_prenet<bf16_t, true>, grid, lds, a, st) : launch(k_df_prenet<bf16_t, false>, grid, lds, a, st);
+    return fast ? launch(k_df_prenet<float, true>, grid, lds, a, st) : launch(k_df_prenet<float, false>, grid, lds, a, st);
+}
+int b2s_df_attn(int dtype, bool self, const DfAttn& a, hipStream_t st) {
+    const size_t lds = b2s_df_attn_lds(dtype, a.c.D, a.dh, a.nmax);
+    const int grid = a.H * ((a.c.B + UBA - 1) / UBA);
+    const bool fast = a.c.D == FD_D && a.dh == FD_DH;
+    if (dtype) {
+        if (fast) return self ? launch(k_df_attn<bf16_t, true, true>, grid, lds, a, st) : launch(k_df_attn<bf16_t, false, true>, grid, lds, a, st);
+        return self ? launch(k_df_attn<bf16_t, true, false>, grid, lds, a, st) : launch(k_df_attn<bf16_t, false, false>, grid, lds, a, st);
+    }
+    if (fast) return self ? launch(k_df_attn<float, true, true>, grid, lds, a, st) : launch(k_df_attn<float, false, true>, grid, lds, a, st);
+    return self ? launch(k_df_attn<float, true, false>, grid, lds, a, st) : launch(k_df_attn<float, false, false>, grid, lds, a, st);
+}
+int b2s_df_ffn(int dtype, const DfFfn& a, hipStream_t st) {
+    const size_t lds = b2s_df_ffn_lds(dtype, a.c.D, a.F, a.ns);
+    const int grid = a.ns * ((a.c.B + UBF - 1) / UBF);
+    const bool fast = a.c.D == FD_D && a.F / a.ns == FD_FS;
+    if (dtype) return fast ? launch(k_df_ffn<bf16_t, true>, grid, lds, a, st) : launch(k_df_ffn<bf16_t, false>, grid, lds, a, st);
+    return fast ? launch(k_df_ffn<float, true>, grid, lds, a, st) : launch(k_df_ffn<float, false>, grid, lds, a, st);
+}
+int b2s_df_final(int dtype, const DfFinal& a, hipStream_t st) {
+    const size_t e = dtype ? 2 : 4;
+    constexpr int UB = UBA;
+    const size_t lds = al16((size_t)UB * a.D * 4 + UB * a.D * e + (size_t)UB * a.NM * 4 + (8 + UB) * 4 + 64);
+    const int grid = (a.B + UB - 1) / UB;
+    const bool fast = a.D == FD_D;
+    if (dtype) return fast ? launch(k_df_final<bf16_t, true>, grid, lds, a, st) : launch(k_df_final<bf16_t, false>, grid, lds, a, st);
+    return fast ? launch(k_df_final<float, true>, grid, lds, a, st) : launch(k_df_final<float, false>, grid, lds, a, st);
+}

@@ -36,13 +36,14 @@ def _lane_bounds(B, lanes):
 
 
 def eval_batch(model_eval, data, use_bar=True, bar_interval=10, use_graph=True, sync_interval=16,
-               keep_self_alignments=False, lanes=None):
+               keep_self_alignments=False, lanes=None, device_results=False):
     """lanes > 1: the batch is decoded as that many independent sub-batches, each with its own KV cache, hipGraph and HIP
     stream.  Utterances are independent (synthesize.py:23-47 never mixes batch rows), so the split changes no result; a
     lane whose utterances have all stopped ends early and its remaining frames are the zeros the reference writes after a
     stop.  Measured on MI355X (64 x 1000 frames): 1 / 2 / 4 lanes = 1.03 / 1.01 / 1.06 ms per frame step -- the frame loop
     is bound by the ~5 us the command processor needs per kernel dispatch, which concurrent streams share, so the default
-    stays one lane (B2S_DECODE_LANES overrides); the option is for batches too large for one KV-cache allocation."""
+    stays one lane (B2S_DECODE_LANES overrides); the option is for batches too large for one KV-cache allocation.
+    device_results=True returns torch tensors on the device instead of NumPy arrays (no host copy)."""
     with torch.no_grad():
         tic = time.time()
         batch = copy.copy(data)
@@ -58,6 +59,8 @@ def eval_batch(model_eval, data, use_bar=True, bar_interval=10, use_graph=True, 
         train = bool(model_eval.decoder.training)          # the reference synthesises with decoder.train() (eval.py:116-117)
         if lanes is None:
             lanes = int(os.environ.get("B2S_DECODE_LANES", "1"))
+        if os.environ.get("B2S_DECODE_EAGER"):              # development switch: plain launches instead of graph replay
+            use_graph = False
         H, NL, NM = eng.cfg.n_attention_head, eng.cfg.n_decoder_layer, hp.num_mels
 
         class Lane(object):
@@ -140,6 +143,12 @@ def eval_batch(model_eval, data, use_bar=True, bar_interval=10, use_graph=True, 
         for ln in Ls:
             torch.cuda.current_stream().wait_stream(ln.stream)
         mel_aft = model_eval.postnet(mels, lengths, _fuse_add=True)        # mels + postnet(mels), BN in eval mode
+        if device_results:
+            # results stay in HBM as torch tensors (the reference returns NumPy arrays: synthesize.py:57-61 -- for 64 x 1000 frames
+            # that is a 2 GB pageable device-to-host copy of the alignments, which a caller that goes on working on the GPU skips)
+            torch.cuda.synchronize(device)
+            return {'names': data.get('names'), 'mel_pre': mels, 'mel_aft': mel_aft, 'alignments': alignments,
+                    'input_lengths': batch['input_lengths'], 'generated_lengths': lengths}
         for key in ('self', 'encdec'):
             alignments[key] = [a.cpu().numpy() for a in alignments[key]]
         toc = time.time()
