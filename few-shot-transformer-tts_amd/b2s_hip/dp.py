@@ -14,11 +14,22 @@ class GradBucketer(object):
     launches one asynchronous all-reduce per bucket.  Stages must be reported in increasing order and their ranges
     must tile the flat buffer in that order (HipEngine lays gradients out that way)."""
 
-    def __init__(self, flat, stage_ranges, n_stages, bucket_elems, group=None, dist=None):
+    def __init__(self, flat, stage_ranges, n_stages, bucket_elems, group=None, dist=None, payload="fp32", pack=None, unpack=None):
+        """payload "bf16": every bucket is converted to a bf16 wire buffer before its all-reduce and back afterwards -- half the
+        bytes over xGMI (167 MB instead of 334 MB per step at the default sizes); the sum over ranks is then taken in bf16,
+        everything inside a rank (accumulation, Adam moments, masters) stays fp32.  pack(src_f32, dst_bf16) / unpack(src_bf16,
+        dst_f32): conversion ops (the trainer passes the HIP kernels b2s_pack_bf16 / b2s_unpack_bf16; default: torch copies, for
+        CPU tests)."""
         self.flat, self.stage_ranges, self.n_stages = flat, stage_ranges, n_stages
         self.bucket_elems = int(bucket_elems)
         self.dist = dist if dist is not None else torch.distributed
         self.group = group
+        if payload not in ("fp32", "bf16"):
+            raise ValueError("payload must be 'fp32' or 'bf16'")
+        self.payload = payload
+        self.wire = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device) if payload == "bf16" else None
+        self.pack = pack or (lambda src, dst: dst.copy_(src))
+        self.unpack = unpack or (lambda src, dst: dst.copy_(src))
         self._pending = None
         self._works = []
         self.launched = []                       # (lo, hi) of every all-reduce of the current step, for tests / logs
@@ -27,8 +38,16 @@ class GradBucketer(object):
         self._pending, self._works, self.launched = None, [], []
 
     def _launch(self):
+        # Called on the thread / stream that enqueued the backward stage.  Ordering: the engine made that stream wait for the
+        # second-stream event that completes the stage's weight gradients before it fired the hook (engine.hip: end_stage);
+        # the conversion kernel (bf16 payload) is enqueued on the same stream; torch.distributed makes its communication
+        # stream wait for the current stream before the collective starts.
         lo, hi = self._pending
-        self._works.append(self.dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
+        buf = self.flat[lo:hi]
+        if self.wire is not None:
+            buf = self.wire[lo:hi]
+            self.pack(self.flat[lo:hi], buf)
+        self._works.append((self.dist.all_reduce(buf, group=self.group, async_op=True), lo, hi))
         self.launched.append((lo, hi))
         self._pending = None
 
@@ -50,8 +69,10 @@ class GradBucketer(object):
         and the replicas would drift apart silently."""
         if self._pending is not None:
             self._launch()
-        for w in self._works:
+        for w, lo, hi in self._works:
             w.wait()
+            if self.wire is not None:
+                self.unpack(self.wire[lo:hi], self.flat[lo:hi])
         self._works = []
         if expect_all:
             pos = 0
@@ -65,7 +86,7 @@ class GradBucketer(object):
 
     def abort(self):
         """Wait for what was launched and drop the rest (a stage hook failed; the step is being abandoned)."""
-        for w in self._works:
+        for w, _lo, _hi in self._works:
             try:
                 w.wait()
             except Exception:

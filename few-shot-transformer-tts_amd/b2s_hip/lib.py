@@ -93,6 +93,8 @@ _PROTOS = {
                                             P]),
     "b2s_align_from_probs": (C.c_int, [C.c_int, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P]),
     "b2s_add": (C.c_int, [P, P, P, C.c_int64, P]),
+    "b2s_pack_bf16": (C.c_int, [P, P, C.c_int64, P]),
+    "b2s_unpack_bf16": (C.c_int, [P, P, C.c_int64, P]),
     "b2s_cast": (C.c_int, [C.c_int, P, P, C.c_int64, P]),
     "b2s_cast_back": (C.c_int, [C.c_int, P, P, C.c_int64, P]),
     "b2s_decode_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -42,7 +42,7 @@ class _SchedView(object):
 
 
 class HipTrainer(object):
-    def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0, overlap_adam=False):
+    def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0, overlap_adam=False, grad_payload=None):
         from transformer.tacotron import learning_rate_schedule
         self.model, self.hp = model, hp
         # overlap_adam: the optimizer step runs on the engine's second stream while the next step's forward pass starts
@@ -84,8 +84,18 @@ class HipTrainer(object):
         self.bucketer = None
         self._hook = _HOOK_T(self._on_stage)      # keep a reference: ctypes callbacks must outlive their use
         if self.world > 1 or (self.dist and os.environ.get("B2S_FORCE_DP")):    # B2S_FORCE_DP: 1-rank group, test aid
+            # grad_payload "bf16": gradients travel as bf16 (half the xGMI bytes), converted by HIP kernels on this stream around
+            # each bucket's all-reduce; default fp32 (exact mean of the rank gradients); B2S_GRAD_PAYLOAD overrides
+            payload = grad_payload or os.environ.get("B2S_GRAD_PAYLOAD", "fp32")
+            lib = self.lib
+            def pack(src, dst):
+                L.check(lib.b2s_pack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()))
+            def unpack(src, dst):
+                L.check(lib.b2s_unpack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()))
+            on_gpu = self.eng._gflat.is_cuda
             self.bucketer = GradBucketer(self.eng._gflat, self.eng.stage_ranges, self.eng.n_stages(),
-                                         bucket_mb * 1024 * 1024 / 4, dist=self.dist)
+                                         bucket_mb * 1024 * 1024 / 4, dist=self.dist, payload=payload,
+                                         pack=pack if on_gpu else None, unpack=unpack if on_gpu else None)
             L.check(self.lib.b2s_model_set_stage_hook(self.eng.handle, C.cast(self._hook, L.P), None))
             # broadcast parameters and BN buffers from rank 0 once (DDP constructor semantics, train.py:125)
             with torch.no_grad():

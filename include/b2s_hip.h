@@ -232,6 +232,10 @@ int b2s_flash_attention_align(int dtype, const void* q, int ldq, const void* k, 
 int b2s_align_from_probs(int dtype, const void* P, float* align, int B, int H, int Lq, int Lk, void* stream);
 /* out = a + b (fp32, n elements) */
 int b2s_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* Gradient payload conversion for the data-parallel exchange (b2s_hip/dp.py): fp32 gradients -> bf16 wire buffer and back (half
+ * the bytes per all-reduce over xGMI; parameters, Adam moments and the accumulation inside a rank stay fp32). */
+int b2s_pack_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
+int b2s_unpack_bf16(const void* src_bf16, float* dst, int64_t n, void* stream);
 int b2s_cast(int dtype, const float* in, void* out, int64_t n, void* stream);      /* fp32 -> compute dtype */
 int b2s_cast_back(int dtype, const void* in, float* out, int64_t n, void* stream); /* compute dtype -> fp32 */
 /* keep-mask of the dropout RNG for element indices [0,n): out[i] = 1 or 0 (statistical tests) */

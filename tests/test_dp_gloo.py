@@ -43,7 +43,7 @@ def _stage_layout(names, sizes):
     return ranges, offsets, off, eng.n_stages()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, payload="fp32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,7 +63,7 @@ def _worker(rank, world, port, out):
         off, sz = offsets[n]
         flat[off:off + sz] = g.flatten()
     local = flat.clone()
-    b = GradBucketer(flat, ranges, n_stages, bucket_elems=60000, dist=dist)
+    b = GradBucketer(flat, ranges, n_stages, bucket_elems=60000, dist=dist, payload=payload)
     b.begin_step()
     for st in range(n_stages):                 # the engine reports stages in backward order
         b.stage_done(st)
@@ -74,7 +74,13 @@ def _worker(rank, world, port, out):
     assert 1 < len(covered) < n_stages, "small stages are merged into buckets"
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
-    assert torch.allclose(flat / world, sum(gathered) / world, atol=1e-7)
+    ref = sum(gathered) / world
+    if payload == "fp32":
+        assert torch.allclose(flat / world, ref, atol=1e-7)
+    else:       # bf16 wire format: every rank's contribution and the sum are rounded to 8 mantissa bits
+        wire = sum(g.to(torch.bfloat16) for g in gathered).to(torch.float32) / world
+        assert torch.allclose(flat / world, wire, atol=1e-7)
+        assert float((flat / world - ref).norm() / ref.norm()) < 6e-3
     if rank == 0:
         np.save(out, (flat / world).numpy())
     dist.destroy_process_group()
@@ -84,5 +90,15 @@ def test_bucketed_allreduce_mean_of_rank_gradients(tmp_path):
     out = str(tmp_path / "mean.npy")
     port = _free_port()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mean = np.load(out)
+    assert np.isfinite(mean).all() and np.abs(mean).max() > 0
+
+
+def test_bucketed_allreduce_bf16_payload(tmp_path):
+    """grad_payload="bf16": same buckets, gradients travel as bf16 (half the bytes per all-reduce), result = bf16 sum of the
+    bf16-rounded rank gradients, within 0.6 % of the exact mean in norm."""
+    out = str(tmp_path / "mean16.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out, "bf16"), nprocs=2, join=True)
     mean = np.load(out)
     assert np.isfinite(mean).all() and np.abs(mean).max() > 0
