@@ -254,8 +254,8 @@ def main():
         dom = variants[0]
         # HBM-side traffic of that kernel from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/gpu_pmc.sh) -- counters cannot be read from inside this process
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_train_bf16_pmc_hbm_traffic.json")
+        traffic = mfma_util = None
+        pmc = os.path.join(ROOT, "profiles", "r02_train_bf16_pmc_hbm_traffic_mfma.json")
         if os.path.exists(pmc) and args.dtype == "bf16" and args.mode == "train" and (B, S, T) == (14, 114, 582):
             pre = dom["kernel"].split(", NB, MW>")[0].replace(", G", ", ")
             rows = [r for r in json.load(open(pmc)) if r["kernel"].startswith(pre)]
@@ -263,6 +263,9 @@ def main():
             if n:
                 traffic = round(sum(r["launches"] * (r["fetch_MB_per_launch_corrected_x2"] + (r["WRITE_SIZE_KB_per_launch"] or 0) / 1024)
                                     for r in rows) / n * 1e6)
+                mu = [r for r in rows if r.get("mfma_util") is not None]
+                if mu:          # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE), same committed PMC run
+                    mfma_util = round(sum(r["launches"] * r["mfma_util"] for r in mu) / sum(r["launches"] for r in mu), 4)
         # the same MFMA kernels with the GPU to themselves: the step's forward / dX shapes launched back-to-back through the
         # C-ABI op (no second stream, operands cache-resident after the first launch) -- what the kernel does when it is
         # not sharing CUs and not paying a fused residual epilogue; context for the in-step figure above, not a replacement
@@ -300,6 +303,7 @@ def main():
             del bufA, bufB, bufC
         out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
                            "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM side, PMC)",
+                           "mfma_util": mfma_util,
                            "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                            "all_gemm": {"tflops": round(tot_f / (tot_ms * 1e-3) / 1e12, 1), "ms_per_step": round(tot_ms / nprof, 3)},
                            "variants": variants, "isolated": isolated,

@@ -740,6 +740,8 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
             else { m->sk_ws[i] = nullptr; (void)hipGetLastError(); }      // (no slab: that stream's split-K launches use atomics)
     }
     if (!m->aux && !getenv("B2S_NO_AUX")) {
+        // (a lowest-priority second stream was measured: no change -- a weight-gradient workgroup holds its CU for ~110 us once it
+        // has started, whatever the queue priorities say)
         B2S_HIP(hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking));
         m->ev_pool.resize(256);
         for (auto& ev : m->ev_pool) B2S_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));

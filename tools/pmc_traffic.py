@@ -3,7 +3,9 @@
 
 usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [mfma_counter_collection.csv]
 The optional third pass (--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE) adds mfma_util = MFMA-busy cycles summed over the
-chip's 1024 SIMDs / (1024 x GRBM_GUI_ACTIVE), i.e. the fraction of matrix-pipe cycles a kernel keeps busy.
+chip's 1024 SIMDs / (1024 x GRBM_GUI_ACTIVE per XCD), i.e. the fraction of matrix-pipe cycles a kernel keeps busy (the rocprofv3
+derived metric MfmaUtil).  rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs' counter instances: it is divided by 8 here
+(cross-check: the GEMM kernels' mfma_util then equals their TFLOP/s over the 2.5 PFLOP/s peak).
 FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts 128-byte requests at 64 bytes, so it is doubled
 (MI355X_MICROARCH.md, section HBM); WRITE_SIZE is reported as is (uncalibrated per that guide).
 """
@@ -40,7 +42,7 @@ def main():
                      "fetch_MB_per_launch_corrected_x2": round(2 * sum(fv) / len(fv) / 1024, 2),
                      "WRITE_SIZE_KB_per_launch": round(sum(wv) / len(wv), 1) if wv else None,
                      "total_fetch_MB_corrected": round(2 * sum(fv) / 1024, 1),
-                     "mfma_util": round(sum(mb[k]) / (1024.0 * sum(ga[k])), 4) if k in mb and k in ga and sum(ga[k]) > 0 else None})
+                     "mfma_util": round(sum(mb[k]) / (1024.0 * sum(ga[k]) / 8.0), 4) if k in mb and k in ga and sum(ga[k]) > 0 else None})
     rows.sort(key=lambda r: -r["total_fetch_MB_corrected"])
     json.dump(rows, open(out, "w"), indent=1)
     for r in rows[:12]:
