@@ -36,6 +36,13 @@ struct b2s_decode_state {
     int* done_cnt = nullptr;
     int ns_ffn = 0;
     bool fused = false;
+    // fragment-packed copies of the projection weights the fused bf16 kernels read (b2s_df_pack; made by b2s_decode_begin)
+    struct Pack { std::string name; int N, K; void* p; };
+    std::vector<Pack> packs;
+    const void* Wd(const b2s_model* m, const std::string& n) const {
+        for (const Pack& k : packs) if (k.name == n) return k.p;
+        return m->W(n);
+    }
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipStream_t graph_stream = nullptr;
@@ -238,6 +245,8 @@ __global__ void k_dec_advance(int* t, const int* finished, int* status, int B) {
 struct DecPlan {
     size_t bytes;
 };
+std::string nm2(const std::string& p, const char* list, int i, const char* leaf) { return p + list + "." + std::to_string(i) + "." + leaf; }
+
 void plan_decode(const b2s_model* m, b2s_decode_state& s, Arena& a) {
     const b2s_config& cf = m->cfg;
     const int B = s.B, S = s.S, T = s.maxT, D = cf.decoder_hidden, H = cf.n_attention_head, L = cf.n_decoder_layer, esz = m->esz;
@@ -264,6 +273,19 @@ void plan_decode(const b2s_model* m, b2s_decode_state& s, Arena& a) {
         const int ns = std::max(H, s.ns_ffn);
         for (int i = 0; i < 2; ++i) { s.Xpp[i] = a.f32((long)B * D); s.Ppp[i] = a.f32((long)ns * B * D); }
         s.done_cnt = (int*)a.take(256);
+        const int dh = D / H, F = 4 * D, HP = cf.prenet_hidden, NM = cf.num_mels;
+        const std::string p = "decoder.decoder.";
+        s.packs.clear();
+        auto add = [&](const std::string& n, int N, int K) { s.packs.push_back({n, N, K, a.T((long)N * K, 2)}); };
+        if (b2s_df_attn_packed(m->dtype, D, dh))
+            for (int l = 0; l < L; ++l) {
+                add(nm2(p, "self_attentions", l, "qkv_transform.weight"), 3 * D, D); add(nm2(p, "self_attentions", l, "output_transform.weight"), D, D);
+                add(nm2(p, "encdec_attentions", l, "q_transform.weight"), D, D); add(nm2(p, "encdec_attentions", l, "output_transform.weight"), D, D);
+            }
+        if (b2s_df_ffn_packed(m->dtype, D, F, s.ns_ffn))
+            for (int l = 0; l < L; ++l) { add(nm2(p, "ffn_layers", l, "input_layer.weight"), F, D); add(nm2(p, "ffn_layers", l, "output_layer.weight"), D, F); }
+        if (b2s_df_prenet_packed(m->dtype, HP, NM)) { add("decoder.prenet.dense1.weight", HP, HP); add("decoder.prenet.dense_final.weight", D, HP); }
+        if (b2s_df_final_packed(m->dtype, D)) add("decoder.mel_net.weight", NM, D);
     }
 }
 
@@ -279,7 +301,6 @@ int lin(const b2s_model* m, hipStream_t st, const void* X, int ldx, const void* 
     }
     return b2s_gemm_launch(g, m->dtype, false, false, st);
 }
-std::string nm2(const std::string& p, const char* list, int i, const char* leaf) { return p + list + "." + std::to_string(i) + "." + leaf; }
 
 // One frame with one kernel per sublayer (decode_fused.hip): prenet + input, 3 kernels per decoder layer, heads + stop logic.
 int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
@@ -291,7 +312,7 @@ int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
     const std::string p = "decoder.decoder.";
     DfPrenet pn;
     pn.mels = s->mels; pn.maxT = maxT; pn.NM = NM; pn.HP = HP; pn.D = D; pn.B = B;
-    pn.W0 = m->W("decoder.prenet.dense0.weight"); pn.W1 = m->W("decoder.prenet.dense1.weight"); pn.Wf = m->W("decoder.prenet.dense_final.weight");
+    pn.W0 = m->W("decoder.prenet.dense0.weight"); pn.W1 = s->Wd(m, "decoder.prenet.dense1.weight"); pn.Wf = s->Wd(m, "decoder.prenet.dense_final.weight");
     pn.b0 = m->P("decoder.prenet.dense0.bias"); pn.b1 = m->P("decoder.prenet.dense1.bias");
     pn.pe = m->pe_dec; pn.pe_scale = m->P(p + "pe_scale"); pn.lengths = s->lengths; pn.t = s->t; pn.X = s->Xpp[0];
     pn.drop0 = make_drop(pd, s->seed, 9001); pn.drop1 = make_drop(pd, s->seed, 9002); pn.drop_x = make_drop(pt, s->seed, 9003);
@@ -308,8 +329,8 @@ int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
                           lnf = p + "ffn_layer_norms." + std::to_string(l);
         DfAttn sa;
         sa.c = common(lna, make_drop(pt, s->seed, 9020 + l));
-        sa.H = H; sa.dh = dh; sa.Wqkv = m->W(nm2(p, "self_attentions", l, "qkv_transform.weight"));
-        sa.Wo = m->W(nm2(p, "self_attentions", l, "output_transform.weight"));
+        sa.H = H; sa.dh = dh; sa.Wqkv = s->Wd(m, nm2(p, "self_attentions", l, "qkv_transform.weight"));
+        sa.Wo = s->Wd(m, nm2(p, "self_attentions", l, "output_transform.weight"));
         sa.Kc = s->selfK[l]; sa.Vc = s->selfV[l]; sa.ldkv = dh; sa.kv_bstride = (long)maxT * D; sa.kv_hstride = (long)maxT * dh; sa.maxT = maxT;
         sa.probs = s->selfP[l]; sa.probs_rows = maxT; sa.probs_ld = maxT; sa.klen = nullptr; sa.nmax = maxT; sa.scale = scale;
         sa.drop_attn = make_drop(pt, s->seed, 9010 + l);
@@ -317,8 +338,8 @@ int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
         ++k; np = H;
         DfAttn xa;
         xa.c = common(lnx, make_drop(pt, s->seed, 9040 + l));
-        xa.H = H; xa.dh = dh; xa.Wqkv = m->W(nm2(p, "encdec_attentions", l, "q_transform.weight"));
-        xa.Wo = m->W(nm2(p, "encdec_attentions", l, "output_transform.weight"));
+        xa.H = H; xa.dh = dh; xa.Wqkv = s->Wd(m, nm2(p, "encdec_attentions", l, "q_transform.weight"));
+        xa.Wo = s->Wd(m, nm2(p, "encdec_attentions", l, "output_transform.weight"));
         xa.Kc = s->crossKV[l]; xa.Vc = (char*)s->crossKV[l] + (size_t)D * m->esz; xa.ldkv = 2 * D; xa.kv_bstride = (long)S * 2 * D; xa.kv_hstride = dh;
         xa.maxT = maxT; xa.probs = s->crossP[l]; xa.probs_rows = maxT; xa.probs_ld = S; xa.klen = s->in_len; xa.nmax = S; xa.scale = scale;
         xa.drop_attn = make_drop(pt, s->seed, 9030 + l);
@@ -326,7 +347,7 @@ int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
         ++k; np = H;
         DfFfn ff;
         ff.c = common(lnf, make_drop(pt, s->seed, 9060 + l));
-        ff.F = 4 * D; ff.ns = s->ns_ffn; ff.W1 = m->W(nm2(p, "ffn_layers", l, "input_layer.weight")); ff.W2 = m->W(nm2(p, "ffn_layers", l, "output_layer.weight"));
+        ff.F = 4 * D; ff.ns = s->ns_ffn; ff.W1 = s->Wd(m, nm2(p, "ffn_layers", l, "input_layer.weight")); ff.W2 = s->Wd(m, nm2(p, "ffn_layers", l, "output_layer.weight"));
         ff.drop_hid = make_drop(pt, s->seed, 9050 + l);
         B2S_TRY(b2s_df_ffn(dt, ff, st));
         ++k; np = s->ns_ffn;
@@ -334,7 +355,7 @@ int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
     DfFinal fn;
     fn.X_in = s->Xpp[k & 1]; fn.P_prev = s->Ppp[(k + 1) & 1]; fn.np_prev = np; fn.B = B; fn.D = D; fn.NM = NM; fn.maxT = maxT;
     fn.ln_g = m->P(p + "output_layer_norm.weight"); fn.ln_b = m->P(p + "output_layer_norm.bias"); fn.eps = 1e-6f;
-    fn.Wmel = m->W("decoder.mel_net.weight"); fn.wstop = m->P("decoder.stop_net.weight"); fn.bstop = m->P("decoder.stop_net.bias");
+    fn.Wmel = s->Wd(m, "decoder.mel_net.weight"); fn.wstop = m->P("decoder.stop_net.weight"); fn.bstop = m->P("decoder.stop_net.bias");
     fn.mels = s->mels; fn.t = s->t; fn.finished = s->finished; fn.lengths = s->lengths; fn.status = s->status; fn.done_cnt = s->done_cnt;
     return b2s_df_final(dt, fn, st);
 }
@@ -442,6 +463,10 @@ extern "C" int b2s_decode_begin(b2s_model* m, const float* memory, const int32_t
         const size_t pb = (size_t)std::max(m->cfg.n_attention_head, s->ns_ffn) * B * m->cfg.decoder_hidden * 4;
         for (int i = 0; i < 2; ++i)
             if (hipMemsetAsync(s->Ppp[i], 0, pb, st) != hipSuccess) { delete s; return b2s_fail(__FILE__, __LINE__, "memset failed"); }
+    }
+    for (const b2s_decode_state::Pack& k : s->packs) {          // (per job: the weights may have been trained since the last one)
+        rc = b2s_df_pack(m->W(k.name), k.N, k.K, k.p, st);
+        if (rc) { delete s; return rc; }
     }
     rc = ro_cast(m->dtype, memory, s->memT, (long)B * S * D, st);
     for (int l = 0; l < cf.n_decoder_layer && !rc; ++l) {

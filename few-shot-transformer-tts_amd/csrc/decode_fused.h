@@ -21,7 +21,7 @@ struct DfCommon {
 struct DfAttn {
     DfCommon c;
     int H, dh;
-    const void* Wqkv;         // self: qkv_transform [3D][D]; cross: q_transform [D][D]
+    const void* Wqkv;         // self: qkv_transform [3D][D]; cross: q_transform [D][D]   (the packed copies when b2s_df_attn_packed)
     const void* Wo;           // output_transform [D][D]
     void *Kc, *Vc;            // self: head-major caches [B][H][maxT][dh] (this frame's row is appended); cross: memory K / V rows
     int ldkv;
@@ -37,13 +37,13 @@ struct DfAttn {
 struct DfFfn {
     DfCommon c;
     int F, ns;                // hidden width (4 D) and number of slices
-    const void *W1, *W2;      // input_layer [F][D], output_layer [D][F]
+    const void *W1, *W2;      // input_layer [F][D], output_layer [D][F]   (packed copies when b2s_df_ffn_packed)
     DropCfg drop_hid;
 };
 struct DfPrenet {
     const float* mels;        // [B][maxT][NM] generated so far
     int maxT, NM, HP, D, B;
-    const void *W0, *W1, *Wf; // dense0 [HP][NM], dense1 [HP][HP], dense_final [D][HP] (compute dtype)
+    const void *W0, *W1, *Wf; // dense0 [HP][NM], dense1 [HP][HP], dense_final [D][HP] (compute dtype; W1, Wf packed when b2s_df_prenet_packed)
     const float *b0, *b1;
     const float *pe, *pe_scale;
     const int* lengths;
@@ -55,7 +55,7 @@ struct DfFinal {
     const float* X_in; const float* P_prev; int np_prev;
     int B, D, NM, maxT;
     const float *ln_g, *ln_b; float eps;
-    const void* Wmel;         // mel_net [NM][D] (compute dtype)
+    const void* Wmel;         // mel_net [NM][D] (compute dtype; packed when b2s_df_final_packed)
     const float *wstop, *bstop;
     float* mels;              // [B][maxT][NM]
     int *t, *finished, *lengths, *status, *done_cnt;
@@ -69,4 +69,12 @@ int b2s_df_attn(int dtype, bool self, const DfAttn& a, hipStream_t st);
 int b2s_df_ffn(int dtype, const DfFfn& a, hipStream_t st);
 int b2s_df_final(int dtype, const DfFinal& a, hipStream_t st);
 bool b2s_df_supported(int dtype, int D, int H, int F, int NM, int HP, int nmax);
+// bf16 at the default widths: the kernels take their projection weights as MFMA-fragment-packed copies -- for every block of 16 rows
+// and every 32-deep k step the 64 lanes' 16-byte fragments are contiguous, so each load instruction of a wave is one coalesced KB.
+// b2s_df_pack writes such a copy of a row-major [N][K] bf16 matrix (N % 16 == 0, K % 32 == 0; same size).
+bool b2s_df_attn_packed(int dtype, int D, int dh);
+bool b2s_df_ffn_packed(int dtype, int D, int F, int ns);
+bool b2s_df_prenet_packed(int dtype, int HP, int NM);
+bool b2s_df_final_packed(int dtype, int D);
+int b2s_df_pack(const void* W, int N, int K, void* out, hipStream_t st);
 int b2s_df_ffn_slices(int dtype, int F);

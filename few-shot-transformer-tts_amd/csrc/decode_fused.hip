@@ -141,14 +141,19 @@ __device__ __forceinline__ void gemv_lds(const T* __restrict__ W, long ldw, int 
 }
 
 // The same product on the matrix pipe (bf16, compile-time K): out[r][j] = sum_k a[r][k] * W[row(j)][k].  With a handful of rows the
-// VALU version above spends as long on v_dot2c as on the loads; one v_mfma_f32_16x16x32_bf16 takes 16 weight rows x 32 k straight from
-// the loaded registers (lane l holds W[row l&15][k = (l>>4)*8 .. +8]: the 16-byte load IS the A fragment) against the activations of
-// up to 16 utterances (B fragment from LDS, columns >= UB repeat the last row and are never stored), accumulates over K in the
-// accumulator and needs no cross-lane reduction.  A wave owns row blocks wave, wave + 8, ...; a set is JB row blocks x CU k-steps
-// (K = 32 * CU * CPR; CPR = 2: the two halves of a row block's K walk are the two alternating sets), two sets in flight.
+// VALU version above spends as long on v_dot2c as on the loads; one v_mfma_f32_16x16x32_bf16 takes 16 weight rows x 32 k (A fragment:
+// lane l holds W[row l&15][k = (l>>4)*8 .. +8]) against the activations of up to 16 utterances (B fragment from LDS, columns >= UB
+// repeat the last row and are never stored), accumulates over K in the accumulator and needs no cross-lane reduction.
+// The weights come from a FRAGMENT-PACKED copy (b2s_df_pack, made once per decode job): fragment (row block RB, k step ku) is the 1 KB
+// at ((RB * KU + ku) * 64 + lane) * 16 bytes, so a wave's load instruction is one contiguous KB.  Read in place from the [N][K]
+// matrix, the 16 lanes of a k group touch 16 different rows -- 64 separate 16-byte requests per instruction, and the texture path
+// then delivers 16 B/clk/CU (measured: 442 KB per workgroup in 11-12 us) instead of the 50+ it has for coalesced loads.
+// A wave owns row blocks wave, wave + 8, ...; a set is JB row blocks x CU k-steps (K = 32 * CU * CPR; CPR = 2: the two halves of
+// a row block's K walk are the two alternating sets), two sets in flight.
+// Product row block r is packed row block rb0 + (r / blk_rb) * blk_rbstride + r % blk_rb, k steps [ku0, ku0 + CU * CPR) of its KU.
 template <int UB, int CU, int JB, int CPR>
-__device__ __forceinline__ void gemv_mfma(const bf16_t* __restrict__ W, long ldw, int ncols, const bf16_t* a, int lda, float* out, int ldo, int tid,
-                                          int blk_rows = 1 << 30, long blk_stride = 0) {
+__device__ __forceinline__ void gemv_mfma(const bf16_t* __restrict__ Wp, int KU, int rb0, int ku0, int ncols, const bf16_t* a, int lda, float* out, int ldo,
+                                          int tid, int blk_rb, int blk_rbstride) {
     static_assert(CPR == 1 || (CPR == 2 && JB == 1), "a row block's K walk is one set or two");
     constexpr int NW = NT / 64;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -159,11 +164,11 @@ __device__ __forceinline__ void gemv_mfma(const bf16_t* __restrict__ W, long ldw
     auto issue = [&](bf16x8_t (&w)[JB][CU], int i, int kc) {          // row blocks i*JB .. of this wave, K part kc
 #pragma unroll
         for (int q = 0; q < JB; ++q) {
-            const int rb = wave + min(i * JB + q, my_nrb - 1) * NW;
-            const int j = min(rb * 16 + li, ncols - 1), blk = j / blk_rows;
-            const bf16_t* wr = W + ((long)blk * blk_stride + (j - blk * blk_rows)) * ldw + kc * CU * 32 + lg * 8;
+            const int r = wave + min(i * JB + q, my_nrb - 1) * NW, blk = r / blk_rb;
+            const long RB = rb0 + (long)blk * blk_rbstride + (r - blk * blk_rb);
+            const bf16_t* wr = Wp + ((RB * KU + ku0 + kc * CU) * 64 + lane) * 8;
 #pragma unroll
-            for (int u = 0; u < CU; ++u) w[q][u] = *reinterpret_cast<const bf16x8_t*>(wr + u * 32);
+            for (int u = 0; u < CU; ++u) w[q][u] = *reinterpret_cast<const bf16x8_t*>(wr + u * 512);
         }
     };
     f32x4_t acc[JB];
@@ -209,13 +214,16 @@ __device__ __forceinline__ void gemv_mfma(const bf16_t* __restrict__ W, long ldw
     }
 }
 
-// Dispatch: bf16 at the default widths -> matrix pipe; anything else -> the VALU walk (fp32: one set at a time -- it is the parity
-// mode, registers matter more than overlap there).
+// Dispatch: bf16 at the default widths -> matrix pipe, packed weights; anything else -> the VALU walk on the [N][K] matrix (fp32: one
+// set at a time -- it is the parity mode, registers matter more than overlap there).
 template <typename T, bool FAST, int UB, int LPR, int U, int JU, int M_CU, int M_JB, int M_CPR>
-__device__ __forceinline__ void gemv(const T* __restrict__ W, long ldw, int ncols, int K, const T* a, int lda, float* out, int ldo, int tid,
-                                     int blk_rows = 1 << 30, long blk_stride = 0) {
-    if constexpr (FAST && sizeof(T) == 2) gemv_mfma<UB, M_CU, M_JB, M_CPR>(reinterpret_cast<const bf16_t*>(W), ldw, ncols, reinterpret_cast<const bf16_t*>(a), lda, out, ldo, tid, blk_rows, blk_stride);
-    else gemv_lds<T, FAST, UB, LPR, U, JU>(W, ldw, ncols, K, a, lda, out, ldo, tid, blk_rows, blk_stride);
+__device__ __forceinline__ void gemv(const T* __restrict__ W, int ldw, int row0, int col0, int ncols, int K, const T* a, int lda, float* out, int ldo, int tid,
+                                     int blk_rows = 1 << 30, int blk_stride = 0) {
+    // the product uses rows row0 + row(j), columns [col0, col0 + K) of the [*][ldw] matrix W (bf16 at the default widths: its packed copy)
+    if constexpr (FAST && sizeof(T) == 2)
+        gemv_mfma<UB, M_CU, M_JB, M_CPR>(reinterpret_cast<const bf16_t*>(W), ldw / 32, row0 / 16, col0 / 32, ncols, reinterpret_cast<const bf16_t*>(a), lda, out, ldo, tid,
+                                         blk_rows / 16, blk_stride / 16);
+    else gemv_lds<T, FAST, UB, LPR, U, JU>(W + (long)row0 * ldw + col0, ldw, ncols, K, a, lda, out, ldo, tid, blk_rows, blk_stride);
 }
 
 // xs[u][:] = X_in[b_u] + sum_s P_prev[s][b_u]  (fixed order), published to X_out by the slice-0 workgroups; hs[u][:] = T(LayerNorm(xs[u]))
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(NT) void k_df_attn(DfAttn a) {
     const T* Wq = reinterpret_cast<const T*>(a.Wqkv);
     // q (and k, v) of this head: rows [h*dh, (h+1)*dh) of each D-row block of the projection weight; the result is [UB][NQ*dh]
     constexpr int NQ = SELF ? 3 : 1;
-    gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(Wq + (long)h * dh * D, D, NQ * dh, D, hs, D, qf, NQ * dh, tid, dh, D);
+    gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(Wq, D, h * dh, 0, NQ * dh, D, hs, D, qf, NQ * dh, tid, dh, D);
     __syncthreads();
     T* Kc = reinterpret_cast<T*>(a.Kc);
     T* Vc = reinterpret_cast<T*>(a.Vc);
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(NT) void k_df_attn(DfAttn a) {
     }
     __syncthreads();
     // this head's share of the output projection: of[u][n] = sum_d ctx[u][d] * Wo[n][h*dh + d]   (K = dh: every row of a pass set in flight)
-    gemv<T, FAST, UB, 4, DH_STEPS<T, FAST>, 3, FD_DH / 32, 3, 1>(reinterpret_cast<const T*>(a.Wo) + (long)h * dh, D, D, dh, cs, dh, xs, D, tid);
+    gemv<T, FAST, UB, 4, DH_STEPS<T, FAST>, 3, FD_DH / 32, 3, 1>(reinterpret_cast<const T*>(a.Wo), D, 0, h * dh, D, dh, cs, dh, xs, D, tid);
     __syncthreads();
     store_partial<UB>(c, h, b0, xs, t, tid);
 }
@@ -542,17 +550,17 @@ __global__ __launch_bounds__(NT) void k_df_ffn(DfFfn a) {
         __builtin_amdgcn_sched_barrier(0);
         bf16x8_t w1[KS1], w2[RB2W][KS2];
         {
-            const bf16_t* wr = W1 + ((long)sl * FS + min(wave, RB1 - 1) * 16 + li) * D + lg * 8;
+            const bf16_t* wr = W1 + (((long)(sl * RB1 + min(wave, RB1 - 1)) * KS1) * 64 + lane) * 8;      // (packed: see gemv_mfma)
 #pragma unroll
-            for (int u = 0; u < KS1; ++u) w1[u] = *reinterpret_cast<const bf16x8_t*>(wr + u * 32);
+            for (int u = 0; u < KS1; ++u) w1[u] = *reinterpret_cast<const bf16x8_t*>(wr + u * 512);
         }
         __builtin_amdgcn_sched_barrier(0);
         finish_x_ln<T, UB, 8, XIT>(c, b0, sl == 0, xr, xs, hs, red, tid);
 #pragma unroll
         for (int q = 0; q < RB2W; ++q) {                 // (streams in under the first projection and the ReLU)
-            const bf16_t* w2r = W2 + (long)((wave + q * NW) * 16 + li) * a.F + sl * FS + lg * 8;
+            const bf16_t* w2r = W2 + (((long)(wave + q * NW) * (a.F / 32) + sl * KS2) * 64 + lane) * 8;
 #pragma unroll
-            for (int u = 0; u < KS2; ++u) w2[q][u] = *reinterpret_cast<const bf16x8_t*>(w2r + u * 32);
+            for (int u = 0; u < KS2; ++u) w2[q][u] = *reinterpret_cast<const bf16x8_t*>(w2r + u * 512);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (wave < RB1) {
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(NT) void k_df_ffn(DfFfn a) {
         store_partial<UB>(c, sl, b0, xs, t, tid);
     } else {
     load_x_ln<T, UB, FAST ? 8 : 0>(c, b0, sl == 0, xs, hs, red, tid);
-    gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(reinterpret_cast<const T*>(a.W1) + (long)sl * FS * D, D, FS, D, hs, D, ff, FS, tid);
+    gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(reinterpret_cast<const T*>(a.W1), D, sl * FS, 0, FS, D, hs, D, ff, FS, tid);
     __syncthreads();
     const DropCfg dh_ = salted(a.drop_hid, t);
     for (int i = tid; i < UB * FS; i += NT) {
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(NT) void k_df_ffn(DfFfn a) {
         TT<T>::st(fs + i, v);
     }
     __syncthreads();
-    gemv<T, FAST, UB, 8, FS_STEPS<T, FAST>, 3, FD_FS / 32, 3, 1>(reinterpret_cast<const T*>(a.W2) + (long)sl * FS, a.F, D, FS, fs, FS, xs, D, tid);
+    gemv<T, FAST, UB, 8, FS_STEPS<T, FAST>, 3, FD_FS / 32, 3, 1>(reinterpret_cast<const T*>(a.W2), a.F, 0, sl * FS, D, FS, fs, FS, xs, D, tid);
     __syncthreads();
     store_partial<UB>(c, sl, b0, xs, t, tid);
     }
@@ -638,7 +646,7 @@ __global__ __launch_bounds__(NT) void k_df_prenet(DfPrenet a) {
         TT<T>::st(a1 + i, v);
     }
     __syncthreads();
-    gemv<T, FAST, UB, 4, HP_STEPS<T, FAST>, 1, FD_HP / 32, 1, 1>(reinterpret_cast<const T*>(a.W1), HP, HP, HP, a1, HP, o, ldo, tid);
+    gemv<T, FAST, UB, 4, HP_STEPS<T, FAST>, 1, FD_HP / 32, 1, 1>(reinterpret_cast<const T*>(a.W1), HP, 0, 0, HP, HP, a1, HP, o, ldo, tid);
     __syncthreads();
     for (int i = tid; i < UB * HP; i += NT) {
         const int u = i / HP, k = i - u * HP, b = min(b0 + u, a.B - 1);
@@ -647,7 +655,7 @@ __global__ __launch_bounds__(NT) void k_df_prenet(DfPrenet a) {
         TT<T>::st(a2 + i, v);
     }
     __syncthreads();
-    gemv<T, FAST, UB, 4, HP_STEPS<T, FAST>, 1, FD_HP / 32, 1, 1>(reinterpret_cast<const T*>(a.Wf), HP, D, HP, a2, HP, o, ldo, tid);
+    gemv<T, FAST, UB, 4, HP_STEPS<T, FAST>, 1, FD_HP / 32, 1, 1>(reinterpret_cast<const T*>(a.Wf), HP, 0, 0, D, HP, a2, HP, o, ldo, tid);
     __syncthreads();
     DropCfg dx = a.drop_x;
     dx.key ^= b2s_hash32((uint32_t)t + 0x9e3779b9u);
@@ -686,7 +694,7 @@ __global__ __launch_bounds__(NT) void k_df_final(DfFinal a) {
     } else {
         load_x_ln<T, UB, 0>(c, b0, false, xs, hs, red, tid);
     }
-    gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(reinterpret_cast<const T*>(a.Wmel), D, a.NM, D, hs, D, mo, a.NM, tid);
+    gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(reinterpret_cast<const T*>(a.Wmel), D, 0, 0, a.NM, D, hs, D, mo, a.NM, tid);
     const int wave = tid >> 6, lane = tid & 63;
     if (wave < UB) {                           // stop logit: fp32 weights against the compute-dtype activations (ro_rowdot_fwd)
         float s = 0.f;
@@ -728,6 +736,18 @@ __global__ __launch_bounds__(NT) void k_df_final(DfFinal a) {
     }
 }
 
+// W [N][K] (row-major bf16) -> MFMA A-fragment order (gemv_mfma): out[((rb * K/32 + ku) * 64 + l) * 8 + j] = W[rb*16 + (l&15)][ku*32 + (l>>4)*8 + j]
+__global__ __launch_bounds__(256) void k_df_pack(const bf16_t* __restrict__ W, int N, int K, bf16_t* __restrict__ out) {
+    const long nfrag = (long)(N / 16) * (K / 32) * 64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nfrag; i += (long)gridDim.x * 256) {
+        const int l = (int)(i & 63);
+        const long f = i >> 6;
+        const int ku = (int)(f % (K / 32));
+        const long rb = f / (K / 32);
+        *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(W + (rb * 16 + (l & 15)) * K + ku * 32 + (l >> 4) * 8);
+    }
+}
+
 template <typename K, typename A>
 int launch(K kern, int grid, size_t lds, const A& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a);
@@ -764,7 +784,18 @@ bool b2s_df_supported(int dtype, int D, int H, int F, int NM, int HP, int nmax) 
     return D % (8 * ve) == 0 && dh % (4 * ve) == 0 && HP % (4 * ve) == 0 && NM % 16 == 0 &&
            b2s_df_attn_lds(dtype, D, dh, nmax) <= 64 * 1024 && b2s_df_ffn_lds(dtype, D, F, b2s_df_ffn_slices(dtype, F)) <= 64 * 1024;
 }
-// the FAST instantiations serve exactly the default sizes (see the top of the file)
+// the FAST instantiations serve exactly the default sizes (see the top of the file); in bf16 they read fragment-packed weights
+bool b2s_df_attn_packed(int dtype, int D, int dh) { return dtype == 1 && D == FD_D && dh == FD_DH; }
+bool b2s_df_ffn_packed(int dtype, int D, int F, int ns) { return dtype == 1 && D == FD_D && ns > 0 && F / ns == FD_FS; }
+bool b2s_df_prenet_packed(int dtype, int HP, int NM) { return dtype == 1 && HP == FD_HP && NM == FD_NM; }
+bool b2s_df_final_packed(int dtype, int D) { return dtype == 1 && D == FD_D; }
+int b2s_df_pack(const void* W, int N, int K, void* out, hipStream_t st) {
+    B2S_CHECK(W && out && N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "pack: %d x %d (needs multiples of 16 x 32)", N, K);
+    const long nfrag = (long)(N / 16) * (K / 32) * 64;
+    hipLaunchKernelGGL(k_df_pack, dim3((unsigned)std::min<long>((nfrag + 255) / 256, 2048)), dim3(256), 0, st, (const bf16_t*)W, N, K, (bf16_t*)out);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
 int b2s_df_prenet(int dtype, const DfPrenet& a, hipStream_t st) {
     const size_t e = dtype ? 2 : 4;
     constexpr int UB = UBA;
