@@ -9,9 +9,9 @@
 struct DfCommon {
     const float* X_in;        // [B][D] residual stream before the previous sublayer's contribution
     float* X_out;             // [B][D] = X_in + sum(P_prev): written by the slice-0 workgroups for the next kernel
-    const float* P_prev;      // [np_prev][B][D] partial outputs of the previous sublayer (np_prev = 0: none)
+    const void* P_prev;       // [np_prev][B][D] partial outputs of the previous sublayer in the compute dtype (np_prev = 0: none)
     int np_prev;
-    float* P_out;             // [ns][B][D]
+    void* P_out;              // [ns][B][D] compute dtype
     int B, D;
     const float *ln_g, *ln_b; // LayerNorm of this sublayer
     float eps;
@@ -52,7 +52,7 @@ struct DfPrenet {
     DropCfg drop0, drop1, drop_x;
 };
 struct DfFinal {
-    const float* X_in; const float* P_prev; int np_prev;
+    const float* X_in; const void* P_prev; int np_prev;
     int B, D, NM, maxT;
     const float *ln_g, *ln_b; float eps;
     const void* Wmel;         // mel_net [NM][D] (compute dtype; packed when b2s_df_final_packed)

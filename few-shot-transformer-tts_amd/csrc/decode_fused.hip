@@ -226,29 +226,51 @@ __device__ __forceinline__ void gemv(const T* __restrict__ W, int ldw, int row0,
     else gemv_lds<T, FAST, UB, LPR, U, JU>(W + (long)row0 * ldw + col0, ldw, ncols, K, a, lda, out, ldo, tid, blk_rows, blk_stride);
 }
 
+// Partial slabs hold the compute dtype (bf16 mode: half the bytes -- every slab row is read by all slices of the next kernel from
+// another XCD's L2, i.e. through the fabric, and that traffic was as large as the KV stream).  A 16-byte item is CW<T> columns.
+template <typename T> constexpr int CW = 16 / (int)sizeof(T);
+template <typename T> __device__ __forceinline__ void slab_add(const uint4& q, float use, float* v);
+template <> __device__ __forceinline__ void slab_add<float>(const uint4& q, float use, float* v) {
+    v[0] += use * __uint_as_float(q.x); v[1] += use * __uint_as_float(q.y); v[2] += use * __uint_as_float(q.z); v[3] += use * __uint_as_float(q.w);
+}
+template <> __device__ __forceinline__ void slab_add<bf16_t>(const uint4& q, float use, float* v) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] += use * bf2f(w[e] & 0xffff); v[2 * e + 1] += use * bf2f(w[e] >> 16); }
+}
+template <typename T> __device__ __forceinline__ uint4 slab_pack(const float* v);
+template <> __device__ __forceinline__ uint4 slab_pack<float>(const float* v) {
+    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+template <> __device__ __forceinline__ uint4 slab_pack<bf16_t>(const float* v) {
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // xs[u][:] = X_in[b_u] + sum_s P_prev[s][b_u]  (fixed order), published to X_out by the slice-0 workgroups; hs[u][:] = T(LayerNorm(xs[u]))
-template <typename T, int UB, int NPS>          // NPS > 0: np_prev is NPS (or 0) -- all slab loads of a row chunk are issued together
+template <typename T, int UB>
 __device__ __forceinline__ void load_x_ln(const DfCommon& c, int b0, bool publish, float* xs, T* hs, float* red, int tid) {
-    const int D = c.D;
-    for (int i = tid; i < UB * (D >> 2); i += NT) {
-        const int u = i / (D >> 2), c4 = (i - u * (D >> 2)) * 4, b = min(b0 + u, c.B - 1);
-        float4 v = *reinterpret_cast<const float4*>(c.X_in + (long)b * D + c4);
-        if (NPS > 0) {
-            if (c.np_prev > 0) {                                      // (uniform; fixed summation order s = 0, 1, ...)
-                float4 q[NPS > 0 ? NPS : 1];
+    constexpr int W = CW<T>;
+    const int D = c.D, DI = D / W;
+    const T* P = reinterpret_cast<const T*>(c.P_prev);
+    for (int i = tid; i < UB * DI; i += NT) {
+        const int u = i / DI, c0 = (i - u * DI) * W, b = min(b0 + u, c.B - 1);
+        float v[W];
 #pragma unroll
-                for (int s = 0; s < NPS; ++s) q[s] = *reinterpret_cast<const float4*>(c.P_prev + ((long)s * c.B + b) * D + c4);
-#pragma unroll
-                for (int s = 0; s < NPS; ++s) { v.x += q[s].x; v.y += q[s].y; v.z += q[s].z; v.w += q[s].w; }
-            }
-        } else {
-            for (int s = 0; s < c.np_prev; ++s) {
-                const float4 q = *reinterpret_cast<const float4*>(c.P_prev + ((long)s * c.B + b) * D + c4);
-                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-            }
+        for (int h = 0; h < W / 4; ++h) {
+            const float4 x = *reinterpret_cast<const float4*>(c.X_in + (long)b * D + c0 + 4 * h);
+            v[4 * h] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
         }
-        *reinterpret_cast<float4*>(xs + u * D + c4) = v;
-        if (publish && b0 + u < c.B) *reinterpret_cast<float4*>(c.X_out + (long)b * D + c4) = v;
+        for (int s = 0; s < c.np_prev; ++s)                               // (fixed summation order s = 0, 1, ...)
+            slab_add<T>(*reinterpret_cast<const uint4*>(P + ((long)s * c.B + b) * D + c0), 1.f, v);
+#pragma unroll
+        for (int h = 0; h < W / 4; ++h) {
+            const float4 o = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+            *reinterpret_cast<float4*>(xs + u * D + c0 + 4 * h) = o;
+            if (publish && b0 + u < c.B) *reinterpret_cast<float4*>(c.X_out + (long)b * D + c0 + 4 * h) = o;
+        }
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
@@ -270,38 +292,54 @@ __device__ __forceinline__ void load_x_ln(const DfCommon& c, int b0, bool publis
 }
 
 // The same in two steps for the default-size kernels: every load of a workgroup's residual rows and partial slabs is issued at once
-// (XIT iterations x (1 + NPS) 16-byte loads per thread), BEFORE the weight prefetch -- the loads of a wave complete in issue order, and
+// ((1 + NPS) 16-byte slab / row loads per item), BEFORE the weight prefetch -- the loads of a wave complete in issue order, and
 // the LayerNorm that waits for these rows heads the kernel's dependency chain, the weights are needed later.
-template <int UB, int NPS, int XIT>
-struct XRegs { float4 x[XIT]; float4 p[XIT][NPS > 0 ? NPS : 1]; float4 g[XIT], be[XIT]; };
-template <int UB, int NPS, int XIT>
-__device__ __forceinline__ void issue_x(const DfCommon& c, int b0, XRegs<UB, NPS, XIT>& r, int tid) {
-    const int D = c.D, n4 = UB * (D >> 2);
+template <typename T, int UB, int NPS>
+struct XRegs {
+    static constexpr int W = CW<T>, NI = UB * FD_D / W, XIT = (NI + NT - 1) / NT;
+    float4 x[XIT][W / 4], g[XIT][W / 4], be[XIT][W / 4];
+    uint4 p[XIT][NPS > 0 ? NPS : 1];
+};
+template <typename T, int UB, int NPS>
+__device__ __forceinline__ void issue_x(const DfCommon& c, int b0, XRegs<T, UB, NPS>& r, int tid) {
+    using XR = XRegs<T, UB, NPS>;
+    constexpr int W = XR::W, DI = FD_D / W;
+    const T* P = reinterpret_cast<const T*>(c.P_prev);
 #pragma unroll
-    for (int it = 0; it < XIT; ++it) {
-        const int i = min(tid + it * NT, n4 - 1);
-        const int u = i / (D >> 2), c4 = (i - u * (D >> 2)) * 4, b = min(b0 + u, c.B - 1);
-        r.x[it] = *reinterpret_cast<const float4*>(c.X_in + (long)b * D + c4);
-        r.g[it] = *reinterpret_cast<const float4*>(c.ln_g + c4);          // (LayerNorm scale / shift of the same columns: no round trip of their own later)
-        r.be[it] = *reinterpret_cast<const float4*>(c.ln_b + c4);
+    for (int it = 0; it < XR::XIT; ++it) {
+        const int i = min(tid + it * NT, XR::NI - 1);
+        const int u = i / DI, c0 = (i - u * DI) * W, b = min(b0 + u, c.B - 1);
 #pragma unroll
-        for (int s = 0; s < NPS; ++s) r.p[it][s] = *reinterpret_cast<const float4*>(c.P_prev + ((long)min(s, max(c.np_prev, 1) - 1) * c.B + b) * D + c4);
+        for (int h = 0; h < W / 4; ++h) {
+            r.x[it][h] = *reinterpret_cast<const float4*>(c.X_in + (long)b * FD_D + c0 + 4 * h);
+            r.g[it][h] = *reinterpret_cast<const float4*>(c.ln_g + c0 + 4 * h);      // (LayerNorm scale / shift of the same columns: no round trip of their own later)
+            r.be[it][h] = *reinterpret_cast<const float4*>(c.ln_b + c0 + 4 * h);
+        }
+#pragma unroll
+        for (int s = 0; s < NPS; ++s) r.p[it][s] = *reinterpret_cast<const uint4*>(P + ((long)min(s, max(c.np_prev, 1) - 1) * c.B + b) * FD_D + c0);
     }
 }
-template <typename T, int UB, int NPS, int XIT>
-__device__ __forceinline__ void finish_x_ln(const DfCommon& c, int b0, bool publish, const XRegs<UB, NPS, XIT>& r, float* xs, T* hs, float* red, int tid) {
-    const int D = c.D, n4 = UB * (D >> 2);
+template <typename T, int UB, int NPS>
+__device__ __forceinline__ void finish_x_ln(const DfCommon& c, int b0, bool publish, const XRegs<T, UB, NPS>& r, float* xs, T* hs, float* red, int tid) {
+    using XR = XRegs<T, UB, NPS>;
+    constexpr int W = XR::W, D = FD_D, DI = D / W;
     const float use = c.np_prev > 0 ? 1.f : 0.f;         // (first sublayer of a frame: no previous partial outputs; the slab loads re-read slab 0)
 #pragma unroll
-    for (int it = 0; it < XIT; ++it) {
+    for (int it = 0; it < XR::XIT; ++it) {
         const int i = tid + it * NT;
-        if (i >= n4) continue;
-        const int u = i / (D >> 2), c4 = (i - u * (D >> 2)) * 4, b = b0 + u;
-        float4 v = r.x[it];
+        if (i >= XR::NI) continue;
+        const int u = i / DI, c0 = (i - u * DI) * W, b = b0 + u;
+        float v[W];
 #pragma unroll
-        for (int s = 0; s < NPS; ++s) { v.x += use * r.p[it][s].x; v.y += use * r.p[it][s].y; v.z += use * r.p[it][s].z; v.w += use * r.p[it][s].w; }
-        *reinterpret_cast<float4*>(xs + u * D + c4) = v;
-        if (publish && b < c.B) *reinterpret_cast<float4*>(c.X_out + (long)b * D + c4) = v;
+        for (int h = 0; h < W / 4; ++h) { v[4 * h] = r.x[it][h].x; v[4 * h + 1] = r.x[it][h].y; v[4 * h + 2] = r.x[it][h].z; v[4 * h + 3] = r.x[it][h].w; }
+#pragma unroll
+        for (int s = 0; s < NPS; ++s) slab_add<T>(r.p[it][s], use, v);
+#pragma unroll
+        for (int h = 0; h < W / 4; ++h) {
+            const float4 o = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+            *reinterpret_cast<float4*>(xs + u * D + c0 + 4 * h) = o;
+            if (publish && b < c.B) *reinterpret_cast<float4*>(c.X_out + (long)b * D + c0 + 4 * h) = o;
+        }
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
@@ -316,144 +354,178 @@ __device__ __forceinline__ void finish_x_ln(const DfCommon& c, int b0, bool publ
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < XIT; ++it) {
+    for (int it = 0; it < XR::XIT; ++it) {
         const int i = tid + it * NT;
-        if (i >= n4) continue;
-        const int u = i / (D >> 2), c4 = (i - u * (D >> 2)) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(xs + u * D + c4);
+        if (i >= XR::NI) continue;
+        const int u = i / DI, c0 = (i - u * DI) * W;
         const float mu = red[2 * u], rs = red[2 * u + 1];
-        TT<T>::st(hs + u * D + c4 + 0, (v.x - mu) * rs * r.g[it].x + r.be[it].x);
-        TT<T>::st(hs + u * D + c4 + 1, (v.y - mu) * rs * r.g[it].y + r.be[it].y);
-        TT<T>::st(hs + u * D + c4 + 2, (v.z - mu) * rs * r.g[it].z + r.be[it].z);
-        TT<T>::st(hs + u * D + c4 + 3, (v.w - mu) * rs * r.g[it].w + r.be[it].w);
+#pragma unroll
+        for (int h = 0; h < W / 4; ++h) {
+            const float4 v = *reinterpret_cast<const float4*>(xs + u * D + c0 + 4 * h);
+            const float4 g = r.g[it][h], be = r.be[it][h];
+            TT<T>::st(hs + u * D + c0 + 4 * h + 0, (v.x - mu) * rs * g.x + be.x);
+            TT<T>::st(hs + u * D + c0 + 4 * h + 1, (v.y - mu) * rs * g.y + be.y);
+            TT<T>::st(hs + u * D + c0 + 4 * h + 2, (v.z - mu) * rs * g.z + be.z);
+            TT<T>::st(hs + u * D + c0 + 4 * h + 3, (v.w - mu) * rs * g.w + be.w);
+        }
     }
     __syncthreads();
 }
 
-// partial slab: P_out[slice][b_u][:] = dropout(of[u][:])
-template <int UB>
+// partial slab: P_out[slice][b_u][:] = T(dropout(of[u][:]))
+template <typename T, int UB>
 __device__ __forceinline__ void store_partial(const DfCommon& c, int slice, int b0, const float* of, int t, int tid) {
+    constexpr int W = CW<T>;
     const DropCfg d = salted(c.drop_res, t);
-    const int D = c.D;
-    for (int i = tid; i < UB * (D >> 2); i += NT) {
-        const int u = i / (D >> 2), k = (i - u * (D >> 2)) * 4, b = b0 + u;
+    const int D = c.D, DI = D / W;
+    T* P = reinterpret_cast<T*>(c.P_out);
+    for (int i = tid; i < UB * DI; i += NT) {
+        const int u = i / DI, k = (i - u * DI) * W, b = b0 + u;
         if (b >= c.B) continue;
-        float4 v = *reinterpret_cast<const float4*>(of + u * D + k);
+        float v[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[e] = of[u * D + k + e];
         if (d.thresh) {
             const uint32_t idx = (uint32_t)((long)b * D + k);
-            v.x = b2s_keep(d, idx) ? v.x * d.scale : 0.f; v.y = b2s_keep(d, idx + 1) ? v.y * d.scale : 0.f;
-            v.z = b2s_keep(d, idx + 2) ? v.z * d.scale : 0.f; v.w = b2s_keep(d, idx + 3) ? v.w * d.scale : 0.f;
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[e] = b2s_keep(d, idx + e) ? v[e] * d.scale : 0.f;
         }
-        *reinterpret_cast<float4*>(c.P_out + ((long)slice * c.B + b) * D + k) = v;
+        *reinterpret_cast<uint4*>(P + ((long)slice * c.B + b) * D + k) = slab_pack<T>(v);
     }
 }
 
 // Single-query attention of one (utterance, head) by HT threads (one half of the workgroup per utterance; both halves run the same
-// phases, the barriers are workgroup-wide): keys [0, n).  sq: the query (fp32, LDS, dh values);
-// result in ctx (LDS, dh values).  Scores: 4 lanes share one key row; softmax through LDS; weighted V sum with one 16-byte column
-// chunk per thread and a cross-row LDS reduction (the structure of the unfused k_dec_attn, decode.hip).
-template <typename T>
+// phases, the barriers are workgroup-wide): keys [0, n).  sq: the query (fp32 values the compute dtype can hold, LDS); result in ctx
+// (LDS, dh values).  ONE pass over the cache: 4 lanes share a key -- each holds the same 16-byte column chunks of the key row (for
+// the score) and of the value row (for the weighted sum), 64 keys per pass -- and keep a running maximum / denominator / weighted
+// value sum of their key slot (online softmax); the 64 slots are merged once at the end (wave butterfly, then 4 partial rows through
+// LDS).  Two barriers instead of the five of the score -> softmax -> value chain (decode.hip: k_dec_attn), K and V rows of the next
+// keys in flight while the current ones are consumed.  p keeps the raw scores so that the alignment row can be written afterwards,
+// off the path to the output projection.
+template <typename T, bool FAST>
 __device__ __forceinline__ void attend(const float* sq, const T* Kb, const T* Vb, int ldkv, int n, int dh, float scale, float* p, float* part,
                                        float* red, float* prow, DropCfg dc, uint32_t drop_row, float* ctx, int tid) {
     constexpr int VE = DV<T>::VE;
+    constexpr int NCH = FAST ? FD_DH / (4 * VE) : DF_MAX_DH / (4 * VE);        // 16-byte chunks per lane and row
+    constexpr int SU = sizeof(T) == 2 ? 2 : 1;                                 // keys per lane and pass set
     const int lane = tid & 63, wave = tid >> 6;
-    const int CH = dh / VE, R = HT / CH;
     const int part4 = tid & 3, kslot = tid >> 2;
-    const int nch = (CH + 3) / 4;                      // 16-byte chunks per lane
-    const int tx = tid % CH, ty = tid / CH;
-    constexpr int SU = sizeof(T) == 2 ? 4 : 2, NCH_MAX = sizeof(T) == 2 ? 4 : 8;      // head width <= 128
-    constexpr int VU = 8;
+    const int nch = FAST ? NCH : dh / (4 * VE);                                // (dh is a multiple of 4 * VE: b2s_df_supported)
     const int nlast = max(n - 1, 0);
-    uint4 u[SU][NCH_MAX], uv[VU];
-    auto load_k = [&](int j0) {
+    // the query columns of this lane
+    float qv[NCH * VE];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) qv[i * VE + e] = (FAST || i < nch) ? sq[(i * 4 + part4) * VE + e] : 0.f;
+    uint4 kA[SU][NCH], vA[SU][NCH], kB[SU][NCH], vB[SU][NCH];
+    auto load = [&](uint4 (&k)[SU][NCH], uint4 (&v)[SU][NCH], int j0) {        // (rows past the end: the last row again, never used)
 #pragma unroll
         for (int uu = 0; uu < SU; ++uu) {
-            const T* kr = Kb + (long)min(j0 + uu * 64 + kslot, nlast) * ldkv;
+            const long ro = (long)min(j0 + uu * 64 + kslot, nlast) * ldkv + part4 * VE;
 #pragma unroll
-            for (int i = 0; i < NCH_MAX; ++i)
-                if (i < nch && i * 4 + part4 < CH) u[uu][i] = *reinterpret_cast<const uint4*>(kr + (i * 4 + part4) * VE);
+            for (int i = 0; i < NCH; ++i)
+                if (FAST || i < nch) {
+                    k[uu][i] = *reinterpret_cast<const uint4*>(Kb + ro + i * 4 * VE);
+                    v[uu][i] = *reinterpret_cast<const uint4*>(Vb + ro + i * 4 * VE);
+                }
         }
     };
-    auto load_v = [&](int j) {
+    float m = -1e30f, l = 0.f, acc[NCH * VE];
 #pragma unroll
-        for (int v = 0; v < VU; ++v) uv[v] = *reinterpret_cast<const uint4*>(Vb + (long)min(j + v * R, nlast) * ldkv + tx * VE);
-    };
-    load_k(0);
-    if (ty < R) load_v(ty);
-    float mx = -INFINITY;
-    for (int j0 = 0; j0 < n; j0 += 64 * SU) {
-        if (j0 > 0) load_k(j0);
+    for (int i = 0; i < NCH * VE; ++i) acc[i] = 0.f;
+    auto consume = [&](const uint4 (&k)[SU][NCH], const uint4 (&v)[SU][NCH], int j0) {
+        float sc[SU];
 #pragma unroll
         for (int uu = 0; uu < SU; ++uu) {
             const int j = j0 + uu * 64 + kslot;
-            if (j0 + uu * 64 >= n) break;              // (workgroup-uniform)
-            float s = 0.f;
+            float d = 0.f;
 #pragma unroll
-            for (int i = 0; i < NCH_MAX; ++i) {
-                if (i >= nch || i * 4 + part4 >= CH) continue;
-                const int c = (i * 4 + part4) * VE;
+            for (int i = 0; i < NCH; ++i) {
+                if (!(FAST || i < nch)) continue;
                 if (sizeof(T) == 2) {
-                    const uint32_t w[4] = {u[uu][i].x, u[uu][i].y, u[uu][i].z, u[uu][i].w};
+                    const uint32_t w[4] = {k[uu][i].x, k[uu][i].y, k[uu][i].z, k[uu][i].w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { s += sq[c + 2 * e] * bf2f(w[e] & 0xffff) + sq[c + 2 * e + 1] * bf2f(w[e] >> 16); }
+                    for (int e = 0; e < 4; ++e) d += qv[i * VE + 2 * e] * bf2f(w[e] & 0xffff) + qv[i * VE + 2 * e + 1] * bf2f(w[e] >> 16);
                 } else {
-                    const float* f = reinterpret_cast<const float*>(&u[uu][i]);
-                    s += sq[c] * f[0] + sq[c + 1] * f[1] + sq[c + 2] * f[2] + sq[c + 3] * f[3];
+                    const float* f = reinterpret_cast<const float*>(&k[uu][i]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d += qv[i * VE + e] * f[e];
                 }
             }
-            if (j >= n) s = 0.f;
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            if (j < n && part4 == 0) { s *= scale; p[j] = s; mx = fmaxf(mx, s); }
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            sc[uu] = j < n ? d * scale : -1e30f;
+            if (j < n && part4 == 0) p[j] = sc[uu];
         }
+        float mn = m;
+#pragma unroll
+        for (int uu = 0; uu < SU; ++uu) mn = fmaxf(mn, sc[uu]);
+        const float corr = __expf(m - mn);
+        m = mn;
+        l *= corr;
+#pragma unroll
+        for (int i = 0; i < NCH * VE; ++i) acc[i] *= corr;
+#pragma unroll
+        for (int uu = 0; uu < SU; ++uu) {
+            const int j = j0 + uu * 64 + kslot;
+            const float e0 = j < n ? __expf(sc[uu] - m) : 0.f;
+            l += e0;
+            float w = e0;
+            if (dc.thresh) w = b2s_keep(dc, drop_row + (uint32_t)j) ? e0 * dc.scale : 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                if (!(FAST || i < nch)) continue;
+                if (sizeof(T) == 2) {
+                    const uint32_t ww[4] = {v[uu][i].x, v[uu][i].y, v[uu][i].z, v[uu][i].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[i * VE + 2 * e] += w * bf2f(ww[e] & 0xffff); acc[i * VE + 2 * e + 1] += w * bf2f(ww[e] >> 16); }
+                } else {
+                    const float* f = reinterpret_cast<const float*>(&v[uu][i]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i * VE + e] += w * f[e];
+                }
+            }
+        }
+    };
+    constexpr int PASS = 64 * SU;
+    load(kA, vA, 0);
+    for (int j0 = 0; j0 < n; j0 += 2 * PASS) {           // (keys past n contribute exact zeros: no conditions around loads or math)
+        load(kB, vB, j0 + PASS);
+        consume(kA, vA, j0);
+        load(kA, vA, j0 + 2 * PASS);
+        consume(kB, vB, j0 + PASS);
     }
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
+    // merge the 64 key slots: common maximum, then plain sums
+    const float wm = wave_max(m);
+    if (lane == 0) red[wave] = wm;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sum = 0.f;
-    for (int j = tid; j < n; j += HT) { const float e = __expf(p[j] - mx); p[j] = e; sum += e; }
-    sum = wave_sum(sum);
-    if (lane == 0) red[4 + wave] = sum;
+    const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float f = __expf(m - M);
+    l *= f;
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) l += __shfl_xor(l, o, 64);
+#pragma unroll
+    for (int i = 0; i < NCH * VE; ++i) {
+        float a = acc[i] * f;
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+        acc[i] = a;
+    }
+    if (lane < 4) {                                      // (lane = part4 here: key slot 0 of the wave holds the wave's sums)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (FAST || i < nch) {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) part[wave * dh + (i * 4 + part4) * VE + e] = acc[i * VE + e];
+            }
+        if (lane == 0) red[4 + wave] = l;
+    }
     __syncthreads();
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-    for (int j = tid; j < n; j += HT) {
-        float w = p[j] * inv;
-        if (prow) prow[j] = w;
-        if (dc.thresh) w = b2s_keep(dc, drop_row + (uint32_t)j) ? w * dc.scale : 0.f;
-        p[j] = w;
-    }
-    __syncthreads();
-    if (ty < R) {
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        for (int j = ty; j < n; j += R * VU) {
-            if (j > ty) load_v(j);
-#pragma unroll
-            for (int v = 0; v < VU; ++v) {
-                if (j + v * R >= n) break;
-                const float w = p[j + v * R];
-                if (sizeof(T) == 2) {
-                    const uint32_t ww[4] = {uv[v].x, uv[v].y, uv[v].z, uv[v].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { acc[2 * e] += w * bf2f(ww[e] & 0xffff); acc[2 * e + 1] += w * bf2f(ww[e] >> 16); }
-                } else {
-                    const float* f = reinterpret_cast<const float*>(&uv[v]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] += w * f[e];
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < VE; ++e) part[ty * dh + tx * VE + e] = acc[e];
-    }
-    __syncthreads();
-    for (int d = tid; d < dh; d += HT) {
-        float o = 0.f;
-        for (int r = 0; r < R; ++r) o += part[r * dh + d];
-        ctx[d] = o;
-    }
+    for (int d = tid; d < dh; d += HT) ctx[d] = (part[d] + part[dh + d] + part[2 * dh + d] + part[3 * dh + d]) * inv;
+    if (prow)
+        for (int j = tid; j < n; j += HT) prow[j] = __expf(p[j] - M) * inv;
     __syncthreads();
 }
 
@@ -467,22 +539,21 @@ __global__ __launch_bounds__(NT) void k_df_attn(DfAttn a) {
     const DfCommon& c = a.c;
     const int tid = threadIdx.x, D = c.D, dh = a.dh, H = a.H;
     const int h = blockIdx.x % H, b0 = (blockIdx.x / H) * UB, t = *c.t;
-    const int CH = dh / VE, R = HT / CH;
     // LDS carve-up (must match b2s_df_attn_lds)
     float* xs = reinterpret_cast<float*>(lds);                         // [UB][D]   residual rows; later the output projection
     T* hs = reinterpret_cast<T*>(xs + UB * D);                         // [UB][D]   LayerNorm output
     float* qf = reinterpret_cast<float*>(hs + UB * D);                 // [3][UB][dh] q / k / v of this head
     T* cs = reinterpret_cast<T*>(qf + 3 * UB * dh);                    // [UB][dh]  attention context
     float* red0 = reinterpret_cast<float*>(cs + UB * dh);              // [8]       LayerNorm statistics
-    float* scr = red0 + 8;                                             // per utterance: ctx [dh] | p [nmax] | part [R][dh] | red [8]
-    const int scr_n = dh + a.nmax + R * dh + 8;
+    float* scr = red0 + 8;                                             // per utterance: ctx [dh] | p [nmax] | part [4][dh] | red [8]
+    const int scr_n = dh + a.nmax + 4 * dh + 8;
     if constexpr (FAST) {                   // default sizes: every row / slab / LayerNorm-parameter load of the workgroup in one go
-        constexpr int NPS = SELF ? 32 : 8, XIT = (UB * FD_D / 4 + NT - 1) / NT;
-        XRegs<UB, NPS, XIT> xr;
-        issue_x<UB, NPS, XIT>(c, b0, xr, tid);
-        finish_x_ln<T, UB, NPS, XIT>(c, b0, h == 0, xr, xs, hs, red0, tid);
+        constexpr int NPS = SELF ? 32 : 8;
+        XRegs<T, UB, NPS> xr;
+        issue_x<T, UB, NPS>(c, b0, xr, tid);
+        finish_x_ln<T, UB, NPS>(c, b0, h == 0, xr, xs, hs, red0, tid);
     } else {
-        load_x_ln<T, UB, 0>(c, b0, h == 0, xs, hs, red0, tid);
+        load_x_ln<T, UB>(c, b0, h == 0, xs, hs, red0, tid);
     }
     const T* Wq = reinterpret_cast<const T*>(a.Wqkv);
     // q (and k, v) of this head: rows [h*dh, (h+1)*dh) of each D-row block of the projection weight; the result is [UB][NQ*dh]
@@ -512,7 +583,7 @@ __global__ __launch_bounds__(NT) void k_df_attn(DfAttn a) {
         const T* Vb = Vc + (long)b * a.kv_bstride + (long)h * a.kv_hstride;
         float* my = scr + (long)u * scr_n;
         float* prow = (a.probs && b0 + u < c.B) ? a.probs + (((long)b * H + h) * a.probs_rows + t) * a.probs_ld : nullptr;
-        attend<T>(qf + u * NQ * dh, Kb, Vb, a.ldkv, n, dh, a.scale, my + dh, my + dh + a.nmax, my + dh + a.nmax + R * dh, prow, dc,
+        attend<T, FAST>(qf + u * NQ * dh, Kb, Vb, a.ldkv, n, dh, a.scale, my + dh, my + dh + a.nmax, my + dh + a.nmax + 4 * dh, prow, dc,
                   (uint32_t)((b * H + h) * 4096), my, ht);
         for (int d = ht; d < dh; d += HT) TT<T>::st(cs + u * dh + d, my[d]);
     }
@@ -520,7 +591,7 @@ __global__ __launch_bounds__(NT) void k_df_attn(DfAttn a) {
     // this head's share of the output projection: of[u][n] = sum_d ctx[u][d] * Wo[n][h*dh + d]   (K = dh: every row of a pass set in flight)
     gemv<T, FAST, UB, 4, DH_STEPS<T, FAST>, 3, FD_DH / 32, 3, 1>(reinterpret_cast<const T*>(a.Wo), D, 0, h * dh, D, dh, cs, dh, xs, D, tid);
     __syncthreads();
-    store_partial<UB>(c, h, b0, xs, t, tid);
+    store_partial<T, UB>(c, h, b0, xs, t, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ FFN sublayer
@@ -544,9 +615,8 @@ __global__ __launch_bounds__(NT) void k_df_ffn(DfFfn a) {
         const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
         const bf16_t* W1 = reinterpret_cast<const bf16_t*>(a.W1);
         const bf16_t* W2 = reinterpret_cast<const bf16_t*>(a.W2);
-        constexpr int XIT = (UB * FD_D / 4 + NT - 1) / NT;
-        XRegs<UB, 8, XIT> xr;
-        issue_x<UB, 8, XIT>(c, b0, xr, tid);
+        XRegs<T, UB, 8> xr;
+        issue_x<T, UB, 8>(c, b0, xr, tid);
         __builtin_amdgcn_sched_barrier(0);
         bf16x8_t w1[KS1], w2[RB2W][KS2];
         {
@@ -555,7 +625,7 @@ __global__ __launch_bounds__(NT) void k_df_ffn(DfFfn a) {
             for (int u = 0; u < KS1; ++u) w1[u] = *reinterpret_cast<const bf16x8_t*>(wr + u * 512);
         }
         __builtin_amdgcn_sched_barrier(0);
-        finish_x_ln<T, UB, 8, XIT>(c, b0, sl == 0, xr, xs, hs, red, tid);
+        finish_x_ln<T, UB, 8>(c, b0, sl == 0, xr, xs, hs, red, tid);
 #pragma unroll
         for (int q = 0; q < RB2W; ++q) {                 // (streams in under the first projection and the ReLU)
             const bf16_t* w2r = W2 + (((long)(wave + q * NW) * (a.F / 32) + sl * KS2) * 64 + lane) * 8;
@@ -599,9 +669,9 @@ __global__ __launch_bounds__(NT) void k_df_ffn(DfFfn a) {
             }
         }
         __syncthreads();
-        store_partial<UB>(c, sl, b0, xs, t, tid);
+        store_partial<T, UB>(c, sl, b0, xs, t, tid);
     } else {
-    load_x_ln<T, UB, FAST ? 8 : 0>(c, b0, sl == 0, xs, hs, red, tid);
+    load_x_ln<T, UB>(c, b0, sl == 0, xs, hs, red, tid);
     gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(reinterpret_cast<const T*>(a.W1), D, sl * FS, 0, FS, D, hs, D, ff, FS, tid);
     __syncthreads();
     const DropCfg dh_ = salted(a.drop_hid, t);
@@ -614,7 +684,7 @@ __global__ __launch_bounds__(NT) void k_df_ffn(DfFfn a) {
     __syncthreads();
     gemv<T, FAST, UB, 8, FS_STEPS<T, FAST>, 3, FD_FS / 32, 3, 1>(reinterpret_cast<const T*>(a.W2), a.F, 0, sl * FS, D, FS, fs, FS, xs, D, tid);
     __syncthreads();
-    store_partial<UB>(c, sl, b0, xs, t, tid);
+    store_partial<T, UB>(c, sl, b0, xs, t, tid);
     }
 }
 
@@ -687,12 +757,11 @@ __global__ __launch_bounds__(NT) void k_df_final(DfFinal a) {
     c.X_in = a.X_in; c.X_out = nullptr; c.P_prev = a.P_prev; c.np_prev = a.np_prev; c.P_out = nullptr; c.B = a.B; c.D = D;
     c.ln_g = a.ln_g; c.ln_b = a.ln_b; c.eps = a.eps; c.t = a.t; c.drop_res = DropCfg{0, 0, 1.f};
     if constexpr (FAST) {
-        constexpr int XIT = (UB * FD_D / 4 + NT - 1) / NT;
-        XRegs<UB, 32, XIT> xr;
-        issue_x<UB, 32, XIT>(c, b0, xr, tid);
-        finish_x_ln<T, UB, 32, XIT>(c, b0, false, xr, xs, hs, red, tid);
+        XRegs<T, UB, 32> xr;
+        issue_x<T, UB, 32>(c, b0, xr, tid);
+        finish_x_ln<T, UB, 32>(c, b0, false, xr, xs, hs, red, tid);
     } else {
-        load_x_ln<T, UB, 0>(c, b0, false, xs, hs, red, tid);
+        load_x_ln<T, UB>(c, b0, false, xs, hs, red, tid);
     }
     gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(reinterpret_cast<const T*>(a.Wmel), D, 0, 0, a.NM, D, hs, D, mo, a.NM, tid);
     const int wave = tid >> 6, lane = tid & 63;
@@ -758,10 +827,9 @@ int launch(K kern, int grid, size_t lds, const A& a, hipStream_t st) {
 }  // namespace
 
 size_t b2s_df_attn_lds(int dtype, int D, int dh, int nmax) {
-    const size_t e = dtype ? 2 : 4, ve = dtype ? 8 : 4;
-    const size_t R = HT / (dh / ve);
+    const size_t e = dtype ? 2 : 4;
     constexpr size_t UB = UBA;
-    return al16((size_t)UB * D * 4 + UB * D * e + 3 * UB * dh * 4 + UB * dh * e + 8 * 4 + (size_t)UB * (dh + nmax + R * dh + 8) * 4 + 64);
+    return al16((size_t)UB * D * 4 + UB * D * e + 3 * UB * dh * 4 + UB * dh * e + 8 * 4 + (size_t)UB * (dh + nmax + 4 * dh + 8) * 4 + 64);
 }
 size_t b2s_df_ffn_lds(int dtype, int D, int F, int ns) {
     const size_t e = dtype ? 2 : 4, FS = F / ns;
