@@ -284,7 +284,7 @@ void plan_decode(const b2s_model* m, b2s_decode_state& s, Arena& a) {
             }
         if (b2s_df_ffn_packed(m->dtype, D, F, s.ns_ffn))
             for (int l = 0; l < L; ++l) { add(nm2(p, "ffn_layers", l, "input_layer.weight"), F, D); add(nm2(p, "ffn_layers", l, "output_layer.weight"), D, F); }
-        if (b2s_df_prenet_packed(m->dtype, HP, NM)) { add("decoder.prenet.dense1.weight", HP, HP); add("decoder.prenet.dense_final.weight", D, HP); }
+        if (b2s_df_prenet_packed(m->dtype, HP, NM, D)) { add("decoder.prenet.dense1.weight", HP, HP); add("decoder.prenet.dense_final.weight", D, HP); }
         if (b2s_df_final_packed(m->dtype, D)) add("decoder.mel_net.weight", NM, D);
     }
 }

@@ -74,7 +74,7 @@ bool b2s_df_supported(int dtype, int D, int H, int F, int NM, int HP, int nmax);
 // b2s_df_pack writes such a copy of a row-major [N][K] bf16 matrix (N % 16 == 0, K % 32 == 0; same size).
 bool b2s_df_attn_packed(int dtype, int D, int dh);
 bool b2s_df_ffn_packed(int dtype, int D, int F, int ns);
-bool b2s_df_prenet_packed(int dtype, int HP, int NM);
+bool b2s_df_prenet_packed(int dtype, int HP, int NM, int D);
 bool b2s_df_final_packed(int dtype, int D);
 int b2s_df_pack(const void* W, int N, int K, void* out, hipStream_t st);
 int b2s_df_ffn_slices(int dtype, int F);

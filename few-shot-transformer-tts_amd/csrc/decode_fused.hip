@@ -37,6 +37,7 @@ typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
 // join of every conditional block, even a workgroup-uniform one, which serialises the loads).  Generic instantiation: anything up
 // to the maxima below, uniform conditions per step (correct, slower); wider models run the unfused path (b2s_df_supported).
 constexpr int FD_D = 768, FD_DH = 96, FD_FS = 96, FD_HP = 256, FD_NM = 80;
+constexpr int PN_SL = 8;                 // prenet: workgroups per utterance group at the default sizes
 constexpr int DF_MAX_D = 768, DF_MAX_DH = 128, DF_MAX_FS = 256, DF_MAX_HP = 256, DF_MAX_NM = 128;
 template <typename T, bool FAST> constexpr int KD_STEPS = (FAST ? FD_D : DF_MAX_D) / (8 * DV<T>::VE);       // K = D, 8 lanes per row
 template <typename T, bool FAST> constexpr int FS_STEPS = (FAST ? FD_FS : DF_MAX_FS) / (8 * DV<T>::VE);     // K = F / NS, 8 lanes per row
@@ -694,8 +695,11 @@ template <typename T, bool FAST>
 __global__ __launch_bounds__(NT) void k_df_prenet(DfPrenet a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int UB = UBA;
-    const int tid = threadIdx.x, b0 = blockIdx.x * UB, t = *a.t;
-    const int NMp = (a.NM + 31) & ~31, HP = a.HP, D = a.D;
+    // default sizes: PN_SL workgroups per utterance pair, each with 1 / PN_SL of dense_final's rows (48 row blocks on 8 waves were six
+    // dependent round trips on 32 CUs); dense0 / dense1 are recomputed by each of them (172 KB of weights from L2)
+    constexpr int NSL = FAST ? PN_SL : 1;
+    const int tid = threadIdx.x, b0 = (blockIdx.x / NSL) * UB, sl = blockIdx.x % NSL, t = *a.t;
+    const int NMp = (a.NM + 31) & ~31, HP = a.HP, D = a.D, DS = D / NSL;
     T* tg = reinterpret_cast<T*>(lds);                                 // [UB][NMp]
     T* a1 = tg + UB * NMp;                                             // [UB][HP]
     T* a2 = a1 + UB * HP;                                              // [UB][HP]
@@ -725,13 +729,13 @@ __global__ __launch_bounds__(NT) void k_df_prenet(DfPrenet a) {
         TT<T>::st(a2 + i, v);
     }
     __syncthreads();
-    gemv<T, FAST, UB, 4, HP_STEPS<T, FAST>, 1, FD_HP / 32, 1, 1>(reinterpret_cast<const T*>(a.Wf), HP, 0, 0, D, HP, a2, HP, o, ldo, tid);
+    gemv<T, FAST, UB, 4, HP_STEPS<T, FAST>, 1, FD_HP / 32, 1, 1>(reinterpret_cast<const T*>(a.Wf), HP, sl * DS, 0, DS, HP, a2, HP, o + sl * DS, ldo, tid);
     __syncthreads();
     DropCfg dx = a.drop_x;
     dx.key ^= b2s_hash32((uint32_t)t + 0x9e3779b9u);
     const float sc = *a.pe_scale;
-    for (int i = tid; i < UB * D; i += NT) {
-        const int u = i / D, k = i - u * D, b = b0 + u;
+    for (int i = tid; i < UB * DS; i += NT) {
+        const int u = i / DS, k = sl * DS + (i - u * DS), b = b0 + u;
         if (b >= a.B) continue;
         const bool have = t > 0 && (t - 1) < a.lengths[b];
         float v = (have ? o[u * ldo + k] : 0.f) + a.pe[(long)t * D + k] * sc;
@@ -855,7 +859,7 @@ bool b2s_df_supported(int dtype, int D, int H, int F, int NM, int HP, int nmax) 
 // the FAST instantiations serve exactly the default sizes (see the top of the file); in bf16 they read fragment-packed weights
 bool b2s_df_attn_packed(int dtype, int D, int dh) { return dtype == 1 && D == FD_D && dh == FD_DH; }
 bool b2s_df_ffn_packed(int dtype, int D, int F, int ns) { return dtype == 1 && D == FD_D && ns > 0 && F / ns == FD_FS; }
-bool b2s_df_prenet_packed(int dtype, int HP, int NM) { return dtype == 1 && HP == FD_HP && NM == FD_NM; }
+bool b2s_df_prenet_packed(int dtype, int HP, int NM, int D) { return dtype == 1 && HP == FD_HP && NM == FD_NM && D == FD_D; }
 bool b2s_df_final_packed(int dtype, int D) { return dtype == 1 && D == FD_D; }
 int b2s_df_pack(const void* W, int N, int K, void* out, hipStream_t st) {
     B2S_CHECK(W && out && N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "pack: %d x %d (needs multiples of 16 x 32)", N, K);
@@ -868,8 +872,8 @@ int b2s_df_prenet(int dtype, const DfPrenet& a, hipStream_t st) {
     const size_t e = dtype ? 2 : 4;
     constexpr int UB = UBA;
     const size_t lds = al16((size_t)UB * ((a.NM + 31) & ~31) * e + 2 * UB * a.HP * e + (size_t)UB * std::max(a.HP, a.D) * 4 + 64);
-    const int grid = (a.B + UB - 1) / UB;
-    const bool fast = a.HP == FD_HP && a.NM == FD_NM;
+    const bool fast = a.HP == FD_HP && a.NM == FD_NM && a.D == FD_D;
+    const int grid = (a.B + UB - 1) / UB * (fast ? PN_SL : 1);
     if (dtype) return fast ? launch(k_df_prenet<bf16_t, true>, grid, lds, a, st) : launch(k_df_prenet<bf16_t, false>, grid, lds, a, st);
     return fast ? launch(k_df_prenet<float, true>, grid, lds, a, st) : launch(k_df_prenet<float, false>, grid, lds, a, st);
 }
