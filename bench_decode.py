@@ -89,6 +89,16 @@ def run_decode(args, rank, world, device):
         step_ms = elapsed / reps / frames * 1e3
         avg_bytes = float(np.mean([decode_bytes_per_step(B, S, t, e) for t in range(frames)]))
         ach = avg_bytes / (step_ms * 1e-3) / 1e9
+        # HBM-side bytes per frame from the committed PMC run (tools/gpu_pmc_decode.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate passes),
+        # summed over the frame's kernels
+        traffic = None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_decode_bf16_pmc_hbm_traffic.json")
+        if os.path.exists(pmc) and args.dtype == "bf16":
+            rows = [r for r in json.load(open(pmc)) if r["kernel"].startswith("k_df_")]
+            nfr = sum(r["launches"] for r in rows if r["kernel"].startswith("k_df_final"))
+            if nfr:
+                traffic = round(sum(r["launches"] * (r["fetch_MB_per_launch_corrected_x2"] + (r["WRITE_SIZE_KB_per_launch"] or 0) / 1024)
+                                    for r in rows) / nfr * 1024 * 1024)
         out = {"metric": "autoregressive decode mel-frames/sec (encoder + KV-cached hipGraph frame loop + postnet)",
                "value": round(world * total / elapsed, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": reps * frames,
                "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak",
@@ -97,7 +107,8 @@ def run_decode(args, rank, world, device):
                                       % (B, frames, S), "parallelism": "replicas x%d" % world},
                "value_incl_host_copy": round(B * frames / host_elapsed, 1),
                "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_step_avg": avg_bytes,
+                            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per frame (HBM side, PMC)",
+                            "bytes_per_step_avg": avg_bytes,
                             "note": "algorithmic bytes per frame step (weights + KV) / wall time per frame incl. encoder and postnet; results "
                                     "(mels, lengths, alignments) complete in HBM -- value_incl_host_copy adds the reference's NumPy return (PCIe)"}}
         if world == 1 and not args.no_cpu_baseline:
