@@ -220,12 +220,14 @@ def test_attention_dense_bias_matches_mask():
     assert torch.equal(a, b) and torch.equal(pa, pb)
 
 
+@pytest.mark.parametrize("Lk", [140, 131])
 @pytest.mark.parametrize("dtype", [0, 1])
-def test_fused_attention_matches_materialised_with_dropout(dtype):
-    """Same seed -> the fused kernels and the GEMM+softmax path draw the same dropout mask: outputs and gradients agree."""
+def test_fused_attention_matches_materialised_with_dropout(dtype, Lk):
+    """Same seed -> the fused kernels and the GEMM+softmax path draw the same dropout mask: outputs and gradients agree.
+    (Even and odd key counts: the row stride of the mask index.)"""
     ops, lib = _ops()
     g = torch.Generator().manual_seed(17)
-    B_, H, dh, Lq, Lk = 2, 2, 96, 75, 140
+    B_, H, dh, Lq = 2, 2, 96, 75
     C = H * dh
     q = torch.randn(B_, Lq, C, generator=g); k = torch.randn(B_, Lk, C, generator=g); v = torch.randn(B_, Lk, C, generator=g)
     go = torch.randn(B_, Lq, C, generator=g)
@@ -240,6 +242,25 @@ def test_fused_attention_matches_materialised_with_dropout(dtype):
     tol = 1e-4 if not dtype else 3e-2
     for a, b, name in zip(res[0], res[1], ("out", "dq", "dk", "dv")):
         assert relerr(a, b) < tol, report("fused vs materialised " + name, a, b)
+
+
+@pytest.mark.parametrize("N", [96, 100, 72])
+def test_gemm_epilogue_dropout_equals_exported_mask(N):
+    """The GEMM epilogue's dropout mask (eight elements per lane and pass) is the one the exported mask op reports element by element.
+    C = A B^T with every product equal to 1 shows the mask directly."""
+    ops, lib = _ops()
+    l = lib.load()
+    M, K, p, seed = 300, 64, 0.25, 99
+    for dtype in (0, 1):
+        A = ops.to_compute(torch.full((M, K), 1.0 / K, device=DEV), dtype)
+        Bm = ops.to_compute(torch.ones(N, K, device=DEV), dtype)
+        C = ops.gemm(dtype, A, Bm, M, N, K, trans_b=False, drop_p=p, seed=seed)
+        m = torch.empty(M * N, dtype=torch.uint8, device=DEV)
+        lib.check(l.b2s_dropout_mask(p, seed, 7, lib.ptr(m), M * N, lib.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal((C.reshape(-1) > 0.5).to(torch.uint8), m), (dtype, N)
+        kept = C.reshape(-1)[m.bool()]
+        assert torch.allclose(kept, torch.full_like(kept, 1.0 / (1 - p)), rtol=1e-2)
 
 
 def test_dropout_rng_statistics():
