@@ -24,11 +24,13 @@ template <typename T> struct DV;
 template <> struct DV<float>  { static constexpr int VE = 4; };
 template <> struct DV<bf16_t> { static constexpr int VE = 8; };
 
-constexpr int UBA = 2;                   // utterances per workgroup: attention sublayers, prenet, heads
+constexpr int UBA = 2;                   // utterances per workgroup: attention sublayers (4: the projections take as long -- they are bound per
+                                         // CU, not by the L2 -- and the attention over the cache gets slower: 0.49 -> 0.56 ms per frame)
+constexpr int UBH = 2;                   //                           prenet, heads
 constexpr int UBF = 8;                   //                           FFN sublayer (twice the slices: every group re-reads a slice's weights
                                          //                           from L2, and that L2 -> CU traffic is what bounds the FFN kernel)
-constexpr int HT = 256;                  // threads that work on one utterance's attention
-constexpr int NT = UBA * HT;             // threads per workgroup (8 waves: 256 VGPRs each, enough to keep a whole K walk of loads in flight)
+constexpr int NT = 512;                  // threads per workgroup (8 waves: 256 VGPRs each, enough to keep a whole K walk of loads in flight)
+constexpr int HT = NT / UBA;             // threads that work on one utterance's attention
 
 typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
 
@@ -410,6 +412,7 @@ __device__ __forceinline__ void attend(const float* sq, const T* Kb, const T* Vb
     constexpr int NCH = FAST ? FD_DH / (4 * VE) : DF_MAX_DH / (4 * VE);        // 16-byte chunks per lane and row
     constexpr int SU = sizeof(T) == 2 ? 2 : 1;                                 // keys per lane and pass set
     const int lane = tid & 63, wave = tid >> 6;
+    constexpr int SL = HT / 4, NWU = HT / 64;                                  // key slots per pass, waves per utterance
     const int part4 = tid & 3, kslot = tid >> 2;
     const int nch = FAST ? NCH : dh / (4 * VE);                                // (dh is a multiple of 4 * VE: b2s_df_supported)
     const int nlast = max(n - 1, 0);
@@ -423,7 +426,7 @@ __device__ __forceinline__ void attend(const float* sq, const T* Kb, const T* Vb
     auto load = [&](uint4 (&k)[SU][NCH], uint4 (&v)[SU][NCH], int j0) {        // (rows past the end: the last row again, never used)
 #pragma unroll
         for (int uu = 0; uu < SU; ++uu) {
-            const long ro = (long)min(j0 + uu * 64 + kslot, nlast) * ldkv + part4 * VE;
+            const long ro = (long)min(j0 + uu * SL + kslot, nlast) * ldkv + part4 * VE;
 #pragma unroll
             for (int i = 0; i < NCH; ++i)
                 if (FAST || i < nch) {
@@ -439,7 +442,7 @@ __device__ __forceinline__ void attend(const float* sq, const T* Kb, const T* Vb
         float sc[SU];
 #pragma unroll
         for (int uu = 0; uu < SU; ++uu) {
-            const int j = j0 + uu * 64 + kslot;
+            const int j = j0 + uu * SL + kslot;
             float d = 0.f;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
@@ -469,7 +472,7 @@ __device__ __forceinline__ void attend(const float* sq, const T* Kb, const T* Vb
         for (int i = 0; i < NCH * VE; ++i) acc[i] *= corr;
 #pragma unroll
         for (int uu = 0; uu < SU; ++uu) {
-            const int j = j0 + uu * 64 + kslot;
+            const int j = j0 + uu * SL + kslot;
             const float e0 = j < n ? __expf(sc[uu] - m) : 0.f;
             l += e0;
             float w = e0;
@@ -489,7 +492,7 @@ __device__ __forceinline__ void attend(const float* sq, const T* Kb, const T* Vb
             }
         }
     };
-    constexpr int PASS = 64 * SU;
+    constexpr int PASS = SL * SU;
     load(kA, vA, 0);
     for (int j0 = 0; j0 < n; j0 += 2 * PASS) {           // (keys past n contribute exact zeros: no conditions around loads or math)
         load(kB, vB, j0 + PASS);
@@ -497,11 +500,13 @@ __device__ __forceinline__ void attend(const float* sq, const T* Kb, const T* Vb
         load(kA, vA, j0 + 2 * PASS);
         consume(kB, vB, j0 + PASS);
     }
-    // merge the 64 key slots: common maximum, then plain sums
+    // merge the key slots: common maximum, then plain sums
     const float wm = wave_max(m);
     if (lane == 0) red[wave] = wm;
     __syncthreads();
-    const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float M = red[0];
+#pragma unroll
+    for (int w = 1; w < NWU; ++w) M = fmaxf(M, red[w]);
     const float f = __expf(m - M);
     l *= f;
 #pragma unroll
@@ -523,8 +528,16 @@ __device__ __forceinline__ void attend(const float* sq, const T* Kb, const T* Vb
         if (lane == 0) red[4 + wave] = l;
     }
     __syncthreads();
-    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-    for (int d = tid; d < dh; d += HT) ctx[d] = (part[d] + part[dh + d] + part[2 * dh + d] + part[3 * dh + d]) * inv;
+    float lsum = red[4];
+#pragma unroll
+    for (int w = 1; w < NWU; ++w) lsum += red[4 + w];
+    const float inv = 1.f / lsum;
+    for (int d = tid; d < dh; d += HT) {
+        float o = part[d];
+#pragma unroll
+        for (int w = 1; w < NWU; ++w) o += part[w * dh + d];
+        ctx[d] = o * inv;
+    }
     if (prow)
         for (int j = tid; j < n; j += HT) prow[j] = __expf(p[j] - M) * inv;
     __syncthreads();
@@ -694,7 +707,7 @@ __global__ __launch_bounds__(NT) void k_df_ffn(DfFfn a) {
 template <typename T, bool FAST>
 __global__ __launch_bounds__(NT) void k_df_prenet(DfPrenet a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int UB = UBA;
+    constexpr int UB = UBH;
     // default sizes: PN_SL workgroups per utterance pair, each with 1 / PN_SL of dense_final's rows (48 row blocks on 8 waves were six
     // dependent round trips on 32 CUs); dense0 / dense1 are recomputed by each of them (172 KB of weights from L2)
     constexpr int NSL = FAST ? PN_SL : 1;
@@ -751,7 +764,7 @@ template <typename T, bool FAST>
 __global__ __launch_bounds__(NT) void k_df_final(DfFinal a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ int last;
-    constexpr int UB = UBA;
+    constexpr int UB = UBH;
     const int tid = threadIdx.x, D = a.D, b0 = blockIdx.x * UB, t = *a.t;
     float* xs = reinterpret_cast<float*>(lds);                         // [UB][D]
     T* hs = reinterpret_cast<T*>(xs + UB * D);                         // [UB][D]
@@ -870,7 +883,7 @@ int b2s_df_pack(const void* W, int N, int K, void* out, hipStream_t st) {
 }
 int b2s_df_prenet(int dtype, const DfPrenet& a, hipStream_t st) {
     const size_t e = dtype ? 2 : 4;
-    constexpr int UB = UBA;
+    constexpr int UB = UBH;
     const size_t lds = al16((size_t)UB * ((a.NM + 31) & ~31) * e + 2 * UB * a.HP * e + (size_t)UB * std::max(a.HP, a.D) * 4 + 64);
     const bool fast = a.HP == FD_HP && a.NM == FD_NM && a.D == FD_D;
     const int grid = (a.B + UB - 1) / UB * (fast ? PN_SL : 1);
@@ -897,7 +910,7 @@ int b2s_df_ffn(int dtype, const DfFfn& a, hipStream_t st) {
 }
 int b2s_df_final(int dtype, const DfFinal& a, hipStream_t st) {
     const size_t e = dtype ? 2 : 4;
-    constexpr int UB = UBA;
+    constexpr int UB = UBH;
     const size_t lds = al16((size_t)UB * a.D * 4 + UB * a.D * e + (size_t)UB * a.NM * 4 + (8 + UB) * 4 + 64);
     const int grid = (a.B + UB - 1) / UB;
     const bool fast = a.D == FD_D;
