@@ -217,6 +217,44 @@ __device__ __forceinline__ void gemv_mfma(const bf16_t* __restrict__ Wp, int KU,
     }
 }
 
+// The q / k / v projection of a head (K = D in two halves): the work is cut into (row block, K half) units, unit id = wave + 8 i, so an even
+// wave always takes first halves and an odd wave second halves, of row blocks (wave >> 1) + 4 i.  18 row blocks are 36 units = 5 / 5 / 5
+// / 5 / 4 / 4 / 4 / 4 per wave (whole row blocks: 3 / 3 / 2 / ... -- the kernel waited for two waves); the two K halves of a row block
+// land in out and out + half_stride and the consumer adds them.  NU (units per wave, rounded up) is compile-time and every wave issues
+// NU loads sets -- a wave with fewer units re-reads its last one -- so there is no control flow around the loads; NBUF sets in flight.
+template <int UB, int CU, int NU, int NBUF>
+__device__ __forceinline__ void gemv_mfma_halves(const bf16_t* __restrict__ Wp, int KU, int rb0, int nrb, const bf16_t* a, int lda, float* out, int ldo,
+                                                 int half_stride, int tid, int blk_rb, int blk_rbstride) {
+    static_assert(NBUF >= 2 && NBUF <= NU + 1, "buffers");
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int kc = wave & 1, r0 = wave >> 1;
+    const int my_n = r0 < nrb ? (nrb - r0 + 3) / 4 : 0;                   // units of this wave
+    const bf16_t* arow = a + min(li, UB - 1) * lda + kc * CU * 32 + lg * 8;
+    bf16x8_t w[NBUF][CU];
+    auto issue = [&](bf16x8_t (&wb)[CU], int i) {
+        const int r = r0 + 4 * min(i, max(my_n, 1) - 1), blk = min(r, nrb - 1) / blk_rb;
+        const long RB = rb0 + (long)blk * blk_rbstride + (min(r, nrb - 1) - blk * blk_rb);
+        const bf16_t* wr = Wp + ((RB * KU + kc * CU) * 64 + lane) * 8;
+#pragma unroll
+        for (int u = 0; u < CU; ++u) wb[u] = *reinterpret_cast<const bf16x8_t*>(wr + u * 512);
+    };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) issue(w[i], i);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        if (i + NBUF - 1 < NU) issue(w[(i + NBUF - 1) % NBUF], i + NBUF - 1);        // (compile-time condition)
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < CU; ++u)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i % NBUF][u], *reinterpret_cast<const bf16x8_t*>(arow + u * 32), acc, 0, 0, 0);
+        if (i < my_n && li < UB) {                                        // D layout: row (= weight row) (lane>>4)*4 + r, column (= utterance) lane & 15
+            float* o = out + kc * half_stride + li * ldo + (r0 + 4 * i) * 16 + lg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = acc[r];
+        }
+    }
+}
+
 // Dispatch: bf16 at the default widths -> matrix pipe, packed weights; anything else -> the VALU walk on the [N][K] matrix (fp32: one
 // set at a time -- it is the parity mode, registers matter more than overlap there).
 template <typename T, bool FAST, int UB, int LPR, int U, int JU, int M_CU, int M_JB, int M_CPR>
@@ -546,6 +584,9 @@ __device__ __forceinline__ void attend(const float* sq, const T* Kb, const T* Vb
 inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // ------------------------------------------------------------------------------------------------ attention sublayer
+typedef __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 template <typename T, bool SELF, bool FAST>
 __global__ __launch_bounds__(NT) void k_df_attn(DfAttn a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -556,34 +597,61 @@ __global__ __launch_bounds__(NT) void k_df_attn(DfAttn a) {
     // LDS carve-up (must match b2s_df_attn_lds)
     float* xs = reinterpret_cast<float*>(lds);                         // [UB][D]   residual rows; later the output projection
     T* hs = reinterpret_cast<T*>(xs + UB * D);                         // [UB][D]   LayerNorm output
-    float* qf = reinterpret_cast<float*>(hs + UB * D);                 // [3][UB][dh] q / k / v of this head
-    T* cs = reinterpret_cast<T*>(qf + 3 * UB * dh);                    // [UB][dh]  attention context
+    float* qf = reinterpret_cast<float*>(hs + UB * D);                 // [2][UB][3 dh] q / k / v of this head (bf16 default sizes: the two K halves)
+    T* cs = reinterpret_cast<T*>(qf + 2 * 3 * UB * dh);                // [UB][dh]  attention context
     float* red0 = reinterpret_cast<float*>(cs + UB * dh);              // [8]       LayerNorm statistics
     float* scr = red0 + 8;                                             // per utterance: ctx [dh] | p [nmax] | part [4][dh] | red [8]
     const int scr_n = dh + a.nmax + 4 * dh + 8;
+    const T* Wq = reinterpret_cast<const T*>(a.Wqkv);
+    constexpr int NQ = SELF ? 3 : 1;
     if constexpr (FAST) {                   // default sizes: every row / slab / LayerNorm-parameter load of the workgroup in one go
         constexpr int NPS = SELF ? 32 : 8;
         XRegs<T, UB, NPS> xr;
         issue_x<T, UB, NPS>(c, b0, xr, tid);
+        if constexpr (sizeof(T) == 2) {
+            // L2 warm-up of this head's weight slice (q / k / v rows + output-projection columns, 590 KB packed): the previous kernels'
+            // KV streams have evicted it, and the projection below would otherwise be a chain of cold-miss round trips (each of its
+            // load sets waited ~2 us for the fabric).  Every workgroup of the head touches its share of the slice's 128-byte lines
+            // once -- 4-byte LDS-DMA loads into a scratch area nobody reads (no destination registers to keep) -- while LayerNorm runs.
+            constexpr int KU = FD_D / 32, RBH = FD_DH / 16;
+            constexpr int LQ = RBH * KU * 8;                           // lines per q / k / v part: RBH row blocks x KU k steps x 1 KB
+            constexpr int LO = (FD_D / 16) * (FD_DH / 32) * 8;         // output projection: FD_D / 16 row blocks x 3 k steps x 1 KB
+            constexpr int TOT = NQ * LQ + LO;
+            const int g = blockIdx.x / H, ng = max((int)gridDim.x / H, 1), share = (TOT + ng - 1) / ng;
+            const char* wq_b = reinterpret_cast<const char*>(Wq);
+            const char* wo_b = reinterpret_cast<const char*>(a.Wo);
+            for (int i = tid; i < share; i += NT) {
+                const int L = min(g * share + i, TOT - 1);
+                const int part = L / LQ, off = L - part * LQ, Lo = L - NQ * LQ, rbk = Lo / (LO / (FD_D / 16)), o = Lo - rbk * (LO / (FD_D / 16));
+                const char* pq = wq_b + ((long)(part * (FD_D / 16) + h * RBH) * KU) * 1024 + (long)off * 128;
+                const char* po = wo_b + ((long)rbk * KU + h * (FD_DH / 32)) * 1024 + (long)o * 128;
+                __builtin_amdgcn_global_load_lds((gptr_t)(L < NQ * LQ ? pq : po), (lptr_t)(reinterpret_cast<char*>(scr) + (tid >> 6) * 256), 4, 0, 0);
+            }
+        }
         finish_x_ln<T, UB, NPS>(c, b0, h == 0, xr, xs, hs, red0, tid);
     } else {
         load_x_ln<T, UB>(c, b0, h == 0, xs, hs, red0, tid);
     }
-    const T* Wq = reinterpret_cast<const T*>(a.Wqkv);
     // q (and k, v) of this head: rows [h*dh, (h+1)*dh) of each D-row block of the projection weight; the result is [UB][NQ*dh]
-    constexpr int NQ = SELF ? 3 : 1;
-    gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(Wq, D, h * dh, 0, NQ * dh, D, hs, D, qf, NQ * dh, tid, dh, D);
+    constexpr bool HALVES = FAST && sizeof(T) == 2;                    // the projection arrives as two partial sums (gemv_mfma_halves)
+    if constexpr (HALVES)
+        gemv_mfma_halves<UB, FD_D / 64, (2 * NQ * FD_DH / 16 + 7) / 8, 3>(reinterpret_cast<const bf16_t*>(Wq), FD_D / 32, h * FD_DH / 16, NQ * FD_DH / 16,
+                                                                        reinterpret_cast<const bf16_t*>(hs), FD_D, qf, NQ * FD_DH, 3 * UB * FD_DH, tid,
+                                                                        FD_DH / 16, FD_D / 16);
+    else
+        gemv<T, FAST, UB, 8, KD_STEPS<T, FAST>, 1, FD_D / 64, 1, 2>(Wq, D, h * dh, 0, NQ * dh, D, hs, D, qf, NQ * dh, tid, dh, D);
     __syncthreads();
     T* Kc = reinterpret_cast<T*>(a.Kc);
     T* Vc = reinterpret_cast<T*>(a.Vc);
     for (int i = tid; i < UB * dh; i += NT) {
         const int u = i / dh, d = i - u * dh, b = b0 + u;
         float* row = qf + u * NQ * dh;
-        row[d] = rnd<T>(row[d]);                                       // the query as the compute dtype holds it
+        const float* row2 = row + 3 * UB * dh;
+        row[d] = rnd<T>(HALVES ? row[d] + row2[d] : row[d]);           // the query as the compute dtype holds it
         if (SELF && b < c.B) {                                          // this frame's key / value row goes to the caches at position t
             const long o = (long)b * a.kv_bstride + (long)h * a.kv_hstride + (long)t * a.ldkv + d;
-            TT<T>::st(Kc + o, row[dh + d]);
-            TT<T>::st(Vc + o, row[2 * dh + d]);
+            TT<T>::st(Kc + o, HALVES ? row[dh + d] + row2[dh + d] : row[dh + d]);
+            TT<T>::st(Vc + o, HALVES ? row[2 * dh + d] + row2[2 * dh + d] : row[2 * dh + d]);
         }
     }
     __syncthreads();                                                   // (workgroup scope: the cache rows just written are visible to the loads below)
@@ -846,7 +914,7 @@ int launch(K kern, int grid, size_t lds, const A& a, hipStream_t st) {
 size_t b2s_df_attn_lds(int dtype, int D, int dh, int nmax) {
     const size_t e = dtype ? 2 : 4;
     constexpr size_t UB = UBA;
-    return al16((size_t)UB * D * 4 + UB * D * e + 3 * UB * dh * 4 + UB * dh * e + 8 * 4 + (size_t)UB * (dh + nmax + 4 * dh + 8) * 4 + 64);
+    return al16((size_t)UB * D * 4 + UB * D * e + 2 * 3 * UB * dh * 4 + UB * dh * e + 8 * 4 + (size_t)UB * (dh + nmax + 4 * dh + 8) * 4 + 64);
 }
 size_t b2s_df_ffn_lds(int dtype, int D, int F, int ns) {
     const size_t e = dtype ? 2 : 4, FS = F / ns;
