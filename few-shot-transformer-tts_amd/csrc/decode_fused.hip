@@ -586,6 +586,18 @@ inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 // ------------------------------------------------------------------------------------------------ attention sublayer
 typedef __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+// L2 warm-up of [base, base + bytes): workgroup `my` of the `n` that run on the same XCD touches its share of the 128-byte lines once
+// (4-byte LDS-DMA loads: no destination registers to keep alive; scratch: 2 KB of LDS whose next write comes after a workgroup
+// barrier -- the compiler does not order a later ds_write behind the DMA, the barrier's vmcnt(0) does).  The
+// weights a frame's kernels use were evicted by the KV streams since the last frame: without this every dependent projection of a
+// kernel starts with a cold-miss round trip (~2 us).
+__device__ __forceinline__ void l2_warm(const void* base, long bytes, int my, int n, void* scratch, int tid) {
+    const int lines = (int)((bytes + 127) >> 7), share = (lines + n - 1) / max(n, 1);
+    for (int i = tid; i < share; i += NT) {
+        const int L = min(my * share + i, lines - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(base) + (long)L * 128), (lptr_t)(reinterpret_cast<char*>(scratch) + (tid >> 6) * 256), 4, 0, 0);
+    }
+}
 
 template <typename T, bool SELF, bool FAST>
 __global__ __launch_bounds__(NT) void k_df_attn(DfAttn a) {
@@ -786,6 +798,12 @@ __global__ __launch_bounds__(NT) void k_df_prenet(DfPrenet a) {
     T* a2 = a1 + UB * HP;                                              // [UB][HP]
     float* o = reinterpret_cast<float*>(a2 + UB * HP);                 // [UB][max(HP, D)]
     const int ldo = max(HP, D);
+    if constexpr (FAST && sizeof(T) == 2) {            // (slice = blockIdx % 8 = XCD: the workgroups of a slice share one L2)
+        const int my = blockIdx.x / NSL, n = gridDim.x / NSL;
+        l2_warm(a.W0, (long)FD_HP * FD_NM * 2, my, n, o, tid);
+        l2_warm(a.W1, (long)FD_HP * FD_HP * 2, my, n, o, tid);
+        l2_warm(reinterpret_cast<const char*>(a.Wf) + (long)sl * (FD_D / NSL) * FD_HP * 2, (long)(FD_D / NSL) * FD_HP * 2, my, n, o, tid);
+    }
     for (int i = tid; i < UB * NMp; i += NT) {
         const int u = i / NMp, k = i - u * NMp, b = min(b0 + u, a.B - 1);
         TT<T>::st(tg + i, (t > 0 && k < a.NM) ? a.mels[((long)b * a.maxT + (t - 1)) * a.NM + k] : 0.f);
