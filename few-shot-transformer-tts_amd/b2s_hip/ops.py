@@ -128,6 +128,16 @@ class LayerNormFn(torch.autograd.Function):
         return dx.reshape(ctx.shape), dg, db, None, None
 
 
+def dropout_mask(shape, p, seed, op_id, device):
+    """fp32 tensor of 0 / 1/(1-p) drawn from the engine's counter RNG (b2s_dropout_mask: the generator the kernels use)."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    m = torch.empty(n, dtype=torch.uint8, device=device)
+    L.check(L.load().b2s_dropout_mask(float(p), int(seed), int(op_id), L.ptr(m), n, L.stream()))
+    return m.reshape(shape).to(torch.float32) * (1.0 / (1.0 - p))
+
+
 def layernorm(x, weight, bias, eps=1e-6, dtype=0):
     return LayerNormFn.apply(x, weight, bias, eps, dtype)
 

@@ -1,6 +1,8 @@
 """Transformer encoder/decoder stacks with the reference's module surface and state_dict layout
-(transformer/modules.py:1-145).  The stacks execute inside libb2s_hip (csrc/engine.hip); these classes
-hold the parameters under the reference's names and dispatch to the engine of the owning Tacotron."""
+(transformer/modules.py:1-145).  Inside Tacotron the stacks execute as fused segments of libb2s_hip (csrc/engine.hip) and
+these classes only hold the parameters under the reference's names.  Called on their own (`stack(inputs, lengths)`), they run
+the reference's layer sequence through the op-level HIP kernels (LayerNorm, GEMM, fused attention) with torch doing the
+element-wise glue between them -- a convenience path for inspection and unit use, not the benchmarked one."""
 import torch
 from torch import nn
 
@@ -33,17 +35,21 @@ class FFNLayer(nn.Module):
         self.compute_dtype = compute_dtype
 
     def forward(self, inputs):
-        """Linear -> ReLU -> dropout -> Linear (modules.py:15-20).  Stand-alone use supports dropout rate 0 / eval only;
-        inside the model the fused engine path applies the in-kernel dropout."""
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("stand-alone FFNLayer with dropout: run it inside Tacotron (engine path)")
+        """Linear -> ReLU -> dropout -> Linear (modules.py:15-20).  Inside the model the fused engine path applies the
+        dropout in the GEMM epilogue; stand-alone it is an element-wise mask from the same counter RNG."""
         self.input_layer.compute_dtype = self.output_layer.compute_dtype = self.compute_dtype
-        return self.output_layer(self.input_layer(inputs, relu=True))
+        h = self.input_layer(inputs, relu=True)
+        return self.output_layer(_dropout(self, h, self.dropout.p))
 
 
-def _no_standalone(name):
-    raise NotImplementedError(
-        "%s runs inside libb2s_hip as part of Encoder/Decoder (csrc/engine.hip); call model.encoder / model.decoder" % name)
+def _dropout(module, x, p):
+    """Inverted dropout with the engine's counter RNG (csrc/b2s_common.h: b2s_keep): a fresh mask per call, regenerated
+    identically in backward by autograd through the saved mask (stand-alone modules only)."""
+    if not module.training or p <= 0:
+        return x
+    module._drop_calls = getattr(module, "_drop_calls", 0) + 1
+    seed = (int(torch.initial_seed()) * 1000003 + module._drop_calls) & 0xFFFFFFFFFFFF
+    return x * ops.dropout_mask(x.shape, p, seed, 23, x.device)
 
 
 class _Stack(nn.Module):
@@ -79,8 +85,24 @@ class TransformerEncoder(_Stack):
     def __init__(self, input_size, hparams):
         super(TransformerEncoder, self).__init__(input_size, hparams.encoder_hidden, hparams.n_encoder_layer, hparams, cross=False)
 
+    def prepare_inputs(self, inputs, input_lengths):
+        """Zero padded positions, add the scaled sinusoid table, dropout; key-padding bias (modules.py:50-57)."""
+        mask = torch.arange(inputs.shape[1], device=input_lengths.device)[None, :] < input_lengths[:, None]
+        bias = attention_bias(mask, "masking")
+        pe = get_sinusoid_encoding_table(inputs.shape[1], inputs.shape[2]).to(inputs.device)
+        x = inputs * mask.unsqueeze(-1).to(inputs.device) + pe * self.pe_scale
+        return _dropout(self, x, self.dropout.p), bias
+
     def forward(self, inputs, input_lengths):
-        _no_standalone("TransformerEncoder")
+        """Pre-LayerNorm stack: x += drop(self_attn(LN(x))); x += drop(ffn(LN(x))); output LayerNorm (modules.py:59-70)."""
+        x, bias = self.prepare_inputs(inputs, input_lengths)
+        p = self.dropout.p
+        for i in range(len(self.self_attentions)):
+            y = self.self_attentions[i](self.attn_layer_norms[i](x), None, bias)["outputs"]
+            x = x + _dropout(self, y, p)
+            y = self.ffn_layers[i](self.ffn_layer_norms[i](x))
+            x = x + _dropout(self, y, p)
+        return self.output_layer_norm(x)
 
 
 class TransformerDecoder(_Stack):
@@ -89,5 +111,31 @@ class TransformerDecoder(_Stack):
     def __init__(self, input_size, hparams):
         super(TransformerDecoder, self).__init__(input_size, hparams.decoder_hidden, hparams.n_decoder_layer, hparams, cross=True)
 
+    def prepare_inputs(self, inputs, targets, input_lengths, target_lengths):
+        """Memory mask bias, causal bias, targets zeroed past their length, shifted right by one frame, plus the scaled
+        sinusoid table, dropout (modules.py:107-121)."""
+        mask = torch.arange(inputs.shape[1], device=input_lengths.device)[None, :] < input_lengths[:, None]
+        enc_bias = attention_bias(mask, "masking")
+        dec_bias = attention_bias(targets.shape[1], "causal")
+        t = impute(targets, target_lengths.to(targets.device))
+        t = torch.cat([torch.zeros([t.shape[0], 1, t.shape[2]], device=t.device, dtype=t.dtype), t], dim=1)[:, :-1]
+        pe = get_sinusoid_encoding_table(t.shape[1], t.shape[2]).to(t.device)
+        t = t + pe * self.pe_scale
+        return inputs, _dropout(self, t, self.dropout.p), dec_bias, enc_bias
+
     def forward(self, inputs, targets, input_lengths, target_lengths):
-        _no_standalone("TransformerDecoder")
+        """-> (outputs zeroed past target_lengths, {'self': [...], 'encdec': [...]} alignments per layer)  (modules.py:123-145)."""
+        memory, x, query_bias, memory_bias = self.prepare_inputs(inputs, targets, input_lengths, target_lengths)
+        p = self.dropout.p
+        attn_align, encdec_align = [], []
+        for i in range(len(self.self_attentions)):
+            y = self.self_attentions[i](self.attn_layer_norms[i](x), None, query_bias)
+            attn_align.append(y["align"])
+            x = x + _dropout(self, y["outputs"], p)
+            y = self.encdec_attentions[i](self.encdec_layer_norms[i](x), memory, memory_bias)
+            encdec_align.append(y["align"])
+            x = x + _dropout(self, y["outputs"], p)
+            y = self.ffn_layers[i](self.ffn_layer_norms[i](x))
+            x = x + _dropout(self, y, p)
+        outputs = impute(self.output_layer_norm(x), target_lengths.to(x.device))
+        return outputs, {"self": attn_align, "encdec": encdec_align}

@@ -65,12 +65,15 @@ class DecoderPrenet(nn.Module):
         self.compute_dtype = compute_dtype
 
     def forward(self, x):
-        """Stand-alone prenet (tacotron.py:55-65); dropout-on use goes through Decoder (in-kernel RNG)."""
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("stand-alone DecoderPrenet with dropout: run it inside Tacotron (engine path)")
+        """Stand-alone prenet: two Linear + ReLU + dropout layers, then a bias-free Linear (tacotron.py:55-65).  Inside Decoder the
+        dropout sits in the GEMM epilogues; here it is an element-wise mask from the same counter RNG."""
+        from transformer.modules import _dropout
         for m in (self.dense0, self.dense1, self.dense_final):
             m.compute_dtype = self.compute_dtype
-        return self.dense_final(self.dense1(self.dense0(x, relu=True), relu=True))
+        p = self.dropout.p
+        h = _dropout(self, self.dense0(x, relu=True), p)
+        h = _dropout(self, self.dense1(h, relu=True), p)
+        return self.dense_final(h)
 
 
 class Postnet(_Segment):

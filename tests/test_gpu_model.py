@@ -236,6 +236,61 @@ def test_modules_standalone():
             assert np.abs(bn.running_var.cpu().numpy() - g["postnet_train/running_var_%d" % i]).max() < 1e-5
 
 
+def test_stacks_standalone_match_oracle():
+    """TransformerEncoder / TransformerDecoder called on their own (modules.py:59-70, 123-145) through the op-level kernels:
+    outputs, alignments and the gradient with respect to the inputs against the oracle; with dropout on they run, differ from
+    call to call and keep the zeroing of padded target positions."""
+    m, cfg, st, hp = build(TINY)
+    P = O.to_torch_state(st)
+    g = torch.Generator().manual_seed(5)
+    B, S, T = 2, 9, 13
+    in_len, tgt_len = torch.tensor([9, 5]), torch.tensor([13, 8])
+    enc, dec = m.encoder.encoder, m.decoder.decoder
+    x = torch.randn(B, S, cfg.embed_size, generator=g)
+    mem = torch.randn(B, S, cfg.decoder_hidden, generator=g)
+    tg = torch.randn(B, T, cfg.decoder_hidden, generator=g)
+    go_e = torch.randn(B, S, cfg.encoder_hidden, generator=g)
+    go_d = torch.randn(B, T, cfg.decoder_hidden, generator=g)
+    m.eval()
+    # encoder stack
+    xo = x.clone().requires_grad_(True)
+    ref = O.transformer_encoder(P, cfg, xo, in_len)
+    ref.backward(go_e)
+    xd = x.clone().to(DEV).requires_grad_(True)
+    out = enc(xd, in_len.to(DEV))
+    out.backward(go_e.to(DEV))
+    torch.cuda.synchronize()
+    assert np.abs(out.detach().cpu().numpy() - ref.detach().numpy()).max() < 2e-4
+    assert np.abs(xd.grad.cpu().numpy() - xo.grad.numpy()).max() < 5e-4
+    # decoder stack
+    mo, to = mem.clone().requires_grad_(True), tg.clone().requires_grad_(True)
+    ref, ral = O.transformer_decoder(P, cfg, mo, to, in_len, tgt_len)
+    ref.backward(go_d)
+    md, td = mem.clone().to(DEV).requires_grad_(True), tg.clone().to(DEV).requires_grad_(True)
+    out, al = dec(md, td, in_len.to(DEV), tgt_len.to(DEV))
+    out.backward(go_d.to(DEV))
+    torch.cuda.synchronize()
+    assert np.abs(out.detach().cpu().numpy() - ref.detach().numpy()).max() < 2e-4
+    assert not out[1, 8:].any()                                  # zeroed past the target length
+    for kind in ("self", "encdec"):
+        for a, b in zip(al[kind], ral[kind]):
+            assert np.abs(a.detach().cpu().numpy() - b.detach().numpy()).max() < 1e-5
+    assert np.abs(md.grad.cpu().numpy() - mo.grad.numpy()).max() < 5e-4
+    assert np.abs(td.grad.cpu().numpy() - to.grad.numpy()).max() < 5e-4
+    # dropout on (the tiny config has rate 0: use the reference's default rate)
+    for mod in (enc, dec):
+        mod.dropout.p = 0.1
+        for f in mod.ffn_layers:
+            f.dropout.p = 0.1
+    m.train()
+    with torch.no_grad():
+        a = enc(x.to(DEV), in_len.to(DEV))
+        b = enc(x.to(DEV), in_len.to(DEV))
+        c, _ = dec(mem.to(DEV), tg.to(DEV), in_len.to(DEV), tgt_len.to(DEV))
+    assert torch.isfinite(a).all() and torch.isfinite(c).all() and not torch.equal(a, b)
+    assert not c[1, 8:].any()
+
+
 @pytest.mark.parametrize("tag,over", [("tiny", TINY), ("tiny96", TINY96)])
 @pytest.mark.parametrize("case", ["never", "mixed", "first"])
 def test_decode_eval_batch(tag, over, case):
