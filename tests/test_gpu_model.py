@@ -171,7 +171,7 @@ def test_fused_trainer_matches_oracle(tag, over, overlap):
             assert abs(float(v[i]) - float(losses[k])) < 2e-4 + 2e-4 * abs(float(losses[k])), (step, k, float(v[i]), float(losses[k]))
     tr.sync()
     sd = m.state_dict()
-    worst = 0.0
+    worst, n_el, n_off = 0.0, 0, 0
     for n, ref in P.items():
         got = sd[n].detach().cpu().double()
         ref = ref.detach().double()
@@ -179,10 +179,17 @@ def test_fused_trainer_matches_oracle(tag, over, overlap):
             assert int(got) == int(ref)
             continue
         # Adam's first steps move every element by ~lr regardless of |g|, so elements whose gradient is ~0 are
-        # ill-conditioned; compare norms tightly and elements loosely (3 steps x lr = 3e-3 worst case)
+        # ill-conditioned (3 steps x lr = 3e-3 is the most an element can move): norms tightly, elements within a tenth of that,
+        # and no more than a handful of elements beyond 3e-4
         assert abs(float(got.norm()) - float(ref.norm())) <= 2e-4 * float(ref.norm()) + 1e-5, n
         worst = max(worst, float((got - ref).abs().max()))
-    assert worst < 6.5e-3, worst
+        if torch.is_floating_point(sd[n]) and "running_" not in n:
+            n_el += got.numel()
+            n_off += int(((got - ref).abs() > 3e-4).sum())              # 10 % of the largest possible movement (3 steps x lr = 3e-3)
+    assert worst < 6e-4, worst                                              # (measured: 1.2e-4)
+    # ... and almost every element individually: only elements whose gradient is ~0 (sign decided by rounding) may be off
+    print("parameters off by more than 3e-4 after 3 steps: %d of %d; largest difference %.2e" % (n_off, n_el, worst))
+    assert n_off <= 1e-5 * n_el, (n_off, n_el)
 
 
 def test_modules_standalone():
