@@ -12,9 +12,11 @@
 //     projection (K = dh or F/NS), which it stores as partial slab `slice`;
 //   * the sum over slices is taken by the next kernel's workgroups in a fixed order (no atomics: frames are bit-reproducible,
 //     eager == graph replay), the residual-dropout mask depends on (utterance, column, frame) only and is applied per slab.
-// With UB rows per workgroup the projections are GEMVs: VALU dot products (v_dot2c_f32_bf16 in bf16 mode), 4 lanes per weight
-// row so that every load instruction covers 64 contiguous bytes of 16 rows; the loads of a row's whole K walk are in flight
-// together.  Bound: the L2 -> CU stream of the slice's weights (every group re-reads them) and the HBM stream of the KV cache.
+// With UB rows per workgroup the projections are GEMVs.  bf16 at the default sizes: on the matrix pipe (16 weight rows x 32 k per
+// MFMA, the UB utterances as columns) from fragment-packed weight copies, so that every load instruction is one contiguous KB, with
+// the head's weight slice pulled into the XCD's L2 while LayerNorm runs (l2_warm); otherwise VALU dot products from an LDS-staged x.
+// Attention over the cache is one pass (online softmax per key slot, merged once).  Bound: the HBM stream of the KV cache, the
+// hand-off of the partial slabs between kernels (other XCDs' L2s) and the per-CU delivery of the weight slices.
 #include <algorithm>
 #include "decode_fused.h"
 
