@@ -53,6 +53,10 @@ def run(nchains, reps=30, bwd=False):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
 
-for bwd in (False, True):
-    for n in (1, 2, 4, 7):
-        print("encoder %s, %d chain(s): %.3f ms" % ("fwd+bwd" if bwd else "fwd", n, run(n, bwd=bwd)))
+if os.environ.get("ENC_CHAINS"):
+    n = int(os.environ["ENC_CHAINS"])
+    print("encoder fwd, %d chain(s): %.3f ms" % (n, run(n, reps=10)))
+else:
+    for bwd in (False, True):
+        for n in (1, 2, 4, 7):
+            print("encoder %s, %d chain(s): %.3f ms" % ("fwd+bwd" if bwd else "fwd", n, run(n, bwd=bwd)))
