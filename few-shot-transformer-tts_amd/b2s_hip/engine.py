@@ -257,14 +257,15 @@ class HipEngine(object):
         self._needs_zero = True
         return mels, stop, _Ctx(h, (ws, memory, in32, targets, tgt32))
 
-    def decoder_backward(self, ctx, dmels, dstop, mem_shape, d_guided=None, want_dmem=True):
-        """d_guided: device scalar d loss / d guided-attention loss (None: that term gets no gradient)."""
+    def decoder_backward(self, ctx, dmels, dstop, mem_shape, d_guided=None, want_dmem=True, defer_join=False):
+        """d_guided: device scalar d loss / d guided-attention loss (None: that term gets no gradient).
+        defer_join: the next engine call is encoder_backward (B2S_DEC_BWD_DEFER_JOIN); ctx must stay alive until it returns."""
         self.begin_backward()
         dmem = torch.empty(mem_shape, dtype=torch.float32, device=dmels.device) if want_dmem else None
         L.check(self.lib.b2s_decoder_backward_ex(self.handle, ctx.handle, L.ptr(dmels.contiguous()),
                                                  L.ptr(dstop.contiguous()) if dstop is not None else None,
                                                  L.ptr(d_guided.contiguous()) if d_guided is not None else None,
-                                                 0 if want_dmem else 1, L.ptr(dmem), L.stream()))
+                                                 (0 if want_dmem else 1) | (2 if defer_join else 0), L.ptr(dmem), L.stream()))
         return dmem
 
     def guided_enabled(self):

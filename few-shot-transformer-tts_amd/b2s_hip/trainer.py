@@ -197,7 +197,8 @@ class HipTrainer(object):
         dbef, daft, dstop = eng.loss_backward(mels, aft, stop, batch["mel_targets"], tgt32, None)
         din = eng.postnet_backward(c_post, daft)
         dmel = eng.add(eng.add(din, daft), dbef)
-        dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape, self._one if guided else None, not self.freeze_encoder)
+        dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape, self._one if guided else None, not self.freeze_encoder,
+                                    defer_join=not self.freeze_encoder)    # (encoder_backward below joins the second stream)
         lr = self.hp.max_lr * self.lr_lambda(self.global_step)
         step_no = self.global_step + 1
         adam = (lr, step_no, self.beta1, self.beta2, self.hp.adam_eps, self.hp.reg_weight, 1.0 / self.world)

@@ -403,7 +403,7 @@ int attn_core_bwd(int dtype, hipStream_t st, const void* dctx, int ldc, const vo
 // ------------------------------------------------------------------------------------------------ planning
 struct Scratch {
     // operands of deferred weight-gradient GEMMs stay live until the stage's group has run: every use takes the next
-    // buffer of a ring that spans two stages (ring size 1 = the plain single scratch buffer when nothing is deferred)
+    // buffer of a ring with one buffer per use and layer (ring size 1 = the plain single scratch buffer when nothing is deferred)
     std::vector<void*> r_dyT, r_dz, r_dqkv, r_dkv;
     int i_dyT = 0, i_dz = 0, i_dqkv = 0, i_dkv = 0;
     bool dy_ready = false;       // dyT already holds bf16(dropout(dx)) for the next sublayer (written by the LayerNorm backward)
@@ -464,8 +464,11 @@ void plan_encoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     // scratch (forward + backward)
     const long pn = (long)B * H * S * rup8(S);
     sc.S = a.f32(pn); sc.dP = a.f32(pn); sc.dS = a.T(pn, esz);
-    const int rings = m->dw_group ? 2 : 1;           // stages a deferred operand must survive
-    for (int i = 0; i < (rings == 1 ? 1 : 4); ++i) sc.r_dyT.push_back(a.T(M * D, esz));            // 2 uses per layer
+    // Operands of deferred weight-gradient GEMMs must survive until their stage's group has run on the second stream.  One buffer
+    // per use and layer (HBM is plentiful): a ring of two stages made the main stream wait on a second-stream event at every reuse
+    // -- 44 event waits of 6-13 us per step although the events had long fired.
+    const int rings = m->dw_group ? cf.n_encoder_layer : 1;
+    for (int i = 0; i < (rings == 1 ? 1 : 2 * rings); ++i) sc.r_dyT.push_back(a.T(M * D, esz));    // 2 uses per layer
     for (int i = 0; i < rings; ++i) { sc.r_dz.push_back(a.T(M * 4 * D, esz)); sc.r_dqkv.push_back(a.T(M * 3 * D, esz)); }
     sc.dyT = sc.r_dyT[0]; sc.dz = sc.r_dz[0]; sc.dqkv = sc.r_dqkv[0];
     sc.dctx = a.T(M * D, esz); sc.dh = a.T(M * D, esz); sc.dx = a.f32(M * D);
@@ -510,9 +513,9 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     const long pn = (long)B * H * T * rup8(std::max(T, S));
     sc.S = a.f32(pn); sc.dP = a.f32(pn); sc.dS = a.T(pn, esz);
     sc.a3 = a.f32(M * D);
-    const int rings = m->dw_group ? 2 : 1;
-    for (int i = 0; i < (rings == 1 ? 1 : 6); ++i) sc.r_dyT.push_back(a.T(M * D, esz));            // 3 uses per layer
-    for (int i = 0; i < (rings == 1 ? 1 : 4); ++i) sc.r_dqkv.push_back(a.T(M * 3 * D, esz));       // 2 uses per layer
+    const int rings = m->dw_group ? cf.n_decoder_layer : 1;                                        // (one buffer per use and layer: see plan_encoder)
+    for (int i = 0; i < (rings == 1 ? 1 : 3 * rings); ++i) sc.r_dyT.push_back(a.T(M * D, esz));    // 3 uses per layer
+    for (int i = 0; i < (rings == 1 ? 1 : 2 * rings); ++i) sc.r_dqkv.push_back(a.T(M * 3 * D, esz));       // 2 uses per layer
     for (int i = 0; i < rings; ++i) { sc.r_dz.push_back(a.T(M * 4 * D, esz)); sc.r_dkv.push_back(a.T(Mk * 2 * D, esz)); }
     sc.dyT = sc.r_dyT[0]; sc.dz = sc.r_dz[0]; sc.dqkv = sc.r_dqkv[0]; sc.dkv = sc.r_dkv[0];
     sc.dctx = a.T(M * D, esz); sc.dh = a.T(M * D, esz); sc.dx = a.f32(M * D);
@@ -1257,7 +1260,9 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
     B2S_TRY(ro_colsum(dt, sc.dz1, 0, HP, nullptr, m->G("decoder.prenet.dense0.bias"), 1, (int)M, HP, st));
     B2S_TRY(linear_dw(m, st, sc.dz1, HP, c->tgtT, NM, (int)M, HP, NM, m->G("decoder.prenet.dense0.weight")));
     B2S_LAUNCH_CHECK();
-    B2S_TRY(end_stage(m, st, 2 + cf.n_decoder_layer, true));
+    // (deferred join: the caller's next call is b2s_encoder_backward on this stream, whose last stage joins the second stream and fires
+    // this stage's hook -- the main stream does not idle here until the prenet's weight-gradient group has finished, ~0.12 ms)
+    B2S_TRY(end_stage(m, st, 2 + cf.n_decoder_layer, !(flags & B2S_DEC_BWD_DEFER_JOIN)));
     return 0;
 }
 

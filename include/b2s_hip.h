@@ -85,8 +85,12 @@ int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_
 int b2s_decoder_backward(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, float* d_memory_out,
                          void* stream);
 /* Extended backward.  d_guided: device scalar = d loss / d guided_loss (NULL: the guided-attention term gets no
- * gradient).  flags bit 0: do not compute d_memory (frozen encoder; d_memory_out may be NULL). */
+ * gradient).  flags bit 0: do not compute d_memory (frozen encoder; d_memory_out may be NULL).  bit 1: the caller's next call
+ * on this model and stream is b2s_encoder_backward -- the second stream (weight-gradient GEMMs) is then joined at the end of
+ * that call instead of this one; ctx (its workspace) must stay alive until that call has returned, and the last decoder
+ * stage's hook fires from inside it. */
 #define B2S_DEC_BWD_NO_DMEMORY 1
+#define B2S_DEC_BWD_DEFER_JOIN 2
 int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, const float* d_guided,
                             int flags, float* d_memory_out, void* stream);
 /* Guided-attention loss of the forward held in ctx (already multiplied by guided_attention_weight):
