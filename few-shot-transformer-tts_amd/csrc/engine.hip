@@ -246,6 +246,8 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
     hipEvent_t ready = m->next_event();
     B2S_HIP(hipEventRecord(ready, st));
     B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
+    // the stage's LayerNorm parameter-gradient reductions ride along: nothing on the main stream needs them before the join
+    if (m->ln_jobs.n > 0) { B2S_TRY(ro_ln_param_reduce_batch(m->ln_jobs, m->aux)); m->ln_jobs.n = 0; }
     // a stage with only a few output tiles (prenet: 9, mel / stop heads: 6) would walk the whole token dimension inside
     // each of them (127 K steps, > 100 us on a handful of CUs, and the drain at the end of the entry point waits for it):
     // those go through the split-K launch instead
@@ -281,7 +283,8 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
 // of this C entry point -- the main stream rejoins the aux stream and every outstanding hook fires.
 int flush_ln_jobs(const b2s_model* m, hipStream_t st);
 int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain) {
-    B2S_TRY(flush_ln_jobs(m, st));                     // the stage's LayerNorm parameter gradients
+    static const bool serial = getenv("B2S_DW_GROUP_SERIAL") != nullptr;
+    if (!m->dw_group || m->dw_pending.empty() || serial) B2S_TRY(flush_ln_jobs(m, st));      // the stage's LayerNorm parameter gradients (otherwise: flush_dw, second stream)
     if (!m->dw_group) {
         B2S_TRY(join_aux(m, st));
         m->stage_done(stage);
@@ -411,7 +414,10 @@ struct Scratch {
     float *S = nullptr, *dP = nullptr; void* dS = nullptr;
     void *dyT = nullptr, *dz = nullptr, *dqkv = nullptr, *dctx = nullptr, *dh = nullptr, *dkv = nullptr;
     float *dx = nullptr, *a3 = nullptr, *dmem = nullptr, *dstop_m = nullptr, *lnws = nullptr;
-    float* r_lnws[RO_LN_BATCH] = {nullptr, nullptr, nullptr, nullptr};      // one partial buffer per LayerNorm whose reduction is pending
+    // one partial buffer per LayerNorm whose reduction is pending; with deferred weight gradients the reduction runs on the second
+    // stream at the end of the stage, so every LayerNorm of the pass has its own (no reuse, no hazard)
+    std::vector<float*> r_lnws;
+    int i_lnws = 0;
     void *dmelT = nullptr, *doutT = nullptr, *da3 = nullptr, *dz1 = nullptr, *dz2 = nullptr;
     void* dkvcat = nullptr;          // [Mk][L*2D]: dK / dV of every decoder layer (models with a kv_cat weight slab)
 };
@@ -473,7 +479,7 @@ void plan_encoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     sc.dyT = sc.r_dyT[0]; sc.dz = sc.r_dz[0]; sc.dqkv = sc.r_dqkv[0];
     sc.dctx = a.T(M * D, esz); sc.dh = a.T(M * D, esz); sc.dx = a.f32(M * D);
     sc.lnws = a.f32((long)RO_LN_WS_ROWS * 2 * D);
-    for (int i = 0; i < RO_LN_BATCH; ++i) sc.r_lnws[i] = a.f32((long)RO_LN_WS_ROWS * 2 * D);
+    for (int i = 0; i < (m->dw_group ? 2 * cf.n_encoder_layer + 2 : RO_LN_BATCH); ++i) sc.r_lnws.push_back(a.f32((long)RO_LN_WS_ROWS * 2 * D));
 }
 
 void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::vector<float*>& xs) {
@@ -524,7 +530,7 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     sc.dstop_m = a.f32(M);
     if (m->kv_cat) sc.dkvcat = a.T(Mk * cf.n_decoder_layer * 2 * D, esz);
     sc.lnws = a.f32((long)RO_LN_WS_ROWS * 2 * D);
-    for (int i = 0; i < RO_LN_BATCH; ++i) sc.r_lnws[i] = a.f32((long)RO_LN_WS_ROWS * 2 * D);
+    for (int i = 0; i < (m->dw_group ? 3 * cf.n_decoder_layer + 2 : RO_LN_BATCH); ++i) sc.r_lnws.push_back(a.f32((long)RO_LN_WS_ROWS * 2 * D));
 }
 
 struct PostScratch { std::vector<void*> du; float* stat; };
@@ -928,7 +934,7 @@ int ln_bwd_exit(b2s_model* m, hipStream_t st, Scratch& sc, const void* dh, int d
     // the parameter-gradient partials of up to RO_LN_BATCH LayerNorms are reduced by one launch (flush_ln_jobs: end of the stage)
     if (m->ln_jobs.n == RO_LN_BATCH) B2S_TRY(flush_ln_jobs(m, st));
     LnReduceJob& jb = m->ln_jobs.j[m->ln_jobs.n];
-    jb.ws = sc.r_lnws[m->ln_jobs.n]; jb.D = D; jb.dgamma = m->G(lnp + ".weight"); jb.dbeta = m->G(lnp + ".bias");
+    jb.ws = m->dw_group ? sc.r_lnws[(size_t)sc.i_lnws++ % sc.r_lnws.size()] : sc.r_lnws[m->ln_jobs.n]; jb.D = D; jb.dgamma = m->G(lnp + ".weight"); jb.dbeta = m->G(lnp + ".bias");
     B2S_TRY(ro_layernorm_bwd(m->dtype, dh, dh_fp32, lddh, x_in, m->P(lnp + ".weight"), mean, rstd, sc.dx, accumulate,
                              jb.dgamma, jb.dbeta, (int)M, D, row_len, rpb, st, const_cast<float*>(jb.ws), dy2, nd, &jb.nblk));
     ++m->ln_jobs.n;
