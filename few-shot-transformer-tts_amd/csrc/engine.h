@@ -127,6 +127,9 @@ struct b2s_model {
     // the main stream on the group it has just launched.
     mutable bool dw_group = false;
     mutable std::vector<GemmArgs> dw_pending;
+    // column sums that only feed parameter gradients (bias / stop-net gradients): queued with the stage's weight-gradient group
+    struct ColsumJob { int dtype; const void* X; int x_fp32, ldx; const float* wgt; float* out; int accumulate, M, C; };
+    mutable std::vector<ColsumJob> colsum_pending;
     // Optimizer step overlapped with the next forward pass (b2s_adam_step_ex, overlap = 1): the fused Adam runs on the aux
     // stream in three groups -- postnet, encoder, decoder parameters (the order the next step first needs them) -- and
     // every entry point waits on its caller's stream for the groups it reads before it touches a weight.

@@ -181,6 +181,19 @@ int guard_write(const b2s_model* m, const void* buf, hipStream_t st) {       // 
     if (it != m->aux_readers.end()) { B2S_HIP(hipStreamWaitEvent(st, it->second, 0)); m->aux_readers.erase(it); }
     return 0;
 }
+// column sum whose result is a parameter gradient: with deferred weight gradients it joins the stage's group on the second stream
+// (its operand is one of the group's operands, i.e. alive until then)
+int grad_colsum(const b2s_model* m, hipStream_t st, int dtype, const void* X, int x_fp32, int ldx, const float* wgt, float* out, int accumulate,
+                int M, int C) {
+    if (m->dw_group) { m->colsum_pending.push_back({dtype, X, x_fp32, ldx, wgt, out, accumulate, M, C}); return 0; }
+    return ro_colsum(dtype, X, x_fp32, ldx, wgt, out, accumulate, M, C, st);
+}
+int flush_colsums(const b2s_model* m, hipStream_t st) {
+    for (const b2s_model::ColsumJob& j : m->colsum_pending)
+        B2S_TRY(ro_colsum(j.dtype, j.X, j.x_fp32, j.ldx, j.wgt, j.out, j.accumulate, j.M, j.C, st));
+    m->colsum_pending.clear();
+    return 0;
+}
 int join_aux(const b2s_model* m, hipStream_t st) {                           // main stream waits for every queued dW GEMM
     if (m->aux && m->aux_dirty) {
         hipEvent_t e = m->next_event();
@@ -233,7 +246,7 @@ int linear_dw(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
 
 // launch the deferred weight-gradient problems of the current stage as grouped GEMMs on the aux stream
 int flush_dw(const b2s_model* m, hipStream_t st) {
-    if (m->dw_pending.empty()) return 0;
+    if (m->dw_pending.empty()) return flush_colsums(m, st);
     std::vector<GemmArgs>& q = m->dw_pending;
     std::stable_sort(q.begin(), q.end(), [](const GemmArgs& a, const GemmArgs& b) { return a.K > b.K; });    // long tiles first
     static const bool serial = getenv("B2S_DW_GROUP_SERIAL") != nullptr;       // experiment: groups on the main stream
@@ -241,13 +254,14 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
         for (size_t i = 0; i < q.size(); i += B2S_MAX_GROUP)
             B2S_TRY(b2s_gemm_grouped_launch(q.data() + i, (int)std::min<size_t>(B2S_MAX_GROUP, q.size() - i), st));
         q.clear();
-        return 0;
+        return flush_colsums(m, st);
     }
     hipEvent_t ready = m->next_event();
     B2S_HIP(hipEventRecord(ready, st));
     B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
     // the stage's LayerNorm parameter-gradient reductions ride along: nothing on the main stream needs them before the join
     if (m->ln_jobs.n > 0) { B2S_TRY(ro_ln_param_reduce_batch(m->ln_jobs, m->aux)); m->ln_jobs.n = 0; }
+    B2S_TRY(flush_colsums(m, m->aux));
     // a stage with only a few output tiles (prenet: 9, mel / stop heads: 6) would walk the whole token dimension inside
     // each of them (127 K steps, > 100 us on a handful of CUs, and the drain at the end of the entry point waits for it):
     // those go through the split-K launch instead
@@ -1183,8 +1197,8 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
     B2S_TRY(linear_dx(m, st, sc.dmelT, NM, m->W("decoder.mel_net.weight"), (int)M, D, NM, sc.doutT, 0, D, eo));
     if (d_stop) {
         hipLaunchKernelGGL(k_rowmask_copy, dim3(cdiv(M, 256)), dim3(256), 0, st, d_stop, sc.dstop_m, c->tgt_len, T, M);
-        B2S_TRY(ro_colsum(dt, c->outT, 0, D, sc.dstop_m, m->G("decoder.stop_net.weight"), 1, (int)M, D, st));
-        B2S_TRY(ro_colsum(0, sc.dstop_m, 1, 1, nullptr, m->G("decoder.stop_net.bias"), 1, (int)M, 1, st));
+        B2S_TRY(grad_colsum(m, st, dt, c->outT, 0, D, sc.dstop_m, m->G("decoder.stop_net.weight"), 1, (int)M, D));
+        B2S_TRY(grad_colsum(m, st, 0, sc.dstop_m, 1, 1, nullptr, m->G("decoder.stop_net.bias"), 1, (int)M, 1));
     }
     DropCfg nd;
     if (cf.n_decoder_layer > 0) nd = make_drop(pt, c->seed, c->ffn[cf.n_decoder_layer - 1].op_res);
@@ -1259,11 +1273,11 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
     B2S_TRY(linear_dw(m, st, sc.da3, D, c->a2, HP, (int)M, D, HP, m->G("decoder.prenet.dense_final.weight")));
     GemmEpilogue e2; e2.relu_aux = c->a2; e2.ld_aux = HP; e2.aux_scale = d2.scale;
     B2S_TRY(linear_dx(m, st, sc.da3, D, m->W("decoder.prenet.dense_final.weight"), (int)M, HP, D, sc.dz2, 0, HP, e2));
-    B2S_TRY(ro_colsum(dt, sc.dz2, 0, HP, nullptr, m->G("decoder.prenet.dense1.bias"), 1, (int)M, HP, st));
+    B2S_TRY(grad_colsum(m, st, dt, sc.dz2, 0, HP, nullptr, m->G("decoder.prenet.dense1.bias"), 1, (int)M, HP));
     B2S_TRY(linear_dw(m, st, sc.dz2, HP, c->a1, HP, (int)M, HP, HP, m->G("decoder.prenet.dense1.weight")));
     GemmEpilogue e1; e1.relu_aux = c->a1; e1.ld_aux = HP; e1.aux_scale = d1.scale;
     B2S_TRY(linear_dx(m, st, sc.dz2, HP, m->W("decoder.prenet.dense1.weight"), (int)M, HP, HP, sc.dz1, 0, HP, e1));
-    B2S_TRY(ro_colsum(dt, sc.dz1, 0, HP, nullptr, m->G("decoder.prenet.dense0.bias"), 1, (int)M, HP, st));
+    B2S_TRY(grad_colsum(m, st, dt, sc.dz1, 0, HP, nullptr, m->G("decoder.prenet.dense0.bias"), 1, (int)M, HP));
     B2S_TRY(linear_dw(m, st, sc.dz1, HP, c->tgtT, NM, (int)M, HP, NM, m->G("decoder.prenet.dense0.weight")));
     B2S_LAUNCH_CHECK();
     // (deferred join: the caller's next call is b2s_encoder_backward on this stream, whose last stage joins the second stream and fires
