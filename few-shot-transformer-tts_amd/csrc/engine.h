@@ -127,6 +127,7 @@ struct b2s_model {
     // the main stream on the group it has just launched.
     mutable bool dw_group = false;
     mutable std::vector<GemmArgs> dw_pending;
+    mutable int dw_stages_pending = 0;                        // backward stages whose weight-gradient GEMMs are queued in dw_pending
     // column sums that only feed parameter gradients (bias / stop-net gradients): queued with the stage's weight-gradient group
     struct ColsumJob { int dtype; const void* X; int x_fp32, ldx; const float* wgt; float* out; int accumulate, M, C; };
     mutable std::vector<ColsumJob> colsum_pending;

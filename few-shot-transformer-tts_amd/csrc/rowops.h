@@ -25,7 +25,7 @@ int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const flo
 // partial rows and the caller reduces several LayerNorms' partials in one launch (ro_ln_param_reduce_batch)
 constexpr int RO_LN_WS_ROWS = 768;
 struct LnReduceJob { const float* ws; int nblk, D; float* dgamma; float* dbeta; };
-constexpr int RO_LN_BATCH = 4;
+constexpr int RO_LN_BATCH = 8;
 struct LnReduceBatch { int n; LnReduceJob j[RO_LN_BATCH]; };
 int ro_ln_param_reduce_batch(const LnReduceBatch& b, hipStream_t st);
 
