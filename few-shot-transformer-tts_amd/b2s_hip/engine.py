@@ -296,10 +296,13 @@ class HipEngine(object):
         self._needs_zero = True
         return out, (_Ctx(h, (ws, inputs, len32, add)) if keep_ctx else None)
 
-    def postnet_backward(self, ctx, dout):
+    def postnet_backward(self, ctx, dout, defer_join=False):
+        """defer_join: the next engine call is decoder_backward (B2S_POST_BWD_DEFER_JOIN); ctx must stay alive until the
+        second stream has been joined (end of the decoder / encoder backward)."""
         self.begin_backward()
         din = torch.empty_like(dout)
-        L.check(self.lib.b2s_postnet_backward(self.handle, ctx.handle, L.ptr(dout.contiguous()), L.ptr(din), L.stream()))
+        L.check(self.lib.b2s_postnet_backward_ex(self.handle, ctx.handle, L.ptr(dout.contiguous()), L.ptr(din), 1 if defer_join else 0,
+                                                 L.stream()))
         return din
 
     def add(self, a, b):

@@ -68,6 +68,7 @@ _PROTOS = {
     "b2s_postnet_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int]),
     "b2s_postnet_forward": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, C.POINTER(P)]),
     "b2s_postnet_backward": (C.c_int, [P, P, P, P, P]),
+    "b2s_postnet_backward_ex": (C.c_int, [P, P, P, P, C.c_int, P]),
     "b2s_ctx_free": (None, [P]),
     "b2s_loss_forward": (C.c_int, [P, P, P, P, P, P, C.c_int, C.c_int, P, P, P, P]),
     "b2s_loss_backward": (C.c_int, [P, P, P, P, P, P, C.c_int, C.c_int, P, P, P, P, P]),

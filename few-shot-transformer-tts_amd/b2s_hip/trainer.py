@@ -195,7 +195,7 @@ class HipTrainer(object):
             self.bucketer.begin_step()
         self._hook_error = None
         dbef, daft, dstop = eng.loss_backward(mels, aft, stop, batch["mel_targets"], tgt32, None)
-        din = eng.postnet_backward(c_post, daft)
+        din = eng.postnet_backward(c_post, daft, defer_join=True)           # (the decoder backward below takes over the second stream's join)
         dmel = eng.add(eng.add(din, daft), dbef)
         dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape, self._one if guided else None, not self.freeze_encoder,
                                     defer_join=not self.freeze_encoder)    # (encoder_backward below joins the second stream)

@@ -301,6 +301,7 @@ int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain) {
     if (!m->dw_group || m->dw_pending.empty() || serial) B2S_TRY(flush_ln_jobs(m, st));      // the stage's LayerNorm parameter gradients (otherwise: flush_dw, second stream)
     if (!m->dw_group) {
         B2S_TRY(join_aux(m, st));
+        if (m->pending_stage >= 0) { m->stage_done(m->pending_stage); m->pending_stage = -1; m->pending_ev = nullptr; }     // (a deferred postnet stage)
         m->stage_done(stage);
         return 0;
     }
@@ -552,7 +553,7 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     for (int i = 0; i < (m->dw_group ? 3 * cf.n_decoder_layer + 2 : RO_LN_BATCH); ++i) sc.r_lnws.push_back(a.f32((long)RO_LN_WS_ROWS * 2 * D));
 }
 
-struct PostScratch { std::vector<void*> du; float* stat; };
+struct PostScratch { std::vector<void*> du, dy; float* stat; };
 void plan_postnet(const b2s_model* m, b2s_ctx& c, Arena& a, PostScratch& ps) {
     const b2s_config& cf = m->cfg;
     const long M = (long)c.B * c.T;
@@ -569,7 +570,11 @@ void plan_postnet(const b2s_model* m, b2s_ctx& c, Arena& a, PostScratch& ps) {
         // dy (gradient w.r.t. conv output) reuses du slot i+1 sized below
     }
     int maxc = std::max(cf.num_mels, cf.postnet_hidden);
-    ps.du[n] = a.T(M * maxc, esz);                    // dy buffer (T), reused by every layer
+    ps.du[n] = a.T(M * maxc, esz);
+    // dy (gradient w.r.t. a conv output, T): one buffer per layer -- the weight-gradient GEMMs that read them run on the second stream
+    // after the whole backward pass of the postnet
+    ps.dy.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) ps.dy[i] = a.T(M * (i == n - 1 ? cf.num_mels : cf.postnet_hidden), esz);
     ps.stat = a.f32(2 * maxc);
 }
 
@@ -1364,6 +1369,9 @@ extern "C" int b2s_postnet_forward(b2s_model* m, const float* inputs, const int3
 }
 
 extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out, float* d_inputs_out, void* stream) {
+    return b2s_postnet_backward_ex(m, c, d_out, d_inputs_out, 0, stream);
+}
+extern "C" int b2s_postnet_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_out, float* d_inputs_out, int flags, void* stream) {
     B2S_TRY(check_bound(m));
     B2S_TRY(wait_adam(m, S_(stream), 7));
     B2S_CHECK(c && c->kind == 3 && d_out && d_inputs_out, "bad postnet context");
@@ -1377,12 +1385,16 @@ extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out
     b2s_ctx tmp; tmp.B = B; tmp.T = T;
     PostScratch ps;
     plan_postnet(m, tmp, a, ps);
-    void* dy = ps.du[n];
+    // The conv weight gradients (5 split-K GEMMs over all tokens + their slab reductions, ~0.3 ms) are not on the path to d_inputs:
+    // with a second stream they are queued and run there after the pass, behind one event, while the caller's decoder backward
+    // proceeds on the main stream.
+    std::vector<GemmArgs> dws;
     for (int i = n - 1; i >= 0; --i) {
         const int cin = i == 0 ? cf.num_mels : cf.postnet_hidden, cout = i == n - 1 ? cf.num_mels : cf.postnet_hidden;
         const std::string q = "postnet.batchnorm_layers." + std::to_string(i) + ".";
         DropCfg d = make_drop(pd, c->seed, opid(3, i, 1));
         const void* dout = i == n - 1 ? (const void*)d_out : ps.du[i + 1];
+        void* dy = ps.dy[i];
         B2S_TRY(ro_bn_bwd(dt, dout, i == n - 1 ? 1 : 0, c->y[i], c->bn_mean[i], c->bn_rstd[i], m->P(q + "weight"), m->P(q + "bias"),
                           i < n - 1 ? 1 : 0, m->G(q + "weight"), m->G(q + "bias"), dy, (int)M, cout, d, st));
         {   // dW[co, ci, j] = sum_m dy[m, co] * xg[m, j*cin + ci]
@@ -1392,8 +1404,8 @@ extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out
             g.M = cout; g.N = 5 * cin; g.K = (int)M;
             g.C = m->G("postnet.conv_layers." + std::to_string(i) + ".weight"); g.c_fp32 = 1; g.ldc = 5 * cin;
             g.epi.conv_dw_cin = cin; g.epi.accumulate = 1; g.splitk = pick_splitk(cout, 5 * cin, (int)M, dt);
-            m->set_ws(g, st);
-            B2S_TRY(b2s_gemm_launch(g, dt, true, true, st));
+            if (m->aux) dws.push_back(g);
+            else { m->set_ws(g, st); B2S_TRY(b2s_gemm_launch(g, dt, true, true, st)); }
         }
         {   // dx[m, ci] = mask(m) * sum_{j', co} dy[m + j' - 2, co] * w[co, ci, 4 - j']
             GemmArgs g;
@@ -1406,7 +1418,30 @@ extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out
             B2S_TRY(b2s_gemm_launch(g, dt, false, false, st));
         }
     }
-    B2S_TRY(end_stage(m, st, 0, true));
+    if (!dws.empty()) {
+        hipEvent_t ready = m->next_event();
+        B2S_HIP(hipEventRecord(ready, st));
+        B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
+        for (GemmArgs& g : dws) { m->set_ws(g, m->aux); B2S_TRY(b2s_gemm_launch(g, dt, true, true, m->aux)); }
+        hipEvent_t done = m->next_event();
+        B2S_HIP(hipEventRecord(done, m->aux));
+        m->aux_dirty = true;
+        m->pending_ev = done;                             // (the stage hook, if any, waits for it: end_stage)
+    }
+    // (deferred join: the caller's next call on this model and stream is b2s_decoder_backward(_ex), whose stages -- or final join --
+    // take care of this stage's hook and of the second stream)
+    if ((flags & B2S_POST_BWD_DEFER_JOIN) && m->aux) {
+        B2S_TRY(flush_ln_jobs(m, st));
+        if (m->stage_hook && m->pending_stage >= 0) {     // an earlier deferred stage (none in the usual order)
+            if (m->pending_ev) B2S_HIP(hipStreamWaitEvent(st, m->pending_ev, 0));
+            m->stage_done(m->pending_stage);
+        }
+        m->pending_stage = 0;
+        return 0;
+    }
+    B2S_TRY(join_aux(m, st));
+    m->stage_done(0);
+    m->pending_stage = -1; m->pending_ev = nullptr;
     return 0;
 }
 

@@ -109,6 +109,11 @@ int b2s_postnet_forward(b2s_model* m, const float* inputs, const int32_t* length
                         b2s_ctx** ctx_out);
 /* d_inputs_out [B,T,num_mels] = gradient through the conv stack only (caller adds the skip path). */
 int b2s_postnet_backward(b2s_model* m, b2s_ctx* ctx, const float* d_out, float* d_inputs_out, void* stream);
+/* flags bit 0: the caller's next call on this model and stream is b2s_decoder_backward(_ex) -- the second stream (the conv
+ * weight-gradient GEMMs run there) is joined by that call (or, with B2S_DEC_BWD_DEFER_JOIN, by the encoder backward after it);
+ * ctx must stay alive until the joining call has returned. */
+#define B2S_POST_BWD_DEFER_JOIN 1
+int b2s_postnet_backward_ex(b2s_model* m, b2s_ctx* ctx, const float* d_out, float* d_inputs_out, int flags, void* stream);
 
 void b2s_ctx_free(b2s_ctx* ctx);
 
