@@ -2,6 +2,7 @@
 #pragma once
 #include <map>
 #include <string>
+#include <functional>
 #include <vector>
 #include "../../include/b2s_hip.h"
 #include "b2s_common.h"
@@ -128,9 +129,9 @@ struct b2s_model {
     mutable bool dw_group = false;
     mutable std::vector<GemmArgs> dw_pending;
     mutable int dw_stages_pending = 0;                        // backward stages whose weight-gradient GEMMs are queued in dw_pending
-    // column sums that only feed parameter gradients (bias / stop-net gradients): queued with the stage's weight-gradient group
-    struct ColsumJob { int dtype; const void* X; int x_fp32, ldx; const float* wgt; float* out; int accumulate, M, C; };
-    mutable std::vector<ColsumJob> colsum_pending;
+    // launches that only feed parameter gradients (bias / stop-net column sums, the speaker / language nets' backward): queued and
+    // issued on the second stream with the next weight-gradient hand-over
+    mutable std::vector<std::function<int(hipStream_t)>> aux_jobs;
     // Optimizer step overlapped with the next forward pass (b2s_adam_step_ex, overlap = 1): the fused Adam runs on the aux
     // stream in three groups -- postnet, encoder, decoder parameters (the order the next step first needs them) -- and
     // every entry point waits on its caller's stream for the groups it reads before it touches a weight.

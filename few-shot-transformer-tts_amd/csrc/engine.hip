@@ -181,17 +181,19 @@ int guard_write(const b2s_model* m, const void* buf, hipStream_t st) {       // 
     if (it != m->aux_readers.end()) { B2S_HIP(hipStreamWaitEvent(st, it->second, 0)); m->aux_readers.erase(it); }
     return 0;
 }
-// column sum whose result is a parameter gradient: with deferred weight gradients it joins the stage's group on the second stream
-// (its operand is one of the group's operands, i.e. alive until then)
+// a launch whose result is only a parameter gradient: with deferred weight gradients it joins the next hand-over to the second stream
+// (its operands must stay alive until then: they are operands of the group or live in the context)
+int grad_job(const b2s_model* m, hipStream_t st, std::function<int(hipStream_t)> job) {
+    if (m->dw_group) { m->aux_jobs.push_back(std::move(job)); return 0; }
+    return job(st);
+}
 int grad_colsum(const b2s_model* m, hipStream_t st, int dtype, const void* X, int x_fp32, int ldx, const float* wgt, float* out, int accumulate,
                 int M, int C) {
-    if (m->dw_group) { m->colsum_pending.push_back({dtype, X, x_fp32, ldx, wgt, out, accumulate, M, C}); return 0; }
-    return ro_colsum(dtype, X, x_fp32, ldx, wgt, out, accumulate, M, C, st);
+    return grad_job(m, st, [=](hipStream_t s) { return ro_colsum(dtype, X, x_fp32, ldx, wgt, out, accumulate, M, C, s); });
 }
 int flush_colsums(const b2s_model* m, hipStream_t st) {
-    for (const b2s_model::ColsumJob& j : m->colsum_pending)
-        B2S_TRY(ro_colsum(j.dtype, j.X, j.x_fp32, j.ldx, j.wgt, j.out, j.accumulate, j.M, j.C, st));
-    m->colsum_pending.clear();
+    for (const auto& j : m->aux_jobs) B2S_TRY(j(st));
+    m->aux_jobs.clear();
     return 0;
 }
 int join_aux(const b2s_model* m, hipStream_t st) {                           // main stream waits for every queued dW GEMM
@@ -298,6 +300,8 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
 int flush_ln_jobs(const b2s_model* m, hipStream_t st);
 int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain) {
     static const bool serial = getenv("B2S_DW_GROUP_SERIAL") != nullptr;
+    // a stage without weight-gradient GEMMs (the output LayerNorm): its reductions / gradient-only launches wait for the next hand-over
+    if (m->dw_group && !serial && !m->stage_hook && !drain && m->dw_pending.empty()) return 0;
     if (!m->dw_group || m->dw_pending.empty() || serial) B2S_TRY(flush_ln_jobs(m, st));      // the stage's LayerNorm parameter gradients (otherwise: flush_dw, second stream)
     if (!m->dw_group) {
         B2S_TRY(join_aux(m, st));
@@ -1017,17 +1021,19 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
     plan_encoder(m, tmp, a, sc, xs);
     const std::string p = "encoder.encoder.";
     int col = D;
+    // (the speaker / language nets' backward reads d_memory only and produces parameter gradients only: off the main stream)
     if (cf.multi_speaker) {
-        B2S_TRY(ro_spk_embed_bwd(d_memory, Dm, col, (const long*)c->spk_ids, c->spk_e, c->spk_h, m->P("encoder.speaker_layer.weight"),
-                                 m->G("encoder.speaker_embed.weight"), m->G("encoder.speaker_layer.weight"),
-                                 m->G("encoder.speaker_layer.bias"), c->spk_dh, B, S, cf.speaker_embedding_size, st));
+        const int c0 = col, E = cf.speaker_embedding_size;
+        const long* ids = (const long*)c->spk_ids; const float *e = c->spk_e, *h = c->spk_h, *W = m->P("encoder.speaker_layer.weight");
+        float *gt = m->G("encoder.speaker_embed.weight"), *gW = m->G("encoder.speaker_layer.weight"), *gb = m->G("encoder.speaker_layer.bias"), *dh = c->spk_dh;
+        B2S_TRY(grad_job(m, st, [=](hipStream_t s) { return ro_spk_embed_bwd(d_memory, Dm, c0, ids, e, h, W, gt, gW, gb, dh, B, S, E, s); }));
         col += cf.speaker_embedding_size;
     }
     if (cf.multi_lingual) {
-        B2S_TRY(ro_lang_embed_bwd(d_memory, Dm, col, c->lang_vecs, cf.max_num_language, c->lang_e, c->lang_h,
-                                  m->P("encoder.language_embed.weight"), m->P("encoder.language_layer.weight"),
-                                  m->G("encoder.language_embed.weight"), m->G("encoder.language_layer.weight"),
-                                  m->G("encoder.language_layer.bias"), c->lang_dh, B, S, cf.language_embedding_size, st));
+        const int c0 = col, E = cf.language_embedding_size, NL = cf.max_num_language;
+        const float *lv = c->lang_vecs, *e = c->lang_e, *h = c->lang_h, *Wl = m->P("encoder.language_embed.weight"), *W = m->P("encoder.language_layer.weight");
+        float *gWl = m->G("encoder.language_embed.weight"), *gW = m->G("encoder.language_layer.weight"), *gb = m->G("encoder.language_layer.bias"), *dh = c->lang_dh;
+        B2S_TRY(grad_job(m, st, [=](hipStream_t s) { return ro_lang_embed_bwd(d_memory, Dm, c0, lv, NL, e, h, Wl, W, gWl, gW, gb, dh, B, S, E, s); }));
     }
     // every LayerNorm backward below also emits the dY operand (bf16, residual dropout applied) of the sublayer that runs next
     DropCfg nd;
