@@ -14,12 +14,14 @@ class GradBucketer(object):
     launches one asynchronous all-reduce per bucket.  Stages must be reported in increasing order and their ranges
     must tile the flat buffer in that order (HipEngine lays gradients out that way)."""
 
-    def __init__(self, flat, stage_ranges, n_stages, bucket_elems, group=None, dist=None, payload="fp32", pack=None, unpack=None):
+    def __init__(self, flat, stage_ranges, n_stages, bucket_elems, group=None, dist=None, payload="fp32", pack=None, unpack=None,
+                 stream=None):
         """payload "bf16": every bucket is converted to a bf16 wire buffer before its all-reduce and back afterwards -- half the
         bytes over xGMI (167 MB instead of 334 MB per step at the default sizes); the sum over ranks is then taken in bf16,
         everything inside a rank (accumulation, Adam moments, masters) stays fp32.  pack(src_f32, dst_bf16) / unpack(src_bf16,
         dst_f32): conversion ops (the trainer passes the HIP kernels b2s_pack_bf16 / b2s_unpack_bf16; default: torch copies, for
-        CPU tests)."""
+        CPU tests).  stream: torch.cuda.Stream the collectives (and the pack kernels) are launched on -- the engine orders THAT
+        stream behind the stage's gradient work (b2s_model_set_stage_hook_stream), the backward's own stream is not held up."""
         self.flat, self.stage_ranges, self.n_stages = flat, stage_ranges, n_stages
         self.bucket_elems = int(bucket_elems)
         self.dist = dist if dist is not None else torch.distributed
@@ -30,6 +32,7 @@ class GradBucketer(object):
         self.wire = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device) if payload == "bf16" else None
         self.pack = pack or (lambda src, dst: dst.copy_(src))
         self.unpack = unpack or (lambda src, dst: dst.copy_(src))
+        self.stream = stream
         self._pending = None
         self._works = []
         self.launched = []                       # (lo, hi) of every all-reduce of the current step, for tests / logs
@@ -38,18 +41,26 @@ class GradBucketer(object):
         self._pending, self._works, self.launched = None, [], []
 
     def _launch(self):
-        # Called on the thread / stream that enqueued the backward stage.  Ordering: the engine made that stream wait for the
-        # second-stream event that completes the stage's weight gradients before it fired the hook (engine.hip: end_stage);
-        # the conversion kernel (bf16 payload) is enqueued on the same stream; torch.distributed makes its communication
-        # stream wait for the current stream before the collective starts.
+        # Called on the thread that enqueued the backward stage.  Ordering: before it fired the hook the engine made the hook's
+        # stream (self.stream, or the backward's stream when there is none) wait for the event that completes the stage's
+        # gradients (engine.hip: end_stage / hook_after_*); the conversion kernel (bf16 payload) is enqueued on that stream;
+        # torch.distributed makes its communication stream wait for the current stream before the collective starts.
         lo, hi = self._pending
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                work = self._launch_on_current(lo, hi)
+        else:
+            work = self._launch_on_current(lo, hi)
+        self._works.append((work, lo, hi))
+        self.launched.append((lo, hi))
+        self._pending = None
+
+    def _launch_on_current(self, lo, hi):
         buf = self.flat[lo:hi]
         if self.wire is not None:
             buf = self.wire[lo:hi]
             self.pack(self.flat[lo:hi], buf)
-        self._works.append((self.dist.all_reduce(buf, group=self.group, async_op=True), lo, hi))
-        self.launched.append((lo, hi))
-        self._pending = None
+        return self.dist.all_reduce(buf, group=self.group, async_op=True)
 
     def stage_done(self, stage):
         rng = self.stage_ranges.get(stage)

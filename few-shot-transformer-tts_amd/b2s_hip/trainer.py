@@ -93,10 +93,15 @@ class HipTrainer(object):
             def unpack(src, dst):
                 L.check(lib.b2s_unpack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()))
             on_gpu = self.eng._gflat.is_cuda
+            # the collectives are launched from a stream of their own: the engine orders it behind each stage's gradient work,
+            # the backward pass itself never waits for the second stream on their account
+            self._hook_stream = torch.cuda.Stream(device=self.eng._gflat.device) if on_gpu else None
             self.bucketer = GradBucketer(self.eng._gflat, self.eng.stage_ranges, self.eng.n_stages(),
                                          bucket_mb * 1024 * 1024 / 4, dist=self.dist, payload=payload,
-                                         pack=pack if on_gpu else None, unpack=unpack if on_gpu else None)
+                                         pack=pack if on_gpu else None, unpack=unpack if on_gpu else None, stream=self._hook_stream)
             L.check(self.lib.b2s_model_set_stage_hook(self.eng.handle, C.cast(self._hook, L.P), None))
+            if self._hook_stream is not None:
+                L.check(self.lib.b2s_model_set_stage_hook_stream(self.eng.handle, self._hook_stream.cuda_stream))
             # broadcast parameters and BN buffers from rank 0 once (DDP constructor semantics, train.py:125)
             with torch.no_grad():
                 for t in self.eng._tensors():

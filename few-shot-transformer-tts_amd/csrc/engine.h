@@ -144,11 +144,14 @@ struct b2s_model {
     // (K = L*2D) instead of L launches of 56-112 tiles each
     void* kv_cat = nullptr;
     mutable LnReduceBatch ln_jobs = {};                       // LayerNorm parameter-gradient reductions queued for the stage's single launch
-    mutable int pending_stage = -1;
+    // stages whose gradient work has been handed to the second stream (completed by pending_ev) and whose hook has not fired yet /
+    // stages that ended since the last hand-over
+    mutable std::vector<int> pending_stages, unflushed_stages;
     mutable hipEvent_t pending_ev = nullptr;
     void (*stage_hook)(int, void*) = nullptr;       // called on the host after each backward stage is enqueued
     void* stage_user = nullptr;
-    void stage_done(int s) const { if (stage_hook) stage_hook(s, stage_user); }   // callers join the aux stream first
+    void stage_done(int s) const { if (stage_hook) stage_hook(s, stage_user); }   // callers order the hook's stream first (hook_after_*)
+    hipStream_t hook_stream = nullptr;              // stream the hook launches its collective on (b2s_model_set_stage_hook_stream); null: the backward's
 
     int id(const std::string& n) const;
     float* P(const std::string& n) const { return (float*)data[id(n)]; }

@@ -298,35 +298,65 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
 // end of backward stage `stage`: its parameter gradients are complete once the aux stream has drained.  drain: last stage
 // of this C entry point -- the main stream rejoins the aux stream and every outstanding hook fires.
 int flush_ln_jobs(const b2s_model* m, hipStream_t st);
+// Ordering for the stage hook.  The hook launches a collective on gradients that the second stream completes: the stream the hook
+// works on must wait for that.  With a dedicated hook stream the backward's own stream never waits for the second stream here (it
+// used to, at every stage -- 0.45 ms per step in data-parallel runs).
+int hook_after_event(const b2s_model* m, hipStream_t st, hipEvent_t ev) {      // ev: second-stream event after the stage's last gradient work
+    if (ev) B2S_HIP(hipStreamWaitEvent(m->hook_stream ? m->hook_stream : st, ev, 0));
+    return 0;
+}
+int hook_after_stream(const b2s_model* m, hipStream_t st) {                    // the stage's gradients are complete at this point of `st`
+    if (m->stage_hook && m->hook_stream && m->hook_stream != st) {
+        hipEvent_t e = m->next_event();
+        B2S_HIP(hipEventRecord(e, st));
+        B2S_HIP(hipStreamWaitEvent(m->hook_stream, e, 0));
+    }
+    return 0;
+}
+// fire the hooks of the stages in `v` (in order) and empty it
+void fire_stages(const b2s_model* m, std::vector<int>& v) {
+    for (int s : v) m->stage_done(s);
+    v.clear();
+}
 int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain) {
     static const bool serial = getenv("B2S_DW_GROUP_SERIAL") != nullptr;
-    // a stage without weight-gradient GEMMs (the output LayerNorm): its reductions / gradient-only launches wait for the next hand-over
-    if (m->dw_group && !serial && !m->stage_hook && !drain && m->dw_pending.empty()) return 0;
-    if (!m->dw_group || m->dw_pending.empty() || serial) B2S_TRY(flush_ln_jobs(m, st));      // the stage's LayerNorm parameter gradients (otherwise: flush_dw, second stream)
     if (!m->dw_group) {
+        B2S_TRY(flush_ln_jobs(m, st));                     // the stage's LayerNorm parameter gradients
         B2S_TRY(join_aux(m, st));
-        if (m->pending_stage >= 0) { m->stage_done(m->pending_stage); m->pending_stage = -1; m->pending_ev = nullptr; }     // (a deferred postnet stage)
+        B2S_TRY(hook_after_stream(m, st));
+        fire_stages(m, m->pending_stages);                 // (a deferred postnet stage)
+        m->pending_ev = nullptr;
         m->stage_done(stage);
         return 0;
     }
-    // Without a stage hook nobody needs a stage's gradients before the join: the groups of TWO stages are handed to the second stream
-    // together -- every hand-over costs the main stream one event record (~6.5 us of idle queue), 14 per step otherwise.
+    // The weight-gradient groups -- and with them the LayerNorm parameter reductions and the gradient-only launches -- of TWO stages are
+    // handed to the second stream together: every hand-over costs the main stream one event record (~6.5 us of idle queue), and a
+    // stage without weight-gradient GEMMs (an output LayerNorm) has nothing to hand over by itself.  The hooks of the stages a
+    // hand-over covers fire together at the next one, once the hook's stream has been ordered behind the second stream's event
+    // (two decoder-layer stages are one 32 MB bucket of the gradient exchange anyway).
     static const int per_flush = getenv("B2S_DW_STAGES") ? atoi(getenv("B2S_DW_STAGES")) : 2;
-    if (!m->stage_hook && !drain && !m->dw_pending.empty() && ++m->dw_stages_pending < per_flush) return 0;
+    if (!serial && !drain && (m->dw_pending.empty() || ++m->dw_stages_pending < per_flush)) {
+        m->unflushed_stages.push_back(stage);
+        return 0;
+    }
     m->dw_stages_pending = 0;
-    const int prev = m->pending_stage;
+    if (serial || m->dw_pending.empty()) B2S_TRY(flush_ln_jobs(m, st));
     hipEvent_t prev_ev = m->pending_ev;
     m->pending_ev = nullptr;
     B2S_TRY(flush_dw(m, st));                          // sets pending_ev when it launched something
-    if (m->stage_hook && prev >= 0) {
-        if (prev_ev) B2S_HIP(hipStreamWaitEvent(st, prev_ev, 0));
-        m->stage_done(prev);
+    if (m->stage_hook && !m->pending_stages.empty()) {
+        if (prev_ev) B2S_TRY(hook_after_event(m, st, prev_ev));        // (the event implies the main stream's part of those stages: the group waited for it)
+        else B2S_TRY(hook_after_stream(m, st));                        // stages without second-stream work
     }
-    m->pending_stage = stage;
+    fire_stages(m, m->pending_stages);
+    m->pending_stages = m->unflushed_stages;
+    m->unflushed_stages.clear();
+    m->pending_stages.push_back(stage);
     if (drain) {
         B2S_TRY(join_aux(m, st));
-        m->stage_done(stage);
-        m->pending_stage = -1; m->pending_ev = nullptr;
+        B2S_TRY(hook_after_stream(m, st));
+        fire_stages(m, m->pending_stages);
+        m->pending_ev = nullptr;
     }
     return 0;
 }
@@ -816,6 +846,11 @@ extern "C" int b2s_model_sync_weights_ex(b2s_model* m, void* stream, int shadows
 }
 
 extern "C" void b2s_ctx_free(b2s_ctx* ctx) { delete ctx; }
+extern "C" int b2s_model_set_stage_hook_stream(b2s_model* m, void* stream) {
+    B2S_CHECK(m, "null model");
+    m->hook_stream = (hipStream_t)stream;
+    return 0;
+}
 extern "C" int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int, void*), void* user) {
     B2S_CHECK(m, "null model");
     m->stage_hook = hook; m->stage_user = user;
@@ -1438,16 +1473,14 @@ extern "C" int b2s_postnet_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
     // take care of this stage's hook and of the second stream)
     if ((flags & B2S_POST_BWD_DEFER_JOIN) && m->aux) {
         B2S_TRY(flush_ln_jobs(m, st));
-        if (m->stage_hook && m->pending_stage >= 0) {     // an earlier deferred stage (none in the usual order)
-            if (m->pending_ev) B2S_HIP(hipStreamWaitEvent(st, m->pending_ev, 0));
-            m->stage_done(m->pending_stage);
-        }
-        m->pending_stage = 0;
+        m->pending_stages.push_back(0);                   // fires at the decoder backward's first hand-over (or its join)
         return 0;
     }
     B2S_TRY(join_aux(m, st));
+    B2S_TRY(hook_after_stream(m, st));
+    fire_stages(m, m->pending_stages);
     m->stage_done(0);
-    m->pending_stage = -1; m->pending_ev = nullptr;
+    m->pending_ev = nullptr;
     return 0;
 }
 

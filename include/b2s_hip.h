@@ -124,6 +124,11 @@ void b2s_ctx_free(b2s_ctx* ctx);
  * + decoder pe_scale; 3+Ld speaker/language nets + encoder output LayerNorm; 4+Ld..3+Ld+Le encoder layers
  * Le-1..0; 4+Ld+Le byte embedding + encoder pe_scale. */
 int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int stage, void* user), void* user);
+/* The stream the hook launches its collective on.  NULL (default): the stream of the backward call -- the library then makes
+ * that stream wait for the second stream's weight-gradient work of the stage before the hook fires.  A dedicated stream: only
+ * that stream waits, the backward pass is not held up (the hook must launch its work on it; the final optimizer step has to
+ * wait for the collectives as before). */
+int b2s_model_set_stage_hook_stream(b2s_model* m, void* stream);
 
 /* ---- compute_loss (tacotron.py:136-158) ------------------------------------------------------------
  * losses_out[7] = loss, bef_loss, aft_loss, mse_loss, l2, stop_loss, sum(lengths); aft_losses_out[B].
