@@ -25,7 +25,8 @@ struct b2s_decode_state {
     int* status = nullptr;       // device [2]: {t, all_finished}
     float* mels = nullptr;       // [B, maxT, NM]
     void* memT = nullptr;
-    std::vector<void*> crossKV, selfK, selfV;
+    std::vector<void*> crossKV, selfK, selfV;    // crossKV[l]: K then V of the memory, head-major [2][B][H][S][dh] (contiguous rows per (utterance, head))
+    void* kv_tmp = nullptr;                      // [B*S][2D] projection output before the re-layout
     std::vector<float*> crossP, selfP;   // attention rows of every step: [B,H,maxT,S] / [B,H,maxT,maxT]
     void *tgt = nullptr, *a1 = nullptr, *a2 = nullptr, *h = nullptr, *qkv = nullptr, *ctx = nullptr, *f = nullptr, *outT = nullptr;
     float *a3 = nullptr, *x = nullptr, *mean = nullptr, *rstd = nullptr, *mel_step = nullptr, *stop_step = nullptr;
@@ -54,6 +55,18 @@ int b2s_ensure_pe_export(b2s_model* m, int len);      // engine.hip
 namespace {
 inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 
+// [B*S][2][H][dh] (projection output: K | V halves of a row, heads interleaved) -> [2][B][H][S][dh]; c16: 16-byte chunks per head row
+__global__ void k_kv_headmajor(const uint4* __restrict__ src, uint4* __restrict__ dst, int B, int S, int H, int c16) {
+    const long n = (long)B * S * 2 * H * c16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c16);
+        long r = i / c16;
+        const int h = (int)(r % H); r /= H;
+        const int kv = (int)(r % 2); r /= 2;
+        const int sidx = (int)(r % S); const int b = (int)(r / S);
+        dst[((((long)kv * B + b) * H + h) * S + sidx) * c16 + c] = src[i];
+    }
+}
 __global__ void k_dec_begin(int* t, int* finished, int* lengths, int* status, int B) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B) { finished[i] = 0; lengths[i] = 1; }
@@ -257,6 +270,7 @@ void plan_decode(const b2s_model* m, b2s_decode_state& s, Arena& a) {
     s.crossKV.assign(L, nullptr); s.selfK.assign(L, nullptr); s.selfV.assign(L, nullptr); s.crossP.assign(L, nullptr); s.selfP.assign(L, nullptr);
     for (int l = 0; l < L; ++l) {
         s.crossKV[l] = a.T((long)B * S * 2 * D, esz);
+        if (l == 0) s.kv_tmp = a.T((long)B * S * 2 * D, esz);
         s.selfK[l] = a.T((long)B * T * D, esz);
         s.selfV[l] = a.T((long)B * T * D, esz);
         s.crossP[l] = a.f32((long)B * H * T * S);
@@ -340,7 +354,7 @@ int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
         xa.c = common(lnx, make_drop(pt, s->seed, 9040 + l));
         xa.H = H; xa.dh = dh; xa.Wqkv = s->Wd(m, nm2(p, "encdec_attentions", l, "q_transform.weight"));
         xa.Wo = s->Wd(m, nm2(p, "encdec_attentions", l, "output_transform.weight"));
-        xa.Kc = s->crossKV[l]; xa.Vc = (char*)s->crossKV[l] + (size_t)D * m->esz; xa.ldkv = 2 * D; xa.kv_bstride = (long)S * 2 * D; xa.kv_hstride = dh;
+        xa.Kc = s->crossKV[l]; xa.Vc = (char*)s->crossKV[l] + (size_t)B * S * D * m->esz; xa.ldkv = dh; xa.kv_bstride = (long)S * D; xa.kv_hstride = (long)S * dh;
         xa.maxT = maxT; xa.probs = s->crossP[l]; xa.probs_rows = maxT; xa.probs_ld = S; xa.klen = s->in_len; xa.nmax = S; xa.scale = scale;
         xa.drop_attn = make_drop(pt, s->seed, 9030 + l);
         B2S_TRY(b2s_df_attn(dt, false, xa, st));
@@ -404,7 +418,7 @@ int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
                                  nullptr, 1, st));
         B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "encdec_attentions", l, "q_transform.weight")), B, D, D, s->qkv, 0, D, GemmEpilogue()));
         hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(256), sh_cross, st, (const T*)s->qkv, D, (const T*)s->crossKV[l],
-                           (const T*)s->crossKV[l] + D, 2 * D, (long)S * 2 * D, (long)dh, (T*)s->ctx, D, s->crossP[l], maxT, S, s->t, s->in_len, 0, H, dh,
+                           (const T*)s->crossKV[l] + (long)B * S * D, dh, (long)S * D, (long)S * dh, (T*)s->ctx, D, s->crossP[l], maxT, S, s->t, s->in_len, 0, H, dh,
                            S, scale, make_drop(pt, s->seed, 9030 + l));
         GemmEpilogue ex; ex.drop = make_drop(pt, s->seed, 9040 + l); ex.drop_salt = s->t; ex.residual = s->x; ex.ldr = D;
         B2S_TRY(lin(m, st, s->ctx, D, m->W(nm2(p, "encdec_attentions", l, "output_transform.weight")), B, D, D, s->x, 1, D, ex));
@@ -470,8 +484,15 @@ extern "C" int b2s_decode_begin(b2s_model* m, const float* memory, const int32_t
     }
     rc = ro_cast(m->dtype, memory, s->memT, (long)B * S * D, st);
     for (int l = 0; l < cf.n_decoder_layer && !rc; ++l) {
-        rc = lin(m, st, s->memT, D, m->W(nm2("decoder.decoder.", "encdec_attentions", l, "kv_transform.weight")), B * S, 2 * D, D, s->crossKV[l], 0,
+        // memory K / V of the layer, then head-major: a head's rows of an utterance become one contiguous block (read in place
+        // from the [B*S][2D] projection a 192-byte head row straddles two 128-byte lines: 1.5x the bytes, every frame)
+        rc = lin(m, st, s->memT, D, m->W(nm2("decoder.decoder.", "encdec_attentions", l, "kv_transform.weight")), B * S, 2 * D, D, s->kv_tmp, 0,
                  2 * D, GemmEpilogue());
+        if (!rc) {
+            const long n16 = (long)B * S * 2 * D * m->esz / 16;
+            hipLaunchKernelGGL(k_kv_headmajor, dim3((unsigned)std::min<long>((n16 + 255) / 256, 4096)), dim3(256), 0, st, (const uint4*)s->kv_tmp,
+                               (uint4*)s->crossKV[l], B, S, cf.n_attention_head, D / cf.n_attention_head * m->esz / 16);
+        }
         if (!rc) rc = hipMemsetAsync(s->crossP[l], 0, (size_t)B * cf.n_attention_head * max_frames * S * 4, st) == hipSuccess ? 0 : 1;
         if (!rc && s->selfP[l]) rc = hipMemsetAsync(s->selfP[l], 0, (size_t)B * cf.n_attention_head * max_frames * max_frames * 4, st) == hipSuccess ? 0 : 1;
     }
