@@ -84,9 +84,12 @@ class HipTrainer(object):
         self.bucketer = None
         self._hook = _HOOK_T(self._on_stage)      # keep a reference: ctypes callbacks must outlive their use
         if self.world > 1 or (self.dist and os.environ.get("B2S_FORCE_DP")):    # B2S_FORCE_DP: 1-rank group, test aid
-            # grad_payload "bf16": gradients travel as bf16 (half the xGMI bytes), converted by HIP kernels on this stream around
-            # each bucket's all-reduce; default fp32 (exact mean of the rank gradients); B2S_GRAD_PAYLOAD overrides
-            payload = grad_payload or os.environ.get("B2S_GRAD_PAYLOAD", "fp32")
+            # grad_payload "bf16" (default for world > 1): gradients travel as bf16 -- 167 MB instead of 334 MB per step over xGMI,
+            # whose point-to-point links (7 x ~153 GB/s per GPU) bound the ring all-reduce -- converted by HIP
+            # kernels on the exchange stream around each bucket's all-reduce; everything inside a rank (accumulation, Adam moments,
+            # masters) stays fp32.  "fp32": the exact mean of the rank gradients (the reference's DDP arithmetic).
+            # B2S_GRAD_PAYLOAD overrides the default, the constructor argument overrides both.
+            payload = grad_payload or os.environ.get("B2S_GRAD_PAYLOAD", "bf16" if self.world > 1 else "fp32")
             lib = self.lib
             def pack(src, dst):
                 L.check(lib.b2s_pack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()))
@@ -108,6 +111,11 @@ class HipTrainer(object):
                     self.dist.broadcast(t.data, 0)
             self.eng._versions = None
             self.eng.ensure_bound()                   # re-sync the compute-dtype shadows with the broadcast values
+        # DDP(broadcast_buffers=True) re-broadcasts rank 0's BatchNorm buffers before EVERY forward (train.py:125): one 17 KB message
+        # per step.  B2S_BN_BROADCAST=0 keeps the running statistics rank-local between steps (rank 0's -- the ones the reference
+        # checkpoints -- are identical either way).
+        self._bn_buffers = [b for _, b in model.named_buffers()]
+        self.bn_broadcast = self.world > 1 and os.environ.get("B2S_BN_BROADCAST", "1") != "0"
 
     # ------------------------------------------------------------------ checkpoint interchange (utils/checkpoint.py)
     def _param_names(self):
@@ -183,6 +191,9 @@ class HipTrainer(object):
     def train_step(self, batch):
         """batch: the dataloader dict (dataloader.py:498-508) on the device.  Returns the 7 loss values (device)."""
         eng, lib = self.eng, self.lib
+        if self.bn_broadcast and self._bn_buffers:
+            from .dp import broadcast_buffers
+            broadcast_buffers(self._bn_buffers, self.dist, 0)
         # the fused Adam kernel rewrote the fp32 masters AND their bf16 shadows; only conv re-layouts remain
         L.check(lib.b2s_model_sync_weights_ex(eng.handle, L.stream(), int(self.global_step > 0)))
         in32, tgt32 = _i32(batch["input_lengths"]), _i32(batch["target_lengths"])
@@ -202,16 +213,19 @@ class HipTrainer(object):
         dbef, daft, dstop = eng.loss_backward(mels, aft, stop, batch["mel_targets"], tgt32, None)
         din = eng.postnet_backward(c_post, daft, defer_join=True)           # (the decoder backward below takes over the second stream's join)
         dmel = eng.add(eng.add(din, daft), dbef)
+        # split: the decoder / postnet gradients (78 % of the parameters) get their optimizer update (HBM-bound, no LDS) on the
+        # engine's second stream under the encoder backward, whose GEMMs are 78..208 workgroups on 256 CUs; the encoder group
+        # follows on this stream.  Data parallel: those gradients' all-reduce must be complete first, so the split is used only
+        # without a process group (the exchange itself overlaps the encoder backward there).
+        split = self.split_adam and self.bucketer is None and not self.freeze_encoder and not self.overlap_adam
+        # With a deferred join the last stages' weight-gradient groups, bias column sums and LayerNorm reductions of the decoder
+        # backward are still queued when it returns (the encoder backward launches them): the split update must not run on
+        # incomplete decoder gradients, so it takes the join here.
         dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape, self._one if guided else None, not self.freeze_encoder,
-                                    defer_join=not self.freeze_encoder)    # (encoder_backward below joins the second stream)
+                                    defer_join=not self.freeze_encoder and not split)    # (encoder_backward below joins the second stream)
         lr = self.hp.max_lr * self.lr_lambda(self.global_step)
         step_no = self.global_step + 1
         adam = (lr, step_no, self.beta1, self.beta2, self.hp.adam_eps, self.hp.reg_weight, 1.0 / self.world)
-        # The decoder / postnet gradients (78 % of the parameters) are final here.  Their optimizer update (HBM-bound, no LDS)
-        # goes to the engine's second stream and runs under the encoder backward, whose GEMMs are 78..208 workgroups on
-        # 256 CUs; the encoder group follows on this stream.  Data parallel: those gradients' all-reduce must be complete
-        # first, so the split is used only without a process group (the exchange itself overlaps the encoder backward there).
-        split = self.split_adam and self.bucketer is None and not self.freeze_encoder and not self.overlap_adam
         if split:
             L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 1, L.stream()))
         if not self.freeze_encoder:

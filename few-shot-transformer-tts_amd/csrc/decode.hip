@@ -37,6 +37,7 @@ struct b2s_decode_state {
     int* done_cnt = nullptr;
     int ns_ffn = 0;
     bool fused = false;
+    bool fast = false;          // every decoder sublayer has the default widths (b2s_df_fast_model): default-size kernel instantiations
     // fragment-packed copies of the projection weights the fused bf16 kernels read (b2s_df_pack; made by b2s_decode_begin)
     struct Pack { std::string name; int N, K; void* p; };
     std::vector<Pack> packs;
@@ -281,7 +282,7 @@ void plan_decode(const b2s_model* m, b2s_decode_state& s, Arena& a) {
     s.h = a.T((long)B * D, esz); s.qkv = a.T((long)B * 3 * D, esz); s.ctx = a.T((long)B * D, esz); s.f = a.T((long)B * 4 * D, esz);
     s.outT = a.T((long)B * D, esz); s.mel_step = a.f32((long)B * cf.num_mels); s.stop_step = a.f32(B);
     static const bool no_fused = getenv("B2S_DECODE_UNFUSED") != nullptr;          // A/B switch: one kernel per op (round-1 path)
-    s.ns_ffn = b2s_df_ffn_slices(m->dtype, 4 * D);
+    s.ns_ffn = b2s_df_ffn_slices(m->dtype, D, H, 4 * D);
     s.fused = !no_fused && b2s_df_supported(m->dtype, D, H, 4 * D, cf.num_mels, cf.prenet_hidden, std::max(T, S));
     if (s.fused) {
         const int ns = std::max(H, s.ns_ffn);
@@ -291,15 +292,16 @@ void plan_decode(const b2s_model* m, b2s_decode_state& s, Arena& a) {
         const std::string p = "decoder.decoder.";
         s.packs.clear();
         auto add = [&](const std::string& n, int N, int K) { s.packs.push_back({n, N, K, a.T((long)N * K, 2)}); };
-        if (b2s_df_attn_packed(m->dtype, D, dh))
+        s.fast = b2s_df_fast_model(D, H, F);
+        if (b2s_df_attn_packed(m->dtype, D, H, F))
             for (int l = 0; l < L; ++l) {
                 add(nm2(p, "self_attentions", l, "qkv_transform.weight"), 3 * D, D); add(nm2(p, "self_attentions", l, "output_transform.weight"), D, D);
                 add(nm2(p, "encdec_attentions", l, "q_transform.weight"), D, D); add(nm2(p, "encdec_attentions", l, "output_transform.weight"), D, D);
             }
-        if (b2s_df_ffn_packed(m->dtype, D, F, s.ns_ffn))
+        if (b2s_df_ffn_packed(m->dtype, D, H, F))
             for (int l = 0; l < L; ++l) { add(nm2(p, "ffn_layers", l, "input_layer.weight"), F, D); add(nm2(p, "ffn_layers", l, "output_layer.weight"), D, F); }
         if (b2s_df_prenet_packed(m->dtype, HP, NM, D)) { add("decoder.prenet.dense1.weight", HP, HP); add("decoder.prenet.dense_final.weight", D, HP); }
-        if (b2s_df_final_packed(m->dtype, D)) add("decoder.mel_net.weight", NM, D);
+        if (b2s_df_final_packed(m->dtype, D, H, F)) add("decoder.mel_net.weight", NM, D);
     }
 }
 
@@ -336,6 +338,7 @@ int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
         DfCommon c;
         c.X_in = s->Xpp[k & 1]; c.X_out = s->Xpp[(k + 1) & 1]; c.P_prev = s->Ppp[(k + 1) & 1]; c.np_prev = np; c.P_out = s->Ppp[k & 1];
         c.B = B; c.D = D; c.ln_g = m->P(ln + ".weight"); c.ln_b = m->P(ln + ".bias"); c.eps = 1e-6f; c.t = s->t; c.drop_res = dres;
+        c.fast = s->fast ? 1 : 0;
         return c;
     };
     for (int l = 0; l < L; ++l) {
@@ -367,6 +370,7 @@ int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
         ++k; np = s->ns_ffn;
     }
     DfFinal fn;
+    fn.fast = s->fast ? 1 : 0;
     fn.X_in = s->Xpp[k & 1]; fn.P_prev = s->Ppp[(k + 1) & 1]; fn.np_prev = np; fn.B = B; fn.D = D; fn.NM = NM; fn.maxT = maxT;
     fn.ln_g = m->P(p + "output_layer_norm.weight"); fn.ln_b = m->P(p + "output_layer_norm.bias"); fn.eps = 1e-6f;
     fn.Wmel = s->Wd(m, "decoder.mel_net.weight"); fn.wstop = m->P("decoder.stop_net.weight"); fn.bstop = m->P("decoder.stop_net.bias");

@@ -17,6 +17,9 @@ struct DfCommon {
     float eps;
     const int* t;             // device: frame index
     DropCfg drop_res;         // dropout on the sublayer output (keyed by the frame index in the kernel)
+    // 1: the whole decoder has the reference's default widths (b2s_df_fast_model), so the default-size kernel instantiations apply: they
+    // hard-code how many partial slabs the previous sublayer wrote (heads = 8, FFN slices = 32) and, in bf16, read fragment-packed weights
+    int fast = 0;
 };
 struct DfAttn {
     DfCommon c;
@@ -53,6 +56,7 @@ struct DfPrenet {
 };
 struct DfFinal {
     const float* X_in; const void* P_prev; int np_prev;
+    int fast = 0;             // see DfCommon::fast
     int B, D, NM, maxT;
     const float *ln_g, *ln_b; float eps;
     const void* Wmel;         // mel_net [NM][D] (compute dtype; packed when b2s_df_final_packed)
@@ -72,9 +76,12 @@ bool b2s_df_supported(int dtype, int D, int H, int F, int NM, int HP, int nmax);
 // bf16 at the default widths: the kernels take their projection weights as MFMA-fragment-packed copies -- for every block of 16 rows
 // and every 32-deep k step the 64 lanes' 16-byte fragments are contiguous, so each load instruction of a wave is one coalesced KB.
 // b2s_df_pack writes such a copy of a row-major [N][K] bf16 matrix (N % 16 == 0, K % 32 == 0; same size).
-bool b2s_df_attn_packed(int dtype, int D, int dh);
-bool b2s_df_ffn_packed(int dtype, int D, int F, int ns);
+// The default-size attention / FFN / heads kernels assume the WHOLE decoder stack has the default widths: each of them sums a
+// compile-time number of partial slabs written by the sublayer before it (8 heads, 32 FFN slices).  One predicate for all three.
+bool b2s_df_fast_model(int D, int H, int F);
+bool b2s_df_attn_packed(int dtype, int D, int H, int F);
+bool b2s_df_ffn_packed(int dtype, int D, int H, int F);
 bool b2s_df_prenet_packed(int dtype, int HP, int NM, int D);
-bool b2s_df_final_packed(int dtype, int D);
+bool b2s_df_final_packed(int dtype, int D, int H, int F);
 int b2s_df_pack(const void* W, int N, int K, void* out, hipStream_t st);
-int b2s_df_ffn_slices(int dtype, int F);
+int b2s_df_ffn_slices(int dtype, int D, int H, int F);

@@ -941,8 +941,9 @@ size_t b2s_df_ffn_lds(int dtype, int D, int F, int ns) {
     constexpr size_t UB = UBF;
     return al16((size_t)UB * D * 4 + UB * D * e + UB * FS * 4 + UB * FS * e + 2 * UB * 4 + 64);
 }
-int b2s_df_ffn_slices(int dtype, int F) {
-    if (F == 32 * FD_FS) return 32;                    // the default sizes: 32 slices of FD_FS hidden units (FAST instantiation)
+int b2s_df_ffn_slices(int dtype, int D, int H, int F) {
+    if (b2s_df_fast_model(D, H, F)) return 32;         // the default sizes: 32 slices of FD_FS hidden units (FAST instantiation only: 96 is
+                                                       // not a whole number of the generic walk's 64-element bf16 steps)
     const int step = 8 * (dtype ? 8 : 4);              // generic: the slice is a K walk of 8 lanes per row
     for (int ns = 16; ns >= 1; --ns)
         if (F % ns == 0 && (F / ns) % step == 0 && F / ns <= DF_MAX_FS) return ns;
@@ -952,16 +953,17 @@ bool b2s_df_supported(int dtype, int D, int H, int F, int NM, int HP, int nmax) 
     const int ve = dtype ? 8 : 4;
     if (H <= 0 || D % H) return false;
     const int dh = D / H;
-    if (D > DF_MAX_D || dh > DF_MAX_DH || HP > DF_MAX_HP || NM > DF_MAX_NM || b2s_df_ffn_slices(dtype, F) == 0) return false;
+    if (D > DF_MAX_D || dh > DF_MAX_DH || HP > DF_MAX_HP || NM > DF_MAX_NM || b2s_df_ffn_slices(dtype, D, H, F) == 0) return false;
     // every GEMV walks K in whole steps of (lanes per row) x (16 bytes)
     return D % (8 * ve) == 0 && dh % (4 * ve) == 0 && HP % (4 * ve) == 0 && NM % 16 == 0 &&
-           b2s_df_attn_lds(dtype, D, dh, nmax) <= 64 * 1024 && b2s_df_ffn_lds(dtype, D, F, b2s_df_ffn_slices(dtype, F)) <= 64 * 1024;
+           b2s_df_attn_lds(dtype, D, dh, nmax) <= 64 * 1024 && b2s_df_ffn_lds(dtype, D, F, b2s_df_ffn_slices(dtype, D, H, F)) <= 64 * 1024;
 }
 // the FAST instantiations serve exactly the default sizes (see the top of the file); in bf16 they read fragment-packed weights
-bool b2s_df_attn_packed(int dtype, int D, int dh) { return dtype == 1 && D == FD_D && dh == FD_DH; }
-bool b2s_df_ffn_packed(int dtype, int D, int F, int ns) { return dtype == 1 && D == FD_D && ns > 0 && F / ns == FD_FS; }
+bool b2s_df_fast_model(int D, int H, int F) { return D == FD_D && H == FD_D / FD_DH && F == 32 * FD_FS; }
+bool b2s_df_attn_packed(int dtype, int D, int H, int F) { return dtype == 1 && b2s_df_fast_model(D, H, F); }
+bool b2s_df_ffn_packed(int dtype, int D, int H, int F) { return dtype == 1 && b2s_df_fast_model(D, H, F); }
 bool b2s_df_prenet_packed(int dtype, int HP, int NM, int D) { return dtype == 1 && HP == FD_HP && NM == FD_NM && D == FD_D; }
-bool b2s_df_final_packed(int dtype, int D) { return dtype == 1 && D == FD_D; }
+bool b2s_df_final_packed(int dtype, int D, int H, int F) { return dtype == 1 && b2s_df_fast_model(D, H, F); }
 int b2s_df_pack(const void* W, int N, int K, void* out, hipStream_t st) {
     B2S_CHECK(W && out && N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "pack: %d x %d (needs multiples of 16 x 32)", N, K);
     const long nfrag = (long)(N / 16) * (K / 32) * 64;
@@ -981,7 +983,8 @@ int b2s_df_prenet(int dtype, const DfPrenet& a, hipStream_t st) {
 int b2s_df_attn(int dtype, bool self, const DfAttn& a, hipStream_t st) {
     const size_t lds = b2s_df_attn_lds(dtype, a.c.D, a.dh, a.nmax);
     const int grid = a.H * ((a.c.B + UBA - 1) / UBA);
-    const bool fast = a.c.D == FD_D && a.dh == FD_DH;
+    // (the default-size instantiation sums a compile-time number of partial slabs: every sublayer of the stack must have the default widths)
+    const bool fast = a.c.fast && a.c.D == FD_D && a.dh == FD_DH && a.H == FD_D / FD_DH && (a.c.np_prev == 0 || a.c.np_prev == (self ? 32 : 8));
     if (dtype) {
         if (fast) return self ? launch(k_df_attn<bf16_t, true, true>, grid, lds, a, st) : launch(k_df_attn<bf16_t, false, true>, grid, lds, a, st);
         return self ? launch(k_df_attn<bf16_t, true, false>, grid, lds, a, st) : launch(k_df_attn<bf16_t, false, false>, grid, lds, a, st);
@@ -992,7 +995,7 @@ int b2s_df_attn(int dtype, bool self, const DfAttn& a, hipStream_t st) {
 int b2s_df_ffn(int dtype, const DfFfn& a, hipStream_t st) {
     const size_t lds = b2s_df_ffn_lds(dtype, a.c.D, a.F, a.ns);
     const int grid = a.ns * ((a.c.B + UBF - 1) / UBF);
-    const bool fast = a.c.D == FD_D && a.F / a.ns == FD_FS;
+    const bool fast = a.c.fast && a.c.D == FD_D && a.ns == 32 && a.F / a.ns == FD_FS && a.c.np_prev == 8;
     if (dtype) return fast ? launch(k_df_ffn<bf16_t, true>, grid, lds, a, st) : launch(k_df_ffn<bf16_t, false>, grid, lds, a, st);
     return fast ? launch(k_df_ffn<float, true>, grid, lds, a, st) : launch(k_df_ffn<float, false>, grid, lds, a, st);
 }
@@ -1001,7 +1004,7 @@ int b2s_df_final(int dtype, const DfFinal& a, hipStream_t st) {
     constexpr int UB = UBH;
     const size_t lds = al16((size_t)UB * a.D * 4 + UB * a.D * e + (size_t)UB * a.NM * 4 + (8 + UB) * 4 + 64);
     const int grid = (a.B + UB - 1) / UB;
-    const bool fast = a.D == FD_D;
+    const bool fast = a.fast && a.D == FD_D && a.np_prev == 32;
     if (dtype) return fast ? launch(k_df_final<bf16_t, true>, grid, lds, a, st) : launch(k_df_final<bf16_t, false>, grid, lds, a, st);
     return fast ? launch(k_df_final<float, true>, grid, lds, a, st) : launch(k_df_final<float, false>, grid, lds, a, st);
 }

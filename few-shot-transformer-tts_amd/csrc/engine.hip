@@ -1587,6 +1587,12 @@ extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta
     B2S_HIP(hipMemcpyAsync(dhp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
     const bool cover = !m->cfg.freeze_encoder;
     hipStream_t run = st;
+    // A backward entry point called with a deferred join leaves the last stages' weight-gradient groups, column sums and LayerNorm
+    // reductions queued for the next entry point: an update issued now would consume incomplete gradients (and those parameters would
+    // never train -- the late gradients are zeroed at the next step).  Refuse instead of guessing.
+    B2S_CHECK(m->dw_pending.empty() && m->aux_jobs.empty() && m->ln_jobs.n == 0 && m->dw_stages_pending == 0 && m->unflushed_stages.empty(),
+              "b2s_adam_step_groups: gradient work of the last backward stages is still queued (the preceding backward call deferred its "
+              "join): call it without B2S_DEC_BWD_DEFER_JOIN / B2S_POST_BWD_DEFER_JOIN before a partial optimizer step");
     if (on_aux && m->aux) {
         hipEvent_t ready = m->next_event();
         B2S_HIP(hipEventRecord(ready, st));                    // gradients of `groups` (and their all-reduce) are complete here

@@ -16,6 +16,7 @@ import ctypes as C
 import logging
 import os
 import time
+import traceback
 
 import torch
 
@@ -34,7 +35,9 @@ def _to_host(tensors):
         return [t.cpu().numpy() for t in tensors]
     for h, t in zip(host, tensors):
         h.copy_(t, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
+    # every copy was queued on the current stream of ITS source device (not necessarily the current device): wait for each of those
+    for dev in {t.device for t in tensors if t.is_cuda}:
+        torch.cuda.current_stream(dev).synchronize()
     return [h.numpy() for h in host]
 
 
@@ -96,19 +99,44 @@ def eval_batch(model_eval, data, use_bar=True, bar_interval=10, use_graph=True, 
                 L.check(lib.b2s_decode_begin(eng.handle, L.ptr(ln.enc), L.ptr(ln.in32), ln.B, S, max_frames, int(train), eng.next_seed(),
                                              int(keep_self_alignments), L.ptr(ln.ws), ln.nbytes, ln.stream.cuda_stream, C.byref(ln.state)))
             shown = 0
+            bar = None
+            if use_bar and bar_interval != -1:                  # the reference's progress display (synthesize.py:33-34,47-49)
+                try:
+                    import tqdm
+                    bar = tqdm.tqdm()
+                except ImportError:
+                    bar = None
             while any(ln.active for ln in Ls):
-                for ln in Ls:                                   # enqueue every lane's next frames before waiting on any of them
-                    if ln.active:
-                        n = min(sync_interval, max_frames - ln.frames.value)
-                        L.check(lib.b2s_decode_run(eng.handle, ln.state, n, int(use_graph), ln.stream.cuda_stream))
-                for ln in Ls:
-                    if ln.active:
-                        L.check(lib.b2s_decode_status(ln.state, C.byref(ln.frames), C.byref(ln.done), ln.stream.cuda_stream))
-                        ln.active = ln.frames.value < max_frames and not ln.done.value
+                # A failing step ends the loop, it does not lose the job (synthesize.py:36,52-54: `except: traceback.print_exc(); break`):
+                # what was generated up to the last completed status read is returned.
+                try:
+                    for ln in Ls:                               # enqueue every lane's next frames before waiting on any of them
+                        if ln.active:
+                            n = min(sync_interval, max_frames - ln.frames.value)
+                            L.check(lib.b2s_decode_run(eng.handle, ln.state, n, int(use_graph), ln.stream.cuda_stream))
+                    for ln in Ls:
+                        if ln.active:
+                            L.check(lib.b2s_decode_status(ln.state, C.byref(ln.frames), C.byref(ln.done), ln.stream.cuda_stream))
+                            ln.active = ln.frames.value < max_frames and not ln.done.value
+                except Exception:
+                    traceback.print_exc()
+                    logging.error("eval_batch: decode step failed after %d frames; returning what was generated" % max(ln.frames.value for ln in Ls))
+                    for ln in Ls:
+                        ln.active = False
+                        try:                                    # frames completed before the failure (a dead device leaves the last count)
+                            L.check(lib.b2s_decode_status(ln.state, C.byref(ln.frames), C.byref(ln.done), ln.stream.cuda_stream))
+                        except Exception:
+                            pass
+                    break
                 f = max(ln.frames.value for ln in Ls)
-                if bar_interval != -1 and not use_bar and f // bar_interval > shown:
+                if bar_interval != -1 and f // bar_interval > shown:
+                    if bar is not None:
+                        bar.update((f // bar_interval - shown) * bar_interval)
+                    elif not use_bar:
+                        print(f)
                     shown = f // bar_interval
-                    print(f)
+            if bar is not None:
+                bar.close()
             for ln in Ls:
                 ln.lengths = torch.empty(ln.B, dtype=torch.int32, device=device)
                 with torch.cuda.stream(ln.stream):
@@ -120,6 +148,8 @@ def eval_batch(model_eval, data, use_bar=True, bar_interval=10, use_graph=True, 
                 ln.t_gen = int(ln.lengths.max().item()) if ln.done.value else max_frames
                 ln.t_gen = min(ln.t_gen, ln.frames.value)
             t_gen = max(ln.t_gen for ln in Ls)
+            if t_gen <= 0:      # (a failure before the first frame: the reference loop has no `align` to return either and raises)
+                raise L.B2SError("eval_batch: no frame was generated")
             one = len(Ls) == 1
             mels = torch.empty(B, t_gen, NM, dtype=torch.float32, device=device) if one else \
                 torch.zeros(B, t_gen, NM, dtype=torch.float32, device=device)

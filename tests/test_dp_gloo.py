@@ -102,3 +102,30 @@ def test_bucketed_allreduce_bf16_payload(tmp_path):
     mp.spawn(_worker, args=(2, port, out, "bf16"), nprocs=2, join=True)
     mean = np.load(out)
     assert np.isfinite(mean).all() and np.abs(mean).max() > 0
+
+
+def _bn_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from b2s_hip.dp import broadcast_buffers
+    torch.manual_seed(rank)
+    bufs = []
+    for c in (512, 512, 80):
+        bufs += [torch.randn(c), torch.rand(c) + 0.5, torch.tensor(7 + rank, dtype=torch.long)]     # running_mean, running_var, num_batches_tracked
+    mine = [b.clone() for b in bufs]
+    broadcast_buffers(bufs, dist, 0)
+    torch.manual_seed(0)
+    for c, i in ((512, 0), (512, 3), (80, 6)):
+        rm, rv = torch.randn(c), torch.rand(c) + 0.5
+        assert torch.equal(bufs[i], rm) and torch.equal(bufs[i + 1], rv) and int(bufs[i + 2]) == 7
+        assert bufs[i + 2].dtype == torch.long and bufs[i + 2].dim() == 0
+        if rank == 0:
+            assert torch.equal(bufs[i], mine[i])
+    dist.destroy_process_group()
+
+
+def test_buffer_broadcast_every_step_semantics():
+    """DDP(broadcast_buffers=True), train.py:125: every rank's BatchNorm buffers become rank 0's (one flat float message + one int64
+    message; shapes, dtypes and 0-dim counters preserved)."""
+    mp.spawn(_bn_worker, args=(2, _free_port()), nprocs=2, join=True)

@@ -334,6 +334,40 @@ def test_decode_eval_batch(tag, over, case):
     assert np.array_equal(re_["mel_pre"], r["mel_pre"]) and np.array_equal(re_["mel_aft"], r["mel_aft"])
 
 
+def test_decode_step_failure_returns_frames_generated_so_far(capsys):
+    """synthesize.py:36,52-54 of the reference: an exception inside a decode step is printed, the loop breaks and what was generated
+    so far is returned.  The failure is injected through the C ABI itself (an invalid n_steps makes b2s_decode_run return an error);
+    the frames of the completed intervals must equal the un-failed job's; use_bar=True runs the progress bar path."""
+    import synthesize
+
+    def edit(st):
+        st["decoder.stop_net.bias"] = np.full((1,), -100.0, dtype=np.float32)
+    m, cfg, st, hp = build(TINY + ",max_generation_frames=40", state_edit=edit)
+    m.eval()
+    nb = synth.synthetic_batch(cfg, B=3, S=10, T=4, seed=11, in_lens=[10, 6, 8])
+    nb.pop("mel_targets"); nb.pop("target_lengths")
+    b = dev_batch(nb)
+    ref = synthesize.eval_batch(m, b, use_bar=True, bar_interval=10, sync_interval=7)
+    lib = m.engine().lib
+    real, calls = lib.b2s_decode_run, []
+
+    class Failing(object):          # ctypes function objects are read-only: substitute the attribute on the library object
+        def __call__(self, handle, state, n, use_graph, stream):
+            calls.append(n)
+            return real(handle, state, -1 if len(calls) == 3 else n, use_graph, stream)
+    lib.b2s_decode_run = Failing()
+    try:
+        r = synthesize.eval_batch(m, b, use_bar=False, bar_interval=-1, sync_interval=7)
+    finally:
+        lib.b2s_decode_run = real
+    assert len(calls) == 3
+    assert r["mel_pre"].shape == (3, 14, cfg.num_mels)                   # two completed intervals of 7 frames
+    assert np.array_equal(r["mel_pre"], ref["mel_pre"][:, :14])
+    assert [int(x) for x in r["generated_lengths"]] == [15, 15, 15]      # nobody had stopped: lengths keep the reference's +1
+    assert r["alignments"]["encdec"][0].shape[-1] == 14
+    assert "bad argument" in capsys.readouterr().err                    # the traceback was printed, as the reference does
+
+
 @pytest.mark.parametrize("case", ["never", "mixed"])
 def test_decode_lanes_match_single_batch(case):
     """eval_batch(lanes=k) decodes k independent sub-batches on their own streams / graphs / KV caches: same lengths,

@@ -137,14 +137,18 @@ def test_autograd_path_refuses_two_forwards_in_one_backward():
         assert abs(float(p.grad.double().norm()) - float(ref.double().norm())) <= 2e-3 * float(ref.double().norm()) + 1e-6, n
 
 
-def test_split_optimizer_step_matches_single_launch(monkeypatch):
+@pytest.mark.parametrize("extra", ["", ",n_decoder_layer=3"])
+def test_split_optimizer_step_matches_single_launch(monkeypatch, extra):
     """b2s_adam_step_groups (decoder + postnet parameters updated on the second stream under the encoder backward, encoder
-    group afterwards) is the same arithmetic as the single-launch step: identical parameters after three steps."""
+    group afterwards) is the same arithmetic as the single-launch step: identical parameters after three steps.  An odd number of
+    decoder stages leaves the prenet stage's weight-gradient group un-handed-over when the decoder backward returns with a deferred
+    join: the split step must take the join itself (decoder.prenet.* would otherwise never train -- checked explicitly)."""
     from b2s_hip.trainer import HipTrainer
     res = []
     for split in ("0", "1"):
         monkeypatch.setenv("B2S_SPLIT_ADAM", split)
-        m, cfg, _, hp = build(TINY96, compute_dtype="bf16")
+        m, cfg, _, hp = build(TINY96 + extra, compute_dtype="bf16")
+        w0 = m.decoder.prenet.dense0.weight.detach().clone()
         _, b = _batch(cfg)
         m.train()
         tr = HipTrainer(m, hp)
@@ -152,6 +156,7 @@ def test_split_optimizer_step_matches_single_launch(monkeypatch):
         for _ in range(3):
             v = tr.train_step(b)
         res.append(({k: t.detach().clone() for k, t in m.state_dict().items()}, v.cpu().numpy()))
+        assert float((m.decoder.prenet.dense0.weight.detach() - w0).abs().max()) > 1e-4      # the prenet did train
     for k, t in res[0][0].items():
         d = float((t.double() - res[1][0][k].double()).abs().max())
         assert d <= 2e-2 * (1.0 + float(t.double().abs().max())), (k, d)           # bf16 + atomics: runs are not bit-reproducible
