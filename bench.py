@@ -44,8 +44,8 @@ def fwd_flops(B, S, T, De=512, Fe=2048, Dd=768, Fd=3072, Le=6, Ld=6):
 
 
 def make_batch(cfg, B, S, T, seed, device):
-    from oracle import synth
-    nb = synth.synthetic_batch(cfg, B, S, T, seed=seed, n_spk=1, n_lang=1)      # LJSpeech: one speaker, en-us
+    from benchdata import synthetic_batch
+    nb = synthetic_batch(cfg, B, S, T, seed=seed, n_spk=1, n_lang=1)      # LJSpeech: one speaker, en-us
     return {k: (torch.from_numpy(np.asarray(v)).to(device) if not isinstance(v, list) else v) for k, v in nb.items()}
 
 
@@ -84,7 +84,7 @@ def _sub_bench(extra):
         return {"error": (r.stderr or r.stdout)[-400:]}
     d = json.loads(lines[-1])
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "final_loss", "config", "roofline", "roofline_step",
-            "cpu_baseline")
+            "cpu_baseline", "value_incl_host_copy", "ms_per_step_incl_host_copy", "valid_frames_per_s")
     d = {k: d[k] for k in keep if k in d}
     if isinstance(d.get("roofline"), dict):
         d["roofline"] = {k: v for k, v in d["roofline"].items() if k not in ("variants", "isolated", "note")}
@@ -146,7 +146,6 @@ def main():
     from transformer.tacotron import Tacotron, initialize_variables
     from b2s_hip.trainer import HipTrainer
     from b2s_hip import lib as L
-    from oracle import make_config
     hp.parse("compute_dtype=%s" % args.dtype)
     if args.hparams:
         hp.parse(args.hparams)
@@ -160,7 +159,7 @@ def main():
     # B2S_ADAM_OVERLAP=1: optimizer step on the second stream under the next forward pass (measured: no gain -- the GEMM
     # workgroups fill a CU's registers and LDS, so nothing co-resides with them)
     trainer = HipTrainer(model, hp, overlap_adam=bool(os.environ.get("B2S_ADAM_OVERLAP")))
-    cfg = make_config("")
+    cfg = hp                                           # (synthetic_batch reads vocab_size / num_mels / max_num_* only)
     B, S, T = args.batch, args.S, args.T
     batch = make_batch(cfg, B, S, T, seed=rank, device=device)     # same shape on every rank, different data
     batches = [batch]
@@ -177,25 +176,42 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        vals = trainer.train_step(batches[i % len(batches)])
-    sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        vals = trainer.train_step(batches[i % len(batches)])
-    ev1.record()
-    host_s = time.perf_counter() - t0                  # launch loop only: ~= elapsed means the step is host- (launch-) bound
-    sync()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if world > 1 or force_dp:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(bs, steps, warmup):
+        """warmup untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
+        v = None
+        for i in range(warmup):
+            v = trainer.train_step(bs[i % len(bs)])
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(steps):
+            v = trainer.train_step(bs[i % len(bs)])
+        e1.record()
+        host = time.perf_counter() - t0                # launch loop only: ~= elapsed means the step is host- (launch-) bound
+        sync()
+        el = time.perf_counter() - t0
+        dev = e0.elapsed_time(e1)
+        if world > 1 or force_dp:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        return v, el, host, dev
+
+    vals, elapsed, host_s, dev_ms = timed(batches, args.steps, args.warmup)
     loss = float(vals[0])
     assert np.isfinite(loss), "training diverged: loss = %r" % loss
+    # the two extremes of the reference's packer (dataloader.py:401-410: <= 8000 frames and B (S^2 + T^2) <= 7e6 per batch) next to the
+    # typical batch: same model, same step, a few steps each (SURVEY section 8d, C2)
+    extremes = {}
+    if world == 1 and args.mode == "train" and (B, S, T) == (14, 114, 582) and not args.no_extras:
+        for (b_, s_, t_) in ((32, 50, 250), (9, 158, 808)):
+            _, el, _, _ = timed([make_batch(cfg, b_, s_, t_, seed=7, device=device)], max(5, args.steps // 2), 2)
+            n_ = max(5, args.steps // 2)
+            fl = 3.0 * fwd_flops(b_, s_, t_)
+            extremes["B%d_S%d_T%d" % (b_, s_, t_)] = {
+                "ms_per_step": round(el / n_ * 1e3, 3), "value": round(b_ * t_ * n_ / el, 1), "unit": "mel-frames/s",
+                "roofline_step_frac": round(fl / (el / n_) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS), 4)}
 
     out = None
     if rank == 0:
@@ -215,10 +231,14 @@ def main():
                                                                                  "batches drawn from a 30-utterance pool" if finetune else ""),
                           "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world},
                "device_ms_per_step": round(dev_ms / args.steps, 3), "host_launch_ms_per_step": round(host_s / args.steps * 1e3, 3)}
+        valid = float(np.mean([int(b["target_lengths"].sum()) for b in batches]))
+        out["valid_frames_per_s"] = round(world * valid * args.steps / elapsed, 1)     # sum(target_lengths): the batch is ~10 % padding
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS
         ach = step_flops / (ms * 1e-3) / 1e12
         out["roofline_step"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                                 "frac": round(ach / peak, 4), "flops_per_step": step_flops}
+        if extremes:
+            out["packer_extremes"] = extremes
     if rank == 0 and world == 1 and not args.no_roofline_pass:
         # dominant kernel (MFMA GEMM): per-launch HIP events on the launch stream, same steps, separate pass
         lib = L.load()

@@ -11,7 +11,6 @@
 //
 // Operand layouts: q [B, Lq, H*dh] with leading dimension ldq (heads interleaved, exactly as the fused QKV / KV
 // projection GEMMs write them), k, v likewise; ctx [B, Lq, H*dh].
-#include <cstdlib>
 #include "b2s_common.h"
 #include "attention.h"
 
@@ -36,13 +35,7 @@ __device__ inline f32x4_t mma(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __buil
 // in two halves so that the global loads of the NEXT tile are in flight while the current tile is being consumed
 // (register double buffer; a single fused loop compiled to load -> wait -> store round trips, 3 per tile, and was the
 // whole cost of these kernels).
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));      // (a first-class vector value: HIP's uint4 is a struct, and copies of it through a
-                                                                    // register array that lives across loop iterations ended up in scratch memory)
-template <typename T, int DH> struct TileRegs { u32x4_t v[64 * (DH / AT<T>::VE) / 256]; };
-// Every load is UNCONDITIONAL: rows past the end re-read the last valid row (their logits are masked / their weights are exact zeros,
-// so any finite row will do).  A load under a condition -- per lane or wave-uniform -- makes hipcc branch around it, and its wait-count
-// pass then has to assume that the loads issued since an older load may not have happened: it waited vmcnt(0) for the (long landed)
-// query fragments at the first MFMA of every tile, i.e. for the prefetch it had just issued -- a full memory round trip per tile.
+template <typename T, int DH> struct TileRegs { uint4 v[64 * (DH / AT<T>::VE) / 256]; };
 template <typename T, int DH>
 __device__ inline void tile_fetch(TileRegs<T, DH>& r, const T* src, long ld, int row0, int nrows, int tid) {
     constexpr int VE = AT<T>::VE, VPR = DH / VE, NV = 64 * VPR / 256;
@@ -50,20 +43,17 @@ __device__ inline void tile_fetch(TileRegs<T, DH>& r, const T* src, long ld, int
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = tid + i * 256, rr = v / VPR, c = (v - rr * VPR) * VE;
-        r.v[i] = *reinterpret_cast<const u32x4_t*>(src + (long)min(row0 + rr, nrows - 1) * ld + c);
+        r.v[i] = make_uint4(0, 0, 0, 0);
+        if (row0 + rr < nrows) r.v[i] = *reinterpret_cast<const uint4*>(src + (long)(row0 + rr) * ld + c);
     }
 }
-// s_waitcnt vmcnt(0) as a compiler-visible instruction (hipcc's wait-count pass models it; an inline-asm wait it does not): everything
-// loaded so far -- the wave's own fragments, the first tile -- has landed, so no later use of those registers needs a vmcnt wait that
-// would also drain the prefetch in flight
-__device__ __forceinline__ void wait_all_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 template <typename T, int DH>
 __device__ inline void tile_store(T* lds, const TileRegs<T, DH>& r, int tid) {
     constexpr int VE = AT<T>::VE, LD = DH + AT<T>::PAD, VPR = DH / VE, NV = 64 * VPR / 256;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = tid + i * 256, rr = v / VPR, c = (v - rr * VPR) * VE;
-        *reinterpret_cast<u32x4_t*>(lds + rr * LD + c) = r.v[i];
+        *reinterpret_cast<uint4*>(lds + rr * LD + c) = r.v[i];
     }
 }
 
@@ -131,57 +121,6 @@ template <int DH, int LD> struct SP<bf16_t, DH, LD> {
     __device__ static inline void run(f32x4_t (&acc)[DH / 16], const bf16_t* tile, const f32x4_t (&w)[4], int li, int lg) { second_product_bf16<DH, LD>(acc, tile, w, li, lg); }
 };
 
-// the same for RB row blocks that share the tile: every transposed tile fragment feeds RB MFMAs
-template <typename T, int DH, int LD, int RB> struct SPR;
-template <int DH, int LD, int RB> struct SPR<float, DH, LD, RB> {
-    __device__ static inline void run(f32x4_t (&acc)[RB][DH / 16], const float* tile, const f32x4_t (&w)[RB][4], int li, int lg) {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) second_product_f32<DH, LD>(acc[rb], tile, w[rb], li, lg);
-    }
-    // rows [kb*32, kb*32 + 32) of the tile only: w[rb][u] belongs to tile rows (2 kb + u)*16 + lg*4 + r
-    __device__ static inline void half(f32x4_t (&acc)[RB][DH / 16], const float* tile, const f32x4_t (&w)[RB][2], int kb, int li, int lg) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* row = tile + ((2 * kb + u) * 16 + lg * 4 + r) * LD + li;
-#pragma unroll
-                for (int dt = 0; dt < DH / 16; ++dt) {
-                    const float av = row[dt * 16];
-#pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) acc[rb][dt] = mma(av, w[rb][u][r], acc[rb][dt]);
-                }
-            }
-    }
-};
-template <int DH, int LD, int RB> struct SPR<bf16_t, DH, LD, RB> {
-    __device__ static inline void run(f32x4_t (&acc)[RB][DH / 16], const bf16_t* tile, const f32x4_t (&w)[RB][4], int li, int lg) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            bf16x8_t b[RB];
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) b[rb] = pack8(w[rb][2 * kb], w[rb][2 * kb + 1]);
-#pragma unroll
-            for (int dt = 0; dt < DH / 16; ++dt) {
-                const bf16x8_t f = frag_tr<LD>(tile, kb * 32, kb * 32 + 16, dt * 16, li, lg);
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) acc[rb][dt] = mma(f, b[rb], acc[rb][dt]);
-            }
-        }
-    }
-    __device__ static inline void half(f32x4_t (&acc)[RB][DH / 16], const bf16_t* tile, const f32x4_t (&w)[RB][2], int kb, int li, int lg) {
-        bf16x8_t b[RB];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) b[rb] = pack8(w[rb][0], w[rb][1]);
-#pragma unroll
-        for (int dt = 0; dt < DH / 16; ++dt) {
-            const bf16x8_t f = frag_tr<LD>(tile, kb * 32, kb * 32 + 16, dt * 16, li, lg);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc[rb][dt] = mma(f, b[rb], acc[rb][dt]);
-        }
-    }
-};
-
 // first product: c[t] = sum_d tile[t*16 + i][d] * own[d][j]  -> c[t][r] = value(row t*16 + lg*4 + r of the tile, own row li)
 template <typename T, int DH, int LD>
 __device__ inline void first_product(f32x4_t (&c)[4], const T* tile, const typename AT<T>::frag (&own)[DH / (sizeof(T) == 2 ? 32 : 4)], int li, int lg) {
@@ -246,161 +185,107 @@ __device__ inline void store_rows(T* dst, const f32x4_t (&acc)[DH / 16], float m
 }
 
 // ================================================================================================ forward
-// RB: 16-row query blocks per wave.  RB = 2 (bf16): a workgroup owns 128 query rows, every K / V fragment read from LDS feeds two
-// MFMAs (the kernel is bound by latency and by the LDS reads per MFMA, not by the matrix pipe: 24 MFMAs against 36 fragment reads per
-// wave and key tile at RB = 1), each K / V tile is fetched and staged once per 128 rows, and the two row blocks are two independent
-// dependency chains the scheduler interleaves.  K / V tiles are double-buffered in LDS: tile t + 1 is written to the other buffer
-// while tile t is consumed, one barrier per tile; its global loads were issued a whole tile earlier.
-// Causal: the query tiles of a head run last-tile-first (the last tile walks the most key tiles; dispatched first, the short tiles
-// fill the tail of the launch).
-template <int RB> __device__ inline int attn_qtile(const AttnArgs& a, int tile) { return (a.mask_mode & 2) ? (int)gridDim.x - 1 - tile : tile; }
-
-template <typename T, int DH, int RB>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? (RB == 1 ? 3 : 2) : 1) void attn_fwd_kernel(AttnArgs a) {
-    constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4), QT = 64 * RB, NB = sizeof(T) == 2 ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) T sK[NB][64 * LD];
-    __shared__ __attribute__((aligned(16))) T sV[NB][64 * LD];
+template <typename T, int DH>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_fwd_kernel(AttnArgs a) {     // (3 workgroups per CU: the kernel is latency-bound, 41 -> 34 us)
+    constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
+    __shared__ __attribute__((aligned(16))) T sK[64 * LD];
+    __shared__ __attribute__((aligned(16))) T sV[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     int tile_, z;
     xcd_block(tile_, z);
-    tile_ = attn_qtile<RB>(a, tile_);
     const int b = z / a.H, h = z - b * a.H;
-    const int qb0 = tile_ * QT, qw0 = qb0 + wave * 16 * RB;          // first query row of the workgroup / of this wave
+    const int qb0 = tile_ * 64, q = qb0 + wave * 16 + li;
+    const int qc = min(q, a.Lq - 1);
     const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
     const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
     const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
-    int q[RB], qc[RB];
-    typename AT<T>::frag qf[RB][NKS];
+    typename AT<T>::frag qf[NKS];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        q[rb] = qw0 + rb * 16 + li; qc[rb] = min(q[rb], a.Lq - 1);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[rb][ks] = frag_global<T>(Q, a.ldq, qc[rb], ks, lg);
-    }
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = frag_global<T>(Q, a.ldq, qc, ks, lg);
+
     int kend = a.Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     int ktiles = (kend + 63) / 64;
-    if (a.mask_mode & 2) ktiles = min(ktiles, (min(qb0 + QT - 1, a.Lq - 1)) / 64 + 1);
-    f32x4_t o[RB][DH / 16];
-    float m[RB], l[RB], g[RB];                       // m: reference exponent (log2 domain), l: this lane's part of the row sum
-    uint32_t drow[RB];
+    if (a.mask_mode & 2) ktiles = min(ktiles, (min(qb0 + 63, a.Lq - 1)) / 64 + 1);
+    f32x4_t o[DH / 16];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-#pragma unroll
-        for (int dt = 0; dt < DH / 16; ++dt) o[rb][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        m[rb] = -INFINITY; l[rb] = 0.f; g[rb] = 0.f;
-        drow[rb] = (uint32_t)(((long)z * a.Lq + qc[rb]) * a.Lk);
-    }
+    for (int dt = 0; dt < DH / 16; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;                    // m: reference exponent (log2 domain), l: this lane's part of the row sum
     const bool ga = a.ga_rows != nullptr;
-    float ga_iq = 0.f, ga_ik = 0.f;
+    float g = 0.f, ga_iq = 0.f, ga_ik = 0.f;
     if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
     const float sl2 = a.scale * B2S_LOG2E;
+    const int qw0 = qb0 + wave * 16;                 // first query row of this wave
+    const uint32_t drow = (uint32_t)(((long)z * a.Lq + qc) * a.Lk);
     TileRegs<T, DH> rk, rv;
-    tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid);
-    wait_all_loads();
-    tile_store<T, DH>(sK[0], rk, tid); tile_store<T, DH>(sV[0], rv, tid);
-    tile_fetch<T, DH>(rk, K, a.ldk, 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 64, a.Lk, tid);
-    __syncthreads();
+    if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid); }
     for (int kt = 0; kt < ktiles; ++kt) {
         const int k0 = kt * 64;
-        const T* cK = sK[NB == 2 ? (kt & 1) : 0];
-        const T* cV = sV[NB == 2 ? (kt & 1) : 0];
-        if (NB == 2) {
-            // tile kt + 1 (in registers since the previous iteration) -> the other buffer, whose last readers passed the barrier below;
-            // then the loads of tile kt + 2 (unconditional, see tile_fetch: past the last tile they re-read the last rows)
-            tile_store<T, DH>(sK[(kt + 1) & 1], rk, tid); tile_store<T, DH>(sV[(kt + 1) & 1], rv, tid);
-            __builtin_amdgcn_sched_barrier(0);       // (the loads below re-use the registers just stored: hoisted above the stores they need 24 more)
-            tile_fetch<T, DH>(rk, K, a.ldk, k0 + 128, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 128, a.Lk, tid);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // causal: a wave whose rows all precede this key tile has nothing to add (wave-uniform)
-        const bool skip = (a.mask_mode & 2) && k0 > qw0 + 16 * RB - 1;
-        if (!skip) {
-        f32x4_t s[RB][4];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) s[rb][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const typename AT<T>::frag kf = frag_row<LD>(cK, t * 16, ks, li, lg);
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) s[rb][t] = mma(kf, qf[rb][ks], s[rb][t]);
-            }
+        __syncthreads();
+        tile_store<T, DH>(sK, rk, tid);
+        tile_store<T, DH>(sV, rv, tid);
+        __syncthreads();
+        if (kt + 1 < ktiles) { tile_fetch<T, DH>(rk, K, a.ldk, k0 + 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 64, a.Lk, tid); }
+        f32x4_t s[4];
+        first_product<T, DH, LD>(s, sK, qf, li, lg);
         // every key of the tile visible to every row of this wave?  (wave-uniform; the common case skips all mask math)
         const bool interior = k0 + 64 <= kend && (!(a.mask_mode & 2) || k0 + 63 <= qw0);
+        float mx = -INFINITY;
+        if (interior) {
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            float mx = -INFINITY;
-            if (interior) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[rb][t][0], s[rb][t][1])), fmaxf(s[rb][t][2], s[rb][t][3]));
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = k0 + t * 16 + lg * 4 + r;
-                        const bool ok = key < kend && (!(a.mask_mode & 2) || key <= q[rb]);
-                        s[rb][t][r] = ok ? s[rb][t][r] : -INFINITY;
-                        mx = fmaxf(mx, s[rb][t][r]);
-                    }
-            }
-            mx = group_max(mx) * sl2;
-            const bool grow = mx > m[rb] + B2S_LAZY;         // also true for the first finite maximum (m = -inf)
-            if (__any(grow)) {
-                const float mn = grow ? mx : m[rb];
-                const float alpha = mn == m[rb] ? 1.f : fast_exp2(m[rb] - mn);      // m = -inf -> 0
-                m[rb] = mn; l[rb] *= alpha; g[rb] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < DH / 16; ++dt) { o[rb][dt][0] *= alpha; o[rb][dt][1] *= alpha; o[rb][dt][2] *= alpha; o[rb][dt][3] *= alpha; }
-            }
-            const float mref = m[rb] == -INFINITY ? 0.f : m[rb];
+            for (int t = 0; t < 4; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+        } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(fmaf(s[rb][t][r], sl2, -mref));   // masked: 2^-inf = 0
-                    l[rb] += p;
-                    s[rb][t][r] = p;
+                    const int key = k0 + t * 16 + lg * 4 + r;
+                    const bool ok = key < kend && (!(a.mask_mode & 2) || key <= q);
+                    s[t][r] = ok ? s[t][r] : -INFINITY;
+                    mx = fmaxf(mx, s[t][r]);
                 }
-            if (ga) {
+        }
+        mx = group_max(mx) * sl2;
+        const bool grow = mx > m + B2S_LAZY;             // also true for the first finite maximum (m = -inf)
+        if (__any(grow)) {
+            const float mn = grow ? mx : m;
+            const float alpha = mn == m ? 1.f : fast_exp2(m - mn);      // m = -inf -> 0
+            m = mn; l *= alpha; g *= alpha;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+            for (int dt = 0; dt < DH / 16; ++dt) { o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha; }
+        }
+        const float mref = m == -INFINITY ? 0.f : m;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) g[rb] += s[rb][t][r] * ga_w(q[rb], k0 + t * 16 + lg * 4 + r, ga_iq, ga_ik, a.ga_inv2s2);
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = fast_exp2(fmaf(s[t][r], sl2, -mref));   // masked: 2^-inf = 0
+                l += p;
+                s[t][r] = p;
             }
-            if (a.drop.thresh) {
+        if (ga) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        s[rb][t][r] = b2s_keep(a.drop, drow[rb] + (uint32_t)(k0 + t * 16 + lg * 4 + r)) ? s[rb][t][r] * a.drop.scale : 0.f;
-            }
+                for (int r = 0; r < 4; ++r) g += s[t][r] * ga_w(q, k0 + t * 16 + lg * 4 + r, ga_iq, ga_ik, a.ga_inv2s2);
         }
-        SPR<T, DH, LD, RB>::run(o, cV, s, li, lg);
+        if (a.drop.thresh) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s[t][r] = b2s_keep(a.drop, drow + (uint32_t)(k0 + t * 16 + lg * 4 + r)) ? s[t][r] * a.drop.scale : 0.f;
         }
-        if (NB == 2) __syncthreads();              // tile kt + 1 is in LDS, every wave is done with tile kt
-        else if (kt + 1 < ktiles) {                // fp32 (parity mode): one buffer -- re-stage in place
-            __syncthreads();
-            tile_fetch<T, DH>(rk, K, a.ldk, k0 + 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 64, a.Lk, tid);
-            tile_store<T, DH>(sK[0], rk, tid); tile_store<T, DH>(sV[0], rv, tid);
-            __syncthreads();
-        }
+        SP<T, DH, LD>::run(o, sV, s, li, lg);
     }
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const float lt = group_sum(l[rb]);
-        const float gt = ga ? group_sum(g[rb]) : 0.f;
-        if (q[rb] < a.Lq) {
-            const float inv = 1.f / lt;
-            T* out = reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q[rb]) * a.ldo + h * DH;
-            store_rows<T, DH>(out, o[rb], inv, lg);
-            if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q[rb]] = (m[rb] + __log2f(lt)) * B2S_LN2;
-            if (lg == 0 && ga) a.ga_rows[(long)z * a.Lq + q[rb]] = q[rb] < a.qlen[b] ? gt * inv : 0.f;
-        }
+    l = group_sum(l);
+    if (ga) g = group_sum(g);
+    if (q < a.Lq) {
+        const float inv = 1.f / l;
+        T* out = reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q) * a.ldo + h * DH;
+        store_rows<T, DH>(out, o, inv, lg);
+        if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = (m + __log2f(l)) * B2S_LN2;
+        if (lg == 0 && ga) a.ga_rows[(long)z * a.Lq + q] = q < a.qlen[b] ? g * inv : 0.f;
     }
 }
 
@@ -420,256 +305,217 @@ __global__ void attn_bwd_prep_kernel(const T* dO, const T* O, int ldo, float* D,
     if (lane == 0) D[((long)b * H + h) * Lq + q] = acc;
 }
 
-// dQ: per workgroup 64 * RB query rows; loops over key tiles (same structure as the forward kernel)
-template <typename T, int DH, int RB>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kernel(AttnArgs a) {
-    constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4), QT = 64 * RB, NB = sizeof(T) == 2 ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) T sK[NB][64 * LD];
-    __shared__ __attribute__((aligned(16))) T sV[NB][64 * LD];
+// dQ: per workgroup 64 query rows; loops over key tiles
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
+    __shared__ __attribute__((aligned(16))) T sK[64 * LD];
+    __shared__ __attribute__((aligned(16))) T sV[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     int tile_, z;
     xcd_block(tile_, z);
-    tile_ = attn_qtile<RB>(a, tile_);
     const int b = z / a.H, h = z - b * a.H;
-    const int qb0 = tile_ * QT, qw0 = qb0 + wave * 16 * RB;
+    const int qb0 = tile_ * 64, q = qb0 + wave * 16 + li;
+    const int qc = min(q, a.Lq - 1);
     const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
     const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
     const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
     const T* dO = reinterpret_cast<const T*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
-    const T* O = reinterpret_cast<const T*>(a.oref) + (long)b * a.Lq * a.ldo + h * DH;
+    typename AT<T>::frag qf[NKS], dof[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) { qf[ks] = frag_global<T>(Q, a.ldq, qc, ks, lg); dof[ks] = frag_global<T>(dO, a.ldo, qc, ks, lg); }
+    const float lse = a.lse[(long)z * a.Lq + qc];
+    // D[q] = sum_d dO[q][d] * O[q][d], from the same fragments (each lane holds 1/4 of the row; two shuffles finish it)
+    float Dq = 0.f;
+    {
+        const T* O = reinterpret_cast<const T*>(a.oref) + (long)b * a.Lq * a.ldo + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) Dq += frag_dot(frag_global<T>(O, a.ldo, qc, ks, lg), dof[ks]);
+        Dq = group_sum(Dq);
+    }
     int kend = a.Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     // guided attention: dP += c W, D += c * rowsum(P W) on valid query rows
-    float ga_iq = 0.f, ga_ik = 0.f;
-    int ql = 0;
-    const bool ga_on = a.ga_rows != nullptr;             // (kernel argument: scalar branch)
+    float gc = 0.f, ga_iq = 0.f, ga_ik = 0.f;
     if (a.ga_rows) {
-        ql = min(a.qlen[b], a.Lq);
+        const int ql = min(a.qlen[b], a.Lq);
+        if (q < ql) gc = *a.ga_scale;
         ga_iq = 1.f / (float)max(ql, 1); ga_ik = 1.f / (float)max(kend, 1);
+        Dq += gc * a.ga_rows[(long)z * a.Lq + qc];
     }
-    int q[RB], qc[RB];
-    typename AT<T>::frag qf[RB][NKS], dof[RB][NKS];
-    float lse2[RB], Dq[RB], gc[RB];
-    uint32_t drow[RB];
-    f32x4_t dq[RB][DH / 16];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        q[rb] = qw0 + rb * 16 + li; qc[rb] = min(q[rb], a.Lq - 1);
-        // D[q] = sum_d dO[q][d] * O[q][d], from the same fragments (each lane holds 1/4 of the row; two shuffles finish it)
-        float d = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            qf[rb][ks] = frag_global<T>(Q, a.ldq, qc[rb], ks, lg); dof[rb][ks] = frag_global<T>(dO, a.ldo, qc[rb], ks, lg);
-            d += frag_dot(frag_global<T>(O, a.ldo, qc[rb], ks, lg), dof[rb][ks]);
-        }
-        d = group_sum(d);
-        gc[rb] = 0.f;
-        if (a.ga_rows) {
-            if (q[rb] < ql) gc[rb] = *a.ga_scale;
-            d += gc[rb] * a.ga_rows[(long)z * a.Lq + qc[rb]];
-        }
-        Dq[rb] = d;
-        if (lg == 0 && q[rb] < a.Lq) a.dsum[(long)z * a.Lq + q[rb]] = d;              // the dK/dV kernel reads it
-        lse2[rb] = a.lse[(long)z * a.Lq + qc[rb]] * B2S_LOG2E;
-        drow[rb] = (uint32_t)(((long)z * a.Lq + qc[rb]) * a.Lk);
-#pragma unroll
-        for (int dt = 0; dt < DH / 16; ++dt) dq[rb][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
+    if (lg == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;              // the dK/dV kernel reads it
     int ktiles = (kend + 63) / 64;
-    if (a.mask_mode & 2) ktiles = min(ktiles, (min(qb0 + QT - 1, a.Lq - 1)) / 64 + 1);
-    const float sl2 = a.scale * B2S_LOG2E;
+    if (a.mask_mode & 2) ktiles = min(ktiles, (min(qb0 + 63, a.Lq - 1)) / 64 + 1);
+    f32x4_t dq[DH / 16];
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const uint32_t drow = (uint32_t)(((long)z * a.Lq + qc) * a.Lk);
+    const float sl2 = a.scale * B2S_LOG2E, lse2 = lse * B2S_LOG2E;
+    const int qw0 = qb0 + wave * 16;
     TileRegs<T, DH> rk, rv;
-    tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid);
-    wait_all_loads();
-    tile_store<T, DH>(sK[0], rk, tid); tile_store<T, DH>(sV[0], rv, tid);
-    tile_fetch<T, DH>(rk, K, a.ldk, 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 64, a.Lk, tid);
-    __syncthreads();
+    if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid); }
     for (int kt = 0; kt < ktiles; ++kt) {
         const int k0 = kt * 64;
-        const T* cK = sK[NB == 2 ? (kt & 1) : 0];
-        const T* cV = sV[NB == 2 ? (kt & 1) : 0];
-        if (NB == 2) {
-            tile_store<T, DH>(sK[(kt + 1) & 1], rk, tid); tile_store<T, DH>(sV[(kt + 1) & 1], rv, tid);
-            __builtin_amdgcn_sched_barrier(0);
-            tile_fetch<T, DH>(rk, K, a.ldk, k0 + 128, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 128, a.Lk, tid);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const bool skip = (a.mask_mode & 2) && k0 > qw0 + 16 * RB - 1;
-        if (!skip) {
-        // the tile's 64 keys in two halves of 32 (one bf16 MFMA k step of the second product each): S, dP of a half -> dS -> dQ += dS K,
-        // so that only half of the logits / dP are live at a time (both row blocks of a 96-wide head would not fit the register file)
+        __syncthreads();
+        tile_store<T, DH>(sK, rk, tid);
+        tile_store<T, DH>(sV, rv, tid);
+        __syncthreads();
+        if (kt + 1 < ktiles) { tile_fetch<T, DH>(rk, K, a.ldk, k0 + 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 64, a.Lk, tid); }
+        f32x4_t s[4], dp[4];
+        first_product<T, DH, LD>(s, sK, qf, li, lg);
+        first_product<T, DH, LD>(dp, sV, dof, li, lg);
         const bool interior = k0 + 64 <= kend && (!(a.mask_mode & 2) || k0 + 63 <= qw0);
+        if (interior) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f32x4_t s[RB][2], dp[RB][2];
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
+                for (int r = 0; r < 4; ++r) s[t][r] = fast_exp2(fmaf(s[t][r], sl2, -lse2));
+        } else {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) { s[rb][u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[rb][u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const typename AT<T>::frag kf = frag_row<LD>(cK, (2 * kb + u) * 16, ks, li, lg);
-                    const typename AT<T>::frag vf = frag_row<LD>(cV, (2 * kb + u) * 16, ks, li, lg);
-#pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) { s[rb][u] = mma(kf, qf[rb][ks], s[rb][u]); dp[rb][u] = mma(vf, dof[rb][ks], dp[rb][u]); }
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + t * 16 + lg * 4 + r;
+                    const bool ok = key < kend && (!(a.mask_mode & 2) || key <= q);
+                    s[t][r] = ok ? fast_exp2(fmaf(s[t][r], sl2, -lse2)) : 0.f;
                 }
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = k0 + (2 * kb + u) * 16 + lg * 4 + r;
-                        float p = fast_exp2(fmaf(s[rb][u][r], sl2, -lse2[rb]));
-                        if (!interior) p = (key < kend && (!(a.mask_mode & 2) || key <= q[rb])) ? p : 0.f;
-                        float d = dp[rb][u][r];
-                        if (a.drop.thresh) d = b2s_keep(a.drop, drow[rb] + (uint32_t)key) ? d * a.drop.scale : 0.f;
-                        if (ga_on) d += gc[rb] * ga_w(q[rb], key, ga_iq, ga_ik, a.ga_inv2s2);      // (gc = 0 on padded rows)
-                        s[rb][u][r] = p * (d - Dq[rb]) * a.scale;
-                    }
-            }
-            SPR<T, DH, LD, RB>::half(dq, cK, s, kb, li, lg);
         }
+        if (a.drop.thresh) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dp[t][r] = b2s_keep(a.drop, drow + (uint32_t)(k0 + t * 16 + lg * 4 + r)) ? dp[t][r] * a.drop.scale : 0.f;
         }
-        if (NB == 2) __syncthreads();
-        else if (kt + 1 < ktiles) {
-            __syncthreads();
-            tile_fetch<T, DH>(rk, K, a.ldk, k0 + 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 64, a.Lk, tid);
-            tile_store<T, DH>(sK[0], rk, tid); tile_store<T, DH>(sV[0], rv, tid);
-            __syncthreads();
+        if (__any(gc != 0.f)) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dp[t][r] += gc * ga_w(q, k0 + t * 16 + lg * 4 + r, ga_iq, ga_ik, a.ga_inv2s2);
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - Dq) * a.scale;
+        SP<T, DH, LD>::run(dq, sK, s, li, lg);
     }
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-        if (q[rb] < a.Lq) store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)b * a.Lq + q[rb]) * a.lddq + h * DH, dq[rb], 1.f, lg);
+    if (q < a.Lq) store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)b * a.Lq + q) * a.lddq + h * DH, dq, 1.f, lg);
 }
 
-// dK, dV: per workgroup 64 * KBW keys (a wave owns KBW blocks of 16); loops over query tiles of 64, each consumed in two halves of
-// 32 queries (S, dP of a half -> Pd, dS -> dV += dO^T Pd, dK += Q^T dS: only half a tile of logits is live, and the Q / dO fragments
-// read from LDS feed KBW MFMAs each).  Q / dO tiles are double-buffered in LDS like the K / V tiles of the forward kernel.
-template <typename T, int DH, int KBW>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkv_kernel(AttnArgs a) {
-    constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4), KT = 64 * KBW, NB = sizeof(T) == 2 ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) T sQ[NB][64 * LD];
-    __shared__ __attribute__((aligned(16))) T sO[NB][64 * LD];
-    __shared__ __attribute__((aligned(16))) float sL[NB][64], sD[NB][64];
+// dK, dV: per workgroup 64 keys; loops over query tiles
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
+    __shared__ __attribute__((aligned(16))) T sQ[64 * LD];
+    __shared__ __attribute__((aligned(16))) T sO[64 * LD];
+    __shared__ __attribute__((aligned(16))) float sL[64], sD[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     int tile_, z;
     xcd_block(tile_, z);
     const int b = z / a.H, h = z - b * a.H;
-    const int kb0 = tile_ * KT, kw0 = kb0 + wave * 16 * KBW;          // first key of the workgroup / of this wave
+    const int kb0 = tile_ * 64, key = kb0 + wave * 16 + li;
+    const int kc = min(key, a.Lk - 1);
     const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
     const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
     const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
     const T* dO = reinterpret_cast<const T*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
+    typename AT<T>::frag kf[NKS], vf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) { kf[ks] = frag_global<T>(K, a.ldk, kc, ks, lg); vf[ks] = frag_global<T>(V, a.ldv, kc, ks, lg); }
     int kend = a.Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
-    int key[KBW], kc[KBW];
-    typename AT<T>::frag kf[KBW][NKS], vf[KBW][NKS];
-    f32x4_t dk[KBW][DH / 16], dv[KBW][DH / 16];
-#pragma unroll
-    for (int kb = 0; kb < KBW; ++kb) {
-        key[kb] = kw0 + kb * 16 + li; kc[kb] = min(key[kb], a.Lk - 1);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) { kf[kb][ks] = frag_global<T>(K, a.ldk, kc[kb], ks, lg); vf[kb][ks] = frag_global<T>(V, a.ldv, kc[kb], ks, lg); }
-#pragma unroll
-        for (int dt = 0; dt < DH / 16; ++dt) { dk[kb][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[kb][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-    }
+    const bool key_ok = key < kend;
     float gc = 0.f, ga_iq = 0.f, ga_ik = 0.f;
     int ga_ql = 0;
-    const bool ga_on = a.ga_rows != nullptr;
     if (a.ga_rows) {
         ga_ql = min(a.qlen[b], a.Lq);
         gc = *a.ga_scale;
         ga_iq = 1.f / (float)max(ga_ql, 1); ga_ik = 1.f / (float)max(kend, 1);
     }
+    f32x4_t dk[DH / 16], dv[DH / 16];
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     const int qtiles = (a.Lq + 63) / 64;
     const int qt0 = (a.mask_mode & 2) ? kb0 / 64 : 0;          // causal: queries before this key tile never see it
     TileRegs<T, DH> rq, ro;
     float r_l = 0.f, r_d = 0.f;
     const float sl2 = a.scale * B2S_LOG2E;
+    const int kw0 = kb0 + wave * 16;                 // first key of this wave
     const uint32_t zq = (uint32_t)z * (uint32_t)a.Lq;
-    auto fetch = [&](int qt) {              // (unconditional loads: see tile_fetch; every wave loads the tile's 64 row statistics, wave 0 stages them)
-        tile_fetch<T, DH>(rq, Q, a.ldq, qt * 64, a.Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, qt * 64, a.Lq, tid);
-        const int qq = min(qt * 64 + lane, a.Lq - 1);
-        r_l = a.lse[(long)z * a.Lq + qq]; r_d = a.dsum[(long)z * a.Lq + qq];
-    };
-    auto stage = [&](int buf) {
-        tile_store<T, DH>(sQ[buf], rq, tid); tile_store<T, DH>(sO[buf], ro, tid);
-        if (tid < 64) { sL[buf][tid] = r_l * B2S_LOG2E; sD[buf][tid] = r_d; }
-    };
-    fetch(qt0);
-    wait_all_loads();
-    stage(0);
-    fetch(qt0 + 1);
-    __syncthreads();
-    for (int qt = qt0; qt < qtiles; ++qt) {
-        const int q0 = qt * 64, cur = NB == 2 ? ((qt - qt0) & 1) : 0;
-        const T* cQ = sQ[cur];
-        const T* cO = sO[cur];
-        if (NB == 2) { stage(cur ^ 1); __builtin_amdgcn_sched_barrier(0); fetch(qt + 2); __builtin_amdgcn_sched_barrier(0); }
-        // causal: a wave whose keys all come after this query tile has nothing to add (wave-uniform)
-        const bool skip = (a.mask_mode & 2) && kw0 > q0 + 63;
-        if (!skip) {
-        // all keys of this wave valid and visible to all 64 queries of the tile?  (wave-uniform)
-        const bool interior = kw0 + 16 * KBW <= kend && q0 + 64 <= a.Lq && (!(a.mask_mode & 2) || kw0 + 16 * KBW - 1 <= q0);
-#pragma unroll 1
-        for (int hq = 0; hq < 2; ++hq) {
-            f32x4_t s[KBW][2], dp[KBW][2], pd[KBW][2];
-#pragma unroll
-            for (int kb = 0; kb < KBW; ++kb)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) { s[kb][u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[kb][u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const typename AT<T>::frag fq = frag_row<LD>(cQ, (2 * hq + u) * 16, ks, li, lg);      // rows = queries
-                    const typename AT<T>::frag fo = frag_row<LD>(cO, (2 * hq + u) * 16, ks, li, lg);
-#pragma unroll
-                    for (int kb = 0; kb < KBW; ++kb) { s[kb][u] = mma(fq, kf[kb][ks], s[kb][u]); dp[kb][u] = mma(fo, vf[kb][ks], dp[kb][u]); }
-                }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const f32x4_t lq = *reinterpret_cast<const f32x4_t*>(sL[cur] + (2 * hq + u) * 16 + lg * 4);
-                const f32x4_t dsum4 = *reinterpret_cast<const f32x4_t*>(sD[cur] + (2 * hq + u) * 16 + lg * 4);
-#pragma unroll
-                for (int kb = 0; kb < KBW; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int qq = q0 + (2 * hq + u) * 16 + lg * 4 + r;
-                        float p = fast_exp2(fmaf(s[kb][u][r], sl2, -lq[r]));
-                        if (!interior) p = (key[kb] < kend && qq < a.Lq && (!(a.mask_mode & 2) || key[kb] <= qq)) ? p : 0.f;
-                        float d = dp[kb][u][r], pdr = p;
-                        if (a.drop.thresh) {
-                            const bool keep = b2s_keep(a.drop, (zq + (uint32_t)qq) * (uint32_t)a.Lk + (uint32_t)kc[kb]);
-                            d = keep ? d * a.drop.scale : 0.f;
-                            pdr = keep ? p * a.drop.scale : 0.f;
-                        }
-                        if (ga_on) d += qq < ga_ql ? gc * ga_w(qq, key[kb], ga_iq, ga_ik, a.ga_inv2s2) : 0.f;
-                        pd[kb][u][r] = pdr;
-                        s[kb][u][r] = p * (d - dsum4[r]) * a.scale;
-                    }
-            }
-            SPR<T, DH, LD, KBW>::half(dv, cO, pd, hq, li, lg);        // dV^T[d][key] += sum_q dO[q][d] * Pd[q][key]
-            SPR<T, DH, LD, KBW>::half(dk, cQ, s, hq, li, lg);         // dK^T[d][key] += sum_q Q[q][d]  * dS[q][key]
-        }
-        }
-        if (NB == 2) __syncthreads();
-        else if (qt + 1 < qtiles) {
-            __syncthreads();
-            fetch(qt + 1); stage(0);
-            __syncthreads();
-        }
+    if (qt0 < qtiles) {
+        tile_fetch<T, DH>(rq, Q, a.ldq, qt0 * 64, a.Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, qt0 * 64, a.Lq, tid);
+        if (tid < 64) { const int qq = min(qt0 * 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq] * B2S_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq]; }
     }
-#pragma unroll
-    for (int kb = 0; kb < KBW; ++kb)
-        if (key[kb] < a.Lk) {
-            store_rows<T, DH>(reinterpret_cast<T*>(a.dk) + ((long)b * a.Lk + key[kb]) * a.lddk + h * DH, dk[kb], 1.f, lg);
-            store_rows<T, DH>(reinterpret_cast<T*>(a.dv) + ((long)b * a.Lk + key[kb]) * a.lddv + h * DH, dv[kb], 1.f, lg);
+    for (int qt = qt0; qt < qtiles; ++qt) {
+        const int q0 = qt * 64;
+        __syncthreads();
+        tile_store<T, DH>(sQ, rq, tid);
+        tile_store<T, DH>(sO, ro, tid);
+        if (tid < 64) { sL[tid] = r_l; sD[tid] = r_d; }
+        __syncthreads();
+        if (qt + 1 < qtiles) {
+            tile_fetch<T, DH>(rq, Q, a.ldq, q0 + 64, a.Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, q0 + 64, a.Lq, tid);
+            if (tid < 64) { const int qq = min(q0 + 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq] * B2S_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq]; }
         }
+        f32x4_t s[4], dp[4], pd[4];
+        first_product<T, DH, LD>(s, sQ, kf, li, lg);          // s[t][r] = S[q = q0 + t*16 + lg*4 + r][key = own]
+        first_product<T, DH, LD>(dp, sO, vf, li, lg);
+        // all 16 keys of this wave valid and visible to all 64 queries of the tile?  (wave-uniform)
+        const bool interior = kw0 + 16 <= kend && q0 + 64 <= a.Lq && (!(a.mask_mode & 2) || kw0 + 15 <= q0);
+        if (interior) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4_t lq = *reinterpret_cast<const f32x4_t*>(sL + t * 16 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t][r] = fast_exp2(fmaf(s[t][r], sl2, -lq[r]));
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4_t lq = *reinterpret_cast<const f32x4_t*>(sL + t * 16 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = q0 + t * 16 + lg * 4 + r;
+                    const bool ok = key_ok && qq < a.Lq && (!(a.mask_mode & 2) || key <= qq);
+                    s[t][r] = ok ? fast_exp2(fmaf(s[t][r], sl2, -lq[r])) : 0.f;
+                }
+            }
+        }
+        if (a.drop.thresh) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool keep = b2s_keep(a.drop, (zq + (uint32_t)(q0 + t * 16 + lg * 4 + r)) * (uint32_t)a.Lk + (uint32_t)kc);
+                    dp[t][r] = keep ? dp[t][r] * a.drop.scale : 0.f;
+                    pd[t][r] = keep ? s[t][r] * a.drop.scale : 0.f;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pd[t] = s[t];
+        }
+        if (gc != 0.f) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = q0 + t * 16 + lg * 4 + r;
+                    dp[t][r] += qq < ga_ql ? gc * ga_w(qq, key, ga_iq, ga_ik, a.ga_inv2s2) : 0.f;
+                }
+        }
+        SP<T, DH, LD>::run(dv, sO, pd, li, lg);                // dV^T[d][key] += sum_q dO[q][d] * Pd[q][key]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4_t dsum4 = *reinterpret_cast<const f32x4_t*>(sD + t * 16 + lg * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - dsum4[r]) * a.scale;
+        }
+        SP<T, DH, LD>::run(dk, sQ, s, li, lg);                 // dK^T[d][key] += sum_q Q[q][d]  * dS[q][key]
+    }
+    if (key < a.Lk) {
+        store_rows<T, DH>(reinterpret_cast<T*>(a.dk) + ((long)b * a.Lk + key) * a.lddk + h * DH, dk, 1.f, lg);
+        store_rows<T, DH>(reinterpret_cast<T*>(a.dv) + ((long)b * a.Lk + key) * a.lddv + h * DH, dv, 1.f, lg);
+    }
 }
 
 // alignment rows on demand: align[z][k][q] = softmax weight, recomputed from q, k and the saved log-sum-exp
@@ -696,38 +542,18 @@ __global__ __launch_bounds__(256) void attn_align_kernel(AttnArgs a, float* alig
     }
 }
 
-// query row blocks per wave of the forward / dQ kernels: 2 in bf16 (128-row workgroups), 1 in the fp32 parity mode
-// (B2S_ATTN_RB=1: A/B switch back to 64-row workgroups)
-template <typename T, int DH, int RB>
-int launch_rb(const AttnArgs& a, int which, hipStream_t st) {
-    dim3 grid(cdiv(a.Lq, 64 * RB), a.B * a.H);
-    if (which == 0) hipLaunchKernelGGL((attn_fwd_kernel<T, DH, RB>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH, RB>), grid, dim3(256), 0, st, a);
-    B2S_LAUNCH_CHECK();
-    return 0;
-}
 template <typename T, int DH>
 int launch_dh(const AttnArgs& a, int which, hipStream_t st) {
-    if (which < 2) {
-        if constexpr (sizeof(T) == 2) {
-            static const int rb_all = getenv("B2S_ATTN_RB") ? atoi(getenv("B2S_ATTN_RB")) : 2;
-            static const int rb_f = getenv("B2S_ATTN_RB_FWD") ? atoi(getenv("B2S_ATTN_RB_FWD")) : rb_all;
-            static const int rb_q = getenv("B2S_ATTN_RB_DQ") ? atoi(getenv("B2S_ATTN_RB_DQ")) : rb_all;
-            if ((which == 0 ? rb_f : rb_q) == 2) return launch_rb<T, DH, 2>(a, which, st);
-        }
-        return launch_rb<T, DH, 1>(a, which, st);
+    if (which == 0) {
+        dim3 grid(cdiv(a.Lq, 64), a.B * a.H);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(256), 0, st, a);
+    } else if (which == 1) {
+        dim3 grid(cdiv(a.Lq, 64), a.B * a.H);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid(cdiv(a.Lk, 64), a.B * a.H);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DH>), grid, dim3(256), 0, st, a);
     }
-    // 128-key workgroups when they still give the chip at least one workgroup per CU (decoder self-attention: 5 x 112); the 114-key
-    // memory of the encoder-decoder attention keeps 64-key workgroups (2 x 112 instead of 1 x 112)
-    if constexpr (sizeof(T) == 2) {
-        static const int kbw = getenv("B2S_ATTN_KBW") ? atoi(getenv("B2S_ATTN_KBW")) : 2;
-        if (kbw == 2 && (long)cdiv(a.Lk, 128) * a.B * a.H >= 256) {
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DH, 2>), dim3(cdiv(a.Lk, 128), a.B * a.H), dim3(256), 0, st, a);
-            B2S_LAUNCH_CHECK();
-            return 0;
-        }
-    }
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DH, 1>), dim3(cdiv(a.Lk, 64), a.B * a.H), dim3(256), 0, st, a);
     B2S_LAUNCH_CHECK();
     return 0;
 }

@@ -3,6 +3,7 @@
 // with 64-lane wavefront shuffles; sequence masks come from the per-utterance lengths (no dense
 // bias tensors are built, unlike transformer/common.py:32-48).
 #include <algorithm>
+#include <cstdlib>
 #include "rowops.h"
 
 namespace {
@@ -194,6 +195,118 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
         if (ws) ws[(long)blockIdx.x * 2 * D + i] = v; else atomicAdd(i < D ? dgamma + i : dbeta + (i - D), v);
     }
 }
+// ---- compile-time widths (D = 256 * NCH: 768 -> 3, 512 -> 2 -- the decoder / encoder of the default model).
+// Every load of a row is UNCONDITIONAL and issued before anything waits: in the generic kernels above each `if (ci < nch)` chunk is a
+// branch around its loads, and hipcc waits vmcnt(0) at the join of every such block -- a row became ~8 dependent memory round trips.
+// Here a wave issues all loads of its NEXT row before it reduces the current one (two rows in flight per wave).
+template <int NCH> struct LnRow { float4 d[NCH], xv[NCH], pv[NCH]; float mu, rs; };
+template <typename TD, int NCH, bool ACC>
+__device__ __forceinline__ void ln_row_load(LnRow<NCH>& r, const TD* __restrict__ dy, int lddy, const float* __restrict__ x, const float* dx,
+                                            const float* __restrict__ mean, const float* __restrict__ rstd, int row, int lane) {
+    constexpr int D = NCH * 256;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        r.d[i] = ld4(dy + (long)row * lddy + c);
+        r.xv[i] = ld4(x + (long)row * D + c);
+        if (ACC) r.pv[i] = ld4(dx + (long)row * D + c);
+    }
+    r.mu = mean[row]; r.rs = rstd[row];
+}
+template <typename TD, int NCH, bool ACC, bool DY2>
+__global__ __launch_bounds__(256) void k_ln_bwd_fast(const TD* __restrict__ dy, int lddy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, float* dx, int M,
+                                                     const int* __restrict__ row_len, int rpb, float* __restrict__ ws, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, bf16_t* __restrict__ dy2, DropCfg drop2) {
+    constexpr int D = NCH * 256;
+    __shared__ float sacc[4 * 2 * D];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (scalar: row indices, the row_len lookup and the row bases stay off the vector unit)
+    float4 pg[NCH], pb[NCH], gm[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { pg[i] = pb[i] = make_float4(0, 0, 0, 0); gm[i] = ld4(gamma + (lane + 64 * i) * 4); }
+    const int nw = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    LnRow<NCH> cur, nxt;
+    ln_row_load<TD, NCH, ACC>(cur, dy, lddy, x, dx, mean, rstd, min(row, M - 1), lane);
+    for (; row < M; row += nw) {
+        ln_row_load<TD, NCH, ACC>(nxt, dy, lddy, x, dx, mean, rstd, min(row + nw, M - 1), lane);      // (past the end: the last row again, unused)
+        bool zero = false;
+        if (row_len) { const int b = row / rpb; zero = (row - b * rpb) >= row_len[b]; }
+        const float mu = cur.mu, rs = cur.rs;
+        float4 g[NCH], xh[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const float4 d = zero ? make_float4(0, 0, 0, 0) : cur.d[i];
+            const float4 xv = cur.xv[i];
+            xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            pb[i].x += d.x; pb[i].y += d.y; pb[i].z += d.z; pb[i].w += d.w;
+            pg[i].x += d.x * xh[i].x; pg[i].y += d.y * xh[i].y; pg[i].z += d.z * xh[i].z; pg[i].w += d.w * xh[i].w;
+            g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+            s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+            s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+        }
+        s1 = wave_sum(s1) * (1.f / D); s2 = wave_sum(s2) * (1.f / D);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            float4 o;
+            o.x = rs * (g[i].x - s1 - xh[i].x * s2); o.y = rs * (g[i].y - s1 - xh[i].y * s2);
+            o.z = rs * (g[i].z - s1 - xh[i].z * s2); o.w = rs * (g[i].w - s1 - xh[i].w * s2);
+            if (ACC) { o.x += cur.pv[i].x; o.y += cur.pv[i].y; o.z += cur.pv[i].z; o.w += cur.pv[i].w; }
+            st4(dx + (long)row * D + c, o);
+            if (DY2) st4(dy2 + (long)row * D + c, drop4(o, drop2, (uint32_t)((long)row * D + c)));
+        }
+        cur = nxt;
+    }
+    float* mine = sacc + wave * 2 * D;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { st4(mine + (lane + 64 * i) * 4, pg[i]); st4(mine + D + (lane + 64 * i) * 4, pb[i]); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const float v = sacc[i] + sacc[2 * D + i] + sacc[4 * D + i] + sacc[6 * D + i];
+        if (ws) ws[(long)blockIdx.x * 2 * D + i] = v; else atomicAdd(i < D ? dgamma + i : dbeta + (i - D), v);
+    }
+}
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void k_ln_fwd_fast(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     T* __restrict__ y, int ldy, float* __restrict__ y32, int ldy32, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int M, float eps, const int* __restrict__ row_len, int rpb) {
+    constexpr int D = NCH * 256;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= M) return;                                 // (wave-uniform)
+    float4 v[NCH], g[NCH], be[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        v[i] = ld4(x + (long)row * D + c); g[i] = ld4(gamma + c); be[i] = ld4(beta + c);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+        q += a * a + b * b + c * c + d * d;
+    }
+    const float rs = 1.f / sqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    bool zero = false;
+    if (row_len) { const int b = row / rpb; zero = (row - b * rpb) >= row_len[b]; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        float4 o;
+        o.x = (v[i].x - mu) * rs * g[i].x + be[i].x; o.y = (v[i].y - mu) * rs * g[i].y + be[i].y;
+        o.z = (v[i].z - mu) * rs * g[i].z + be[i].z; o.w = (v[i].w - mu) * rs * g[i].w + be[i].w;
+        if (zero) o = make_float4(0, 0, 0, 0);
+        if (y) st4(y + (long)row * ldy + c, o);
+        if (y32) st4(y32 + (long)row * ldy32 + c, o);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ln_param_reduce(const float* ws, int nblk, int D, float* dgamma, float* dbeta) {
     // column sums of ws [nblk, 2D]: 64 columns per workgroup, rows split over 4 row-lanes and gridDim.y workgroups
     __shared__ float sh[4][64];
@@ -818,6 +931,14 @@ int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float*
                      int ldy32, float* mean, float* rstd, int M, int D, float eps, const int* row_len,
                      int rows_per_batch, hipStream_t st) {
     B2S_CHECK(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
+    static const bool no_fast = getenv("B2S_LN_GENERIC") != nullptr;             // A/B switch
+    if (!no_fast && (D == 768 || D == 512) && M > 0) {
+        if (D == 768) RO_DISPATCH(dtype, hipLaunchKernelGGL((k_ln_fwd_fast<TY, 3>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, (TY*)y, ldy,
+                                                            y32, ldy32, mean, rstd, M, eps, row_len, rows_per_batch));
+        else RO_DISPATCH(dtype, hipLaunchKernelGGL((k_ln_fwd_fast<TY, 2>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, (TY*)y, ldy,
+                                                   y32, ldy32, mean, rstd, M, eps, row_len, rows_per_batch));
+        B2S_LAUNCH_CHECK(); return 0;
+    }
     RO_DISPATCH(dtype, hipLaunchKernelGGL((k_ln_fwd<TY>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, (TY*)y, ldy,
                                           y32, ldy32, mean, rstd, M, D, eps, row_len, rows_per_batch));
     B2S_LAUNCH_CHECK(); return 0;
@@ -828,7 +949,20 @@ int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const flo
                      int* defer_nblk) {
     B2S_CHECK(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
     int grid = cdiv(M, 4); if (grid > (ws ? RO_LN_WS_ROWS : 512)) grid = ws ? RO_LN_WS_ROWS : 512;
-    if (dy_fp32 || !dtype)
+    static const bool no_fast = getenv("B2S_LN_GENERIC") != nullptr;             // A/B switch
+    const bool f32 = dy_fp32 || !dtype;
+    if (!no_fast && (D == 768 || D == 512) && M > 0 && (lddy & 3) == 0) {
+        // ~3 rows per wave (the next row's loads fly under the current row's reductions); at most RO_LN_WS_ROWS partial rows
+        grid = std::max(1, std::min(cdiv(M, 12), ws ? RO_LN_WS_ROWS : 512));
+#define B2S_LN_FAST(TD, NCH, ACC, DY2) hipLaunchKernelGGL((k_ln_bwd_fast<TD, NCH, ACC, DY2>), dim3(grid), dim3(256), 0, st, (const TD*)dy, lddy, x, \
+            gamma, mean, rstd, dx, M, row_len, rows_per_batch, ws, dgamma, dbeta, (bf16_t*)dy2, drop2)
+#define B2S_LN_FAST_AD(TD, NCH) do { if (accumulate) { if (dy2) B2S_LN_FAST(TD, NCH, true, true); else B2S_LN_FAST(TD, NCH, true, false); } \
+                                     else { if (dy2) B2S_LN_FAST(TD, NCH, false, true); else B2S_LN_FAST(TD, NCH, false, false); } } while (0)
+        if (D == 768) { if (f32) B2S_LN_FAST_AD(float, 3); else B2S_LN_FAST_AD(bf16_t, 3); }
+        else          { if (f32) B2S_LN_FAST_AD(float, 2); else B2S_LN_FAST_AD(bf16_t, 2); }
+#undef B2S_LN_FAST_AD
+#undef B2S_LN_FAST
+    } else if (dy_fp32 || !dtype)
         hipLaunchKernelGGL((k_ln_bwd<float>), dim3(grid), dim3(256), 0, st, (const float*)dy, lddy, x, gamma, mean, rstd,
                            dx, accumulate, dgamma, dbeta, M, D, row_len, rows_per_batch, ws, (bf16_t*)dy2, drop2);
     else
