@@ -587,7 +587,7 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     for (int i = 0; i < (m->dw_group ? 3 * cf.n_decoder_layer + 2 : RO_LN_BATCH); ++i) sc.r_lnws.push_back(a.f32((long)RO_LN_WS_ROWS * 2 * D));
 }
 
-struct PostScratch { std::vector<void*> du, dy; float* stat; };
+struct PostScratch { std::vector<void*> du, dy; float* stat; int stat_stride; };       // stat: [n layers][2 maxc] column sums (zeroed once per forward)
 void plan_postnet(const b2s_model* m, b2s_ctx& c, Arena& a, PostScratch& ps) {
     const b2s_config& cf = m->cfg;
     const long M = (long)c.B * c.T;
@@ -609,7 +609,8 @@ void plan_postnet(const b2s_model* m, b2s_ctx& c, Arena& a, PostScratch& ps) {
     // after the whole backward pass of the postnet
     ps.dy.assign(n, nullptr);
     for (int i = 0; i < n; ++i) ps.dy[i] = a.T(M * (i == n - 1 ? cf.num_mels : cf.postnet_hidden), esz);
-    ps.stat = a.f32(2 * maxc);
+    ps.stat_stride = 2 * maxc;
+    ps.stat = a.f32((long)n * ps.stat_stride);
 }
 
 int check_bound(const b2s_model* m) {
@@ -1378,23 +1379,38 @@ extern "C" int b2s_postnet_forward(b2s_model* m, const float* inputs, const int3
     const long M = (long)B * T;
     const int n = cf.n_postnet_layer, dt = m->dtype;
     const float pd = train ? cf.decoder_dropout_rate : 0.f;
+    // Training: the batch statistics are column sums taken by the conv GEMM's epilogue (GemmEpilogue::colstat) and turned into mean /
+    // rstd / running statistics by the normalisation kernel itself: conv + one row kernel per layer (was conv + memset + two reduction
+    // passes + finalize + apply).  B2S_BN_SEPARATE=1 keeps the separate two-pass statistics (A/B switch).
+    static const bool bn_separate = getenv("B2S_BN_SEPARATE") != nullptr;
+    const bool fused_stats = train && !bn_separate && M > 1;
     auto run = [&]() -> int {
         B2S_TRY(ro_cast(dt, inputs, c->u[0], M * cf.num_mels, st));
+        if (fused_stats) B2S_HIP(hipMemsetAsync(ps.stat, 0, sizeof(float) * (size_t)n * ps.stat_stride, st));
         for (int i = 0; i < n; ++i) {
             const int cin = i == 0 ? cf.num_mels : cf.postnet_hidden, cout = i == n - 1 ? cf.num_mels : cf.postnet_hidden;
             const std::string q = "postnet.batchnorm_layers." + std::to_string(i) + ".";
+            float* sums = ps.stat + (size_t)i * ps.stat_stride;
             GemmArgs g;       // y[m, co] = sum_{j,ci} x[m + j - 2, ci] * w[co, ci, j]   (impute + Conv1d k5 p2)
             g.A.p = c->u[i]; g.A.ld = cin; g.A.R = (int)M; g.A.C = 5 * cin; g.A.g_cin = cin; g.A.g_T = T; g.A.g_len = lengths;
             g.B.p = m->conv_wf[i]; g.B.ld = 5 * cin; g.B.R = cout; g.B.C = 5 * cin;
             g.M = (int)M; g.N = cout; g.K = 5 * cin; g.C = c->y[i]; g.c_fp32 = 1; g.ldc = cout;
+            if (fused_stats) g.epi.colstat = sums;
             B2S_TRY(b2s_gemm_launch(g, dt, false, false, st));
+            DropCfg d = make_drop(pd, seed, opid(3, i, 1));
+            const bool last = i == n - 1;
+            if (fused_stats) {
+                B2S_TRY(ro_bn_apply_train(dt, c->y[i], sums, c->bn_mean[i], c->bn_rstd[i], 1e-5f, m->P(q + "running_mean"), m->P(q + "running_var"),
+                                          (long*)m->data[m->id(q + "num_batches_tracked")], 0.1f, m->P(q + "weight"), m->P(q + "bias"), last ? 0 : 1,
+                                          last ? nullptr : c->u[i + 1], last ? out : nullptr, last ? add : nullptr, (int)M, cout, d, st));
+                continue;
+            }
             if (train)
                 B2S_TRY(ro_bn_stats(c->y[i], (int)M, cout, c->bn_mean[i], c->bn_rstd[i], 1e-5f, m->P(q + "running_mean"),
-                                    m->P(q + "running_var"), (long*)m->data[m->id(q + "num_batches_tracked")], 0.1f, ps.stat, st));
+                                    m->P(q + "running_var"), (long*)m->data[m->id(q + "num_batches_tracked")], 0.1f, sums, st));
             else
                 B2S_TRY(ro_bn_eval_stats(m->P(q + "running_mean"), m->P(q + "running_var"), c->bn_mean[i], c->bn_rstd[i], 1e-5f, cout, st));
-            DropCfg d = make_drop(pd, seed, opid(3, i, 1));
-            if (i < n - 1)
+            if (!last)
                 B2S_TRY(ro_bn_apply(dt, c->y[i], c->bn_mean[i], c->bn_rstd[i], m->P(q + "weight"), m->P(q + "bias"), 1, c->u[i + 1],
                                     nullptr, nullptr, (int)M, cout, d, st));
             else

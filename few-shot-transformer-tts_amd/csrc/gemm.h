@@ -31,6 +31,8 @@ struct GemmEpilogue {
     int rows_per_batch = 1;
     int conv_dw_cin = 0;                  // >0: output column n = j*cin+ci is stored at ci*5 + j
     int accumulate = 0;                   // fp32 output only: C += v
+    float* colstat = nullptr;             // [2 N] fp32, zeroed by the caller: colstat[n] += sum_m v[m][n], colstat[N + n] += sum_m v[m][n]^2 of the
+                                          // raw products (before any other epilogue step) -- the BatchNorm batch statistics of a conv layer's output
     // decode-step fusion, honoured by the weight-streaming kernel only (gemm_skinny.hip; the tiled kernels reject it): output
     // columns [kv_D, 2 kv_D) / [2 kv_D, 3 kv_D) are also appended to the head-major caches kv_k / kv_v [M][kv_D/kv_dh][kv_maxT][kv_dh] at position *kv_t
     void *kv_k = nullptr, *kv_v = nullptr;

@@ -15,6 +15,7 @@
 //     transposed copy of any activation or weight is ever written to HBM.
 #include <mutex>
 #include "gemm.h"
+#include "gemm_epi.h"
 
 namespace {
 
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     // ---------------- epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4)*4 + r
     const GemmEpilogue& e = g.epi;
+    if (e.colstat && g.splitk == 1) epi_colstat<4>(acc, e.colstat, e.alpha, g.M, g.N, m0 + wrow, n0 + wcol, lane);
     const long cbase = zo * g.cs_o + zi * g.cs_i;
     float* Cf = reinterpret_cast<float*>(g.C);
     T* Ct = reinterpret_cast<T*>(g.C);

@@ -6,12 +6,35 @@
 // 16-byte global store.  (Measured: write-through `sc1` stores, meant to spare the end-of-kernel L2 write-back, gain 1 us on
 // the bf16-output GEMMs and lose 5 us on the fp32 residual ones -- plain stores stay.)
 __device__ __forceinline__ void epi_store16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+// Column sums of a wave's accumulator block (MFMA C layout: column nb + b*16 + (lane & 15), rows mb + a*16 + (lane >> 4)*4 + r) added to
+// colstat[n] / colstat[N + n]: two shuffles fold the four 16-lane groups, one atomic pair per column and wave.
+template <int NBv>
+__device__ __forceinline__ void epi_colstat(const f32x4_t (&acc)[4][NBv], float* colstat, float alpha, int M, int N, int mb, int nb, int lane) {
+    const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < NBv; ++b) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (mb + a * 16 + lg * 4 + r) < M ? acc[a][b][r] * alpha : 0.f;
+                s1 += v; s2 += v * v;
+            }
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        const int n = nb + b * 16 + li;
+        if (lg == 0 && n < N) { atomicAdd(colstat + n, s1); atomicAdd(colstat + N + n, s2); }
+    }
+}
+
 // Fast paths for the epilogues the training step is made of (a wave's 64 x NB*16 block completely inside the matrix, 16-byte aligned
 // rows, alpha = 1, no bias / row masking / accumulation):
 //   MODE 0  compute-dtype output, plain                          (qkv / q projections, every dX GEMM)
 //   MODE 1  compute-dtype output, ReLU [+ dropout]               (FFN input layer)
 //   MODE 2  compute-dtype output, ReLU-mask of `relu_aux`        (FFN dX: d hidden)
 //   MODE 3  fp32 output = dropout(acc) + fp32 residual           (attention output / FFN output projections: the residual stream)
+//   MODE 4  fp32 output, plain                                   (postnet convolutions: the BatchNorm input)
 // No control flow between the first load and the last store: the generic epilogue below branches around every optional operand, and
 // hipcc waits vmcnt(0) at the join of every block that contains a load or a store -- its passes ran as a chain of memory round trips.
 // Here the residual / mask rows of ALL of a lane's tasks are requested before the accumulators are staged through LDS, every lane task
@@ -93,7 +116,10 @@ __device__ __forceinline__ void gemm_wave_epilogue_fast(const EpiFast g, f32x4_t
             for (int j = 0; j < 8; ++j) v[j] = b2s_keep(dcfg, idx + j) ? v[j] * dcfg.scale : 0.f;
         }
         const long off = cbase + (long)m * g.ldc + n;
-        if (MODE == 3) {
+        if (MODE == 4) {
+            const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<f32x4_t*>(Cf + off) = o0; *reinterpret_cast<f32x4_t*>(Cf + off + 4) = o1;
+        } else if (MODE == 3) {
             const f32x4_t o0 = {v[0] + r0[k][0], v[1] + r0[k][1], v[2] + r0[k][2], v[3] + r0[k][3]};
             const f32x4_t o1 = {v[4] + r1[k][0], v[5] + r1[k][1], v[6] + r1[k][2], v[7] + r1[k][3]};
             *reinterpret_cast<f32x4_t*>(Cf + off) = o0; *reinterpret_cast<f32x4_t*>(Cf + off + 4) = o1;
@@ -108,6 +134,7 @@ template <int NB>     // the wave's block is 64 rows x NB*16 columns
 __device__ __forceinline__ void gemm_wave_epilogue(GemmArgs g, f32x4_t (&acc)[4][NB], float* stg, int mb, int nb, int lane, int z, int zo, int zi,
                                           int ksplit, float* splitk_ws) {
     const int li = lane & 15, lg = lane >> 4;
+    if (g.epi.colstat && g.splitk == 1) epi_colstat<NB>(acc, g.epi.colstat, g.epi.alpha, g.M, g.N, mb, nb, lane);
 #if B2S_EPI_FAST
     {
         const GemmEpilogue& e = g.epi;
@@ -126,6 +153,8 @@ __device__ __forceinline__ void gemm_wave_epilogue(GemmArgs g, f32x4_t (&acc)[4]
                 }
             } else if (g.c_fp32 && e.residual && !e.relu && !e.relu_aux && (e.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(e.residual) & 15) == 0) {
                 gemm_wave_epilogue_fast<NB, 3>(f, acc, stg, mb, nb, lane, z, cb); return;
+            } else if (g.c_fp32 && !e.residual && !e.relu && !e.relu_aux && !e.drop.thresh) {
+                gemm_wave_epilogue_fast<NB, 4>(f, acc, stg, mb, nb, lane, z, cb); return;
             }
         }
     }

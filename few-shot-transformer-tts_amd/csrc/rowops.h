@@ -77,6 +77,9 @@ int ro_colsum(int dtype, const void* X, int x_fp32, int ldx, const float* wgt, f
 // BatchNorm1d over all M = B*T rows (tacotron.py:83-89)
 int ro_bn_stats(const float* y, int M, int C, float* mean, float* rstd, float eps, float* running_mean,
                 float* running_var, long* num_batches_tracked, float momentum, float* scratch, hipStream_t st);
+int ro_bn_apply_train(int dtype, const float* y, const float* sums, float* mean, float* rstd, float eps, float* running_mean, float* running_var,
+                      long* num_batches_tracked, float momentum, const float* gamma, const float* beta, int use_tanh, void* outT, float* out32,
+                      const float* add32, int M, int C, DropCfg drop, hipStream_t st);
 int ro_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* rstd, float eps, int C,
                      hipStream_t st);
 // u = dropout(act(gamma*(y-mean)*rstd+beta)); act = tanh if use_tanh.  out T (ldo) or, if out32, fp32 = add32 + u

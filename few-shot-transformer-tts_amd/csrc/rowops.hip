@@ -703,6 +703,131 @@ __global__ void k_bn_bwd_apply(const TD* dout, const float* y, const float* mean
     }
 }
 
+// ---- vectorised BatchNorm kernels (C % 4 == 0): a thread owns FOUR adjacent channels and RU rows whose loads are all issued before
+// the first use (one memory round trip per thread), 4 row lanes per workgroup.  The scalar kernels above read 4 bytes per lane and
+// walked their rows one dependent round trip at a time (1-2 TB/s).
+constexpr int BN_RU = 8;
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }      // (|err| ~ 1e-7: exp overflow -> 1, underflow -> -1)
+struct BnStat {                   // how the forward kernel gets mean / rstd
+    const float* sums;            // train: [2C] column sums of y and y^2 (written by the conv GEMM's epilogue); null: mean / rstd given
+    float *mean, *rstd;           // train: outputs (saved for the backward pass); eval: inputs
+    float *rm, *rv; long* nbt;    // running statistics to update (train; may be null)
+    float eps, mom;
+};
+// out = dropout(tanh?(gamma * (y - mean) * rstd + beta)) [+ add32]; in training mode mean / rstd come from the column sums and the
+// workgroups of grid row 0 also store them and update the running statistics (k_bn_finalize's job, without its launch)
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_apply_v(const float* __restrict__ y, BnStat bs, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    int use_tanh, T* __restrict__ outT, float* __restrict__ out32, const float* __restrict__ add32, int M,
+                                                    int C, DropCfg drop) {
+    const int cq = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
+    const int c = min(cq * 4, C - 4);                    // (threads past the last channel group re-do it: no divergent loads; they do not store)
+    const bool own = cq * 4 < C;
+    float4 mu, rs;
+    if (bs.sums) {
+        const float4 s1 = ld4(bs.sums + c), s2 = ld4(bs.sums + C + c);
+        const float im = 1.f / M;
+        mu = make_float4(s1.x * im, s1.y * im, s1.z * im, s1.w * im);
+        const float4 var = make_float4(fmaxf(s2.x * im - mu.x * mu.x, 0.f), fmaxf(s2.y * im - mu.y * mu.y, 0.f), fmaxf(s2.z * im - mu.z * mu.z, 0.f),
+                                       fmaxf(s2.w * im - mu.w * mu.w, 0.f));
+        rs = make_float4(1.f / sqrtf(var.x + bs.eps), 1.f / sqrtf(var.y + bs.eps), 1.f / sqrtf(var.z + bs.eps), 1.f / sqrtf(var.w + bs.eps));
+        if (blockIdx.y == 0 && ry == 0 && own) {
+            st4(bs.mean + c, mu); st4(bs.rstd + c, rs);
+            if (bs.rm) {
+                const float unb = (float)M / (float)(M - 1), a = 1.f - bs.mom, b = bs.mom;
+                const float4 m0 = ld4(bs.rm + c), v0 = ld4(bs.rv + c);
+                st4(bs.rm + c, make_float4(a * m0.x + b * mu.x, a * m0.y + b * mu.y, a * m0.z + b * mu.z, a * m0.w + b * mu.w));
+                st4(bs.rv + c, make_float4(a * v0.x + b * var.x * unb, a * v0.y + b * var.y * unb, a * v0.z + b * var.z * unb, a * v0.w + b * var.w * unb));
+            }
+            if (bs.nbt && cq == 0) *bs.nbt += 1;
+        }
+    } else { mu = ld4(bs.mean + c); rs = ld4(bs.rstd + c); }
+    const float4 g = ld4(gamma + c), be = ld4(beta + c);
+    const int m0 = (blockIdx.y * 4 + ry) * BN_RU;
+    float4 v[BN_RU], ad[BN_RU];
+#pragma unroll
+    for (int j = 0; j < BN_RU; ++j) {
+        const long o = (long)min(m0 + j, M - 1) * C + c;
+        v[j] = ld4(y + o);
+        if (add32) ad[j] = ld4(add32 + o);
+    }
+#pragma unroll
+    for (int j = 0; j < BN_RU; ++j) {
+        const int m = m0 + j;
+        float4 o;
+        o.x = (v[j].x - mu.x) * rs.x * g.x + be.x; o.y = (v[j].y - mu.y) * rs.y * g.y + be.y;
+        o.z = (v[j].z - mu.z) * rs.z * g.z + be.z; o.w = (v[j].w - mu.w) * rs.w * g.w + be.w;
+        if (use_tanh) { o.x = fast_tanh(o.x); o.y = fast_tanh(o.y); o.z = fast_tanh(o.z); o.w = fast_tanh(o.w); }
+        o = drop4(o, drop, (uint32_t)((long)m * C + c));
+        if (m < M && own) {
+            if (outT) st4(outT + (long)m * C + c, o);
+            if (out32) {
+                if (add32) { o.x += ad[j].x; o.y += ad[j].y; o.z += ad[j].z; o.w += ad[j].w; }
+                st4(out32 + (long)m * C + c, o);
+            }
+        }
+    }
+}
+// dz = dropout-mask(dout) * tanh'(gamma xhat + beta) for 4 channels of one row
+template <typename TD>
+__device__ __forceinline__ float4 bn_dz4(float4 d, float4 yv, float4 mu, float4 rs, float4 g, float4 be, int use_tanh, const DropCfg& drop, uint32_t off,
+                                         float4* xh) {
+    d = drop4(d, drop, off);
+    *xh = make_float4((yv.x - mu.x) * rs.x, (yv.y - mu.y) * rs.y, (yv.z - mu.z) * rs.z, (yv.w - mu.w) * rs.w);
+    if (use_tanh) {
+        const float a0 = fast_tanh(g.x * xh->x + be.x), a1 = fast_tanh(g.y * xh->y + be.y), a2 = fast_tanh(g.z * xh->z + be.z), a3 = fast_tanh(g.w * xh->w + be.w);
+        d.x *= 1.f - a0 * a0; d.y *= 1.f - a1 * a1; d.z *= 1.f - a2 * a2; d.w *= 1.f - a3 * a3;
+    }
+    return d;
+}
+// APPLY = false: dgamma[c] += sum_m dz xhat, dbeta[c] += sum_m dz.   APPLY = true: dy = gamma rstd (dz - dbeta / M - xhat dgamma / M)
+template <typename TD, typename T, bool APPLY>
+__global__ __launch_bounds__(256) void k_bn_bwd_v(const TD* __restrict__ dout, const float* __restrict__ y, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  int use_tanh, float* dgamma, float* dbeta, T* __restrict__ dy, int M, int C, DropCfg drop) {
+    __shared__ float sh[2][4][256];
+    const int cx = threadIdx.x & 63, cq = blockIdx.x * 64 + cx, ry = threadIdx.x >> 6;
+    const int c = min(cq * 4, C - 4);
+    const bool own = cq * 4 < C;
+    const float4 mu = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), be = ld4(beta + c);
+    float4 sg = make_float4(0, 0, 0, 0), sb = make_float4(0, 0, 0, 0);
+    if (APPLY) { sg = ld4(dgamma + c); sb = ld4(dbeta + c); }
+    const int m0 = (blockIdx.y * 4 + ry) * BN_RU;
+    float4 dv[BN_RU], yv[BN_RU];
+#pragma unroll
+    for (int j = 0; j < BN_RU; ++j) {
+        const long o = (long)min(m0 + j, M - 1) * C + c;
+        dv[j] = ld4(dout + o); yv[j] = ld4(y + o);
+    }
+    const float invM = 1.f / M;
+    float4 a1 = make_float4(0, 0, 0, 0), a2 = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < BN_RU; ++j) {
+        const int m = m0 + j;
+        float4 xh;
+        float4 dz = bn_dz4<TD>(dv[j], yv[j], mu, rs, g, be, use_tanh, drop, (uint32_t)((long)min(m, M - 1) * C + c), &xh);
+        if (APPLY) {
+            float4 o;
+            o.x = g.x * rs.x * (dz.x - sb.x * invM - xh.x * sg.x * invM); o.y = g.y * rs.y * (dz.y - sb.y * invM - xh.y * sg.y * invM);
+            o.z = g.z * rs.z * (dz.z - sb.z * invM - xh.z * sg.z * invM); o.w = g.w * rs.w * (dz.w - sb.w * invM - xh.w * sg.w * invM);
+            if (m < M && own) st4(dy + (long)m * C + c, o);
+        } else if (m < M) {
+            a1.x += dz.x; a1.y += dz.y; a1.z += dz.z; a1.w += dz.w;
+            a2.x += dz.x * xh.x; a2.y += dz.y * xh.y; a2.z += dz.z * xh.z; a2.w += dz.w * xh.w;
+        }
+    }
+    if (!APPLY) {
+        st4(&sh[0][ry][cx * 4], a1); st4(&sh[1][ry][cx * 4], a2);
+        __syncthreads();
+        const int cc = blockIdx.x * 256 + threadIdx.x;        // one thread per channel of the workgroup's 256
+        if (cc < C) {
+            const int i = threadIdx.x;
+            atomicAdd(dbeta + cc, sh[0][0][i] + sh[0][1][i] + sh[0][2][i] + sh[0][3][i]);
+            atomicAdd(dgamma + cc, sh[1][0][i] + sh[1][1][i] + sh[1][2][i] + sh[1][3][i]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- loss
 __device__ inline float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
 __global__ __launch_bounds__(256) void k_loss_partial(const float* bef, const float* aft, const float* stop,
@@ -733,6 +858,43 @@ __global__ __launch_bounds__(256) void k_loss_partial(const float* bef, const fl
     tc = block_sum_256(tc, sh);
     if (threadIdx.x == 0) {
         atomicAdd(scratch + 0, tb); atomicAdd(scratch + 1, ta); atomicAdd(scratch + 2, tc);
+        atomicAdd(scratch + 3 + b, ta);
+    }
+}
+// The same sums, vectorised: the valid frames of an utterance are one contiguous prefix of len * C floats of its [T, C] block, so the squared
+// errors stream as float4 with four independent positions per thread in flight (the kernel above walks rows one dependent round trip at a time)
+__global__ __launch_bounds__(256) void k_loss_partial_v(const float* __restrict__ bef, const float* __restrict__ aft, const float* __restrict__ stop,
+                                                        const float* __restrict__ tgt, const int* __restrict__ lens, float* scratch, int T, int C, float pw) {
+    __shared__ float sh[4];
+    const int b = blockIdx.y, len = min(lens[b], T);
+    const long base = (long)b * T * C;
+    const int n4 = len * C / 4, stride = gridDim.x * 256;
+    float tb = 0.f, ta = 0.f, tc = 0.f;
+    for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+        float4 y[4], p[4], q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long o = base + 4L * min(i0 + k * stride, n4 - 1);
+            y[k] = ld4(tgt + o); p[k] = ld4(bef + o); q[k] = ld4(aft + o);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k * stride >= n4) continue;
+            const float a0 = p[k].x - y[k].x, a1 = p[k].y - y[k].y, a2 = p[k].z - y[k].z, a3 = p[k].w - y[k].w;
+            const float c0 = q[k].x - y[k].x, c1 = q[k].y - y[k].y, c2 = q[k].z - y[k].z, c3 = q[k].w - y[k].w;
+            tb += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3; ta += c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3;
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int t = threadIdx.x; t < len; t += 256) {
+            const float x = stop[(long)b * T + t];
+            tc += (t == len - 1) ? pw * softplusf(-x) : softplusf(x);
+        }
+    tb = block_sum_256(tb, sh) / C;
+    ta = block_sum_256(ta, sh) / C;
+    tc = block_sum_256(tc, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(scratch + 0, tb); atomicAdd(scratch + 1, ta); if (blockIdx.x == 0) atomicAdd(scratch + 2, tc);
         atomicAdd(scratch + 3 + b, ta);
     }
 }
@@ -1107,10 +1269,28 @@ int ro_bn_eval_stats(const float* running_mean, const float* running_var, float*
     hipLaunchKernelGGL(k_bn_eval_stats, dim3(cdiv(C, 256)), dim3(256), 0, st, running_mean, running_var, mean, rstd, eps, C);
     B2S_LAUNCH_CHECK(); return 0;
 }
+// training forward from the column sums the conv GEMM's epilogue left in sums[2C] (GemmEpilogue::colstat): statistics, running-statistics
+// update and the normalisation in one launch
+int ro_bn_apply_train(int dtype, const float* y, const float* sums, float* mean, float* rstd, float eps, float* running_mean, float* running_var,
+                      long* num_batches_tracked, float momentum, const float* gamma, const float* beta, int use_tanh, void* outT, float* out32,
+                      const float* add32, int M, int C, DropCfg drop, hipStream_t st) {
+    B2S_CHECK(C % 4 == 0 && M > 1, "bn_apply_train: C=%d must be a multiple of 4, M=%d > 1", C, M);
+    BnStat bs = {sums, mean, rstd, running_mean, running_var, num_batches_tracked, eps, momentum};
+    dim3 grid(cdiv(C / 4, 64), cdiv(M, 4 * BN_RU));
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply_v<TY>), grid, dim3(256), 0, st, y, bs, gamma, beta, use_tanh, (TY*)outT, out32, add32, M, C, drop));
+    B2S_LAUNCH_CHECK(); return 0;
+}
 int ro_bn_apply(int dtype, const float* y, const float* mean, const float* rstd, const float* gamma,
                 const float* beta, int use_tanh, void* outT, float* out32, const float* add32, int M, int C,
                 DropCfg drop, hipStream_t st) {
     B2S_CHECK(C % 4 == 0, "bn_apply: C=%d must be a multiple of 4", C);
+    static const bool scalar = getenv("B2S_BN_SCALAR") != nullptr;               // A/B switch: the round-2 kernels
+    if (!scalar) {
+        BnStat bs = {nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), nullptr, nullptr, nullptr, 0.f, 0.f};
+        dim3 grid(cdiv(C / 4, 64), cdiv(M, 4 * BN_RU));
+        RO_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply_v<TY>), grid, dim3(256), 0, st, y, bs, gamma, beta, use_tanh, (TY*)outT, out32, add32, M, C, drop));
+        B2S_LAUNCH_CHECK(); return 0;
+    }
     RO_DISPATCH(dtype, hipLaunchKernelGGL((k_bn_apply<TY>), dim3(ew_grid((long)M * C / 4)), dim3(256), 0, st, y, mean, rstd,
                                           gamma, beta, use_tanh, (TY*)outT, out32, add32, M, C, drop));
     B2S_LAUNCH_CHECK(); return 0;
@@ -1118,6 +1298,17 @@ int ro_bn_apply(int dtype, const float* y, const float* mean, const float* rstd,
 int ro_bn_bwd(int dtype, const void* dout, int dout_fp32, const float* y, const float* mean, const float* rstd,
               const float* gamma, const float* beta, int use_tanh, float* dgamma, float* dbeta, void* dyT, int M,
               int C, DropCfg drop, hipStream_t st) {
+    static const bool scalar = getenv("B2S_BN_SCALAR") != nullptr;               // A/B switch: the round-2 kernels
+    if (!scalar && C % 4 == 0) {
+        dim3 gv(cdiv(C / 4, 64), cdiv(M, 4 * BN_RU));
+#define B2S_BN_BWD(TD, T) do { \
+        hipLaunchKernelGGL((k_bn_bwd_v<TD, T, false>), gv, dim3(256), 0, st, (const TD*)dout, y, mean, rstd, gamma, beta, use_tanh, dgamma, dbeta, (T*)dyT, M, C, drop); \
+        hipLaunchKernelGGL((k_bn_bwd_v<TD, T, true>), gv, dim3(256), 0, st, (const TD*)dout, y, mean, rstd, gamma, beta, use_tanh, dgamma, dbeta, (T*)dyT, M, C, drop); } while (0)
+        if (dout_fp32 || !dtype) { if (dtype) B2S_BN_BWD(float, bf16_t); else B2S_BN_BWD(float, float); }
+        else B2S_BN_BWD(bf16_t, bf16_t);
+#undef B2S_BN_BWD
+        B2S_LAUNCH_CHECK(); return 0;
+    }
     int gy = cdiv(M, 4 * 16); if (gy > 128) gy = 128; if (gy < 1) gy = 1;
     dim3 grid(cdiv(C, 64), gy);
     const int g2 = ew_grid((long)M * C);
@@ -1140,8 +1331,12 @@ int ro_loss_fwd(const float* bef, const float* aft, const float* stop, const flo
                 const float* l2, float* out, float* aft_losses, int B, int T, int C, float pos_weight, float* scratch,
                 hipStream_t st) {
     B2S_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * (3 + B), st));
-    hipLaunchKernelGGL(k_loss_partial, dim3(std::min(cdiv(T, 4), 32), B), dim3(256), 0, st, bef, aft, stop, tgt, lens, scratch, B,
-                       T, C, pos_weight);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(k_loss_partial_v, dim3(std::max(1, std::min(cdiv((long)T * C / 4, 1024), 16)), B), dim3(256), 0, st, bef, aft, stop, tgt, lens,
+                           scratch, T, C, pos_weight);
+    else
+        hipLaunchKernelGGL(k_loss_partial, dim3(std::min(cdiv(T, 4), 32), B), dim3(256), 0, st, bef, aft, stop, tgt, lens, scratch, B,
+                           T, C, pos_weight);
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, (const float*)scratch, lens, l2, out, aft_losses, B);
     B2S_LAUNCH_CHECK(); return 0;
 }

@@ -33,3 +33,33 @@ def report(name, a, b):
     d = (a - b).abs()
     return "%s: max|d|=%.3e max|ref|=%.3e rel=%.3e" % (name, float(d.max()), float(b.abs().max()),
                                                         float(d.max() / (b.abs().max() + 1e-12)))
+
+
+def record_drift(key, value):
+    """bf16 drift measured by a GPU test -> gpurun_out/r03_bf16_drift.json (merged back by gpurun; the committed copy lives in
+    profiles/r03_bf16_drift.json and is what the gates below are derived from: gate = 2 x the committed measurement)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "r03_bf16_drift.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = float(value)
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def drift_gate(key, fallback):
+    """2 x the committed measurement of `key` (profiles/r03_bf16_drift.json); `fallback` when it has not been measured yet."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "profiles", "r03_bf16_drift.json")
+    if os.path.exists(path):
+        v = json.load(open(path)).get(key)
+        if v is not None:
+            return 2.0 * float(v)
+    return fallback

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import b2s_oracle as O                     # checker only
 from oracle import synth, make_config, TINY, TINY96
-from gpu_util import DEV, relerr, report
+from gpu_util import DEV, relerr, report, record_drift, drift_gate
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -111,15 +111,19 @@ def test_forward_bf16_drift_recorded():
     torch.cuda.synchronize()
     drift = float(np.abs(o["mel_bef"].detach().cpu().numpy() - g["mel_bef"]).max())
     print("bf16 mel_bef max abs drift vs fp32 reference: %.4f" % drift)
-    assert drift < 0.15
-    assert abs(float(losses["loss"]) - float(g["loss_loss"])) < 0.05 * abs(float(g["loss_loss"]))
+    record_drift("tiny96/mel_bef_max_abs", drift)
+    assert drift < drift_gate("tiny96/mel_bef_max_abs", 0.15)
+    lrel = abs(float(losses["loss"]) - float(g["loss_loss"])) / abs(float(g["loss_loss"]))
+    record_drift("tiny96/loss_rel", lrel)
+    assert lrel < max(drift_gate("tiny96/loss_rel", 0.05), 1e-3)
     worst = 0.0
     for n, p in m.named_parameters():
         ref = float(g["gnorm/" + n])
         if ref > 1e-3:
             worst = max(worst, abs(float(p.grad.double().norm()) - ref) / ref)
     print("bf16 worst relative gradient-norm error: %.4f" % worst)
-    assert worst < 0.2
+    record_drift("tiny96/worst_grad_norm_rel", worst)
+    assert worst < drift_gate("tiny96/worst_grad_norm_rel", 0.2)
 
 
 def test_adam_training_steps_match_oracle():
