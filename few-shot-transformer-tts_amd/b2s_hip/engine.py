@@ -240,7 +240,9 @@ class HipEngine(object):
         self.begin_backward()
         L.check(self.lib.b2s_encoder_backward(self.handle, ctx.handle, L.ptr(dmem.contiguous()), L.stream()))
 
-    def decoder_forward(self, memory, in32, targets, tgt32, train, seed, keep_ctx):
+    def decoder_forward(self, memory, in32, targets, tgt32, train, seed, keep_ctx, memory_ready=None):
+        """memory_ready: torch.cuda.Event recorded behind the encoder forward on ANOTHER stream; this stream waits for it only when the
+        decoder first reads `memory` (b2s_decoder_forward_ev)."""
         dev = self.ensure_bound()
         B, T, NM = targets.shape
         S = memory.shape[1]
@@ -251,21 +253,24 @@ class HipEngine(object):
         mels = torch.empty(B, T, NM, dtype=torch.float32, device=dev)
         stop = torch.empty(B, T, dtype=torch.float32, device=dev)
         h = L.P()
-        L.check(self.lib.b2s_decoder_forward(self.handle, L.ptr(memory), L.ptr(in32), L.ptr(targets), L.ptr(tgt32), B, S, T,
-                                             int(train), seed, L.ptr(ws), nbytes, L.ptr(mels), L.ptr(stop), L.stream(),
-                                             C.byref(h)))
+        L.check(self.lib.b2s_decoder_forward_ev(self.handle, L.ptr(memory), L.ptr(in32), L.ptr(targets), L.ptr(tgt32), B, S, T,
+                                                int(train), seed, L.ptr(ws), nbytes, L.ptr(mels), L.ptr(stop),
+                                                memory_ready.cuda_event if memory_ready is not None else None, L.stream(), C.byref(h)))
         self._needs_zero = True
         return mels, stop, _Ctx(h, (ws, memory, in32, targets, tgt32))
 
-    def decoder_backward(self, ctx, dmels, dstop, mem_shape, d_guided=None, want_dmem=True, defer_join=False):
+    def decoder_backward(self, ctx, dmels, dstop, mem_shape, d_guided=None, want_dmem=True, defer_join=False, dmem_done=None):
         """d_guided: device scalar d loss / d guided-attention loss (None: that term gets no gradient).
-        defer_join: the next engine call is encoder_backward (B2S_DEC_BWD_DEFER_JOIN); ctx must stay alive until it returns."""
+        defer_join: the next engine call is encoder_backward (B2S_DEC_BWD_DEFER_JOIN); ctx must stay alive until it returns.
+        dmem_done: torch.cuda.Event recorded as soon as d(memory) is complete; the encoder backward may then run on another stream that
+        waits for it (the last stages' weight-gradient work is handed over by this call: B2S_DEC_BWD_FLUSH_TAIL)."""
         self.begin_backward()
         dmem = torch.empty(mem_shape, dtype=torch.float32, device=dmels.device) if want_dmem else None
-        L.check(self.lib.b2s_decoder_backward_ex(self.handle, ctx.handle, L.ptr(dmels.contiguous()),
+        flags = (0 if want_dmem else 1) | ((4 if dmem_done is not None else 2) if defer_join else 0)
+        L.check(self.lib.b2s_decoder_backward_ev(self.handle, ctx.handle, L.ptr(dmels.contiguous()),
                                                  L.ptr(dstop.contiguous()) if dstop is not None else None,
                                                  L.ptr(d_guided.contiguous()) if d_guided is not None else None,
-                                                 (0 if want_dmem else 1) | (2 if defer_join else 0), L.ptr(dmem), L.stream()))
+                                                 flags, L.ptr(dmem), dmem_done.cuda_event if dmem_done is not None else None, L.stream()))
         return dmem
 
     def guided_enabled(self):

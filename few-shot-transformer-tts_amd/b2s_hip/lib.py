@@ -61,6 +61,8 @@ _PROTOS = {
     "b2s_encoder_backward": (C.c_int, [P, P, P, P]),
     "b2s_decoder_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int, C.c_int]),
     "b2s_decoder_forward": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, P, C.POINTER(P)]),
+    "b2s_decoder_forward_ev": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, P, P, C.POINTER(P)]),
+    "b2s_decoder_backward_ev": (C.c_int, [P, P, P, P, P, C.c_int, P, P, P]),
     "b2s_decoder_backward": (C.c_int, [P, P, P, P, P, P]),
     "b2s_decoder_backward_ex": (C.c_int, [P, P, P, P, P, C.c_int, P, P]),
     "b2s_decoder_guided_loss": (C.c_int, [P, P, P, P, P]),

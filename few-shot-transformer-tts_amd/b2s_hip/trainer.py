@@ -55,6 +55,12 @@ class HipTrainer(object):
         # them CUs but its HBM stream raises memory latency and the latency-bound encoder kernels run 1.6x slower while it
         # lasts; a CU-masked stream serialised the two queues.  Off by default, kept as an option (B2S_SPLIT_ADAM=1).
         self.split_adam = os.environ.get("B2S_SPLIT_ADAM", "0") == "1"
+        # overlap_encoder: the encoder is 5 % of the step's FLOPs in ~55 launches per pass of 78..208 workgroups -- a fifth of the step on
+        # a quarter of the chip.  Its forward runs on a stream of its own beside the decoder's prenet and first self-attention (which
+        # do not read the encoder output), its backward starts as soon as d(memory) is complete, beside the first decoder layer's
+        # self-attention backward, the prenet backward and their weight gradients.  B2S_ENC_OVERLAP=0 restores the single chain.
+        self.overlap_encoder = os.environ.get("B2S_ENC_OVERLAP", "1") != "0"
+        self._enc_stream = None
         self.eng = model.engine()
         self.eng.ensure_bound()
         self.lib = self.eng.lib
@@ -197,9 +203,23 @@ class HipTrainer(object):
         # the fused Adam kernel rewrote the fp32 masters AND their bf16 shadows; only conv re-layouts remain
         L.check(lib.b2s_model_sync_weights_ex(eng.handle, L.stream(), int(self.global_step > 0)))
         in32, tgt32 = _i32(batch["input_lengths"]), _i32(batch["target_lengths"])
-        mem, c_enc = eng.encoder_forward(batch["inputs"], in32, batch.get("input_spk_ids"), batch.get("input_language_vecs"),
-                                         True, eng.next_seed(), not self.freeze_encoder)
-        mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed(), True)
+        cur = torch.cuda.current_stream()
+        ovl = self.overlap_encoder and not self.split_adam
+        if ovl and self._enc_stream is None:
+            self._enc_stream = torch.cuda.Stream(device=eng._gflat.device)
+        enc_s = self._enc_stream if ovl else None
+        if enc_s is not None:
+            enc_s.wait_stream(cur)                         # (weights synced above; the previous step's optimizer update)
+            with torch.cuda.stream(enc_s):
+                mem, c_enc = eng.encoder_forward(batch["inputs"], in32, batch.get("input_spk_ids"), batch.get("input_language_vecs"),
+                                                 True, eng.next_seed(), not self.freeze_encoder)
+                mem_ready = torch.cuda.Event()
+                mem_ready.record(enc_s)
+            mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed(), True, memory_ready=mem_ready)
+        else:
+            mem, c_enc = eng.encoder_forward(batch["inputs"], in32, batch.get("input_spk_ids"), batch.get("input_language_vecs"),
+                                             True, eng.next_seed(), not self.freeze_encoder)
+            mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed(), True)
         aft, c_post = eng.postnet_forward(mels, tgt32, mels, True, eng.next_seed(), True)
         vals, per = eng.loss_forward(mels, aft, stop, batch["mel_targets"], tgt32)
         guided = eng.guided_enabled()
@@ -221,15 +241,28 @@ class HipTrainer(object):
         # With a deferred join the last stages' weight-gradient groups, bias column sums and LayerNorm reductions of the decoder
         # backward are still queued when it returns (the encoder backward launches them): the split update must not run on
         # incomplete decoder gradients, so it takes the join here.
+        enc_bwd_s = enc_s if (enc_s is not None and not self.freeze_encoder) else None
+        dmem_done = None
+        if enc_bwd_s is not None:
+            dmem_done = torch.cuda.Event()
+            dmem_done.record(cur)                          # (torch creates the HIP event at its first record: the library re-records this handle)
         dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape, self._one if guided else None, not self.freeze_encoder,
-                                    defer_join=not self.freeze_encoder and not split)    # (encoder_backward below joins the second stream)
+                                    defer_join=not self.freeze_encoder and not split, dmem_done=dmem_done)    # (encoder_backward below joins the second stream)
         lr = self.hp.max_lr * self.lr_lambda(self.global_step)
         step_no = self.global_step + 1
         adam = (lr, step_no, self.beta1, self.beta2, self.hp.adam_eps, self.hp.reg_weight, 1.0 / self.world)
         if split:
             L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 1, L.stream()))
         if not self.freeze_encoder:
-            eng.encoder_backward(c_enc, dmem)
+            if enc_bwd_s is not None:
+                enc_bwd_s.wait_event(dmem_done)            # d(memory) only: the rest of the decoder backward runs beside the encoder's
+                with torch.cuda.stream(enc_bwd_s):
+                    eng.encoder_backward(c_enc, dmem)
+                cur.wait_stream(enc_bwd_s)                 # (its last stage joined the engine's second stream)
+            else:
+                eng.encoder_backward(c_enc, dmem)
+        elif enc_s is not None:
+            cur.wait_stream(enc_s)
         for c in (c_post, c_dec, c_enc):
             if c is not None:
                 c.free()

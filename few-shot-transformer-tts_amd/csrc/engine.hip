@@ -318,7 +318,7 @@ void fire_stages(const b2s_model* m, std::vector<int>& v) {
     for (int s : v) m->stage_done(s);
     v.clear();
 }
-int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain) {
+int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain, bool force_flush = false) {
     static const bool serial = getenv("B2S_DW_GROUP_SERIAL") != nullptr;
     if (!m->dw_group) {
         B2S_TRY(flush_ln_jobs(m, st));                     // the stage's LayerNorm parameter gradients
@@ -335,7 +335,7 @@ int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain) {
     // hand-over covers fire together at the next one, once the hook's stream has been ordered behind the second stream's event
     // (two decoder-layer stages are one 32 MB bucket of the gradient exchange anyway).
     static const int per_flush = getenv("B2S_DW_STAGES") ? atoi(getenv("B2S_DW_STAGES")) : 2;
-    if (!serial && !drain && (m->dw_pending.empty() || ++m->dw_stages_pending < per_flush)) {
+    if (!serial && !drain && !force_flush && (m->dw_pending.empty() || ++m->dw_stages_pending < per_flush)) {
         m->unflushed_stages.push_back(stage);
         return 0;
     }
@@ -1105,6 +1105,14 @@ extern "C" size_t b2s_decoder_ws_bytes(const b2s_model* m, int B, int S, int T) 
 extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
                                    const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
                                    size_t ws_bytes, float* mels_out, float* stop_out, void* stream, b2s_ctx** ctx_out) {
+    return b2s_decoder_forward_ev(m, memory, input_lengths, targets, target_lengths, B, S, T, train, seed, ws, ws_bytes, mels_out, stop_out, nullptr,
+                                  stream, ctx_out);
+}
+// memory_ready (hipEvent_t or NULL): `memory` is produced on ANOTHER stream (the encoder forward); this call's stream waits for the event
+// right before the first kernel that reads it -- the prenet and the first decoder layer's self-attention do not, and run beside the encoder.
+extern "C" int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
+                                      const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
+                                      size_t ws_bytes, float* mels_out, float* stop_out, void* memory_ready, void* stream, b2s_ctx** ctx_out) {
     B2S_TRY(check_bound(m));
     B2S_TRY(wait_adam(m, S_(stream), 7));
     const b2s_config& cf = m->cfg;
@@ -1126,10 +1134,18 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
     const float pt = train ? cf.transformer_dropout_rate : 0.f, pd = train ? cf.decoder_dropout_rate : 0.f;
     const std::string p = "decoder.decoder.";
     auto run = [&]() -> int {
-        B2S_TRY(ro_cast(dt, memory, c->memT, Mk * D, st));
-        if (c->kvcat)       // memory K/V of every layer in one projection: [Mk, D] x [L*2D, D]^T
-            B2S_TRY(linear(m, st, c->memT, D, m->kv_cat, (int)Mk, cf.n_decoder_layer * 2 * D, D, c->kvcat, 0, cf.n_decoder_layer * 2 * D,
-                           GemmEpilogue()));
+        bool have_memory = false;
+        auto need_memory = [&]() -> int {          // first use of the encoder output: cast + the memory K/V projection of every layer
+            if (have_memory) return 0;
+            have_memory = true;
+            if (memory_ready) B2S_HIP(hipStreamWaitEvent(st, (hipEvent_t)memory_ready, 0));
+            B2S_TRY(ro_cast(dt, memory, c->memT, Mk * D, st));
+            if (c->kvcat)       // memory K/V of every layer in one projection: [Mk, D] x [L*2D, D]^T
+                B2S_TRY(linear(m, st, c->memT, D, m->kv_cat, (int)Mk, cf.n_decoder_layer * 2 * D, D, c->kvcat, 0, cf.n_decoder_layer * 2 * D,
+                               GemmEpilogue()));
+            return 0;
+        };
+        if (!memory_ready) B2S_TRY(need_memory());          // (single-stream callers keep the round-2 order)
         B2S_TRY(ro_cast(dt, targets, c->tgtT, M * NM, st));
         // prenet (tacotron.py:55-65)
         GemmEpilogue e0; e0.bias = m->P("decoder.prenet.dense0.bias"); e0.relu = 1; e0.drop = make_drop(pd, seed, opid(2, 0, 1));
@@ -1164,6 +1180,7 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
             B2S_TRY(ro_layernorm_fwd(dt, x1, m->P(lnx + ".weight"), m->P(lnx + ".bias"), x.h, D, nullptr, 0, x.mean, x.rstd, (int)M, D,
                                      1e-6f, nullptr, 1, st));
             B2S_TRY(linear(m, st, x.h, D, m->W(nm(p, "encdec_attentions", l, "q_transform.weight")), (int)M, D, D, x.qkv, 0, D, GemmEpilogue()));
+            B2S_TRY(need_memory());
             if (!c->kvcat)
                 B2S_TRY(linear(m, st, c->memT, D, m->W(nm(p, "encdec_attentions", l, "kv_transform.weight")), (int)Mk, 2 * D, D, x.kv, 0, 2 * D,
                                GemmEpilogue()));
@@ -1189,6 +1206,7 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
             GemmEpilogue f2; f2.drop = make_drop(pt, seed, f.op_res); f2.residual = x2; f2.ldr = D;
             B2S_TRY(linear(m, st, f.f, 4 * D, m->W(nm(p, "ffn_layers", l, "output_layer.weight")), (int)M, D, 4 * D, x3, 1, D, f2));
         }
+        B2S_TRY(need_memory());                             // (a model without decoder layers still has to order itself behind the event)
         B2S_TRY(ro_layernorm_fwd(dt, c->x_final, m->P(p + "output_layer_norm.weight"), m->P(p + "output_layer_norm.bias"), c->outT, D,
                                  nullptr, 0, c->mean_f, c->rstd_f, (int)M, D, 1e-6f, target_lengths, T, st));
         GemmEpilogue em; em.row_len = target_lengths; em.rows_per_batch = T;
@@ -1225,6 +1243,14 @@ extern "C" int b2s_decoder_guided_loss(b2s_model* m, b2s_ctx* c, float* out, flo
 }
 extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_mels, const float* d_stop, const float* d_guided,
                                        int flags, float* d_memory_out, void* stream) {
+    return b2s_decoder_backward_ev(m, c, d_mels, d_stop, d_guided, flags, d_memory_out, nullptr, stream);
+}
+// dmem_done (hipEvent_t or NULL): recorded on `stream` as soon as d_memory_out is complete -- right after the first decoder layer's
+// encoder-decoder attention backward, before that layer's self-attention, the input / prenet backward and their weight gradients.  A caller
+// that runs the encoder backward on another stream makes that stream wait for the event only (B2S_DEC_BWD_FLUSH_TAIL must then be set:
+// this call hands its last stages' weight-gradient work to the second stream itself instead of leaving it to the next entry point).
+extern "C" int b2s_decoder_backward_ev(b2s_model* m, b2s_ctx* c, const float* d_mels, const float* d_stop, const float* d_guided,
+                                       int flags, float* d_memory_out, void* dmem_done, void* stream) {
     B2S_TRY(check_bound(m));
     B2S_TRY(wait_adam(m, S_(stream), 7));
     const bool want_dmem = !(flags & B2S_DEC_BWD_NO_DMEMORY);
@@ -1257,7 +1283,29 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
     B2S_TRY(ln_bwd_exit(m, st, sc, sc.doutT, 0, D, c->x_final, p + "output_layer_norm", c->mean_f, c->rstd_f, 0, M, D, c->tgt_len, T,
                         cf.n_decoder_layer > 0 ? &nd : nullptr));
     B2S_TRY(end_stage(m, st, 1, false));
-    bool first_mem = true;
+    bool first_mem = true, dmem_finished = false;
+    auto finish_dmem = [&]() -> int {
+        if (dmem_finished) return 0;
+        dmem_finished = true;
+        if (want_dmem && sc.dkvcat && cf.n_decoder_layer > 0) {
+            // d(memory) = [dKV_0 .. dKV_{L-1}] [Mk, L*2D] x Wcat [L*2D, D]: one GEMM with K = L*2D instead of L accumulating launches.
+            // 56 output tiles only -> K split over 4 workgroups each (slab workspace; free here: with grouped weight gradients
+            // nothing on the second stream uses it)
+            const int Kc = cf.n_decoder_layer * 2 * D;
+            GemmArgs g;
+            g.A.p = sc.dkvcat; g.A.ld = Kc; g.A.R = (int)Mk; g.A.C = Kc;
+            g.B.p = m->kv_cat; g.B.ld = D; g.B.R = Kc; g.B.C = D;
+            g.M = (int)Mk; g.N = D; g.K = Kc; g.C = d_memory_out; g.c_fp32 = 1; g.ldc = D;
+            if (m->dw_group) {
+                B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
+                g.epi.accumulate = 1; g.splitk = 4;
+                m->set_ws(g, st);
+            }
+            B2S_TRY(b2s_gemm_launch(g, dt, false, true, st));
+        } else if (first_mem && want_dmem) B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
+        if (dmem_done) B2S_HIP(hipEventRecord((hipEvent_t)dmem_done, st));
+        return 0;
+    };
     for (int l = cf.n_decoder_layer - 1; l >= 0; --l) {
         const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lnx = p + "encdec_layer_norms." + std::to_string(l),
                           lna = p + "attn_layer_norms." + std::to_string(l);
@@ -1295,6 +1343,7 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
                 B2S_TRY(linear_dx(m, st, sc.dkv, 2 * D, m->W(wkv), (int)Mk, D, 2 * D, d_memory_out, 1, D, em));
                 first_mem = false;
             }
+            if (l == 0) B2S_TRY(finish_dmem());              // every layer's dK / dV is in: d(memory) does not wait for the rest of this call
             nd = make_drop(pt, c->seed, c->self_attn[l].op_res);
             B2S_TRY(ln_bwd_exit(m, st, sc, sc.dh, 0, D, x.x_in, lnx, x.mean, x.rstd, 1, M, D, nullptr, 1, &nd));
         }
@@ -1303,22 +1352,7 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
                               nm(p, "self_attentions", l, "output_transform.weight"), lna, nullptr, l > 0 ? &nd : nullptr));
         B2S_TRY(end_stage(m, st, 2 + (cf.n_decoder_layer - 1 - l), false));
     }
-    if (want_dmem && sc.dkvcat && cf.n_decoder_layer > 0) {
-        // d(memory) = [dKV_0 .. dKV_{L-1}] [Mk, L*2D] x Wcat [L*2D, D]: one GEMM with K = L*2D instead of L accumulating launches.
-        // 56 output tiles only -> K split over 4 workgroups each (slab workspace; free here: with grouped weight gradients
-        // nothing on the second stream uses it)
-        const int Kc = cf.n_decoder_layer * 2 * D;
-        GemmArgs g;
-        g.A.p = sc.dkvcat; g.A.ld = Kc; g.A.R = (int)Mk; g.A.C = Kc;
-        g.B.p = m->kv_cat; g.B.ld = D; g.B.R = Kc; g.B.C = D;
-        g.M = (int)Mk; g.N = D; g.K = Kc; g.C = d_memory_out; g.c_fp32 = 1; g.ldc = D;
-        if (m->dw_group) {
-            B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
-            g.epi.accumulate = 1; g.splitk = 4;
-            m->set_ws(g, st);
-        }
-        B2S_TRY(b2s_gemm_launch(g, dt, false, true, st));
-    } else if (first_mem && want_dmem) B2S_HIP(hipMemsetAsync(d_memory_out, 0, (size_t)Mk * D * 4, st));
+    B2S_TRY(finish_dmem());                                  // (no decoder layers)
     B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, opid(2, 0, 3)), st));
     // prenet backward
     DropCfg d1 = make_drop(pd, c->seed, opid(2, 0, 1)), d2 = make_drop(pd, c->seed, opid(2, 0, 2));
@@ -1334,6 +1368,12 @@ extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
     B2S_LAUNCH_CHECK();
     // (deferred join: the caller's next call is b2s_encoder_backward on this stream, whose last stage joins the second stream and fires
     // this stage's hook -- the main stream does not idle here until the prenet's weight-gradient group has finished, ~0.12 ms)
+    if (flags & B2S_DEC_BWD_FLUSH_TAIL) {
+        // hand everything that is still queued to the second stream behind an event of THIS stream (the operands were produced here), but
+        // leave the join to the caller's next entry point -- which may run on another stream and must not be the one that orders them
+        B2S_TRY(end_stage(m, st, 2 + cf.n_decoder_layer, false, true));
+        return 0;
+    }
     B2S_TRY(end_stage(m, st, 2 + cf.n_decoder_layer, !(flags & B2S_DEC_BWD_DEFER_JOIN)));
     return 0;
 }

@@ -81,6 +81,12 @@ size_t b2s_decoder_ws_bytes(const b2s_model* m, int B, int S, int T);
 int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
                         const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
                         size_t ws_bytes, float* mels_out, float* stop_out, void* stream, b2s_ctx** ctx_out);
+/* The same with the encoder output arriving from another stream: memory_ready (hipEvent_t as void*, or NULL) is waited for on `stream`
+ * right before the first kernel that reads `memory` (the memory K / V projection ahead of the first encoder-decoder attention); the prenet
+ * and the first layer's self-attention are enqueued before the wait and overlap the encoder forward running on the other stream. */
+int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
+                           const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
+                           size_t ws_bytes, float* mels_out, float* stop_out, void* memory_ready, void* stream, b2s_ctx** ctx_out);
 /* d_memory_out [B,S,Dm] is overwritten. */
 int b2s_decoder_backward(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, float* d_memory_out,
                          void* stream);
@@ -91,8 +97,16 @@ int b2s_decoder_backward(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const 
  * stage's hook fires from inside it. */
 #define B2S_DEC_BWD_NO_DMEMORY 1
 #define B2S_DEC_BWD_DEFER_JOIN 2
+/* bit 2: like DEFER_JOIN the second stream is not joined here, but everything still queued (the last stages' weight-gradient groups) is
+ * handed to it by this call, ordered behind this call's stream -- required when the next entry point runs on a DIFFERENT stream */
+#define B2S_DEC_BWD_FLUSH_TAIL 4
 int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, const float* d_guided,
                             int flags, float* d_memory_out, void* stream);
+/* dmem_done (hipEvent_t as void*, or NULL) is recorded on `stream` as soon as d_memory_out is complete -- after the FIRST decoder layer's
+ * encoder-decoder attention backward, ahead of that layer's self-attention, the prenet backward and their weight gradients -- so that an
+ * encoder backward on another stream can start then (train.py has no counterpart: autograd runs one stream). */
+int b2s_decoder_backward_ev(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, const float* d_guided,
+                            int flags, float* d_memory_out, void* dmem_done, void* stream);
 /* Guided-attention loss of the forward held in ctx (already multiplied by guided_attention_weight):
  *   weight * mean over layers, heads and valid (b, t < T_b, n < N_b) of  A[b,h,t,n] * (1 - exp(-(n/N_b - t/T_b)^2 / (2 sigma^2)))
  * written to out[0]; if add_to != NULL it is also added to add_to[0] (the total loss).  Error if the weight is 0. */

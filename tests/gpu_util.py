@@ -52,8 +52,9 @@ def record_drift(key, value):
         pass
 
 
-def drift_gate(key, fallback):
-    """2 x the committed measurement of `key` (profiles/r03_bf16_drift.json); `fallback` when it has not been measured yet."""
+def drift_gate(key, fallback, floor=0.0):
+    """2 x the committed measurement of `key` (profiles/r03_bf16_drift.json), not below `floor` (run-to-run spread of a bf16 step with
+    fp32 atomics); `fallback` when it has not been measured yet."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,5 +62,5 @@ def drift_gate(key, fallback):
     if os.path.exists(path):
         v = json.load(open(path)).get(key)
         if v is not None:
-            return 2.0 * float(v)
+            return max(2.0 * float(v), floor)
     return fallback
