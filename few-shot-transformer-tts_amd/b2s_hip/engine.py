@@ -240,9 +240,11 @@ class HipEngine(object):
         self.begin_backward()
         L.check(self.lib.b2s_encoder_backward(self.handle, ctx.handle, L.ptr(dmem.contiguous()), L.stream()))
 
-    def decoder_forward(self, memory, in32, targets, tgt32, train, seed, keep_ctx, memory_ready=None):
+    def decoder_forward(self, memory, in32, targets, tgt32, train, seed, keep_ctx, memory_ready=None, padded_unobserved=False):
         """memory_ready: torch.cuda.Event recorded behind the encoder forward on ANOTHER stream; this stream waits for it only when the
-        decoder first reads `memory` (b2s_decoder_forward_ev)."""
+        decoder first reads `memory` (b2s_decoder_forward_ev).
+        padded_unobserved: the caller will not ask for alignments of query rows >= target length (B2S_DEC_PADDED_UNOBSERVED): the
+        attention kernels skip tiles of padded query rows."""
         dev = self.ensure_bound()
         B, T, NM = targets.shape
         S = memory.shape[1]
@@ -254,7 +256,7 @@ class HipEngine(object):
         stop = torch.empty(B, T, dtype=torch.float32, device=dev)
         h = L.P()
         L.check(self.lib.b2s_decoder_forward_ev(self.handle, L.ptr(memory), L.ptr(in32), L.ptr(targets), L.ptr(tgt32), B, S, T,
-                                                int(train), seed, L.ptr(ws), nbytes, L.ptr(mels), L.ptr(stop),
+                                                int(bool(train)) | (2 if padded_unobserved else 0), seed, L.ptr(ws), nbytes, L.ptr(mels), L.ptr(stop),
                                                 memory_ready.cuda_event if memory_ready is not None else None, L.stream(), C.byref(h)))
         self._needs_zero = True
         return mels, stop, _Ctx(h, (ws, memory, in32, targets, tgt32))

@@ -26,6 +26,10 @@ struct AttnArgs {
     const int* qlen = nullptr;
     const float* ga_scale = nullptr;                       // device scalar (backward only)
     float ga_inv2s2 = 0.f;
+    // padded query rows: when set, 64-row query tiles that lie entirely at or beyond qskip[b] are not computed -- their context / dQ rows
+    // are written as zeros (lse = dsum = 0) and the dK/dV loop stops before them.  Only for callers whose rows >= qskip[b] are padding
+    // that nothing reads and whose upstream gradient is zero (the decoder: its outputs and gradients are masked by target_lengths).
+    const int* qskip = nullptr;
 };
 
 bool b2s_flash_supported(int dh);

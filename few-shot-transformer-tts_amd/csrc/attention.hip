@@ -196,6 +196,17 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_fwd_kernel(A
     const int b = z / a.H, h = z - b * a.H;
     const int qb0 = tile_ * 64, q = qb0 + wave * 16 + li;
     const int qc = min(q, a.Lq - 1);
+    if (a.qskip && qb0 >= a.qskip[b]) {              // a tile of padded query rows (workgroup-uniform)
+        if (q < a.Lq) {
+            f32x4_t zero[DH / 16];
+#pragma unroll
+            for (int dt = 0; dt < DH / 16; ++dt) zero[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            store_rows<T, DH>(reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q) * a.ldo + h * DH, zero, 1.f, lg);
+            if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = 0.f;
+            if (lg == 0 && a.ga_rows) a.ga_rows[(long)z * a.Lq + q] = 0.f;
+        }
+        return;
+    }
     const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
     const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
     const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
@@ -317,6 +328,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const int b = z / a.H, h = z - b * a.H;
     const int qb0 = tile_ * 64, q = qb0 + wave * 16 + li;
     const int qc = min(q, a.Lq - 1);
+    if (a.qskip && qb0 >= a.qskip[b]) {              // padded query rows: d context is zero there, so is dQ (the dK/dV kernel never reads dsum)
+        if (q < a.Lq) {
+            f32x4_t zero[DH / 16];
+#pragma unroll
+            for (int dt = 0; dt < DH / 16; ++dt) zero[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)b * a.Lq + q) * a.lddq + h * DH, zero, 1.f, lg);
+            if (lg == 0) a.dsum[(long)z * a.Lq + q] = 0.f;
+        }
+        return;
+    }
     const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
     const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
     const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
@@ -435,7 +456,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     f32x4_t dk[DH / 16], dv[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-    const int qtiles = (a.Lq + 63) / 64;
+    int qtiles = (a.Lq + 63) / 64;
+    if (a.qskip) qtiles = min(qtiles, (a.qskip[b] + 63) / 64);             // tiles of padded query rows contribute nothing (d context = 0)
     const int qt0 = (a.mask_mode & 2) ? kb0 / 64 : 0;          // causal: queries before this key tile never see it
     TileRegs<T, DH> rq, ro;
     float r_l = 0.f, r_d = 0.f;
@@ -530,7 +552,23 @@ __global__ __launch_bounds__(256) void attn_align_kernel(AttnArgs a, float* alig
     int kend = a.Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     if (a.mask_mode & 2) kend = min(kend, q + 1);
-    const float lse = a.lse[r];
+    float lse = a.lse[r];
+    if (a.qskip && (q & ~63) >= a.qskip[b]) {          // a row the forward kernel skipped: its log-sum-exp is computed here
+        float mx = -INFINITY;
+        for (int k = lane; k < kend; k += 64) {
+            float s = 0.f;
+            for (int d = 0; d < dh; ++d) s += TT<T>::ld(Q + d) * TT<T>::ld(K + (long)k * a.ldk + d);
+            mx = fmaxf(mx, s * a.scale);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int k = lane; k < kend; k += 64) {
+            float s = 0.f;
+            for (int d = 0; d < dh; ++d) s += TT<T>::ld(Q + d) * TT<T>::ld(K + (long)k * a.ldk + d);
+            sum += __expf(s * a.scale - mx);
+        }
+        lse = mx + __logf(wave_sum(sum));
+    }
     for (int k = lane; k < a.Lk; k += 64) {
         float p = 0.f;
         if (k < kend) {

@@ -46,6 +46,7 @@ struct AttnSave {            // one attention sub-layer
     int mask_mode = 0;
     int Lq = 0, Lk = 0, ldp = 0;
     uint32_t op_attn = 0, op_res = 0;
+    const int* qskip = nullptr;   // fused path: per-utterance row count beyond which whole query tiles were skipped (attention.h), or null
 };
 struct FfnSave {
     float* x_in = nullptr;

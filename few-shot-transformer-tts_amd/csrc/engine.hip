@@ -380,10 +380,10 @@ AttnArgs flash_args(const void* q, int ldq, const void* k, int ldk, const void* 
 int attn_core_fwd(int dtype, hipStream_t st, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                   void* ctx, int ldc, int B, int H, int Lq, int Lk, int dh, int mask_mode, const int* klen,
                   const float* bias, long bias_sb, long bias_sq, DropCfg drop, float* S, void* P, void* Pd, float* lse = nullptr,
-                  const GuidedArgs* ga = nullptr) {
+                  const GuidedArgs* ga = nullptr, const int* qskip = nullptr) {
     if (lse && !bias && use_flash(dh)) {
         AttnArgs a = flash_args(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, mask_mode, klen, drop, lse);
-        a.out = ctx; a.ldo = ldc;
+        a.out = ctx; a.ldo = ldc; a.qskip = qskip;
         if (ga) { a.ga_rows = ga->rows; a.qlen = ga->qlen; a.ga_inv2s2 = ga->inv2s2; }
         return b2s_flash_fwd(dtype, a, dh, st);
     }
@@ -409,9 +409,10 @@ int attn_core_bwd(int dtype, hipStream_t st, const void* dctx, int ldc, const vo
                   const void* v, int ldv, const void* P, const void* Pd, void* dq, int lddq, void* dk, int lddk,
                   void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, DropCfg drop, float* dP, void* dS,
                   float* lse = nullptr, const void* O = nullptr, int mask_mode = 0, const int* klen = nullptr,
-                  const GuidedArgs* ga = nullptr) {
+                  const GuidedArgs* ga = nullptr, const int* qskip = nullptr) {
     if (lse && use_flash(dh)) {
         AttnArgs a = flash_args(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, mask_mode, klen, drop, lse);
+        a.qskip = qskip;
         a.dout = dctx; a.ldo = ldc; a.dsum = dP; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
         if (ga) { a.ga_rows = ga->rows; a.qlen = ga->qlen; a.ga_scale = ga->scale; a.ga_inv2s2 = ga->inv2s2; }
         return b2s_flash_bwd(dtype, a, dh, O, st);
@@ -1035,7 +1036,7 @@ int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, 
     const char* q = (const char*)s.qkv; char* dq = (char*)sc.dqkv;
     B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, q, 3 * D, q + (size_t)D * esz, 3 * D, q + (size_t)2 * D * esz, 3 * D, s.P, s.Pd,
                           dq, 3 * D, dq + (size_t)D * esz, 3 * D, dq + (size_t)2 * D * esz, 3 * D, B, H, L, L, dh, datt, sc.dP, sc.dS,
-                          s.lse, s.ctx, s.mask_mode, klen));
+                          s.lse, s.ctx, s.mask_mode, klen, nullptr, s.qskip));
     B2S_TRY(linear_dw(m, st, sc.dqkv, 3 * D, s.h, D, (int)M, 3 * D, D, m->G(wq)));
     B2S_TRY(linear_dx(m, st, sc.dqkv, 3 * D, m->W(wq), (int)M, D, 3 * D, sc.dh, 0, D, GemmEpilogue()));
     return ln_bwd_exit(m, st, sc, sc.dh, 0, D, s.x_in, lnp, s.mean, s.rstd, 1, M, D, nullptr, 1, next);
@@ -1113,6 +1114,8 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
 extern "C" int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
                                       const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
                                       size_t ws_bytes, float* mels_out, float* stop_out, void* memory_ready, void* stream, b2s_ctx** ctx_out) {
+    const bool padded_unobserved = (train & B2S_DEC_PADDED_UNOBSERVED) != 0;
+    train &= 1;
     B2S_TRY(check_bound(m));
     B2S_TRY(wait_adam(m, S_(stream), 7));
     const b2s_config& cf = m->cfg;
@@ -1156,6 +1159,12 @@ extern "C" int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const i
         B2S_TRY(ro_shift_pe_fwd(sc.a3, target_lengths, m->pe_dec, m->P(p + "pe_scale"), xs[0], B, T, D,
                                 make_drop(pt, seed, opid(2, 0, 3)), st));
         const bool guided = cf.guided_attention_weight > 0.f;
+        // rows >= target_lengths[b] are padding: the heads mask them (row_len below) and the backward zeroes their gradient, and causal /
+        // per-row sub-layers never let a valid row read them -- the attention kernels skip whole 64-row tiles of them (attention.h: qskip)
+        // -- only for callers that declare those rows unobserved (B2S_DEC_PADDED_UNOBSERVED): the alignments the reference returns for
+        // padded query rows of later layers depend on what earlier layers computed there
+        static const bool no_qskip = getenv("B2S_ATTN_QSKIP") && atoi(getenv("B2S_ATTN_QSKIP")) == 0;
+        const int* qskip = (no_qskip || !padded_unobserved) ? nullptr : target_lengths;
         if (guided)
             hipLaunchKernelGGL(k_ga_scale, dim3(1), dim3(64), 0, st, input_lengths, target_lengths, B, S, T,
                                cf.guided_attention_weight / (float)(cf.n_decoder_layer * H), c->ga_small);
@@ -1171,8 +1180,8 @@ extern "C" int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const i
             s.op_attn = opid(2, l, 4); s.op_res = opid(2, l, 5);
             const char* q = (const char*)s.qkv;
             B2S_TRY(attn_core_fwd(dt, st, q, 3 * D, q + (size_t)D * esz, 3 * D, q + (size_t)2 * D * esz, 3 * D, s.ctx, D, B, H, T, T, dh,
-                                  2, nullptr, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd, s.lse));
-            s.mask_mode = 2;
+                                  2, nullptr, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd, s.lse, nullptr, qskip));
+            s.mask_mode = 2; s.qskip = qskip;
             GemmEpilogue ea; ea.drop = make_drop(pt, seed, s.op_res); ea.residual = x0; ea.ldr = D;
             B2S_TRY(linear(m, st, s.ctx, D, m->W(nm(p, "self_attentions", l, "output_transform.weight")), (int)M, D, D, x1, 1, D, ea));
             // encoder-decoder attention
@@ -1192,8 +1201,8 @@ extern "C" int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const i
                 ga.inv2s2 = 1.f / (2.f * cf.guided_attention_sigma * cf.guided_attention_sigma);
             }
             B2S_TRY(attn_core_fwd(dt, st, x.qkv, D, kv, x.ldkv, kv + (size_t)D * esz, x.ldkv, x.ctx, D, B, H, T, S, dh, 1, input_lengths,
-                                  nullptr, 0, 0, make_drop(pt, seed, x.op_attn), sc.S, x.P, x.Pd, x.lse, guided ? &ga : nullptr));
-            x.mask_mode = 1;
+                                  nullptr, 0, 0, make_drop(pt, seed, x.op_attn), sc.S, x.P, x.Pd, x.lse, guided ? &ga : nullptr, qskip));
+            x.mask_mode = 1; x.qskip = qskip;
             GemmEpilogue ex; ex.drop = make_drop(pt, seed, x.op_res); ex.residual = x1; ex.ldr = D;
             B2S_TRY(linear(m, st, x.ctx, D, m->W(nm(p, "encdec_attentions", l, "output_transform.weight")), (int)M, D, D, x2, 1, D, ex));
             // FFN
@@ -1334,7 +1343,7 @@ extern "C" int b2s_decoder_backward_ev(b2s_model* m, b2s_ctx* c, const float* d_
             }
             B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, x.qkv, D, kv, x.ldkv, kv + (size_t)D * esz, x.ldkv, x.P, x.Pd, sc.dqkv, D, dkv, lddkv,
                                   dkv + (size_t)D * esz, lddkv, B, H, T, S, dh, datt, sc.dP, sc.dS, x.lse, x.ctx, x.mask_mode, c->in_len,
-                                  guided ? &ga : nullptr));
+                                  guided ? &ga : nullptr, x.qskip));
             B2S_TRY(linear_dw(m, st, sc.dqkv, D, x.h, D, (int)M, D, D, m->G(wq)));
             B2S_TRY(linear_dx(m, st, sc.dqkv, D, m->W(wq), (int)M, D, D, sc.dh, 0, D, GemmEpilogue()));
             B2S_TRY(linear_dw(m, st, sc.dkv, lddkv, c->memT, D, (int)Mk, 2 * D, D, m->G(wkv)));
@@ -1387,6 +1396,7 @@ extern "C" int b2s_decoder_alignment(b2s_model* m, b2s_ctx* c, int which, int la
         AttnArgs a;
         if (which) a = flash_args(s.qkv, D, s.kv, s.ldkv, nullptr, 0, c->B, H, s.Lq, s.Lk, dh, 1, c->in_len, DropCfg{0, 0, 1.f}, s.lse);
         else a = flash_args(s.qkv, 3 * D, (const char*)s.qkv + (size_t)D * esz, 3 * D, nullptr, 0, c->B, H, s.Lq, s.Lk, dh, 2, nullptr, DropCfg{0, 0, 1.f}, s.lse);
+        a.qskip = s.qskip;
         return b2s_flash_align(m->dtype, a, dh, out, S_(stream));
     }
     return ro_align_transpose(m->dtype, s.P, out, c->B * m->cfg.n_attention_head, s.Lq, s.Lk, s.ldp, S_(stream));

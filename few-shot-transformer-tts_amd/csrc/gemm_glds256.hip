@@ -417,8 +417,11 @@ __global__ __launch_bounds__(nthreads_of(false), 1) void gemm_glds256_grouped_ke
     }
     const int local = before + (i - (s0 + ((xcd - s0) & 7))) / 8;
     const int tiles_n = (grp.p[p].N + NB * 32 - 1) / (NB * 32);
-    const int by = local / tiles_n, bx = local - by * tiles_n;
-    gemm256_body<true, true, 0, NB>(grp.p[p], zero, nullptr, bx, by, 0);
+    // K split over `splitk` workgroups per output tile (fp32 atomic accumulate; with two halves added to a zeroed gradient the result does
+    // not depend on their order): the K parts of a tile are adjacent in the XCD's list, so they share its A / B panels' neighbours in L2
+    const int sk = grp.p[p].splitk, t = local / sk, bz = local - t * sk;
+    const int by = t / tiles_n, bx = t - by * tiles_n;
+    gemm256_body<true, true, 0, NB>(grp.p[p], zero, nullptr, bx, by, bz);
 }
 
 template <bool TA, bool TB, int GATHER, int NB, int MW = 4>
@@ -508,9 +511,12 @@ int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* 
     for (int k = 0; k < n; ++k) {
         const GemmArgs& g = probs[order[k]];
         B2S_CHECK(g.batch == 1 && g.c_fp32 && g.epi.accumulate && g.A.g_cin == 0 && g.B.g_cin == 0, "grouped GEMM: problem %d is not a plain fp32-accumulate dW", order[k]);
-        grp.p[k] = g; grp.p[k].splitk = 1;
+        // B2S_DW_SPLIT = 2: every tile's K walk in two halves.  The weight-gradient groups share the chip with the backward's main-stream
+        // kernels; ~290 tiles of 127 K steps each on fewer than 256 free CUs need a second full-length round, half-length units pack better.
+        static const int split = getenv("B2S_DW_SPLIT") ? std::max(1, std::min(atoi(getenv("B2S_DW_SPLIT")), 4)) : 1;
+        grp.p[k] = g; grp.p[k].splitk = (split > 1 && g.K >= 4 * split * t256::BK) ? split : 1;
         grp.tile0[k] = tiles;
-        tiles += cdiv(g.M, t256::BM) * cdiv(g.N, 128);
+        tiles += cdiv(g.M, t256::BM) * cdiv(g.N, 128) * grp.p[k].splitk;
     }
     grp.tile0[n] = tiles;
     constexpr size_t smem = (size_t)t256::NSTAGE * t256::STAGE_BYTES;

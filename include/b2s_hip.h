@@ -84,6 +84,11 @@ int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_
 /* The same with the encoder output arriving from another stream: memory_ready (hipEvent_t as void*, or NULL) is waited for on `stream`
  * right before the first kernel that reads `memory` (the memory K / V projection ahead of the first encoder-decoder attention); the prenet
  * and the first layer's self-attention are enqueued before the wait and overlap the encoder forward running on the other stream. */
+/* train: bit 0 = training mode (dropout live).  Bit 1 (B2S_DEC_PADDED_UNOBSERVED): the caller reads nothing of this forward at query rows
+ * t >= target_lengths[b] except the (masked) outputs -- in particular no alignments of those rows; the attention kernels then skip whole
+ * 64-row tiles of padded queries (forward and backward).  Losses, outputs and every gradient are unchanged: the heads mask those rows and
+ * the backward zeroes their gradient whatever d_mels / d_stop hold there. */
+#define B2S_DEC_PADDED_UNOBSERVED 2
 int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
                            const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
                            size_t ws_bytes, float* mels_out, float* stop_out, void* memory_ready, void* stream, b2s_ctx** ctx_out);

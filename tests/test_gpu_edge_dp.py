@@ -205,3 +205,39 @@ def test_training_step_at_packer_extreme_shapes(B, S, T):
     for a, b in zip(vals["fp32"], vals["bf16"]):
         assert abs(a - b) < 0.03 * abs(a) + 1e-3, vals
     hp.override_from_dict(hyperparams.DEFAULTS)
+
+
+@pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
+def test_padded_query_tiles_skipped_is_result_neutral(compute_dtype):
+    """B2S_DEC_PADDED_UNOBSERVED (the trainer's decoder forward): the attention kernels do not compute 64-row tiles of padded target rows.
+    Outputs (masked by target_lengths), the guided-attention term and d(memory) must be bit-identical to the full computation, the
+    weight gradients equal up to the summation order of their atomics."""
+    from b2s_hip.engine import _i32
+    over = TINY + ",guided_attention_weight=2.0,transformer_dropout_rate=0.1,decoder_dropout_rate=0.1"
+    m, cfg, st, hp = _build(over, compute_dtype=compute_dtype)
+    B, S, T = 4, 70, 200
+    nb = synth.synthetic_batch(cfg, B=B, S=S, T=T, seed=5, in_lens=[70, 9, 64, 33], tgt_lens=[200, 64, 1, 130])
+    b = _dev(nb)
+    eng = m.engine()
+    in32, tgt32 = _i32(b["input_lengths"]), _i32(b["target_lengths"])
+    g = torch.Generator(device="cpu").manual_seed(3)
+    mem = torch.randn(B, S, hp.decoder_hidden, generator=g).to(DEV)          # (memory width = decoder width)
+    dm = torch.randn(B, T, hp.num_mels, generator=g).to(DEV)          # (gradients at padded rows are NOT zero on entry: the engine masks them)
+    ds = torch.randn(B, T, generator=g).to(DEV)
+    dg = torch.ones(1, device=DEV)
+    res = []
+    for flag in (False, True):
+        mels, stop, c = eng.decoder_forward(mem, in32, b["mel_targets"], tgt32, True, 77, True, padded_unobserved=flag)
+        gl = eng.guided_loss(c).clone()
+        dmem = eng.decoder_backward(c, dm, ds, mem.shape, dg)
+        torch.cuda.synchronize()
+        grads = {n: eng.grad_view(n).clone() for n, _ in m.named_parameters() if n.startswith("decoder.")}
+        res.append((mels.clone(), stop.clone(), gl, dmem.clone(), grads))
+        eng._needs_zero = True
+    a, bb = res
+    for i in range(4):
+        assert torch.equal(a[i], bb[i]), i
+    for n in a[4]:            # (weight-gradient reductions use fp32 atomics: run-to-run order differs, so not bit-for-bit)
+        d = float((a[4][n] - bb[4][n]).abs().max())
+        assert d <= 2e-5 * max(1.0, float(a[4][n].abs().max())), (n, d)
+    assert float(a[3].abs().max()) > 0
