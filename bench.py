@@ -274,11 +274,13 @@ def main():
         dom = variants[0]
         # HBM-side traffic of that kernel from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/gpu_pmc.sh) -- counters cannot be read from inside this process
-        traffic = mfma_util = None
-        pmc = os.path.join(ROOT, "profiles", "r02_train_bf16_pmc_hbm_traffic_mfma.json")
-        if os.path.exists(pmc) and args.dtype == "bf16" and args.mode == "train" and (B, S, T) == (14, 114, 582):
+        traffic = mfma_util = traffic_source = None
+        from bench_decode import load_pmc
+        pmc, pmc_commit, pmc_rows = load_pmc("train_bf16_pmc_hbm_traffic_mfma.json")
+        if pmc and args.dtype == "bf16" and args.mode == "train" and (B, S, T) == (14, 114, 582):
             pre = dom["kernel"].split(", NB, MW>")[0].replace(", G", ", ")
-            rows = [r for r in json.load(open(pmc)) if r["kernel"].startswith(pre)]
+            rows = [r for r in pmc_rows if r["kernel"].startswith(pre)]
+            traffic_source = "profiles/%s @ commit %s (committed rocprofv3 --pmc run, not measured in this process)" % (pmc, pmc_commit)
             n = sum(r["launches"] for r in rows)
             if n:
                 traffic = round(sum(r["launches"] * (r["fetch_MB_per_launch_corrected_x2"] + (r["WRITE_SIZE_KB_per_launch"] or 0) / 1024)
@@ -322,7 +324,7 @@ def main():
                              "frac_of_peak": round(fl_sum / us_sum / 1e6 / peak, 4)})
             del bufA, bufB, bufC
         out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM side, PMC)",
+                           "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM side, PMC)", "traffic_source": traffic_source,
                            "mfma_util": mfma_util,
                            "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                            "all_gemm": {"tflops": round(tot_f / (tot_ms * 1e-3) / 1e12, 1), "ms_per_step": round(tot_ms / nprof, 3)},

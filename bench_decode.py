@@ -14,6 +14,18 @@ import torch
 PEAK_HBM_GBS = 8000.0
 
 
+def load_pmc(suffix):
+    """Newest committed PMC summary profiles/rNN_<suffix> -> (file name, commit it was collected at, rows); (None, None, []) if none."""
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    names = sorted(n for n in (os.listdir(pdir) if os.path.isdir(pdir) else []) if n.endswith(suffix) and n[0] == "r" and n[1:3].isdigit())
+    if not names:
+        return None, None, []
+    d = json.load(open(os.path.join(pdir, names[-1])))
+    if isinstance(d, dict):
+        return names[-1], d.get("commit", "unknown"), d["rows"]
+    return names[-1], "unrecorded (round-2 file)", d
+
+
 def decode_bytes_per_step(B, S, t, e, Dd=768, Ld=6, weights=49.9e6):
     """weights once + self-KV read + cross-KV read + KV append."""
     return weights * e + Ld * 2 * B * Dd * e * (t + S + 1)
@@ -98,10 +110,11 @@ def run_decode(args, rank, world, device):
         ach = avg_bytes / (step_ms * 1e-3) / 1e9
         # HBM-side bytes per frame from the committed PMC run (tools/gpu_pmc_decode.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate passes),
         # summed over the frame's kernels
-        traffic = None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_decode_bf16_pmc_hbm_traffic.json")
-        if os.path.exists(pmc) and args.dtype == "bf16":
-            rows = [r for r in json.load(open(pmc)) if r["kernel"].startswith("k_df_")]
+        traffic = traffic_source = None
+        pmc, pmc_commit, pmc_rows = load_pmc("decode_bf16_pmc_hbm_traffic.json")
+        if pmc and args.dtype == "bf16":
+            rows = [r for r in pmc_rows if r["kernel"].startswith("k_df_")]
+            traffic_source = "profiles/%s @ commit %s (committed rocprofv3 --pmc run, not measured in this process)" % (pmc, pmc_commit)
             nfr = sum(r["launches"] for r in rows if r["kernel"].startswith("k_df_final"))
             if nfr:
                 traffic = round(sum(r["launches"] * (r["fetch_MB_per_launch_corrected_x2"] + (r["WRITE_SIZE_KB_per_launch"] or 0) / 1024)
@@ -115,7 +128,7 @@ def run_decode(args, rank, world, device):
                "value_incl_host_copy": round(B * frames / host_elapsed, 1),      # the reference's return contract (synthesize.py:57-61: NumPy)
                "ms_per_step_incl_host_copy": round(host_elapsed / frames * 1e3, 4),
                "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per frame (HBM side, PMC)",
+                            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per frame (HBM side, PMC)", "traffic_source": traffic_source,
                             "bytes_per_step_avg": avg_bytes,
                             "note": "algorithmic bytes per frame step (weights + KV) / wall time per frame incl. encoder and postnet; results "
                                     "(mels, lengths, alignments) complete in HBM -- value_incl_host_copy adds the reference's NumPy return (PCIe)"}}

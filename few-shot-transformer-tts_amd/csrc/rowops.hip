@@ -1007,6 +1007,95 @@ __global__ __launch_bounds__(256) void k_mt_adam(const MtChunk* ch, const float*
         if (threadIdx.x == 0) sumsq_part[blockIdx.x] = c.pad ? ss : 0.f;
     }
 }
+// Second form of the same update (default; B2S_ADAM_V1 selects the one above): the chunk kind (no shadow / bf16 shadow / conv images) is
+// workgroup-uniform, so each kind gets its own straight-line loop -- a store under a condition makes the compiler wait for ALL outstanding
+// memory operations at the join (s_waitcnt vmcnt(0)), which serialised every iteration's loads behind the previous iteration's stores --
+// and four float4 iterations of loads are in flight before the first is used.
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int KIND>
+__device__ __forceinline__ void adam_store_shadow(const MtChunk& c, int i4, f4v p) {
+    if (KIND == 1) {
+        uint2 o;
+        o.x = (uint32_t)f2bf(p[0]) | ((uint32_t)f2bf(p[1]) << 16);
+        o.y = (uint32_t)f2bf(p[2]) | ((uint32_t)f2bf(p[3]) << 16);
+        reinterpret_cast<uint2*>(c.s)[i4] = o;
+    } else if (KIND == 2) {
+        const uint32_t g0 = (uint32_t)c.off + 4u * (uint32_t)i4;
+        const float inv_cin = __builtin_amdgcn_rcpf((float)c.cin);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t gi = g0 + e, r = __umulhi(gi, 0xCCCCCCCDu) >> 2;          // gi / 5
+            const int j = (int)(gi - r * 5u);
+            int co = (int)(((float)r + 0.5f) * inv_cin);                             // r / cin (r < 2^24: one correction step is enough)
+            int ci = (int)r - co * c.cin;
+            if (ci < 0) { --co; ci += c.cin; } else if (ci >= c.cin) { ++co; ci -= c.cin; }
+            const bf16_t pb = f2bf(p[e]);
+            c.s[(long)co * 5 * c.cin + (long)j * c.cin + ci] = pb;
+            c.s2[(long)ci * 5 * c.cout + (long)(4 - j) * c.cout + co] = pb;
+        }
+    }
+}
+template <int KIND>
+__device__ __forceinline__ float adam_chunk(const MtChunk& c, float gs, float l2p, float b1, float b2, float step, float sbc2, float eps) {
+    float ss = 0.f;
+    const int n4 = c.n >> 2;
+    f4v* P = reinterpret_cast<f4v*>(c.a); f4v* M = reinterpret_cast<f4v*>(c.c); f4v* V = reinterpret_cast<f4v*>(c.d);
+    const f4v* G = reinterpret_cast<const f4v*>(c.b);
+    int i = threadIdx.x;
+    for (; i + 768 < n4; i += 1024) {
+        f4v p[4], g[4], m[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { p[u] = P[i + u * 256]; g[u] = __builtin_nontemporal_load(G + i + u * 256); m[u] = M[i + u * 256]; v[u] = V[i + u * 256]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float pe = p[u][e], me = m[u][e], ve = v[u][e]; ss += adam_elem(pe, g[u][e], me, ve, gs, l2p, b1, b2, step, sbc2, eps); p[u][e] = pe; m[u][e] = me; v[u][e] = ve; }
+            M[i + u * 256] = m[u]; V[i + u * 256] = v[u]; P[i + u * 256] = p[u];
+            adam_store_shadow<KIND>(c, i + u * 256, p[u]);
+        }
+    }
+    for (; i < n4; i += 256) {
+        f4v p = P[i], g = G[i], m = M[i], v = V[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float pe = p[e], me = m[e], ve = v[e]; ss += adam_elem(pe, g[e], me, ve, gs, l2p, b1, b2, step, sbc2, eps); p[e] = pe; m[e] = me; v[e] = ve; }
+        M[i] = m; V[i] = v; P[i] = p;
+        adam_store_shadow<KIND>(c, i, p);
+    }
+    return ss;
+}
+__global__ __launch_bounds__(256) void k_mt_adam2(const MtChunk* __restrict__ ch, const float* __restrict__ hp, float b1, float b2, float eps,
+                                                  float l2, float gs, float* sumsq_part) {
+    __shared__ float sh[4];
+    const MtChunk c = ch[blockIdx.x];
+    const float lr = hp[0], bc1 = hp[1], sbc2 = hp[2];
+    const float step = lr / bc1, l2p = c.pad ? l2 : 0.f;
+    float ss = 0.f;
+    int i0 = 0;
+    const bool vec = ((((size_t)c.a | (size_t)c.b | (size_t)c.c | (size_t)c.d) & 15) == 0) && (c.cin || ((size_t)c.s & 7) == 0);
+    if (vec) {
+        if (c.cin) ss = adam_chunk<2>(c, gs, l2p, b1, b2, step, sbc2, eps);
+        else if (c.s) ss = adam_chunk<1>(c, gs, l2p, b1, b2, step, sbc2, eps);
+        else ss = adam_chunk<0>(c, gs, l2p, b1, b2, step, sbc2, eps);
+        i0 = (c.n >> 2) << 2;
+    }
+    for (int i = i0 + threadIdx.x; i < c.n; i += 256) {       // unaligned tensors and the last 0-3 elements of a chunk
+        float p = c.a[i], m = c.c[i], v = c.d[i];
+        ss += adam_elem(p, c.b[i], m, v, gs, l2p, b1, b2, step, sbc2, eps);
+        c.c[i] = m; c.d[i] = v;
+        c.a[i] = p;
+        if (c.cin) {
+            const long gi = c.off + i, r = gi / 5;
+            const int j = (int)(gi - r * 5), co = (int)(r / c.cin), ci = (int)(r - (long)co * c.cin);
+            const bf16_t pb = f2bf(p);
+            c.s[(long)co * 5 * c.cin + (long)j * c.cin + ci] = pb;
+            c.s2[(long)ci * 5 * c.cout + (long)(4 - j) * c.cout + co] = pb;
+        } else if (c.s) c.s[i] = f2bf(p);
+    }
+    if (sumsq_part) {
+        ss = block_sum_256(ss, sh);
+        if (threadIdx.x == 0) sumsq_part[blockIdx.x] = c.pad ? ss : 0.f;
+    }
+}
 // The same update from a NARROW grid: gridDim.x workgroups of 1024 threads walk the chunk list.  For the optimizer update that
 // runs beside the encoder backward: a few dozen 16-wave workgroups settle on as many CUs and stay there, the other CUs remain
 // completely free for the backward's GEMM workgroups (which need a whole CU's LDS and registers and cannot start on a CU
@@ -1357,8 +1446,11 @@ int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gsc
 }
 int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1, float beta2, float eps, float l2,
                float grad_scale, float* sumsq_part, hipStream_t st) {
-    if (nchunks > 0)
+    static const bool v1 = getenv("B2S_ADAM_V1") != nullptr;
+    if (nchunks > 0 && v1)
         hipLaunchKernelGGL(k_mt_adam, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part);
+    else if (nchunks > 0)
+        hipLaunchKernelGGL(k_mt_adam2, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_mt_adam_narrow(const MtChunk* chunks, int nchunks, int nwg, const float* hp, float beta1, float beta2, float eps, float l2,

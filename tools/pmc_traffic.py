@@ -44,7 +44,10 @@ def main():
                      "total_fetch_MB_corrected": round(2 * sum(fv) / 1024, 1),
                      "mfma_util": round(sum(mb[k]) / (1024.0 * sum(ga[k]) / 8.0), 4) if k in mb and k in ga and sum(ga[k]) > 0 else None})
     rows.sort(key=lambda r: -r["total_fetch_MB_corrected"])
-    json.dump(rows, open(out, "w"), indent=1)
+    import os
+    # the tree the counters were collected on (B2S_COMMIT: the GPU box has no .git) -- bench.py copies it into roofline.traffic_source
+    json.dump({"commit": os.environ.get("B2S_COMMIT", "unknown"), "tool": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, "
+               "separate passes (tools/gpu_pmc.sh)", "rows": rows}, open(out, "w"), indent=1)
     for r in rows[:12]:
         print("%-60s launches %5d  fetch %9.2f MB/launch  write %9.2f MB/launch  mfma_util %s" % (
             r["kernel"][:60], r["launches"], r["fetch_MB_per_launch_corrected_x2"], (r["WRITE_SIZE_KB_per_launch"] or 0) / 1024, r["mfma_util"]))
