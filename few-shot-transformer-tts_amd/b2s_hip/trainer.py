@@ -96,6 +96,10 @@ class HipTrainer(object):
             # masters) stays fp32.  "fp32": the exact mean of the rank gradients (the reference's DDP arithmetic).
             # B2S_GRAD_PAYLOAD overrides the default, the constructor argument overrides both.
             payload = grad_payload or os.environ.get("B2S_GRAD_PAYLOAD", "bf16" if self.world > 1 else "fp32")
+            # the exchange's channel kernels hold CUs while the backward (and the next forward) runs: GEMM tiles that do not need all 256
+            # CUs for a whole round (b2s_gemm_set_tile_policy; measured with tools/cu_loss.py, profiles/NOTES_r03.md)
+            if self.world > 1:
+                L.check(self.lib.b2s_gemm_set_tile_policy(4))
             lib = self.lib
             def pack(src, dst):
                 L.check(lib.b2s_pack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()))

@@ -24,6 +24,7 @@
 #include <vector>
 #include <cstdlib>
 #include <mutex>
+#include <atomic>
 #include "gemm.h"
 #include "gemm_epi.h"
 
@@ -453,8 +454,10 @@ int launch256_nb(const GemmArgs& g_in, const bf16_t* zero, hipStream_t stream) {
 
 // BN = 96 when that needs fewer (or cheaper) rounds of one workgroup per CU: N = 768 / 2304 with M = 8148 give exactly
 // 256 / 768 tiles of 256x96, against 192 / 576 tiles of 256x128 (a quarter of the CUs idle)
+std::atomic<int> g_tile_policy{0};          // b2s_gemm_set_tile_policy
 inline int pick_nb(const GemmArgs& g) {
-    static const int force = getenv("B2S_GEMM256_NB") ? atoi(getenv("B2S_GEMM256_NB")) : 0;
+    static const int env_force = getenv("B2S_GEMM256_NB") ? atoi(getenv("B2S_GEMM256_NB")) : 0;
+    const int force = env_force ? env_force : g_tile_policy.load(std::memory_order_relaxed);
     if (force == 3 || force == 4) return force;
     const long per = (long)cdiv(g.M, BM) * g.batch * std::max(1, g.splitk);
     const long r128 = (per * cdiv(g.N, 128) + 255) / 256 * 128, r96 = (per * cdiv(g.N, 96) + 255) / 256 * 101;   // 96 * 1.05
@@ -529,6 +532,16 @@ int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* 
     B2S_HIP(attr_err);
     hipLaunchKernelGGL((t256::gemm_glds256_grouped_kernel<4>), dim3(tiles), dim3(t256::nthreads_of(false)), smem, stream, grp, zero);
     B2S_LAUNCH_CHECK();
+    return 0;
+}
+
+// 0: per-shape choice between 256x96 and 256x128 tiles (fewest rounds of one workgroup per CU on 256 CUs); 4: 256x128 everywhere.
+// The per-shape choice makes N = 768 / 2304 GEMMs exactly 256 / 768 tiles -- one or three FULL rounds, which become two / four as soon as
+// another kernel holds a few CUs (a communication library's channels): measured +11 % on the step with 8 CUs held, +4 % with 256x128 tiles
+// (192 / 576 tiles), at no cost with all CUs free (profiles/NOTES_r03.md).  The data-parallel trainer selects 4.
+extern "C" int b2s_gemm_set_tile_policy(int policy) {
+    if (policy != 0 && policy != 3 && policy != 4) return b2s_fail(__FILE__, __LINE__, "tile policy must be 0 (auto), 3 (256x96) or 4 (256x128), got %d", policy);
+    t256::g_tile_policy.store(policy, std::memory_order_relaxed);
     return 0;
 }
 

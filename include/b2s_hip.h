@@ -148,6 +148,11 @@ int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int stage, void* user), 
  * that stream waits, the backward pass is not held up (the hook must launch its work on it; the final optimizer step has to
  * wait for the collectives as before). */
 int b2s_model_set_stage_hook_stream(b2s_model* m, void* stream);
+/* Process-wide tile-shape policy of the large bf16 GEMMs: 0 = per-shape choice (256x96 tiles where that gives whole rounds of one
+ * workgroup per CU: fastest with all 256 CUs free), 4 = 256x128 tiles everywhere (192 / 576 instead of 256 / 768 workgroups for the
+ * N = 768 / 2304 projections: no second round when a communication library's kernels hold some CUs).  The data-parallel trainer
+ * (world size > 1) selects 4; B2S_GEMM256_NB overrides both.  Results do not depend on the policy beyond fp32 summation order. */
+int b2s_gemm_set_tile_policy(int policy);
 
 /* ---- compute_loss (tacotron.py:136-158) ------------------------------------------------------------
  * losses_out[7] = loss, bef_loss, aft_loss, mse_loss, l2, stop_loss, sum(lengths); aft_losses_out[B].

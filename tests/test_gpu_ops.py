@@ -336,3 +336,28 @@ def test_splitk_weight_gradient_gemms_on_two_streams(slabs):
         torch.cuda.synchronize()
         for d, A, B, Cd, ws, ref in probs:
             assert relerr(Cd.cpu(), ref) < 2e-3, (r, report("splitk", Cd.cpu(), ref))
+
+
+def test_gemm_tile_policy_switch():
+    """b2s_gemm_set_tile_policy (include/b2s_hip.h): the data-parallel trainer's 256x128-everywhere policy against the per-shape choice on
+    a projection-shaped GEMM (N = 768: 96-wide tiles by default) -- same product; a bad policy value is refused."""
+    ops, lib = _ops()
+    L = lib.load()
+    from b2s_hip.lib import B2SError
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 1300, 768, 192
+    A, B = bf16_round(torch.randn(M, K, generator=g)), bf16_round(torch.randn(N, K, generator=g))
+    ref = A.double() @ B.double().t()
+    Ad, Bd = to_dev_compute(A, 1), to_dev_compute(B, 1)
+    out = {}
+    try:
+        for pol in (0, 4, 3):
+            assert L.b2s_gemm_set_tile_policy(pol) == 0
+            out[pol] = ops.gemm(1, Ad, Bd, M, N, K, trans_a=False, trans_b=True, lda=K, ldb=K).cpu()
+            assert relerr(out[pol], ref) < TOL[1], pol
+        assert L.b2s_gemm_set_tile_policy(5) != 0
+        with pytest.raises(B2SError):
+            lib.check(L.b2s_gemm_set_tile_policy(-1))
+    finally:
+        assert L.b2s_gemm_set_tile_policy(0) == 0
+    assert torch.equal(out[0], out[3])              # (N = 768 picks the 96-wide tiles on its own)

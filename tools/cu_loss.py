@@ -1,5 +1,7 @@
 """Training step with n CUs held by another kernel (tools/cu_hold.hip): what the step pays for every CU a communication library's
-channel kernels occupy while it runs.  Prints one row per n."""
+channel kernels occupy while it runs.  Prints one row per n.
+usage: cu_loss.py [step|bwd]     step: the CUs are held for the whole step; bwd (default): from the start of the backward pass for 4.5 ms
+(where a data-parallel run's bucketed all-reduces are in flight)"""
 import ctypes, os, sys, time
 import numpy as np
 import torch
@@ -22,10 +24,23 @@ torch.cuda.synchronize()
 side = torch.cuda.Stream()
 STEPS = 20
 base = None
+mode = sys.argv[1] if len(sys.argv) > 1 else "bwd"
+held = [0]
+orig_loss_backward = tr.eng.loss_backward
+def loss_backward(*a, **k):                                         # first engine call of the backward pass
+    if mode == "bwd" and held[0] > 0:
+        ev = torch.cuda.Event(); ev.record()
+        side.wait_event(ev)
+        assert hold.cu_hold(held[0], 4.5, side.cuda_stream) == 0
+    return orig_loss_backward(*a, **k)
+tr.eng.loss_backward = loss_backward
+print("mode: %s, B2S_GEMM256_NB=%s" % (mode, os.environ.get("B2S_GEMM256_NB", "auto")))
 for n in [0, 8, 16, 32, 64, 0]:
     torch.cuda.synchronize()
-    assert hold.cu_hold(n, 400.0, side.cuda_stream) == 0            # 400 ms: outlives the 20 timed steps
-    time.sleep(0.02)                                                # let its workgroups settle before the step's kernels arrive
+    held[0] = n
+    if mode == "step":
+        assert hold.cu_hold(n, 400.0, side.cuda_stream) == 0        # 400 ms: outlives the 20 timed steps
+        time.sleep(0.02)                                            # let its workgroups settle before the step's kernels arrive
     t0 = time.perf_counter()
     for _ in range(STEPS): tr.train_step(batch)
     torch.cuda.current_stream().synchronize()
