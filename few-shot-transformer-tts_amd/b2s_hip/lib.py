@@ -109,6 +109,7 @@ _PROTOS = {
     "b2s_decode_end": (None, [P]),
     "b2s_model_set_stage_hook_stream": (C.c_int, [P, P]),
     "b2s_gemm_set_tile_policy": (C.c_int, [C.c_int]),
+    "b2s_model_backward_abort": (C.c_int, [P, P]),
     "b2s_model_set_stage_hook": (C.c_int, [P, P, P]),
     "b2s_prof_enable": (None, [C.c_int]),
     "b2s_adam_step_ex": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, P]),

@@ -234,39 +234,55 @@ class HipTrainer(object):
         if self.bucketer is not None:
             self.bucketer.begin_step()
         self._hook_error = None
-        dbef, daft, dstop = eng.loss_backward(mels, aft, stop, batch["mel_targets"], tgt32, None)
-        din = eng.postnet_backward(c_post, daft, defer_join=True)           # (the decoder backward below takes over the second stream's join)
-        dmel = eng.add(eng.add(din, daft), dbef)
-        # split: the decoder / postnet gradients (78 % of the parameters) get their optimizer update (HBM-bound, no LDS) on the
-        # engine's second stream under the encoder backward, whose GEMMs are 78..208 workgroups on 256 CUs; the encoder group
-        # follows on this stream.  Data parallel: those gradients' all-reduce must be complete first, so the split is used only
-        # without a process group (the exchange itself overlaps the encoder backward there).
-        split = self.split_adam and self.bucketer is None and not self.freeze_encoder and not self.overlap_adam
-        # With a deferred join the last stages' weight-gradient groups, bias column sums and LayerNorm reductions of the decoder
-        # backward are still queued when it returns (the encoder backward launches them): the split update must not run on
-        # incomplete decoder gradients, so it takes the join here.
-        enc_bwd_s = enc_s if (enc_s is not None and not self.freeze_encoder) else None
-        dmem_done = None
-        if enc_bwd_s is not None:
-            dmem_done = torch.cuda.Event()
-            dmem_done.record(cur)                          # (torch creates the HIP event at its first record: the library re-records this handle)
-        dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape, self._one if guided else None, not self.freeze_encoder,
-                                    defer_join=not self.freeze_encoder and not split, dmem_done=dmem_done)    # (encoder_backward below joins the second stream)
-        lr = self.hp.max_lr * self.lr_lambda(self.global_step)
-        step_no = self.global_step + 1
-        adam = (lr, step_no, self.beta1, self.beta2, self.hp.adam_eps, self.hp.reg_weight, 1.0 / self.world)
-        if split:
-            L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 1, L.stream()))
-        if not self.freeze_encoder:
+        try:
+            dbef, daft, dstop = eng.loss_backward(mels, aft, stop, batch["mel_targets"], tgt32, None)
+            din = eng.postnet_backward(c_post, daft, defer_join=True)           # (the decoder backward below takes over the second stream's join)
+            dmel = eng.add(eng.add(din, daft), dbef)
+            # split: the decoder / postnet gradients (78 % of the parameters) get their optimizer update (HBM-bound, no LDS) on the
+            # engine's second stream under the encoder backward, whose GEMMs are 78..208 workgroups on 256 CUs; the encoder group
+            # follows on this stream.  Data parallel: those gradients' all-reduce must be complete first, so the split is used only
+            # without a process group (the exchange itself overlaps the encoder backward there).
+            split = self.split_adam and self.bucketer is None and not self.freeze_encoder and not self.overlap_adam
+            # With a deferred join the last stages' weight-gradient groups, bias column sums and LayerNorm reductions of the decoder
+            # backward are still queued when it returns (the encoder backward launches them): the split update must not run on
+            # incomplete decoder gradients, so it takes the join here.
+            enc_bwd_s = enc_s if (enc_s is not None and not self.freeze_encoder) else None
+            dmem_done = None
             if enc_bwd_s is not None:
-                enc_bwd_s.wait_event(dmem_done)            # d(memory) only: the rest of the decoder backward runs beside the encoder's
-                with torch.cuda.stream(enc_bwd_s):
+                dmem_done = torch.cuda.Event()
+                dmem_done.record(cur)                          # (torch creates the HIP event at its first record: the library re-records this handle)
+            dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape, self._one if guided else None, not self.freeze_encoder,
+                                        defer_join=not self.freeze_encoder and not split, dmem_done=dmem_done)    # (encoder_backward below joins the second stream)
+            lr = self.hp.max_lr * self.lr_lambda(self.global_step)
+            step_no = self.global_step + 1
+            adam = (lr, step_no, self.beta1, self.beta2, self.hp.adam_eps, self.hp.reg_weight, 1.0 / self.world)
+            if split:
+                L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 1, L.stream()))
+            if not self.freeze_encoder:
+                if enc_bwd_s is not None:
+                    enc_bwd_s.wait_event(dmem_done)            # d(memory) only: the rest of the decoder backward runs beside the encoder's
+                    with torch.cuda.stream(enc_bwd_s):
+                        eng.encoder_backward(c_enc, dmem)
+                    cur.wait_stream(enc_bwd_s)                 # (its last stage joined the engine's second stream)
+                else:
                     eng.encoder_backward(c_enc, dmem)
-                cur.wait_stream(enc_bwd_s)                 # (its last stage joined the engine's second stream)
-            else:
-                eng.encoder_backward(c_enc, dmem)
-        elif enc_s is not None:
-            cur.wait_stream(enc_s)
+            elif enc_s is not None:
+                cur.wait_stream(enc_s)
+        except BaseException:
+            # the backward entry points hand work to each other (deferred joins): whatever is still queued points into contexts that are
+            # freed below -- drop it and rejoin the second stream before anything else touches the engine (b2s_model_backward_abort)
+            try:
+                if enc_s is not None:
+                    cur.wait_stream(enc_s)
+                lib.b2s_model_backward_abort(eng.handle, L.stream())
+                if self.bucketer is not None:
+                    self.bucketer.abort()
+            finally:
+                for c in (c_post, c_dec, c_enc):
+                    if c is not None:
+                        c.free()
+                eng._needs_zero = True
+            raise
         for c in (c_post, c_dec, c_enc):
             if c is not None:
                 c.free()

@@ -1689,9 +1689,26 @@ extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta
     m->l2_fresh = cover && m->adam_step_mask == 7;
     return 0;
 }
+// A backward pass that was given up between entry points (a failed call, an exception in the caller between postnet / decoder / encoder
+// backward): drop whatever the deferred-join protocol still holds -- queued weight-gradient GEMMs, bias / LayerNorm reductions and stage
+// hooks, all of which point into contexts the caller is about to free -- without launching or firing any of it, and make `stream` wait
+// for what the second stream already runs.  The gradient buffers are left incomplete: zero them before the next backward.
+extern "C" int b2s_model_backward_abort(b2s_model* m, void* stream) {
+    B2S_CHECK(m, "null model");
+    m->dw_pending.clear(); m->dw_stages_pending = 0;
+    m->aux_jobs.clear();
+    m->ln_jobs.n = 0;
+    m->pending_stages.clear(); m->unflushed_stages.clear();
+    m->pending_ev = nullptr;
+    if (m->aux) { m->aux_dirty = true; B2S_TRY(join_aux(m, S_(stream))); }
+    return 0;
+}
 extern "C" int b2s_zero_grads(b2s_model* m, void* stream) {
     B2S_TRY(check_bound(m));
     B2S_TRY(wait_adam(m, S_(stream), 7));
+    // a new backward pass starts here: nothing of an earlier one may still be queued (it would run on freed contexts)
+    if (!m->dw_pending.empty() || !m->aux_jobs.empty() || m->ln_jobs.n > 0 || !m->pending_stages.empty() || !m->unflushed_stages.empty())
+        B2S_TRY(b2s_model_backward_abort(m, stream));
     // coalesce adjacent gradient buffers (the host normally binds one flat buffer) into few memsets
     std::vector<std::pair<char*, size_t>> r;
     for (size_t i = 0; i < m->tinfo.size(); ++i)

@@ -148,6 +148,11 @@ int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int stage, void* user), 
  * that stream waits, the backward pass is not held up (the hook must launch its work on it; the final optimizer step has to
  * wait for the collectives as before). */
 int b2s_model_set_stage_hook_stream(b2s_model* m, void* stream);
+/* Give up a backward pass between its entry points (after a failed call, or when the caller will not make the joining call that
+ * B2S_POST_BWD_DEFER_JOIN / B2S_DEC_BWD_DEFER_JOIN promised): queued weight-gradient work, reductions and stage hooks are dropped
+ * unlaunched / unfired, `stream` waits for what the second stream is already running.  Call before freeing the contexts.  The gradient
+ * buffers are incomplete afterwards.  b2s_zero_grads does the same when it finds such leftovers. */
+int b2s_model_backward_abort(b2s_model* m, void* stream);
 /* Process-wide tile-shape policy of the large bf16 GEMMs: 0 = per-shape choice (256x96 tiles where that gives whole rounds of one
  * workgroup per CU: fastest with all 256 CUs free), 4 = 256x128 tiles everywhere (192 / 576 instead of 256 / 768 workgroups for the
  * N = 768 / 2304 projections: no second round when a communication library's kernels hold some CUs).  The data-parallel trainer

@@ -353,7 +353,7 @@ def test_gemm_tile_policy_switch():
     try:
         for pol in (0, 4, 3):
             assert L.b2s_gemm_set_tile_policy(pol) == 0
-            out[pol] = ops.gemm(1, Ad, Bd, M, N, K, trans_a=False, trans_b=True, lda=K, ldb=K).cpu()
+            out[pol] = ops.gemm(1, Ad, Bd, M, N, K, trans_a=False, trans_b=False, lda=K, ldb=K).cpu()      # (B stored [N, K]: the forward linear form)
             assert relerr(out[pol], ref) < TOL[1], pol
         assert L.b2s_gemm_set_tile_policy(5) != 0
         with pytest.raises(B2SError):

@@ -161,3 +161,44 @@ def test_split_optimizer_step_matches_single_launch(monkeypatch, extra):
         d = float((t.double() - res[1][0][k].double()).abs().max())
         assert d <= 2e-2 * (1.0 + float(t.double().abs().max())), (k, d)           # bf16 + atomics: runs are not bit-reproducible
     assert abs(res[0][1][0] - res[1][1][0]) < 2e-2 * abs(res[0][1][0])
+
+
+@pytest.mark.parametrize("where", ["decoder_backward", "encoder_backward"])
+def test_failed_backward_is_abandoned_cleanly(where):
+    """An exception between the backward entry points (which hand queued weight-gradient work to each other: deferred joins) must not
+    leave that work queued against freed contexts: the trainer calls b2s_model_backward_abort, the step is not applied, and the NEXT
+    step equals the first step of an undisturbed trainer."""
+    from b2s_hip.trainer import HipTrainer
+    ma, cfg, _, hp = build(TINY96, compute_dtype="fp32")
+    nb, b = _batch(cfg)
+    ma.train()
+    ta = HipTrainer(ma, hp)
+    ta.eng._seed = 5; ta.eng._calls = 0
+    before = {k: v.detach().clone() for k, v in ma.state_dict().items() if v.is_floating_point()}
+    orig = getattr(ta.eng, where)
+    def boom(*a, **k):
+        raise RuntimeError("injected failure in " + where)
+    setattr(ta.eng, where, boom)
+    with pytest.raises(RuntimeError, match="injected"):
+        ta.train_step(b)
+    setattr(ta.eng, where, orig)
+    torch.cuda.synchronize()
+    assert ta.global_step == 0
+    for k, v in ma.state_dict().items():
+        if k in before and "running_" not in k and "num_batches" not in k:
+            assert torch.equal(v, before[k]), "parameter %s changed in a step that failed" % k
+    ta.eng._seed = 5; ta.eng._calls = 0                 # same dropout stream as the undisturbed run below
+    la = ta.train_step(b)
+    mb, _, _, hp = build(TINY96, compute_dtype="fp32")
+    mb.train()
+    tb = HipTrainer(mb, hp)
+    tb.eng._seed = 5; tb.eng._calls = 0
+    lb = tb.train_step(b)
+    torch.cuda.synchronize()
+    assert torch.allclose(la, lb, rtol=1e-5, atol=1e-6)
+    sb = mb.state_dict()
+    for k, v in ma.state_dict().items():
+        if "running_" in k or "num_batches" in k:      # (BatchNorm statistics saw the failed step's forward pass as well)
+            continue
+        d = float((v.double() - sb[k].double()).abs().max())
+        assert d <= 1e-5 * (1.0 + float(sb[k].double().abs().max())), (k, d)
