@@ -213,8 +213,11 @@ __device__ __forceinline__ void ln_row_load(LnRow<NCH>& r, const TD* __restrict_
     }
     r.mu = mean[row]; r.rs = rstd[row];
 }
+#ifndef B2S_LN_BWD_WAVES
+#define B2S_LN_BWD_WAVES 3      // waves per SIMD the backward kernel is compiled for (4 = 128 VGPRs spills 12 dwords: 8.59 vs 8.50 ms per step)
+#endif
 template <typename TD, int NCH, bool ACC, bool DY2>
-__global__ __launch_bounds__(256) void k_ln_bwd_fast(const TD* __restrict__ dy, int lddy, const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256, B2S_LN_BWD_WAVES) void k_ln_bwd_fast(const TD* __restrict__ dy, int lddy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, float* dx, int M,
                                                      const int* __restrict__ row_len, int rpb, float* __restrict__ ws, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, bf16_t* __restrict__ dy2, DropCfg drop2) {
@@ -1204,7 +1207,8 @@ int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const flo
     const bool f32 = dy_fp32 || !dtype;
     if (!no_fast && (D == 768 || D == 512) && M > 0 && (lddy & 3) == 0) {
         // ~3 rows per wave (the next row's loads fly under the current row's reductions); at most RO_LN_WS_ROWS partial rows
-        grid = std::max(1, std::min(cdiv(M, 12), ws ? RO_LN_WS_ROWS : 512));
+        static const int rows_per_wg = getenv("B2S_LN_BWD_ROWS") ? atoi(getenv("B2S_LN_BWD_ROWS")) : 12;
+        grid = std::max(1, std::min(cdiv(M, rows_per_wg), ws ? RO_LN_WS_ROWS : 512));
 #define B2S_LN_FAST(TD, NCH, ACC, DY2) hipLaunchKernelGGL((k_ln_bwd_fast<TD, NCH, ACC, DY2>), dim3(grid), dim3(256), 0, st, (const TD*)dy, lddy, x, \
             gamma, mean, rstd, dx, M, row_len, rows_per_batch, ws, dgamma, dbeta, (bf16_t*)dy2, drop2)
 #define B2S_LN_FAST_AD(TD, NCH) do { if (accumulate) { if (dy2) B2S_LN_FAST(TD, NCH, true, true); else B2S_LN_FAST(TD, NCH, true, false); } \
