@@ -1559,14 +1559,15 @@ extern "C" int b2s_loss_forward(b2s_model* m, const float* mel_bef, const float*
     B2S_CHECK(mel_bef && mel_aft && stop_logits && mel_targets && target_lengths && losses_out && aft_losses_out && scratch, "null argument");
     hipStream_t st = S_(stream);
     float* l2 = scratch;                      // scratch[0] = l2, scratch[1..] partial sums
+    const bool fused_zero = m->l2_fresh;
     if (m->l2_fresh) {
-        B2S_TRY(ro_sum_scaled(m->l2_part, m->n_adam_chunks, 0.5f * m->cfg.reg_weight, l2, st));
+        B2S_TRY(ro_sum_scaled(m->l2_part, m->n_adam_chunks, 0.5f * m->cfg.reg_weight, l2, st, scratch + 1, 3 + B));
     } else {
         B2S_HIP(hipMemsetAsync(l2, 0, sizeof(float), st));
         if (m->n_l2_chunks) B2S_TRY(ro_mt_sumsq(m->l2_chunks, m->n_l2_chunks, l2, 0.5f * m->cfg.reg_weight, st));
     }
     return ro_loss_fwd(mel_bef, mel_aft, stop_logits, mel_targets, target_lengths, l2, losses_out, aft_losses_out, B, T,
-                       m->cfg.num_mels, 5.0f, scratch + 1, st);
+                       m->cfg.num_mels, 5.0f, scratch + 1, st, fused_zero);
 }
 extern "C" int b2s_loss_backward(b2s_model* m, const float* mel_bef, const float* mel_aft, const float* stop_logits,
                                  const float* mel_targets, const int32_t* target_lengths, int B, int T, const float* grad_scale,

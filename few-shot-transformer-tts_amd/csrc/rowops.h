@@ -95,7 +95,7 @@ int ro_bn_bwd(int dtype, const void* dout, int dout_fp32, const float* y, const 
 // grads of (w0*bef_loss + w1*aft_loss + w2*stop_loss): d_bef[m,c], d_aft[m,c], d_stop[m]; gscale = device float[3] (null -> 1,1,1)
 int ro_loss_fwd(const float* bef, const float* aft, const float* stop, const float* tgt, const int* lens,
                 const float* l2, float* out, float* aft_losses, int B, int T, int C, float pos_weight, float* scratch,
-                hipStream_t st);
+                hipStream_t st, bool scratch_zeroed = false);       // scratch: 3 + B floats, zeroed here unless the caller did
 int ro_loss_bwd(const float* bef, const float* aft, const float* stop, const float* tgt, const int* lens,
                 const float* gscale, float* d_bef, float* d_aft, float* d_stop, int B, int T, int C, float pos_weight,
                 hipStream_t st);
@@ -114,7 +114,7 @@ int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1,
                float grad_scale, float* sumsq_part, hipStream_t st);
 int ro_mt_adam_narrow(const MtChunk* chunks, int nchunks, int nwg, const float* hp, float beta1, float beta2, float eps, float l2,
                       float grad_scale, float* sumsq_part, hipStream_t st);
-int ro_sum_scaled(const float* part, int n, float scale, float* out, hipStream_t st);
+int ro_sum_scaled(const float* part, int n, float scale, float* out, hipStream_t st, float* zero = nullptr, int nzero = 0);   // (+ clears zero[0..nzero))
 
 // conv weight relayouts (fp32 master [Cout][Cin][5] -> T):  fwd[co][j*Cin+ci] ; bwd[ci][j*Cout+co] = w[co][ci][4-j]
 int ro_conv_w_relayout(int dtype, const float* w, void* wf, void* wb, int Cout, int Cin, hipStream_t st);

@@ -1140,8 +1140,11 @@ __global__ __launch_bounds__(1024) void k_mt_adam_narrow(const MtChunk* ch, int 
     }
 }
 // out[0] = scale * sum(part[0..n))
-__global__ __launch_bounds__(1024) void k_sum_scaled(const float* part, int n, float scale, float* out) {
+// (+ clears nzero floats at zero: the loss kernels' accumulators -- a hipMemsetAsync of an odd-sized, 4-byte-aligned range is up to three
+// 5 us fill kernels on the critical path)
+__global__ __launch_bounds__(1024) void k_sum_scaled(const float* part, int n, float scale, float* out, float* zero, int nzero) {
     __shared__ float sh[16];
+    for (int i = threadIdx.x; i < nzero; i += 1024) zero[i] = 0.f;
     float acc = 0.f;
     for (int i = threadIdx.x; i < n; i += 1024) acc += part[i];
     acc = block_sum_256(acc, sh);
@@ -1422,8 +1425,8 @@ int ro_bn_bwd(int dtype, const void* dout, int dout_fp32, const float* y, const 
 }
 int ro_loss_fwd(const float* bef, const float* aft, const float* stop, const float* tgt, const int* lens,
                 const float* l2, float* out, float* aft_losses, int B, int T, int C, float pos_weight, float* scratch,
-                hipStream_t st) {
-    B2S_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * (3 + B), st));
+                hipStream_t st, bool scratch_zeroed) {
+    if (!scratch_zeroed) B2S_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * (3 + B), st));
     if (C % 4 == 0)
         hipLaunchKernelGGL(k_loss_partial_v, dim3(std::max(1, std::min(cdiv((long)T * C / 4, 1024), 16)), B), dim3(256), 0, st, bef, aft, stop, tgt, lens,
                            scratch, T, C, pos_weight);
@@ -1464,8 +1467,8 @@ int ro_mt_adam_narrow(const MtChunk* chunks, int nchunks, int nwg, const float* 
                            grad_scale, sumsq_part);
     B2S_LAUNCH_CHECK(); return 0;
 }
-int ro_sum_scaled(const float* part, int n, float scale, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_sum_scaled, dim3(1), dim3(1024), 0, st, part, n, scale, out);
+int ro_sum_scaled(const float* part, int n, float scale, float* out, hipStream_t st, float* zero, int nzero) {
+    hipLaunchKernelGGL(k_sum_scaled, dim3(1), dim3(1024), 0, st, part, n, scale, out, zero, nzero);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_conv_w_relayout(int dtype, const float* w, void* wf, void* wb, int Cout, int Cin, hipStream_t st) {
