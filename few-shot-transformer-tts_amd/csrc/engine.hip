@@ -588,7 +588,7 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     for (int i = 0; i < (m->dw_group ? 3 * cf.n_decoder_layer + 2 : RO_LN_BATCH); ++i) sc.r_lnws.push_back(a.f32((long)RO_LN_WS_ROWS * 2 * D));
 }
 
-struct PostScratch { std::vector<void*> du, dy; float* stat; int stat_stride; };       // stat: [n layers][2 maxc] column sums (zeroed once per forward)
+struct PostScratch { std::vector<void*> du, dy; float* stat; int stat_stride; void* col = nullptr; };       // stat: [n layers][2 maxc] column sums (zeroed once per forward)
 void plan_postnet(const b2s_model* m, b2s_ctx& c, Arena& a, PostScratch& ps) {
     const b2s_config& cf = m->cfg;
     const long M = (long)c.B * c.T;
@@ -612,6 +612,11 @@ void plan_postnet(const b2s_model* m, b2s_ctx& c, Arena& a, PostScratch& ps) {
     for (int i = 0; i < n; ++i) ps.dy[i] = a.T(M * (i == n - 1 ? cf.num_mels : cf.postnet_hidden), esz);
     ps.stat_stride = 2 * maxc;
     ps.stat = a.f32((long)n * ps.stat_stride);
+    // bf16: the gathered [tokens, 5 taps x channels] operand of one conv weight gradient, written out (41.7 MB at the default sizes) so
+    // that the weight-gradient GEMM reads a plain matrix: with the gather inside the kernel its MFMA waves issue the loads themselves and
+    // compute two divisions per 16-byte chunk (60-113 us per layer against 12 + ~40 with the copy); one buffer, reused layer after layer
+    // on the second stream
+    if (m->dtype == 1) ps.col = a.T(M * 5 * maxc, esz);
 }
 
 int check_bound(const b2s_model* m) {
@@ -1529,7 +1534,14 @@ extern "C" int b2s_postnet_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
         hipEvent_t ready = m->next_event();
         B2S_HIP(hipEventRecord(ready, st));
         B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
-        for (GemmArgs& g : dws) { m->set_ws(g, m->aux); B2S_TRY(b2s_gemm_launch(g, dt, true, true, m->aux)); }
+        static const bool in_kernel_gather = getenv("B2S_CONV_DW_GATHER") != nullptr;          // A/B switch: the previous form
+        for (GemmArgs& g : dws) {
+            if (ps.col && !in_kernel_gather && g.B.g_cin % 8 == 0) {
+                B2S_TRY(ro_im2col5(dt, g.B.p, g.B.g_len, g.B.g_T, g.B.g_cin, ps.col, (long)g.B.R, m->aux));
+                g.B.p = ps.col; g.B.ld = 5 * g.B.g_cin; g.B.g_cin = 0; g.B.g_T = 0; g.B.g_len = nullptr;
+            }
+            m->set_ws(g, m->aux); B2S_TRY(b2s_gemm_launch(g, dt, true, true, m->aux));
+        }
         hipEvent_t done = m->next_event();
         B2S_HIP(hipEventRecord(done, m->aux));
         m->aux_dirty = true;

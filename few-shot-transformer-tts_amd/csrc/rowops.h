@@ -114,6 +114,9 @@ int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1,
                float grad_scale, float* sumsq_part, hipStream_t st);
 int ro_mt_adam_narrow(const MtChunk* chunks, int nchunks, int nwg, const float* hp, float beta1, float beta2, float eps, float l2,
                       float grad_scale, float* sumsq_part, hipStream_t st);
+// out[m][j*cin + ci] = x[m + j - 2][ci] if 0 <= t + j - 2 < min(lens[b], T) (m = b*T + t) else 0: the conv1d k=5 p=2 input of every token
+// with its five taps side by side (bf16 only; cin % 8 == 0)
+int ro_im2col5(int dtype, const void* x, const int* lens, int T, int cin, void* out, long M, hipStream_t st);
 int ro_sum_scaled(const float* part, int n, float scale, float* out, hipStream_t st, float* zero = nullptr, int nzero = 0);   // (+ clears zero[0..nzero))
 
 // conv weight relayouts (fp32 master [Cout][Cin][5] -> T):  fwd[co][j*Cin+ci] ; bwd[ci][j*Cout+co] = w[co][ci][4-j]

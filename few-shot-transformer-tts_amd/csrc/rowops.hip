@@ -1471,6 +1471,24 @@ int ro_sum_scaled(const float* part, int n, float scale, float* out, hipStream_t
     hipLaunchKernelGGL(k_sum_scaled, dim3(1), dim3(1024), 0, st, part, n, scale, out, zero, nzero);
     B2S_LAUNCH_CHECK(); return 0;
 }
+__global__ __launch_bounds__(256) void k_im2col5(const uint4* __restrict__ x, const int* __restrict__ lens, int T, int c8, uint4* __restrict__ out, long M) {
+    const long total = M * 5 * c8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / (5 * c8);
+        const int rem = (int)(i - m * 5 * c8), j = rem / c8, c = rem - j * c8;
+        const int b = (int)(m / T), t = (int)(m - (long)b * T), ts = t + j - 2;
+        const int lim = lens ? min(lens[b], T) : T;
+        const bool ok = (unsigned)ts < (unsigned)lim;
+        const uint4 v = x[(ok ? m + j - 2 : m) * c8 + c];          // (unconditional load on a clamped row)
+        out[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+}
+int ro_im2col5(int dtype, const void* x, const int* lens, int T, int cin, void* out, long M, hipStream_t st) {
+    B2S_CHECK(dtype == 1 && cin % 8 == 0 && T > 0, "im2col: bf16 rows of a multiple of 8 channels only");
+    const long total = M * 5 * (cin / 8);
+    hipLaunchKernelGGL(k_im2col5, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, st, (const uint4*)x, lens, T, cin / 8, (uint4*)out, M);
+    B2S_LAUNCH_CHECK(); return 0;
+}
 int ro_conv_w_relayout(int dtype, const float* w, void* wf, void* wb, int Cout, int Cin, hipStream_t st) {
     RO_DISPATCH(dtype, hipLaunchKernelGGL((k_conv_w_relayout<TY>), dim3(ew_grid((long)Cout * Cin * 5)), dim3(256), 0, st, w,
                                           (TY*)wf, (TY*)wb, Cout, Cin));
