@@ -201,4 +201,4 @@ def test_failed_backward_is_abandoned_cleanly(where):
         if "running_" in k or "num_batches" in k:      # (BatchNorm statistics saw the failed step's forward pass as well)
             continue
         d = float((v.double() - sb[k].double()).abs().max())
-        assert d <= 1e-5 * (1.0 + float(sb[k].double().abs().max())), (k, d)
+        assert d <= 1e-4 * (1.0 + float(sb[k].double().abs().max())), (k, d)      # (atomics reorder the gradient sums from run to run)
