@@ -9,6 +9,7 @@ device memory, streams and the autograd graph edges; no math runs in torch.
 """
 import ctypes as C
 
+import os
 import torch
 
 from . import lib as L
@@ -131,7 +132,16 @@ class HipEngine(object):
                 want = torch.int64 if k == 2 else torch.float32
                 if t.dtype != want or not t.is_contiguous() or t.device != dev:
                     raise L.B2SError("tensor %s must be contiguous %s on %s" % (n, want, dev))
-            total = sum(t.numel() for t, k in zip(ts, self.kinds) if k == 1)
+            # flat gradient layout = backward execution order, so that every backward stage owns one contiguous
+            # range (a data-parallel bucket) that is complete when b2s_model_set_stage_hook fires for it.  Every tensor starts on a
+            # 256-byte boundary (its slot is padded with zeros that nothing reads): without that the three 1-element parameters
+            # (stop_net.bias, the two pe_scale) left 95 % of the gradient -- and with it the Adam moments and the bf16 wire buffer of
+            # the gradient exchange -- off the 16-byte grid that the vector paths of the optimizer, the weight-gradient epilogues
+            # and the collectives want
+            order = sorted((i for i, k in enumerate(self.kinds) if k == 1), key=lambda i: (self.stage_of(self.names[i]), i))
+            al = max(1, int(os.environ.get("B2S_GRAD_ALIGN", "64")))          # (elements; 1 = the packed layout, A/B switch)
+            slot = lambda n: (n + al - 1) // al * al
+            total = sum(slot(ts[i].numel()) for i in order)
             if self._gflat is None or self._gflat.device != dev:
                 if self._gflat is not None and self._trainer is not None and self._trainer() is not None:
                     raise L.B2SError("the model moved from %s to %s under an attached HipTrainer: its optimizer state lives on "
@@ -141,9 +151,6 @@ class HipEngine(object):
             self._gviews = {}
             data = (L.P * len(ts))(*[t.data_ptr() for t in ts])
             grads = (L.P * len(ts))()
-            # flat gradient layout = backward execution order, so that every backward stage owns one contiguous
-            # range (a data-parallel bucket) that is complete when b2s_model_set_stage_hook fires for it
-            order = sorted((i for i, k in enumerate(self.kinds) if k == 1), key=lambda i: (self.stage_of(self.names[i]), i))
             off = 0
             self.stage_ranges = {}
             self.param_offsets = {}
@@ -155,8 +162,8 @@ class HipEngine(object):
                 self.param_offsets[n] = (off, t.numel())
                 st = self.stage_of(n)
                 lo, hi = self.stage_ranges.get(st, (off, off))
-                self.stage_ranges[st] = (min(lo, off), off + t.numel())
-                off += t.numel()
+                self.stage_ranges[st] = (min(lo, off), off + slot(t.numel()))
+                off += slot(t.numel())
             L.check(self.lib.b2s_model_bind(self.handle, data, grads, len(ts)))
             self._sig = sig
             self._versions = None

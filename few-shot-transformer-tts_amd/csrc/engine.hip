@@ -1731,7 +1731,9 @@ extern "C" int b2s_zero_grads(b2s_model* m, void* stream) {
     while (i < r.size()) {
         char* lo = r[i].first; char* hi = lo + r[i].second;
         size_t j = i + 1;
-        while (j < r.size() && r[j].first <= hi + 0) { hi = std::max(hi, r[j].first + r[j].second); ++j; }
+        // (gaps of up to 256 bytes are alignment padding between the slots of one flat buffer -- or the tail padding of separate device
+        // allocations, which are 256-byte granular: cleared along)
+        while (j < r.size() && r[j].first <= hi + 256) { hi = std::max(hi, r[j].first + r[j].second); ++j; }
         B2S_HIP(hipMemsetAsync(lo, 0, (size_t)(hi - lo), S_(stream)));
         i = j;
     }
