@@ -130,6 +130,12 @@ struct b2s_model {
     mutable bool dw_group = false;
     mutable std::vector<GemmArgs> dw_pending;
     mutable int dw_stages_pending = 0;                        // backward stages whose weight-gradient GEMMs are queued in dw_pending
+    // Tail policy of the decoder backward when the encoder backward runs beside its end (b2s_decoder_backward_ev + B2S_DEC_BWD_FLUSH_TAIL):
+    // the weight-gradient groups of the stages >= dw_hold_from are not handed over stage by stage but all at the end, as a sequence of
+    // launches of at most dw_tail_cap tiles each -- they then fill the CUs the encoder chain's 78..224-workgroup kernels
+    // leave idle, instead of occupying every CU for 150 us at a time while that chain waits (profiles/NOTES_r03.md)
+    mutable int dw_hold_from = -1, dw_tail_cap = 0;
+    mutable bool dw_flush_capped = false;
     // launches that only feed parameter gradients (bias / stop-net column sums, the speaker / language nets' backward): queued and
     // issued on the second stream with the next weight-gradient hand-over
     mutable std::vector<std::function<int(hipStream_t)>> aux_jobs;

@@ -279,10 +279,15 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
         // one grouped launch per depth class (q is sorted by K): a decoder layer is 252 tiles over all 8148 tokens + 36 tiles
         // over the 1596 memory rows; launched together the 288 tiles need a second round of deep tiles on 32 CUs (172 us),
         // apart they take 129 + 20 us
+        // tail policy (engine.h: dw_hold_from): launches of at most dw_tail_cap tiles, one after the other -- the second stream then never
+        // holds more than that many CUs at a time and the encoder chain on the caller's other stream keeps finding free ones
+        const bool capped = m->dw_flush_capped && m->dw_tail_cap > 0;
         size_t i = 0;
         while (i < q.size()) {
             size_t j = i + 1;
-            while (j < q.size() && j - i < B2S_MAX_GROUP && q[j].K * 2 > q[i].K) ++j;
+            long t = b2s_gemm_glds256_tiles(q[i]);
+            while (j < q.size() && j - i < B2S_MAX_GROUP && q[j].K * 2 > q[i].K &&
+                   (!capped || t + b2s_gemm_glds256_tiles(q[j]) <= m->dw_tail_cap)) { t += b2s_gemm_glds256_tiles(q[j]); ++j; }
             B2S_TRY(b2s_gemm_grouped_launch(q.data() + i, (int)(j - i), m->aux));
             i = j;
         }
@@ -335,7 +340,8 @@ int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain, bool fo
     // hand-over covers fire together at the next one, once the hook's stream has been ordered behind the second stream's event
     // (two decoder-layer stages are one 32 MB bucket of the gradient exchange anyway).
     static const int per_flush = getenv("B2S_DW_STAGES") ? atoi(getenv("B2S_DW_STAGES")) : 2;
-    if (!serial && !drain && !force_flush && (m->dw_pending.empty() || ++m->dw_stages_pending < per_flush)) {
+    const bool held = m->dw_hold_from >= 0 && stage >= m->dw_hold_from;          // (tail policy, engine.h)
+    if (!serial && !drain && !force_flush && (held || m->dw_pending.empty() || ++m->dw_stages_pending < per_flush)) {
         m->unflushed_stages.push_back(stage);
         return 0;
     }
@@ -1297,6 +1303,16 @@ extern "C" int b2s_decoder_backward_ev(b2s_model* m, b2s_ctx* c, const float* d_
     B2S_TRY(ln_bwd_exit(m, st, sc, sc.doutT, 0, D, c->x_final, p + "output_layer_norm", c->mean_f, c->rstd_f, 0, M, D, c->tgt_len, T,
                         cf.n_decoder_layer > 0 ? &nd : nullptr));
     B2S_TRY(end_stage(m, st, 1, false));
+    // tail policy (engine.h: dw_hold_from): B2S_DW_TAIL_LAYERS decoder layers' (and the prenet's) weight-gradient groups wait for the end
+    // of this call and are launched capped at B2S_DW_TAIL_CAP workgroups, beside the encoder backward on the caller's other stream
+    // (measured, profiles/NOTES_r03.md: 2 layers / 200 tiles: 8.04 -> 7.88 ms; 1 layer 7.95; 4 layers 7.98; caps <= 176 lose what the holding wins)
+    static const int tail_layers = getenv("B2S_DW_TAIL_LAYERS") ? atoi(getenv("B2S_DW_TAIL_LAYERS")) : 2;
+    static const int tail_cap = getenv("B2S_DW_TAIL_CAP") ? atoi(getenv("B2S_DW_TAIL_CAP")) : 200;
+    m->dw_hold_from = -1; m->dw_tail_cap = 0;
+    if ((flags & B2S_DEC_BWD_FLUSH_TAIL) && m->dw_group && tail_layers > 0 && tail_cap > 0 && dt == 1) {
+        m->dw_hold_from = 2 + std::max(0, cf.n_decoder_layer - tail_layers);      // stage 1 = heads, 2 + k = decoder layer L-1-k
+        m->dw_tail_cap = tail_cap;
+    }
     bool first_mem = true, dmem_finished = false;
     auto finish_dmem = [&]() -> int {
         if (dmem_finished) return 0;
@@ -1385,9 +1401,13 @@ extern "C" int b2s_decoder_backward_ev(b2s_model* m, b2s_ctx* c, const float* d_
     if (flags & B2S_DEC_BWD_FLUSH_TAIL) {
         // hand everything that is still queued to the second stream behind an event of THIS stream (the operands were produced here), but
         // leave the join to the caller's next entry point -- which may run on another stream and must not be the one that orders them
-        B2S_TRY(end_stage(m, st, 2 + cf.n_decoder_layer, false, true));
-        return 0;
+        m->dw_flush_capped = m->dw_hold_from >= 0;
+        m->dw_hold_from = -1;
+        const int rc = end_stage(m, st, 2 + cf.n_decoder_layer, false, true);
+        m->dw_flush_capped = false;
+        return rc;
     }
+    m->dw_hold_from = -1;
     B2S_TRY(end_stage(m, st, 2 + cf.n_decoder_layer, !(flags & B2S_DEC_BWD_DEFER_JOIN)));
     return 0;
 }
