@@ -442,6 +442,28 @@ __global__ void k_cast_back(const T* in, float* out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         out[i] = TT<T>::ld(in + i);
 }
+// bf16 forms on 16-byte-aligned buffers, 8 elements per thread and iteration (the gradient exchange's pack / unpack of 32 MB buckets, the
+// step's mel casts): 2 x 16-byte loads + one 16-byte store instead of 4-byte loads + 2-byte stores; the last n % 8 elements by thread 0..7
+__global__ __launch_bounds__(256) void k_cast_bf16_v(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+    const long n8 = n >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const float4 a = ld4(in + i * 8), b = ld4(in + i * 8 + 4);
+        uint4 o;
+        o.x = (uint32_t)f2bf(a.x) | ((uint32_t)f2bf(a.y) << 16); o.y = (uint32_t)f2bf(a.z) | ((uint32_t)f2bf(a.w) << 16);
+        o.z = (uint32_t)f2bf(b.x) | ((uint32_t)f2bf(b.y) << 16); o.w = (uint32_t)f2bf(b.z) | ((uint32_t)f2bf(b.w) << 16);
+        *reinterpret_cast<uint4*>(out + i * 8) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) out[(n8 << 3) + threadIdx.x] = f2bf(in[(n8 << 3) + threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_cast_back_bf16_v(const bf16_t* __restrict__ in, float* __restrict__ out, long n) {
+    const long n8 = n >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(in + i * 8);
+        st4(out + i * 8, make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)));
+        st4(out + i * 8 + 4, make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) out[(n8 << 3) + threadIdx.x] = TT<bf16_t>::ld(in + (n8 << 3) + threadIdx.x);
+}
 
 // ---------------------------------------------------------------------------------- decoder input prep
 __global__ void k_shift_pe_fwd(const float* a, const int* lens, const float* pe, const float* pe_scale, float* x,
@@ -1269,10 +1291,18 @@ int ro_cast_drop(int dtype, const float* in, int ldin, void* out, int ldo, int M
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_cast(int dtype, const float* in, void* out, long n, hipStream_t st) {
+    if (dtype == 1 && n >= 8 && (((size_t)in | (size_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(k_cast_bf16_v, dim3(ew_grid(n >> 3)), dim3(256), 0, st, in, (bf16_t*)out, n);
+        B2S_LAUNCH_CHECK(); return 0;
+    }
     RO_DISPATCH(dtype, hipLaunchKernelGGL((k_cast<TY>), dim3(ew_grid(n)), dim3(256), 0, st, in, (TY*)out, n));
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_cast_back(int dtype, const void* in, float* out, long n, hipStream_t st) {
+    if (dtype == 1 && n >= 8 && (((size_t)in | (size_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(k_cast_back_bf16_v, dim3(ew_grid(n >> 3)), dim3(256), 0, st, (const bf16_t*)in, out, n);
+        B2S_LAUNCH_CHECK(); return 0;
+    }
     RO_DISPATCH(dtype, hipLaunchKernelGGL((k_cast_back<TY>), dim3(ew_grid(n)), dim3(256), 0, st, (const TY*)in, out, n));
     B2S_LAUNCH_CHECK(); return 0;
 }
