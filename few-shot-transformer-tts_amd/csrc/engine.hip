@@ -907,7 +907,33 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
     const float pt = train ? cf.transformer_dropout_rate : 0.f;
     const std::string p = "encoder.encoder.";
     int rc = 0;
+    // speaker / language embedding nets (tacotron.py:36-43): they depend on the ids only and fill columns [D, Dm) of the memory rows, which
+    // the encoder stack never touches -- with a second stream they run beside the stack instead of 33 us behind it
+    auto embed_nets = [&](hipStream_t s2) -> int {
+        const int D = cf.encoder_hidden, Dm = m->Dm;
+        int col = D;
+        if (cf.multi_speaker) {
+            B2S_TRY(ro_spk_embed_fwd((const long*)spk_ids, m->P("encoder.speaker_embed.weight"), m->P("encoder.speaker_layer.weight"),
+                                     m->P("encoder.speaker_layer.bias"), c->spk_e, c->spk_h, memory_out, c->memT, dt, Dm, col, B, S,
+                                     cf.speaker_embedding_size, s2));
+            col += cf.speaker_embedding_size;
+        }
+        if (cf.multi_lingual)
+            B2S_TRY(ro_lang_embed_fwd(language_vecs, cf.max_num_language, m->P("encoder.language_embed.weight"),
+                                      m->P("encoder.language_layer.weight"), m->P("encoder.language_layer.bias"), c->lang_e,
+                                      c->lang_h, memory_out, c->memT, dt, Dm, col, B, S, cf.language_embedding_size, s2));
+        return 0;
+    };
+    hipEvent_t side_done = nullptr;
     auto run = [&]() -> int {
+        if (m->aux && (cf.multi_speaker || cf.multi_lingual)) {
+            hipEvent_t ready = m->next_event();
+            B2S_HIP(hipEventRecord(ready, st));                 // (orders the second stream behind whatever produced the inputs / freed the buffers)
+            B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
+            B2S_TRY(embed_nets(m->aux));
+            side_done = m->next_event();
+            B2S_HIP(hipEventRecord(side_done, m->aux));
+        }
         B2S_TRY(ro_embed_prep_fwd((const long*)inputs, input_lengths, m->P("encoder.embed.weight"), m->pe_enc,
                                   m->P(p + "pe_scale"), xs[0], B, S, D, make_drop(pt, seed, opid(1, 0, 1)), st));
         for (int l = 0; l < cf.n_encoder_layer; ++l) {
@@ -938,17 +964,8 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
         const int Dm = m->Dm;
         B2S_TRY(ro_layernorm_fwd(dt, c->x_final, m->P(p + "output_layer_norm.weight"), m->P(p + "output_layer_norm.bias"),
                                  c->memT, Dm, memory_out, Dm, c->mean_f, c->rstd_f, (int)M, D, 1e-6f, nullptr, 1, st));
-        int col = D;
-        if (cf.multi_speaker) {
-            B2S_TRY(ro_spk_embed_fwd((const long*)spk_ids, m->P("encoder.speaker_embed.weight"), m->P("encoder.speaker_layer.weight"),
-                                     m->P("encoder.speaker_layer.bias"), c->spk_e, c->spk_h, memory_out, c->memT, dt, Dm, col, B, S,
-                                     cf.speaker_embedding_size, st));
-            col += cf.speaker_embedding_size;
-        }
-        if (cf.multi_lingual)
-            B2S_TRY(ro_lang_embed_fwd(language_vecs, cf.max_num_language, m->P("encoder.language_embed.weight"),
-                                      m->P("encoder.language_layer.weight"), m->P("encoder.language_layer.bias"), c->lang_e,
-                                      c->lang_h, memory_out, c->memT, dt, Dm, col, B, S, cf.language_embedding_size, st));
+        if (side_done) B2S_HIP(hipStreamWaitEvent(st, side_done, 0));       // the speaker / language columns (second stream, see above)
+        else B2S_TRY(embed_nets(st));
         return 0;
     };
     rc = run();
