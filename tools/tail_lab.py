@@ -9,6 +9,8 @@ from transformer.tacotron import Tacotron, initialize_variables
 from b2s_hip.trainer import HipTrainer
 from benchdata import synthetic_batch
 hp.parse("compute_dtype=bf16")
+if os.environ.get("B2S_LAB_HP"):                     # e.g. "freeze_encoder=true,guided_attention_weight=1.0"
+    hp.parse(os.environ["B2S_LAB_HP"])
 torch.manual_seed(0)
 m = Tacotron(hp); initialize_variables(m); m = m.to("cuda").train()
 tr = HipTrainer(m, hp)
@@ -34,7 +36,9 @@ N = 20
 for _ in range(N):
     mark("step_start"); tr.train_step(batch); mark("step_end")
 torch.cuda.synchronize()
-def avg(a, b): return sum(x.elapsed_time(y) for x, y in zip(ev[a], ev[b])) / N * 1e3
+def avg(a, b):
+    if a not in ev or b not in ev: return float("nan")
+    return sum(x.elapsed_time(y) for x, y in zip(ev[a], ev[b])) / N * 1e3
 print("step %.0f us | forward+loss %.0f | backward start -> decoder backward end (main stream) %.0f | decoder backward end -> encoder backward end %.0f | "
       "encoder backward %.0f us on its stream | encoder forward %.0f | encoder backward end -> step end (optimizer) %.0f" % (
       avg("step_start", "step_end"), avg("step_start", "bwd_start"), avg("bwd_start", "dec_bwd_end"), avg("dec_bwd_end", "enc_bwd_end"),
