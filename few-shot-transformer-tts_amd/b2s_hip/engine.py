@@ -165,9 +165,12 @@ class HipEngine(object):
                 self.stage_ranges[st] = (min(lo, off), off + slot(t.numel()))
                 off += slot(t.numel())
             L.check(self.lib.b2s_model_bind(self.handle, data, grads, len(ts)))
+            L.check(self.lib.b2s_model_set_grad_slot_padding(self.handle, 4 * (al - 1) if al > 1 else 0))   # the gaps between the slots above
             self._sig = sig
             self._versions = None
-        vers = tuple(t._version for t in ts)
+        # parameters only: buffers (BatchNorm running statistics) have no compute-dtype shadow -- the kernels read them in place -- and the
+        # data-parallel trainer rewrites them before every step (broadcast_buffers), which must not trigger a re-cast of every weight
+        vers = tuple(t._version for t, k in zip(ts, self.kinds) if k == 1)
         if vers != self._versions:
             L.check(self.lib.b2s_model_sync_weights(self.handle, L.stream()))
             self._versions = vers

@@ -78,6 +78,7 @@ _PROTOS = {
     "b2s_adam_bind": (C.c_int, [P, C.POINTER(P), C.POINTER(P), C.c_int]),
     "b2s_adam_step": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, P]),
     "b2s_zero_grads": (C.c_int, [P, P]),
+    "b2s_model_set_grad_slot_padding": (C.c_int, [P, C.c_int]),
     "b2s_gemm": (C.c_int, [C.POINTER(GemmDesc), P, P, P, P, P, P, P, P]),
     "b2s_gemm_splitk": (C.c_int, [C.POINTER(GemmDesc), C.c_int, P, P, P, P, C.c_size_t, P]),
     "b2s_layernorm_forward": (C.c_int, [C.c_int, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, P]),
@@ -117,6 +118,12 @@ _PROTOS = {
     "b2s_adam_step_groups": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, P]),
     "b2s_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "b2s_dropout_mask": (C.c_int, [C.c_float, C.c_uint64, C.c_uint32, P, C.c_int64, P]),
+    "b2s_encf_attention_forward": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, P, P, P, P, C.c_int, P]),
+    "b2s_encf_attention_backward": (C.c_int, [P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, P, P, C.c_int, P]),
+    "b2s_encf_ffn_sublayer": (C.c_int, [C.c_int, P, P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, P, C.c_int, P]),
+    "b2s_encf_reduce_layernorm_forward": (C.c_int, [P, P, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, P, P, P, P, P, C.c_int, P, P, C.c_int, P]),
+    "b2s_encf_reduce_layernorm_backward": (C.c_int, [P, P, C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, C.c_float, C.c_uint64, C.c_uint32, C.c_int, P]),
+    "b2s_transpose_bf16": (C.c_int, [P, P, C.c_int, C.c_int, P]),
 }
 EXPORTS = sorted(_PROTOS)
 

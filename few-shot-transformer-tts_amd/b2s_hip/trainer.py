@@ -201,6 +201,11 @@ class HipTrainer(object):
     def train_step(self, batch):
         """batch: the dataloader dict (dataloader.py:498-508) on the device.  Returns the 7 loss values (device)."""
         eng, lib = self.eng, self.lib
+        # Re-bind / re-sync on THIS stream before anything forks off it: a full weight sync (parameters loaded or changed behind the
+        # optimizer's back: utils.checkpoint.load_model, load_state_dict) re-casts every bf16 shadow, and both the encoder stream and
+        # the decoder's first kernels on this stream read shadows -- left to the encoder_forward call below it would run on the
+        # encoder stream only, unordered against the decoder prenet / first self-attention.
+        eng.ensure_bound()
         if self.bn_broadcast and self._bn_buffers:
             from .dp import broadcast_buffers
             broadcast_buffers(self._bn_buffers, self.dist, 0)

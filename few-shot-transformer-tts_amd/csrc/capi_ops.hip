@@ -2,6 +2,7 @@
 // the op parity tests.  See include/b2s_hip.h.
 #include "engine.h"
 #include "attention.h"
+#include "enc_fused.h"
 
 namespace {
 inline hipStream_t S_(void* s) { return (hipStream_t)s; }
@@ -155,4 +156,50 @@ extern "C" int b2s_dropout_mask(float p, uint64_t seed, uint32_t op_id, uint8_t*
     hipLaunchKernelGGL(k_dropmask, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), d, out, (long)n);
     B2S_LAUNCH_CHECK();
     return 0;
+}
+
+// ---- fused encoder sublayer kernels (enc_fused.h), op level: what the engine launches per sublayer, for the parity tests
+extern "C" int b2s_encf_attention_forward(const void* hN, const void* Wqkv, const void* Wo, const int32_t* klen, int B, int S, float drop_p,
+                                          uint64_t seed, uint32_t op_id, void* qkv, void* ctx, float* lse, void* slabs, int slab_bf16, void* stream) {
+    EncfAttnFwd a;
+    a.hN = (const bf16_t*)hN; a.Wqkv = (const bf16_t*)Wqkv; a.Wo = (const bf16_t*)Wo; a.klen = klen; a.B = B; a.S = S;
+    a.datt = make_drop(drop_p, seed, op_id); a.qkv = (bf16_t*)qkv; a.ctx = (bf16_t*)ctx; a.lse = lse; a.slabs = slabs;
+    return b2s_encf_attn_fwd(a, slab_bf16, S_(stream));
+}
+extern "C" int b2s_encf_attention_backward(const void* dY, const void* qkv, const void* ctx, const float* lse, const void* WoT, const void* WqkvT,
+                                           const int32_t* klen, int B, int S, float drop_p, uint64_t seed, uint32_t op_id, void* dqkv, void* slabs,
+                                           int slab_bf16, void* stream) {
+    EncfAttnBwd a;
+    a.dY = (const bf16_t*)dY; a.qkv = (const bf16_t*)qkv; a.ctx = (const bf16_t*)ctx; a.lse = lse; a.WoT = (const bf16_t*)WoT;
+    a.WqkvT = (const bf16_t*)WqkvT; a.klen = klen; a.B = B; a.S = S; a.datt = make_drop(drop_p, seed, op_id); a.dqkv = (bf16_t*)dqkv; a.slabs = slabs;
+    return b2s_encf_attn_bwd(a, slab_bf16, S_(stream));
+}
+// backward = 0: X = LN(x), Wa = W1, Wb = W2, f_io receives f;  backward = 1: X = dY, Wa = W2^T, Wb = W1^T, f_io holds the saved f, dz receives dz
+extern "C" int b2s_encf_ffn_sublayer(int backward, const void* X, const void* Wa, const void* Wb, void* f_io, void* dz, int B, int S, float drop_p,
+                                     uint64_t seed, uint32_t op_id, void* slabs, int slab_bf16, void* stream) {
+    EncfFfn a;
+    a.X = (const bf16_t*)X; a.Wa = (const bf16_t*)Wa; a.Wb = (const bf16_t*)Wb; a.F = (bf16_t*)f_io; a.dz = (bf16_t*)dz; a.slabs = slabs; a.B = B; a.S = S;
+    a.dhid = backward ? DropCfg{0, 0, 1.f} : make_drop(drop_p, seed, op_id);
+    a.aux_scale = make_drop(drop_p, seed, op_id).scale;
+    return b2s_encf_ffn(a, backward != 0, slab_bf16, S_(stream));
+}
+extern "C" int b2s_encf_reduce_layernorm_forward(const float* x_in, const void* slabs, int ns, int slab_bf16, float drop_p, uint64_t seed, uint32_t op_id,
+                                                 const float* gamma, const float* beta, float* x_out, void* h, float* h32, int ldh32, float* mean,
+                                                 float* rstd, int M, void* stream) {
+    return b2s_encf_reduce_ln_fwd(x_in, slabs, ns, slab_bf16, make_drop(drop_p, seed, op_id), gamma, beta, x_out, (bf16_t*)h, encf::D, h32, ldh32, mean, rstd,
+                                  M, S_(stream));
+}
+extern "C" int b2s_encf_reduce_layernorm_backward(const void* slabs, int ns, int slab_bf16, const float* x_in, const float* gamma, const float* mean,
+                                                  const float* rstd, float* dx, float* dgamma, float* dbeta, float* ws, void* dy2, float drop_p,
+                                                  uint64_t seed, uint32_t op_id, int M, void* stream) {
+    B2S_CHECK(dgamma && dbeta, "null argument");
+    LnReduceBatch bt; bt.n = 1;
+    bt.j[0].ws = ws; bt.j[0].D = encf::D; bt.j[0].dgamma = dgamma; bt.j[0].dbeta = dbeta;
+    B2S_TRY(b2s_encf_reduce_ln_bwd(slabs, ns, slab_bf16, x_in, gamma, mean, rstd, dx, ws, &bt.j[0].nblk, (bf16_t*)dy2, make_drop(drop_p, seed, op_id), M,
+                                   S_(stream)));
+    return ro_ln_param_reduce_batch(bt, S_(stream));
+}
+extern "C" int b2s_transpose_bf16(const void* src, void* dst, int R, int C, void* stream) {
+    const EncfTransposeJob jb = {(const bf16_t*)src, (bf16_t*)dst, R, C};
+    return b2s_encf_transpose(&jb, 1, S_(stream));
 }

@@ -77,6 +77,7 @@ struct b2s_ctx {
     float *mean_f = nullptr, *rstd_f = nullptr;
     float *spk_e = nullptr, *spk_h = nullptr, *lang_e = nullptr, *lang_h = nullptr, *spk_dh = nullptr, *lang_dh = nullptr;
     // decoder
+    bool enc_fused = false, enc_wT_done = false;     // encoder: forward ran the fused sublayer kernels / left the transposed weight copies behind enc_wT_ev
     void* memT = nullptr;
     void *tgtT = nullptr, *a1 = nullptr, *a2 = nullptr;
     void* outT = nullptr;               // imputed decoder output (T)
@@ -99,6 +100,7 @@ struct b2s_model {
     float *pe_enc = nullptr, *pe_dec = nullptr;
     int pe_len = 0;
     bool bound = false;
+    size_t grad_pad_bytes = 0;                      // b2s_model_set_grad_slot_padding: largest gap between bound gradient ranges that is padding
     // multi-tensor chunk tables (device)
     MtChunk *l2_chunks = nullptr, *adam_chunks = nullptr;
     int n_l2_chunks = 0, n_adam_chunks = 0;
@@ -150,6 +152,14 @@ struct b2s_model {
     // memory K/V of all layers come from ONE GEMM (N = L*2D) and d(memory) from ONE GEMM over the concatenated dK/dV
     // (K = L*2D) instead of L launches of 56-112 tiles each
     void* kv_cat = nullptr;
+    // Fused encoder sublayers (enc_fused.h; bf16 mode, default encoder dims, <= 128 rows per utterance): the backward kernels stream
+    // TRANSPOSED bf16 copies of the encoder GEMM weights so that every operand they DMA is K-contiguous -- per layer {Wqkv^T, Wo^T,
+    // W1^T, W2^T}, rewritten on the second stream by every training-mode encoder forward (the weights change every step) and
+    // ordered before the encoder backward through enc_wT_ev.
+    bool enc_fused = false;
+    int enc_slab_bf16 = 0;
+    std::vector<void*> enc_wT;
+    mutable hipEvent_t enc_wT_ev = nullptr;
     mutable LnReduceBatch ln_jobs = {};                       // LayerNorm parameter-gradient reductions queued for the stage's single launch
     // stages whose gradient work has been handed to the second stream (completed by pending_ev) and whose hook has not fired yet /
     // stages that ended since the last hand-over

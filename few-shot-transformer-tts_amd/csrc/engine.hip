@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include "engine.h"
 #include "attention.h"
+#include "enc_fused.h"
 
 thread_local char g_b2s_err[512] = "";
 int b2s_fail(const char* file, int line, const char* fmt, ...) {
@@ -481,8 +482,13 @@ struct Scratch {
     int i_lnws = 0;
     void *dmelT = nullptr, *doutT = nullptr, *da3 = nullptr, *dz1 = nullptr, *dz2 = nullptr;
     void* dkvcat = nullptr;          // [Mk][L*2D]: dK / dV of every decoder layer (models with a kv_cat weight slab)
+    void* slabs = nullptr;           // fused encoder: [16][M][512] partial sublayer outputs (enc_fused.h)
 };
 
+// the fused encoder sublayer kernels serve this call?  (a pure function of the model and S: forward and backward decide alike)
+bool enc_use_fused(const b2s_model* m, int S) {
+    return m->enc_fused && b2s_encf_supported(m->cfg.encoder_hidden, m->cfg.n_attention_head, 4 * m->cfg.encoder_hidden, S);
+}
 void plan_attn(Arena& a, AttnSave& s, int esz, long M, int D, int B, int H, int Lq, int Lk, bool cross, long Mk,
                bool dropout) {
     s.Lq = Lq; s.Lk = Lk; s.ldp = rup8(Lk);
@@ -541,6 +547,7 @@ void plan_encoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     sc.dctx = a.T(M * D, esz); sc.dh = a.T(M * D, esz); sc.dx = a.f32(M * D);
     sc.lnws = a.f32((long)RO_LN_WS_ROWS * 2 * D);
     for (int i = 0; i < (m->dw_group ? 2 * cf.n_encoder_layer + 2 : RO_LN_BATCH); ++i) sc.r_lnws.push_back(a.f32((long)RO_LN_WS_ROWS * 2 * D));
+    if (enc_use_fused(m, S)) sc.slabs = a.take((size_t)encf::NSF * M * D * (m->enc_slab_bf16 ? 2 : 4));
 }
 
 void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::vector<float*>& xs) {
@@ -655,6 +662,13 @@ extern "C" int b2s_model_create(const b2s_config* cfg, b2s_model** out) {
               "guided_attention_weight must be >= 0 and guided_attention_sigma > 0");
     b2s_model* m = new b2s_model();
     m->cfg = c; m->dtype = c.compute_dtype; m->esz = c.compute_dtype ? 2 : 4; m->Dm = Dm;
+    {
+        static const bool no_fused = getenv("B2S_ENC_FUSED") && atoi(getenv("B2S_ENC_FUSED")) == 0;            // A/B switch: the unfused encoder
+        static const int slab_bf16 = getenv("B2S_ENC_SLAB_BF16") ? atoi(getenv("B2S_ENC_SLAB_BF16")) : 0;
+        m->enc_fused = m->dtype == 1 && !no_fused && c.n_encoder_layer > 0 && c.n_encoder_layer * 4 <= 24 &&
+                       b2s_encf_supported(c.encoder_hidden, c.n_attention_head, 4 * c.encoder_hidden, 1);
+        m->enc_slab_bf16 = slab_bf16;
+    }
     build_layout(m);
     const size_t n = m->tinfo.size();
     m->data.assign(n, nullptr); m->grad.assign(n, nullptr); m->shadow.assign(n, nullptr);
@@ -669,6 +683,7 @@ extern "C" void b2s_model_destroy(b2s_model* m) {
     if (m->aux) (void)hipStreamDestroy(m->aux);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     for (int g = 0; g < 3; ++g) if (m->adam_ev[g]) (void)hipEventDestroy(m->adam_ev[g]);
+    if (m->enc_wT_ev) (void)hipEventDestroy(m->enc_wT_ev);
     for (void* p : m->owned) (void)hipFree(p);
     delete m;
 }
@@ -811,6 +826,19 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
         m->conv_wf[l] = a; m->conv_wb[l] = b;
     }
     if (!m->small) { B2S_HIP(hipMalloc(&m->small, 64 * sizeof(float))); m->owned.push_back(m->small); }
+    {
+        const b2s_config& c = m->cfg;
+        if (m->enc_fused && m->enc_wT.empty()) {
+            const size_t Dh = c.encoder_hidden, sz[4] = {3 * Dh * Dh, Dh * Dh, 4 * Dh * Dh, 4 * Dh * Dh};
+            for (int l = 0; l < c.n_encoder_layer; ++l)
+                for (int k = 0; k < 4; ++k) {
+                    void* p = nullptr;
+                    B2S_HIP(hipMalloc(&p, sz[k] * 2));
+                    m->owned.push_back(p); m->enc_wT.push_back(p);
+                }
+            B2S_HIP(hipEventCreateWithFlags(&m->enc_wT_ev, hipEventDisableTiming));
+        }
+    }
     if (m->dtype == 1 && !m->sk_ws[0]) {
         // largest split-K user: a postnet conv weight gradient, splitk * Cout * 5 Cin floats (6 x 512 x 2560 = 31 MB at the
         // default sizes); sized generously, HBM is 288 GB
@@ -925,17 +953,68 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
         return 0;
     };
     hipEvent_t side_done = nullptr;
+    const bool fused = enc_use_fused(m, S) && cf.n_encoder_layer > 0;
+    // the fused backward streams transposed copies of this step's encoder weights: written now, beside the forward pass (second stream)
+    const bool want_wT = fused && ctx_out && !cf.freeze_encoder;
+    auto transposes = [&](hipStream_t s2) -> int {
+        EncfTransposeJob jobs[24];
+        int n = 0;
+        const int Dh = cf.encoder_hidden;
+        for (int l = 0; l < cf.n_encoder_layer; ++l) {
+            const char* leaf[4] = {"self_attentions", "self_attentions", "ffn_layers", "ffn_layers"};
+            const char* w[4] = {"qkv_transform.weight", "output_transform.weight", "input_layer.weight", "output_layer.weight"};
+            const int R[4] = {3 * Dh, Dh, 4 * Dh, Dh}, C[4] = {Dh, Dh, Dh, 4 * Dh};
+            for (int k = 0; k < 4; ++k)
+                jobs[n++] = EncfTransposeJob{(const bf16_t*)m->W(nm(p, leaf[k], l, w[k])), (bf16_t*)m->enc_wT[(size_t)l * 4 + k], R[k], C[k]};
+        }
+        return b2s_encf_transpose(jobs, n, s2);
+    };
     auto run = [&]() -> int {
-        if (m->aux && (cf.multi_speaker || cf.multi_lingual)) {
+        const bool side_nets = cf.multi_speaker || cf.multi_lingual;
+        if (m->aux && (side_nets || want_wT)) {
             hipEvent_t ready = m->next_event();
             B2S_HIP(hipEventRecord(ready, st));                 // (orders the second stream behind whatever produced the inputs / freed the buffers)
             B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
-            B2S_TRY(embed_nets(m->aux));
-            side_done = m->next_event();
-            B2S_HIP(hipEventRecord(side_done, m->aux));
+            if (side_nets) {
+                B2S_TRY(embed_nets(m->aux));
+                side_done = m->next_event();
+                B2S_HIP(hipEventRecord(side_done, m->aux));
+            }
+            if (want_wT) { B2S_TRY(transposes(m->aux)); B2S_HIP(hipEventRecord(m->enc_wT_ev, m->aux)); c->enc_wT_done = true; }
         }
         B2S_TRY(ro_embed_prep_fwd((const long*)inputs, input_lengths, m->P("encoder.embed.weight"), m->pe_enc,
                                   m->P(p + "pe_scale"), xs[0], B, S, D, make_drop(pt, seed, opid(1, 0, 1)), st));
+        if (fused) {
+            // one kernel per sublayer + one row kernel (slab sum + residual + the NEXT LayerNorm) instead of 7 launches per layer (enc_fused.h)
+            const int L = cf.n_encoder_layer, Dm = m->Dm, sb = m->enc_slab_bf16;
+            const std::string ln0 = p + "attn_layer_norms.0";
+            B2S_TRY(ro_layernorm_fwd(dt, xs[0], m->P(ln0 + ".weight"), m->P(ln0 + ".bias"), c->self_attn[0].h, D, nullptr, 0, c->self_attn[0].mean,
+                                     c->self_attn[0].rstd, (int)M, D, 1e-6f, nullptr, 1, st));
+            for (int l = 0; l < L; ++l) {
+                AttnSave& s = c->self_attn[l];
+                FfnSave& f = c->ffn[l];
+                s.op_attn = opid(1, l, 2); s.op_res = opid(1, l, 3); s.mask_mode = 1;
+                f.op_hid = opid(1, l, 4); f.op_res = opid(1, l, 5);
+                EncfAttnFwd fa;
+                fa.hN = (const bf16_t*)s.h; fa.Wqkv = (const bf16_t*)m->W(nm(p, "self_attentions", l, "qkv_transform.weight"));
+                fa.Wo = (const bf16_t*)m->W(nm(p, "self_attentions", l, "output_transform.weight")); fa.klen = input_lengths; fa.B = B; fa.S = S;
+                fa.datt = make_drop(pt, seed, s.op_attn); fa.qkv = (bf16_t*)s.qkv; fa.ctx = (bf16_t*)s.ctx; fa.lse = s.lse; fa.slabs = sc.slabs;
+                B2S_TRY(b2s_encf_attn_fwd(fa, sb, st));
+                const std::string lnf = p + "ffn_layer_norms." + std::to_string(l);
+                B2S_TRY(b2s_encf_reduce_ln_fwd(xs[2 * l], sc.slabs, encf::NH, sb, make_drop(pt, seed, s.op_res), m->P(lnf + ".weight"), m->P(lnf + ".bias"),
+                                               xs[2 * l + 1], (bf16_t*)f.h, D, nullptr, 0, f.mean, f.rstd, (int)M, st));
+                EncfFfn ff;
+                ff.X = (const bf16_t*)f.h; ff.Wa = (const bf16_t*)m->W(nm(p, "ffn_layers", l, "input_layer.weight"));
+                ff.Wb = (const bf16_t*)m->W(nm(p, "ffn_layers", l, "output_layer.weight")); ff.F = (bf16_t*)f.f; ff.dz = nullptr; ff.slabs = sc.slabs;
+                ff.B = B; ff.S = S; ff.dhid = make_drop(pt, seed, f.op_hid); ff.aux_scale = 1.f;
+                B2S_TRY(b2s_encf_ffn(ff, false, sb, st));
+                const bool last = l + 1 == L;
+                const std::string lnn = last ? p + "output_layer_norm" : p + "attn_layer_norms." + std::to_string(l + 1);
+                B2S_TRY(b2s_encf_reduce_ln_fwd(xs[2 * l + 1], sc.slabs, encf::NSF, sb, make_drop(pt, seed, f.op_res), m->P(lnn + ".weight"), m->P(lnn + ".bias"),
+                                               xs[2 * l + 2], (bf16_t*)(last ? c->memT : c->self_attn[l + 1].h), last ? Dm : D, last ? memory_out : nullptr, Dm,
+                                               last ? c->mean_f : c->self_attn[l + 1].mean, last ? c->rstd_f : c->self_attn[l + 1].rstd, (int)M, st));
+            }
+        } else {
         for (int l = 0; l < cf.n_encoder_layer; ++l) {
             AttnSave& s = c->self_attn[l];
             FfnSave& f = c->ffn[l];
@@ -964,8 +1043,11 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
         const int Dm = m->Dm;
         B2S_TRY(ro_layernorm_fwd(dt, c->x_final, m->P(p + "output_layer_norm.weight"), m->P(p + "output_layer_norm.bias"),
                                  c->memT, Dm, memory_out, Dm, c->mean_f, c->rstd_f, (int)M, D, 1e-6f, nullptr, 1, st));
+        }
         if (side_done) B2S_HIP(hipStreamWaitEvent(st, side_done, 0));       // the speaker / language columns (second stream, see above)
         else B2S_TRY(embed_nets(st));
+        if (want_wT && !c->enc_wT_done) { B2S_TRY(transposes(st)); B2S_HIP(hipEventRecord(m->enc_wT_ev, st)); c->enc_wT_done = true; }
+        c->enc_fused = fused;
         return 0;
     };
     rc = run();
@@ -1106,6 +1188,76 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
     B2S_TRY(ln_bwd_exit(m, st, sc, d_memory, 1, Dm, c->x_final, p + "output_layer_norm", c->mean_f, c->rstd_f, 0, M, D, nullptr, 1,
                         cf.n_encoder_layer > 0 ? &nd : nullptr));
     B2S_TRY(end_stage(m, st, 3 + cf.n_decoder_layer, false));
+    if (c->enc_fused) {
+        // (the transposed weight copies of this step: written on the second stream by the forward pass, or here if it did not)
+        if (!c->enc_wT_done) {
+            EncfTransposeJob jobs[24];
+            int n = 0;
+            for (int l = 0; l < cf.n_encoder_layer; ++l) {
+                const char* leaf[4] = {"self_attentions", "self_attentions", "ffn_layers", "ffn_layers"};
+                const char* w[4] = {"qkv_transform.weight", "output_transform.weight", "input_layer.weight", "output_layer.weight"};
+                const int R[4] = {3 * D, D, 4 * D, D}, C[4] = {D, D, D, 4 * D};
+                for (int k = 0; k < 4; ++k)
+                    jobs[n++] = EncfTransposeJob{(const bf16_t*)m->W(nm(p, leaf[k], l, w[k])), (bf16_t*)m->enc_wT[(size_t)l * 4 + k], R[k], C[k]};
+            }
+            B2S_TRY(b2s_encf_transpose(jobs, n, st));
+        } else B2S_HIP(hipStreamWaitEvent(st, m->enc_wT_ev, 0));
+        const int sb = m->enc_slab_bf16;
+        // slab sum + LayerNorm backward at the exit of a fused sublayer (= ln_bwd_exit with the slab sum as dy)
+        auto rl_exit = [&](int ns, const float* x_in, const std::string& lnp, const float* mean, const float* rstd, const DropCfg* next) -> int {
+            bf16_t* dy2 = nullptr;
+            DropCfg ndc = {0, 0, 1.f};
+            if (next) {
+                sc.dyT = Scratch::rot(sc.r_dyT, sc.i_dyT);
+                B2S_TRY(guard_write(m, sc.dyT, st));
+                dy2 = (bf16_t*)sc.dyT; ndc = *next;
+            }
+            B2S_TRY(guard_write(m, sc.dx, st));
+            if (m->ln_jobs.n == RO_LN_BATCH) B2S_TRY(flush_ln_jobs(m, st));
+            LnReduceJob& jb = m->ln_jobs.j[m->ln_jobs.n];
+            jb.ws = m->dw_group ? sc.r_lnws[(size_t)sc.i_lnws++ % sc.r_lnws.size()] : sc.r_lnws[m->ln_jobs.n];
+            jb.D = D; jb.dgamma = m->G(lnp + ".weight"); jb.dbeta = m->G(lnp + ".bias");
+            B2S_TRY(b2s_encf_reduce_ln_bwd(sc.slabs, ns, sb, x_in, m->P(lnp + ".weight"), mean, rstd, sc.dx, const_cast<float*>(jb.ws), &jb.nblk, dy2, ndc,
+                                           (int)M, st));
+            ++m->ln_jobs.n;
+            sc.dy_ready = dy2 != nullptr;
+            return 0;
+        };
+        for (int l = cf.n_encoder_layer - 1; l >= 0; --l) {
+            const AttnSave& s = c->self_attn[l];
+            const FfnSave& f = c->ffn[l];
+            const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lna = p + "attn_layer_norms." + std::to_string(l);
+            const std::string w1 = nm(p, "ffn_layers", l, "input_layer.weight"), w2 = nm(p, "ffn_layers", l, "output_layer.weight");
+            const std::string wq = nm(p, "self_attentions", l, "qkv_transform.weight"), wo = nm(p, "self_attentions", l, "output_transform.weight");
+            const bf16_t* const* wT = (const bf16_t* const*)&m->enc_wT[(size_t)l * 4];          // {Wqkv^T, Wo^T, W1^T, W2^T}
+            // ---- FFN sublayer
+            const void* dy;
+            B2S_TRY(take_dy(m, st, sc, M, D, make_drop(pt, c->seed, f.op_res), &dy));
+            B2S_TRY(linear_dw(m, st, dy, D, f.f, 4 * D, (int)M, D, 4 * D, m->G(w2)));
+            sc.dz = Scratch::rot(sc.r_dz, sc.i_dz);
+            B2S_TRY(guard_write(m, sc.dz, st));
+            EncfFfn fb;
+            fb.X = (const bf16_t*)dy; fb.Wa = wT[3]; fb.Wb = wT[2]; fb.F = (bf16_t*)f.f; fb.dz = (bf16_t*)sc.dz; fb.slabs = sc.slabs; fb.B = B; fb.S = S;
+            fb.dhid = DropCfg{0, 0, 1.f}; fb.aux_scale = make_drop(pt, c->seed, f.op_hid).scale;
+            B2S_TRY(b2s_encf_ffn(fb, true, sb, st));
+            B2S_TRY(linear_dw(m, st, sc.dz, 4 * D, f.h, D, (int)M, 4 * D, D, m->G(w1)));
+            nd = make_drop(pt, c->seed, s.op_res);
+            B2S_TRY(rl_exit(encf::NSF, f.x_in, lnf, f.mean, f.rstd, &nd));
+            // ---- attention sublayer
+            B2S_TRY(take_dy(m, st, sc, M, D, nd, &dy));
+            B2S_TRY(linear_dw(m, st, dy, D, s.ctx, D, (int)M, D, D, m->G(wo)));
+            sc.dqkv = Scratch::rot(sc.r_dqkv, sc.i_dqkv);
+            B2S_TRY(guard_write(m, sc.dqkv, st));
+            EncfAttnBwd ab;
+            ab.dY = (const bf16_t*)dy; ab.qkv = (const bf16_t*)s.qkv; ab.ctx = (const bf16_t*)s.ctx; ab.lse = s.lse; ab.WoT = wT[1]; ab.WqkvT = wT[0];
+            ab.klen = c->in_len; ab.B = B; ab.S = S; ab.datt = make_drop(pt, c->seed, s.op_attn); ab.dqkv = (bf16_t*)sc.dqkv; ab.slabs = sc.slabs;
+            B2S_TRY(b2s_encf_attn_bwd(ab, sb, st));
+            B2S_TRY(linear_dw(m, st, sc.dqkv, 3 * D, s.h, D, (int)M, 3 * D, D, m->G(wq)));
+            if (l > 0) nd = make_drop(pt, c->seed, c->ffn[l - 1].op_res);
+            B2S_TRY(rl_exit(encf::NH, s.x_in, lna, s.mean, s.rstd, l > 0 ? &nd : nullptr));
+            B2S_TRY(end_stage(m, st, 4 + cf.n_decoder_layer + (cf.n_encoder_layer - 1 - l), false));
+        }
+    } else
     for (int l = cf.n_encoder_layer - 1; l >= 0; --l) {
         const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lna = p + "attn_layer_norms." + std::to_string(l);
         nd = make_drop(pt, c->seed, c->self_attn[l].op_res);
@@ -1750,7 +1902,13 @@ extern "C" int b2s_model_backward_abort(b2s_model* m, void* stream) {
     m->ln_jobs.n = 0;
     m->pending_stages.clear(); m->unflushed_stages.clear();
     m->pending_ev = nullptr;
+    m->dw_hold_from = -1; m->dw_tail_cap = 0; m->dw_flush_capped = false;      // (a decoder backward that failed mid-call leaves its tail policy set)
     if (m->aux) { m->aux_dirty = true; B2S_TRY(join_aux(m, S_(stream))); }
+    return 0;
+}
+extern "C" int b2s_model_set_grad_slot_padding(b2s_model* m, int bytes) {
+    B2S_CHECK(m && bytes >= 0 && bytes <= 4096, "grad slot padding must be 0..4096 bytes");
+    m->grad_pad_bytes = (size_t)bytes;
     return 0;
 }
 extern "C" int b2s_zero_grads(b2s_model* m, void* stream) {
@@ -1768,9 +1926,11 @@ extern "C" int b2s_zero_grads(b2s_model* m, void* stream) {
     while (i < r.size()) {
         char* lo = r[i].first; char* hi = lo + r[i].second;
         size_t j = i + 1;
-        // (gaps of up to 256 bytes are alignment padding between the slots of one flat buffer -- or the tail padding of separate device
-        // allocations, which are 256-byte granular: cleared along)
-        while (j < r.size() && r[j].first <= hi + 256) { hi = std::max(hi, r[j].first + r[j].second); ++j; }
+        // Gaps between gradient ranges are bridged only when the caller declared them padding of ONE flat buffer
+        // (b2s_model_set_grad_slot_padding: the engine's own 256-byte slots).  Separately bound gradient tensors -- views into a larger
+        // buffer with live data in between, sub-allocations of a custom allocator -- are cleared range by range.
+        const size_t bridge = m->grad_pad_bytes;
+        while (j < r.size() && r[j].first <= hi + bridge) { hi = std::max(hi, r[j].first + r[j].second); ++j; }
         B2S_HIP(hipMemsetAsync(lo, 0, (size_t)(hi - lo), S_(stream)));
         i = j;
     }

@@ -219,6 +219,10 @@ int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta1, float be
 /* Zero every bound parameter gradient.  Every *_backward entry point ACCUMULATES into the bound gradient
  * buffers (several use atomics), so the host calls this once at the start of each backward pass. */
 int b2s_zero_grads(b2s_model* m, void* stream);
+/* Gradient tensors bound as slots of ONE flat buffer with up to `bytes` of alignment padding between them (the Python engine: 256):
+ * b2s_zero_grads then clears the padding along with the slots (one memset).  Default 0: separately bound gradient tensors are cleared
+ * range by range and nothing between them is touched. */
+int b2s_model_set_grad_slot_padding(b2s_model* m, int bytes);
 
 /* ---- op level (used by the standalone modules and the op parity tests) --------------------------- */
 /* C[M,N] = A * B^T style GEMM family; see csrc/gemm.h.  dtype operands are fp32 or raw bf16. */
@@ -289,6 +293,35 @@ int b2s_dropout_mask(float p, uint64_t seed, uint32_t op_id, uint8_t* out, int64
  * out[v*3 + {0,1,2}] = flops, milliseconds, launches for v < n_variants. */
 void b2s_prof_enable(int on);
 int b2s_prof_collect(double* out, int n_variants);
+
+/* ---- fused encoder sublayer kernels, op level (csrc/enc_fused.h).  bf16 compute mode, the default encoder dims (hidden 512, 8 heads of 64,
+ * FFN 2048) and S <= 128 rows per utterance; M = B * S token rows, utterance b = rows [b*S, (b+1)*S).  The engine's encoder forward /
+ * backward (b2s_encoder_forward / _backward) launches exactly these per sublayer; the entry points exist for the parity tests.
+ * Reference: transformer/modules.py:49-69 (TransformerEncoder.forward), transformer/attention.py:53-122, transformer/modules.py:8-20.
+ * slabs: [ns][M][512] PARTIAL sublayer outputs (fp32, or bf16 when slab_bf16), one per head (ns = 8) or hidden slice of 128 (ns = 16);
+ * the reduce + LayerNorm kernels sum them in slab order. */
+/* MultiheadAttention.forward minus the residual: slabs[h] = (softmax(q_h k_h^T / 8 + key mask) v_h) Wo[:, h*64:(h+1)*64]^T ; also writes the
+ * head-interleaved qkv [M,1536], ctx [M,512] (bf16) and the log-sum-exp rows [B*8, S] the backward needs. */
+int b2s_encf_attention_forward(const void* hN, const void* Wqkv, const void* Wo, const int32_t* klen, int B, int S, float drop_p, uint64_t seed,
+                               uint32_t op_id, void* qkv, void* ctx, float* lse, void* slabs, int slab_bf16, void* stream);
+/* its backward w.r.t. hN (partial slabs) and the d[q k v] operand [M,1536] of the weight-gradient GEMM; WoT / WqkvT: transposed bf16 weights */
+int b2s_encf_attention_backward(const void* dY, const void* qkv, const void* ctx, const float* lse, const void* WoT, const void* WqkvT,
+                                const int32_t* klen, int B, int S, float drop_p, uint64_t seed, uint32_t op_id, void* dqkv, void* slabs, int slab_bf16,
+                                void* stream);
+/* FFNLayer minus the residual.  backward = 0: slabs[j] = dropout(relu(X W1[j]^T)) W2[:, j]^T, f_io <- the hidden activations [M,2048];
+ * backward = 1: X = dY, Wa = W2^T, Wb = W1^T, f_io = the saved activations (ReLU / dropout mask), dz <- d hidden [M,2048], slabs[j] = partial d LN output */
+int b2s_encf_ffn_sublayer(int backward, const void* X, const void* Wa, const void* Wb, void* f_io, void* dz, int B, int S, float drop_p, uint64_t seed,
+                          uint32_t op_id, void* slabs, int slab_bf16, void* stream);
+/* x_out = x_in + dropout(sum_s slabs[s]); h = LayerNorm(x_out) (bf16 [M,512] and / or fp32 with leading dimension ldh32); mean / rstd rows */
+int b2s_encf_reduce_layernorm_forward(const float* x_in, const void* slabs, int ns, int slab_bf16, float drop_p, uint64_t seed, uint32_t op_id,
+                                      const float* gamma, const float* beta, float* x_out, void* h, float* h32, int ldh32, float* mean, float* rstd,
+                                      int M, void* stream);
+/* dx += LayerNorm'(sum_s slabs[s]); dgamma / dbeta += (caller zeroes); dy2 (optional) = bf16(dropout(dx)); ws: 768 * 1024 floats of scratch */
+int b2s_encf_reduce_layernorm_backward(const void* slabs, int ns, int slab_bf16, const float* x_in, const float* gamma, const float* mean,
+                                       const float* rstd, float* dx, float* dgamma, float* dbeta, float* ws, void* dy2, float drop_p, uint64_t seed,
+                                       uint32_t op_id, int M, void* stream);
+/* dst[C][R] = src[R][C]^T (bf16, R and C multiples of 64): the transposed weight copies of the fused backward kernels */
+int b2s_transpose_bf16(const void* src, void* dst, int R, int C, void* stream);
 
 #ifdef __cplusplus
 }

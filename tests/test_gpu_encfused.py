@@ -1,0 +1,236 @@
+"""Op-level parity of the fused encoder sublayer kernels (csrc/enc_fused.hip, through the C ABI) against plain torch float64 math on the same
+bf16-rounded operands.  Reference semantics: transformer/modules.py:49-69, transformer/attention.py:53-122, transformer/modules.py:8-20.
+
+Row counts cover S = 114 (the LJ-typical batch), 128 (a full tile), 50 / 17 (less than one 64-row granule; not a multiple of 16) and ragged
+key lengths; dropout masks are replayed from the counter RNG (b2s_dropout_mask) with the index convention of the unfused kernels.
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, report  # noqa: E402
+
+D, H, DH, F, HS = 512, 8, 64, 2048, 128
+TOL = 1.5e-2          # bf16 operands: outputs are rounded to bf16 (8 bits), intermediate tiles (q k v, P, ctx, f, dz, dq dk dv) as well
+
+
+def _lib():
+    from b2s_hip import lib as L
+    return L, L.load()
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+def _mask(lib, L, p, seed, op, n):
+    m = torch.empty(n, dtype=torch.uint8, device=DEV)
+    L.check(lib.b2s_dropout_mask(p, seed, op, m.data_ptr(), n, None))
+    return m.bool()
+
+
+def _slab_view(slabs, ns, M, bf16):
+    return (slabs.view(torch.bfloat16) if bf16 else slabs).view(ns, M, D).double()
+
+
+def _alloc_slabs(ns, M, bf16):
+    return torch.full((ns * M * D,), float("nan"), dtype=torch.bfloat16 if bf16 else torch.float32, device=DEV)
+
+
+CASES = [(3, 114, [114, 77, 5]), (2, 128, [128, 64]), (3, 50, [50, 33, 1]), (2, 17, [17, 9]), (14, 114, None)]
+
+
+def _lens(B, S, kl):
+    if kl is None:
+        g = torch.Generator().manual_seed(B * 100 + S)
+        kl = [int(x) for x in torch.randint(S // 2, S + 1, (B,), generator=g)]
+        kl[0] = S
+    return torch.tensor(kl, dtype=torch.int32, device=DEV)
+
+
+def _attn_ref(h, Wqkv, Wo, klen, B, S, keep, scale_d):
+    """float64 reference of the fused attention sublayer; returns per-head slabs [8][M][512], qkv, ctx, lse."""
+    qkv = _bf(h.double() @ Wqkv.double().t()).double()                     # the kernel keeps q / k / v in bf16
+    q, k, v = (qkv[:, i * D:(i + 1) * D].view(B, S, H, DH).permute(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(-1, -2) * 0.125
+    km = torch.arange(S, device=DEV)[None, :] >= klen[:, None].long()          # [B, S] masked keys
+    s = s.masked_fill(km[:, None, None, :], float("-inf"))
+    lse = torch.logsumexp(s, -1)
+    P = torch.exp(s - lse[..., None])
+    Pd = P * keep.view(B, H, S, S).double() * scale_d
+    ctx = (Pd @ v).permute(0, 2, 1, 3).reshape(B * S, D)
+    ctxb = _bf(ctx).double()
+    slabs = torch.stack([ctxb[:, hh * DH:(hh + 1) * DH] @ Wo.double()[:, hh * DH:(hh + 1) * DH].t() for hh in range(H)])
+    return slabs, qkv, ctx, lse
+
+
+@pytest.mark.parametrize("slab_bf16", [0, 1])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("B,S,kl", CASES)
+def test_fused_attention_forward_backward(B, S, kl, p, slab_bf16):
+    L, lib = _lib()
+    M = B * S
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + S)
+    klen = _lens(B, S, kl)
+    h = _bf(torch.randn(M, D, generator=g, device=DEV))
+    Wqkv = _bf(torch.randn(3 * D, D, generator=g, device=DEV) * 0.06)
+    Wo = _bf(torch.randn(D, D, generator=g, device=DEV) * 0.05)
+    seed, op = 1234567, 77
+    qkv = torch.full((M, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ctx = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse = torch.full((B * H, S), float("nan"), dtype=torch.float32, device=DEV)
+    slabs = _alloc_slabs(H, M, slab_bf16)
+    L.check(lib.b2s_encf_attention_forward(h.data_ptr(), Wqkv.data_ptr(), Wo.data_ptr(), klen.data_ptr(), B, S, p, seed, op, qkv.data_ptr(),
+                                           ctx.data_ptr(), lse.data_ptr(), slabs.data_ptr(), slab_bf16, None))
+    torch.cuda.synchronize()
+    keep = _mask(lib, L, p, seed, op, B * H * S * S)
+    sd = 1.0 / (1.0 - p)
+    r_slabs, r_qkv, r_ctx, r_lse = _attn_ref(h, Wqkv, Wo, klen, B, S, keep, sd)
+    assert _rel(qkv, r_qkv) < TOL, report("qkv", qkv.cpu(), r_qkv.cpu())
+    assert float((lse.double() - r_lse.view(B * H, S)).abs().max()) < 2e-2, "lse"
+    assert _rel(ctx, r_ctx) < TOL, report("ctx", ctx.cpu(), r_ctx.cpu())
+    got = _slab_view(slabs, H, M, slab_bf16)
+    assert torch.isfinite(got).all()
+    assert _rel(got, r_slabs) < TOL, report("slabs", got.cpu(), r_slabs.cpu())
+    assert _rel(got.sum(0), r_slabs.sum(0)) < TOL
+
+    # ---- backward on the kernel's own saved tensors
+    dY = _bf(torch.randn(M, D, generator=g, device=DEV))
+    WoT = Wo.t().contiguous()
+    WqkvT = Wqkv.t().contiguous()
+    dqkv = torch.full((M, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    bslabs = _alloc_slabs(H, M, slab_bf16)
+    L.check(lib.b2s_encf_attention_backward(dY.data_ptr(), qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), WoT.data_ptr(), WqkvT.data_ptr(),
+                                            klen.data_ptr(), B, S, p, seed, op, dqkv.data_ptr(), bslabs.data_ptr(), slab_bf16, None))
+    torch.cuda.synchronize()
+    # reference: autograd through softmax(q k^T / 8) v with the same mask, from the saved (bf16) q k v
+    x = qkv.double().clone().requires_grad_(True)
+    q, k, v = (x[:, i * D:(i + 1) * D].view(B, S, H, DH).permute(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(-1, -2) * 0.125
+    km = torch.arange(S, device=DEV)[None, :] >= klen[:, None].long()
+    s = s.masked_fill(km[:, None, None, :], float("-inf"))
+    P = torch.softmax(s, -1)
+    c2 = ((P * keep.view(B, H, S, S).double() * sd) @ v).permute(0, 2, 1, 3).reshape(M, D)
+    dO = _bf(dY.double() @ Wo.double()).double()                             # the kernel holds d ctx in bf16
+    (c2 * dO).sum().backward()
+    r_dqkv = x.grad
+    assert _rel(dqkv, r_dqkv) < 2 * TOL, report("dqkv", dqkv.cpu(), r_dqkv.cpu())
+    r_b = torch.stack([sum(_bf(r_dqkv[:, i * D + hh * DH:i * D + (hh + 1) * DH]).double() @ Wqkv.double()[i * D + hh * DH:i * D + (hh + 1) * DH, :]
+                           for i in range(3)) for hh in range(H)])
+    gotb = _slab_view(bslabs, H, M, slab_bf16)
+    assert torch.isfinite(gotb).all()
+    assert _rel(gotb.sum(0), r_b.sum(0)) < 2 * TOL, report("dh", gotb.sum(0).cpu(), r_b.sum(0).cpu())
+    assert _rel(gotb, r_b) < 3 * TOL, report("dh slabs", gotb.cpu(), r_b.cpu())
+
+
+@pytest.mark.parametrize("slab_bf16", [0, 1])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("B,S", [(3, 114), (2, 128), (3, 50), (2, 17), (14, 114)])
+def test_fused_ffn_forward_backward(B, S, p, slab_bf16):
+    L, lib = _lib()
+    M = B * S
+    NS = F // HS
+    g = torch.Generator(device=DEV).manual_seed(B * 31 + S)
+    h = _bf(torch.randn(M, D, generator=g, device=DEV))
+    W1 = _bf(torch.randn(F, D, generator=g, device=DEV) * 0.05)
+    W2 = _bf(torch.randn(D, F, generator=g, device=DEV) * 0.03)
+    seed, op = 99, 5
+    f = torch.full((M, F), float("nan"), dtype=torch.bfloat16, device=DEV)
+    slabs = _alloc_slabs(NS, M, slab_bf16)
+    L.check(lib.b2s_encf_ffn_sublayer(0, h.data_ptr(), W1.data_ptr(), W2.data_ptr(), f.data_ptr(), None, B, S, p, seed, op, slabs.data_ptr(), slab_bf16, None))
+    torch.cuda.synchronize()
+    keep = _mask(lib, L, p, seed, op, M * F).view(M, F)
+    sd = 1.0 / (1.0 - p)
+    r_f = torch.relu(h.double() @ W1.double().t()) * keep.double() * sd
+    assert _rel(f, r_f) < TOL, report("f", f.cpu(), r_f.cpu())
+    fb = f.double()
+    r_slabs = torch.stack([fb[:, j * HS:(j + 1) * HS] @ W2.double()[:, j * HS:(j + 1) * HS].t() for j in range(NS)])
+    got = _slab_view(slabs, NS, M, slab_bf16)
+    assert torch.isfinite(got).all()
+    assert _rel(got, r_slabs) < TOL, report("slabs", got.cpu(), r_slabs.cpu())
+    assert _rel(got.sum(0), r_slabs.sum(0)) < TOL
+
+    dY = _bf(torch.randn(M, D, generator=g, device=DEV))
+    W2T, W1T = W2.t().contiguous(), W1.t().contiguous()
+    dz = torch.full((M, F), float("nan"), dtype=torch.bfloat16, device=DEV)
+    bslabs = _alloc_slabs(NS, M, slab_bf16)
+    L.check(lib.b2s_encf_ffn_sublayer(1, dY.data_ptr(), W2T.data_ptr(), W1T.data_ptr(), f.data_ptr(), dz.data_ptr(), B, S, p, seed, op, bslabs.data_ptr(),
+                                      slab_bf16, None))
+    torch.cuda.synchronize()
+    r_dz = (dY.double() @ W2.double()) * (fb > 0).double() * sd
+    assert _rel(dz, r_dz) < TOL, report("dz", dz.cpu(), r_dz.cpu())
+    dzb = dz.double()
+    r_b = torch.stack([dzb[:, j * HS:(j + 1) * HS] @ W1.double()[j * HS:(j + 1) * HS, :] for j in range(NS)])
+    gotb = _slab_view(bslabs, NS, M, slab_bf16)
+    assert torch.isfinite(gotb).all()
+    assert _rel(gotb, r_b) < TOL, report("dh slabs", gotb.cpu(), r_b.cpu())
+
+
+@pytest.mark.parametrize("slab_bf16", [0, 1])
+@pytest.mark.parametrize("ns", [8, 16])
+@pytest.mark.parametrize("M,p", [(1596, 0.1), (37, 0.0), (4, 0.1)])
+def test_reduce_layernorm_forward_backward(M, p, ns, slab_bf16):
+    L, lib = _lib()
+    g = torch.Generator(device=DEV).manual_seed(M + ns)
+    x_in = torch.randn(M, D, generator=g, device=DEV)
+    sl = torch.randn(ns, M, D, generator=g, device=DEV) * 0.3
+    slabs = (_bf(sl) if slab_bf16 else sl).contiguous()
+    gamma = torch.randn(D, generator=g, device=DEV) * 0.2 + 1.0
+    beta = torch.randn(D, generator=g, device=DEV) * 0.1
+    seed, op = 4242, 9
+    x_out = torch.empty(M, D, device=DEV); h = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    ld32 = 768
+    h32 = torch.zeros(M, ld32, device=DEV)
+    mean = torch.empty(M, device=DEV); rstd = torch.empty(M, device=DEV)
+    L.check(lib.b2s_encf_reduce_layernorm_forward(x_in.data_ptr(), slabs.data_ptr(), ns, slab_bf16, p, seed, op, gamma.data_ptr(), beta.data_ptr(),
+                                                  x_out.data_ptr(), h.data_ptr(), h32.data_ptr(), ld32, mean.data_ptr(), rstd.data_ptr(), M, None))
+    torch.cuda.synchronize()
+    keep = _mask(lib, L, p, seed, op, M * D).view(M, D).double()
+    ssum = slabs.double().sum(0)
+    r_x = x_in.double() + ssum * keep / (1.0 - p)
+    assert float((x_out.double() - r_x).abs().max()) < 1e-4
+    mu = r_x.mean(-1, keepdim=True); var = r_x.var(-1, unbiased=False, keepdim=True)
+    r_h = (r_x - mu) / torch.sqrt(var + 1e-6) * gamma.double() + beta.double()
+    assert float((h32[:, :D].double() - r_h).abs().max()) < 1e-4
+    assert float(h32[:, D:].abs().max()) == 0.0
+    assert _rel(h, r_h) < 1e-2
+    assert float((mean.double() - mu[:, 0]).abs().max()) < 1e-5
+    assert _rel(rstd, 1.0 / torch.sqrt(var[:, 0] + 1e-6)) < 1e-5
+
+    # backward: dx += LN'(sum slabs) with the saved statistics; dy2 = bf16(dropout(dx))
+    dx0 = torch.randn(M, D, generator=g, device=DEV)
+    dx = dx0.clone()
+    dgamma = torch.zeros(D, device=DEV); dbeta = torch.zeros(D, device=DEV)
+    ws = torch.empty(768 * 2 * D, device=DEV)
+    dy2 = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    op2 = 11
+    L.check(lib.b2s_encf_reduce_layernorm_backward(slabs.data_ptr(), ns, slab_bf16, x_out.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                   dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), dy2.data_ptr(), p, seed, op2, M, None))
+    torch.cuda.synchronize()
+    xr = x_out.double().clone().requires_grad_(True)
+    gr = gamma.double().clone().requires_grad_(True); br = beta.double().clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    (y * ssum).sum().backward()
+    r_dx = dx0.double() + xr.grad
+    assert float((dx.double() - r_dx).abs().max()) < 2e-4 * max(1.0, float(r_dx.abs().max()))
+    assert _rel(dgamma, gr.grad) < 1e-4 and _rel(dbeta, br.grad) < 1e-4
+    keep2 = _mask(lib, L, p, seed, op2, M * D).view(M, D).double()
+    assert _rel(dy2, r_dx * keep2 / (1.0 - p)) < 1e-2
+
+
+def test_transpose_bf16():
+    L, lib = _lib()
+    for R, Cc in [(1536, 512), (512, 2048), (64, 64)]:
+        src = _bf(torch.randn(R, Cc, device=DEV))
+        dst = torch.empty(Cc, R, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.b2s_transpose_bf16(src.data_ptr(), dst.data_ptr(), R, Cc, None))
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src.t().contiguous())
