@@ -122,7 +122,7 @@ _PROTOS = {
     "b2s_encf_attention_backward": (C.c_int, [P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, P, P, C.c_int, P]),
     "b2s_encf_ffn_sublayer": (C.c_int, [C.c_int, P, P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, P, C.c_int, P]),
     "b2s_encf_reduce_layernorm_forward": (C.c_int, [P, P, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, P, P, P, P, P, C.c_int, P, P, C.c_int, P]),
-    "b2s_encf_reduce_layernorm_backward": (C.c_int, [P, P, C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, C.c_float, C.c_uint64, C.c_uint32, C.c_int, P]),
+    "b2s_encf_reduce_layernorm_backward": (C.c_int, [P, C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, C.c_float, C.c_uint64, C.c_uint32, C.c_int, P]),
     "b2s_transpose_bf16": (C.c_int, [P, P, C.c_int, C.c_int, P]),
 }
 EXPORTS = sorted(_PROTOS)

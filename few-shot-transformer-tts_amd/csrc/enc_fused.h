@@ -8,7 +8,7 @@
 // and applies the next LayerNorm (forward) / the LayerNorm backward (backward).
 //
 //   forward  attention sublayer: q/k/v projection of the head (K = 512) -> 128 x 128 attention on chip -> head's columns of the output projection
-//            FFN sublayer:       ReLU(h W1[slice]^T) (dropout) -> . W2[:, slice]^T
+//            FFN sublayer:       ReLU(h W1[slice]^T) (dropout) -> . W2[:, slice]^T   (two hidden slices of 128 per workgroup)
 //   backward the same two shapes with the transposed weight copies (engine: enc_wT), so every streamed operand is K-contiguous:
 //            FFN:       dz = (dy W2[:, slice]) * relu' -> dh partial = dz W1[slice]
 //            attention: d ctx = dy Wo[:, head] -> attention backward on chip -> dh partial = [dq dk dv] Wqkv[head rows]
@@ -20,7 +20,7 @@
 #include "b2s_common.h"
 
 namespace encf {
-constexpr int D = 512, NH = 8, DH = 64, FF = 2048, HS = 128, NSF = FF / HS, MAXS = 128;
+constexpr int D = 512, NH = 8, DH = 64, FF = 2048, HS = 128, NSF = 8, MAXS = 128;      // NSF: FFN slabs (each workgroup sums 2 hidden slices of 128)
 }
 
 // slabs: [ns][M][512] partial sublayer outputs (fp32, or bf16 when slab_bf16); M = B * S token rows
@@ -55,7 +55,7 @@ struct EncfFfn {
     const bf16_t* Wb;        // [512,2048]: forward W2 (output_layer.weight); backward W1^T
     bf16_t* F;               // [M,2048]: forward OUT f = dropout(relu(.)); backward IN (the saved f: relu / dropout mask)
     bf16_t* dz;              // backward OUT [M,2048]
-    void* slabs;             // out [16][M][512]
+    void* slabs;             // out [8][M][512]
     int B, S;
     DropCfg dhid;            // forward: hidden dropout (index row*2048 + col, as the GEMM epilogue)
     float aux_scale;         // backward: 1 / (1 - p) of the hidden dropout

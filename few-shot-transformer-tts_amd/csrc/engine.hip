@@ -664,7 +664,10 @@ extern "C" int b2s_model_create(const b2s_config* cfg, b2s_model** out) {
     m->cfg = c; m->dtype = c.compute_dtype; m->esz = c.compute_dtype ? 2 : 4; m->Dm = Dm;
     {
         static const bool no_fused = getenv("B2S_ENC_FUSED") && atoi(getenv("B2S_ENC_FUSED")) == 0;            // A/B switch: the unfused encoder
-        static const int slab_bf16 = getenv("B2S_ENC_SLAB_BF16") ? atoi(getenv("B2S_ENC_SLAB_BF16")) : 0;
+        // partial sublayer outputs in bf16 (default): the 8 slabs of a sublayer are written and re-read once each -- 26 MB instead of 52 MB per
+        // sublayer and direction; the sum and the residual stream stay fp32 (same rounding point as every other bf16 operand of the step).
+        // B2S_ENC_SLAB_BF16=0: fp32 slabs.  Measured (profiles/NOTES_r04.md): 7.76 -> 7.70 ms per step
+        static const int slab_bf16 = getenv("B2S_ENC_SLAB_BF16") ? atoi(getenv("B2S_ENC_SLAB_BF16")) : 1;
         m->enc_fused = m->dtype == 1 && !no_fused && c.n_encoder_layer > 0 && c.n_encoder_layer * 4 <= 24 &&
                        b2s_encf_supported(c.encoder_hidden, c.n_attention_head, 4 * c.encoder_hidden, 1);
         m->enc_slab_bf16 = slab_bf16;
@@ -990,7 +993,8 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
             const std::string ln0 = p + "attn_layer_norms.0";
             B2S_TRY(ro_layernorm_fwd(dt, xs[0], m->P(ln0 + ".weight"), m->P(ln0 + ".bias"), c->self_attn[0].h, D, nullptr, 0, c->self_attn[0].mean,
                                      c->self_attn[0].rstd, (int)M, D, 1e-6f, nullptr, 1, st));
-            for (int l = 0; l < L; ++l) {
+            static const int lab_skip = getenv("B2S_LAB_ENC_SKIP") ? atoi(getenv("B2S_LAB_ENC_SKIP")) : 0;     // measurement aid: what would a free encoder buy?
+            for (int l = 0; l < L && !lab_skip; ++l) {
                 AttnSave& s = c->self_attn[l];
                 FfnSave& f = c->ffn[l];
                 s.op_attn = opid(1, l, 2); s.op_res = opid(1, l, 3); s.mask_mode = 1;
@@ -1223,9 +1227,21 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
             sc.dy_ready = dy2 != nullptr;
             return 0;
         };
+        static const int lab_skip = getenv("B2S_LAB_ENC_SKIP") ? atoi(getenv("B2S_LAB_ENC_SKIP")) : 0;
         for (int l = cf.n_encoder_layer - 1; l >= 0; --l) {
             const AttnSave& s = c->self_attn[l];
             const FfnSave& f = c->ffn[l];
+            if (lab_skip == 2) continue;                                                     // (no chain, no weight gradients)
+            if (lab_skip == 1) {                                                             // (weight-gradient groups only)
+                sc.dz = Scratch::rot(sc.r_dz, sc.i_dz); sc.dqkv = Scratch::rot(sc.r_dqkv, sc.i_dqkv);
+                const void* dy0 = sc.r_dyT[0];
+                B2S_TRY(linear_dw(m, st, dy0, D, f.f, 4 * D, (int)M, D, 4 * D, m->G(nm(p, "ffn_layers", l, "output_layer.weight"))));
+                B2S_TRY(linear_dw(m, st, sc.dz, 4 * D, f.h, D, (int)M, 4 * D, D, m->G(nm(p, "ffn_layers", l, "input_layer.weight"))));
+                B2S_TRY(linear_dw(m, st, dy0, D, s.ctx, D, (int)M, D, D, m->G(nm(p, "self_attentions", l, "output_transform.weight"))));
+                B2S_TRY(linear_dw(m, st, sc.dqkv, 3 * D, s.h, D, (int)M, 3 * D, D, m->G(nm(p, "self_attentions", l, "qkv_transform.weight"))));
+                B2S_TRY(end_stage(m, st, 4 + cf.n_decoder_layer + (cf.n_encoder_layer - 1 - l), false));
+                continue;
+            }
             const std::string lnf = p + "ffn_layer_norms." + std::to_string(l), lna = p + "attn_layer_norms." + std::to_string(l);
             const std::string w1 = nm(p, "ffn_layers", l, "input_layer.weight"), w2 = nm(p, "ffn_layers", l, "output_layer.weight");
             const std::string wq = nm(p, "self_attentions", l, "qkv_transform.weight"), wo = nm(p, "self_attentions", l, "output_transform.weight");

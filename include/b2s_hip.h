@@ -298,8 +298,8 @@ int b2s_prof_collect(double* out, int n_variants);
  * FFN 2048) and S <= 128 rows per utterance; M = B * S token rows, utterance b = rows [b*S, (b+1)*S).  The engine's encoder forward /
  * backward (b2s_encoder_forward / _backward) launches exactly these per sublayer; the entry points exist for the parity tests.
  * Reference: transformer/modules.py:49-69 (TransformerEncoder.forward), transformer/attention.py:53-122, transformer/modules.py:8-20.
- * slabs: [ns][M][512] PARTIAL sublayer outputs (fp32, or bf16 when slab_bf16), one per head (ns = 8) or hidden slice of 128 (ns = 16);
- * the reduce + LayerNorm kernels sum them in slab order. */
+ * slabs: [8][M][512] PARTIAL sublayer outputs (fp32, or bf16 when slab_bf16), one per head or per pair of hidden slices {j, j + 8} of 128
+ * units; the reduce + LayerNorm kernels sum them in slab order (ns = 8). */
 /* MultiheadAttention.forward minus the residual: slabs[h] = (softmax(q_h k_h^T / 8 + key mask) v_h) Wo[:, h*64:(h+1)*64]^T ; also writes the
  * head-interleaved qkv [M,1536], ctx [M,512] (bf16) and the log-sum-exp rows [B*8, S] the backward needs. */
 int b2s_encf_attention_forward(const void* hN, const void* Wqkv, const void* Wo, const int32_t* klen, int B, int S, float drop_p, uint64_t seed,
@@ -308,8 +308,9 @@ int b2s_encf_attention_forward(const void* hN, const void* Wqkv, const void* Wo,
 int b2s_encf_attention_backward(const void* dY, const void* qkv, const void* ctx, const float* lse, const void* WoT, const void* WqkvT,
                                 const int32_t* klen, int B, int S, float drop_p, uint64_t seed, uint32_t op_id, void* dqkv, void* slabs, int slab_bf16,
                                 void* stream);
-/* FFNLayer minus the residual.  backward = 0: slabs[j] = dropout(relu(X W1[j]^T)) W2[:, j]^T, f_io <- the hidden activations [M,2048];
- * backward = 1: X = dY, Wa = W2^T, Wb = W1^T, f_io = the saved activations (ReLU / dropout mask), dz <- d hidden [M,2048], slabs[j] = partial d LN output */
+/* FFNLayer minus the residual.  backward = 0: slabs[j] = sum over the hidden slices s in {j, j + 8} of dropout(relu(X W1[s]^T)) W2[:, s]^T,
+ * f_io <- the hidden activations [M,2048]; backward = 1: X = dY, Wa = W2^T, Wb = W1^T, f_io = the saved activations (ReLU / dropout
+ * mask), dz <- d hidden [M,2048], slabs[j] = partial d LN output */
 int b2s_encf_ffn_sublayer(int backward, const void* X, const void* Wa, const void* Wb, void* f_io, void* dz, int B, int S, float drop_p, uint64_t seed,
                           uint32_t op_id, void* slabs, int slab_bf16, void* stream);
 /* x_out = x_in + dropout(sum_s slabs[s]); h = LayerNorm(x_out) (bf16 [M,512] and / or fp32 with leading dimension ldh32); mean / rstd rows */

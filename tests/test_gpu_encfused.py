@@ -137,7 +137,7 @@ def test_fused_attention_forward_backward(B, S, kl, p, slab_bf16):
 def test_fused_ffn_forward_backward(B, S, p, slab_bf16):
     L, lib = _lib()
     M = B * S
-    NS = F // HS
+    NS = 8                                   # slab j = hidden slices j and j + 8 (128 units each)
     g = torch.Generator(device=DEV).manual_seed(B * 31 + S)
     h = _bf(torch.randn(M, D, generator=g, device=DEV))
     W1 = _bf(torch.randn(F, D, generator=g, device=DEV) * 0.05)
@@ -152,7 +152,8 @@ def test_fused_ffn_forward_backward(B, S, p, slab_bf16):
     r_f = torch.relu(h.double() @ W1.double().t()) * keep.double() * sd
     assert _rel(f, r_f) < TOL, report("f", f.cpu(), r_f.cpu())
     fb = f.double()
-    r_slabs = torch.stack([fb[:, j * HS:(j + 1) * HS] @ W2.double()[:, j * HS:(j + 1) * HS].t() for j in range(NS)])
+    sl = lambda j: slice(j * HS, (j + 1) * HS)
+    r_slabs = torch.stack([fb[:, sl(j)] @ W2.double()[:, sl(j)].t() + fb[:, sl(j + 8)] @ W2.double()[:, sl(j + 8)].t() for j in range(NS)])
     got = _slab_view(slabs, NS, M, slab_bf16)
     assert torch.isfinite(got).all()
     assert _rel(got, r_slabs) < TOL, report("slabs", got.cpu(), r_slabs.cpu())
@@ -168,14 +169,14 @@ def test_fused_ffn_forward_backward(B, S, p, slab_bf16):
     r_dz = (dY.double() @ W2.double()) * (fb > 0).double() * sd
     assert _rel(dz, r_dz) < TOL, report("dz", dz.cpu(), r_dz.cpu())
     dzb = dz.double()
-    r_b = torch.stack([dzb[:, j * HS:(j + 1) * HS] @ W1.double()[j * HS:(j + 1) * HS, :] for j in range(NS)])
+    r_b = torch.stack([dzb[:, sl(j)] @ W1.double()[sl(j), :] + dzb[:, sl(j + 8)] @ W1.double()[sl(j + 8), :] for j in range(NS)])
     gotb = _slab_view(bslabs, NS, M, slab_bf16)
     assert torch.isfinite(gotb).all()
     assert _rel(gotb, r_b) < TOL, report("dh slabs", gotb.cpu(), r_b.cpu())
 
 
 @pytest.mark.parametrize("slab_bf16", [0, 1])
-@pytest.mark.parametrize("ns", [8, 16])
+@pytest.mark.parametrize("ns", [8])
 @pytest.mark.parametrize("M,p", [(1596, 0.1), (37, 0.0), (4, 0.1)])
 def test_reduce_layernorm_forward_backward(M, p, ns, slab_bf16):
     L, lib = _lib()
