@@ -71,7 +71,7 @@ int b2s_encf_reduce_ln_fwd(const float* x_in, const void* slabs, int ns, int sla
 // dx += LN'(sum_s slabs[s]) ; partial d gamma / d beta rows -> ws [nblk][2*512] (reduced later: ro_ln_param_reduce_batch) ;
 // dy2 (optional) = bf16(dropout(dx)) for the sublayer that runs next in the backward pass
 int b2s_encf_reduce_ln_bwd(const void* slabs, int ns, int slab_bf16, const float* x_in, const float* gamma, const float* mean, const float* rstd,
-                           float* dx, float* ws, int* nblk, bf16_t* dy2, DropCfg drop2, int M, hipStream_t st);
+                           float* dx, float* ws, int* nblk, bf16_t* dy2, DropCfg drop2, int M, hipStream_t st, int dx_bf16 = 0);     // dx_bf16: dx holds bf16
 // dst[c][r] = src[r][c] for n matrices in one launch (bf16)
 struct EncfTransposeJob { const bf16_t* src; bf16_t* dst; int R, C; };
 int b2s_encf_transpose(const EncfTransposeJob* jobs, int n, hipStream_t st);

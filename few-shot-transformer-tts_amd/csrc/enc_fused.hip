@@ -851,8 +851,8 @@ __global__ __launch_bounds__(256) void k_encf_rl_fwd(const float* __restrict__ x
 // LayerNorm backward with dy = sum_s slab_s (rowops.hip: k_ln_bwd_fast with the slab sum as its first input): dx += LN'(dy), optional
 // bf16(dropout(dx)) for the next sublayer of the backward pass, partial d gamma / d beta rows into ws (one row of 2*512 per workgroup)
 template <int NS> struct RlRow { float4 d[2], xv[2], pv[2]; float mu, rs; };
-template <typename ST, int NS>
-__device__ __forceinline__ void rl_row_load(RlRow<NS>& r, const ST* __restrict__ slabs, long slab_stride, const float* __restrict__ x, const float* dx,
+template <typename ST, int NS, typename TX>
+__device__ __forceinline__ void rl_row_load(RlRow<NS>& r, const ST* __restrict__ slabs, long slab_stride, const float* __restrict__ x, const TX* dx,
                                             const float* __restrict__ mean, const float* __restrict__ rstd, int row, int lane) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -869,9 +869,9 @@ __device__ __forceinline__ void rl_row_load(RlRow<NS>& r, const ST* __restrict__
     }
     r.mu = mean[row]; r.rs = rstd[row];
 }
-template <typename ST, int NS, bool DY2>
+template <typename ST, int NS, bool DY2, typename TX>
 __global__ __launch_bounds__(256) void k_encf_rl_bwd(const ST* __restrict__ slabs, long slab_stride, const float* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ mean, const float* __restrict__ rstd, float* dx, int M, float* __restrict__ ws,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, TX* dx, int M, float* __restrict__ ws,
                                                      bf16_t* __restrict__ dy2, DropCfg drop2) {
     __shared__ float sacc[4 * 2 * D];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -881,9 +881,9 @@ __global__ __launch_bounds__(256) void k_encf_rl_bwd(const ST* __restrict__ slab
     const int nw = gridDim.x * 4;
     int row = blockIdx.x * 4 + wave;
     RlRow<NS> cur, nxt;
-    rl_row_load<ST, NS>(cur, slabs, slab_stride, x, dx, mean, rstd, min(row, M - 1), lane);
+    rl_row_load<ST, NS, TX>(cur, slabs, slab_stride, x, dx, mean, rstd, min(row, M - 1), lane);
     for (; row < M; row += nw) {
-        rl_row_load<ST, NS>(nxt, slabs, slab_stride, x, dx, mean, rstd, min(row + nw, M - 1), lane);
+        rl_row_load<ST, NS, TX>(nxt, slabs, slab_stride, x, dx, mean, rstd, min(row + nw, M - 1), lane);
         const float mu = cur.mu, rs = cur.rs;
         float4 g[2], xh[2];
         float s1 = 0.f, s2 = 0.f;
@@ -1008,14 +1008,16 @@ int b2s_encf_reduce_ln_fwd(const float* x_in, const void* slabs, int ns, int sla
     return 0;
 }
 int b2s_encf_reduce_ln_bwd(const void* slabs, int ns, int slab_bf16, const float* x_in, const float* gamma, const float* mean, const float* rstd,
-                           float* dx, float* ws, int* nblk, bf16_t* dy2, DropCfg drop2, int M, hipStream_t st) {
+                           float* dx, float* ws, int* nblk, bf16_t* dy2, DropCfg drop2, int M, hipStream_t st, int dx_bf16) {
     using namespace encf;
     B2S_CHECK(slabs && x_in && gamma && mean && rstd && dx && ws && nblk && M > 0 && (ns == NH || ns == NSF), "fused reduce + LayerNorm backward: bad argument");
     const int grid = std::max(1, std::min(cdiv(M, 12), 768));          // (= rowops: ~3 rows per wave, at most RO_LN_WS_ROWS partial rows)
     const long ss = (long)M * D;
-#define B2S_RLB(T, NS_) do { if (dy2) hipLaunchKernelGGL((k_encf_rl_bwd<T, NS_, true>), dim3(grid), dim3(256), 0, st, (const T*)slabs, ss, x_in, gamma, mean, rstd, dx, M, ws, dy2, drop2); \
-                             else hipLaunchKernelGGL((k_encf_rl_bwd<T, NS_, false>), dim3(grid), dim3(256), 0, st, (const T*)slabs, ss, x_in, gamma, mean, rstd, dx, M, ws, dy2, drop2); } while (0)
+#define B2S_RLB2(T, NS_, DY, TX_) hipLaunchKernelGGL((k_encf_rl_bwd<T, NS_, DY, TX_>), dim3(grid), dim3(256), 0, st, (const T*)slabs, ss, x_in, gamma, mean, rstd, (TX_*)dx, M, ws, dy2, drop2)
+#define B2S_RLB(T, NS_) do { if (dy2) { if (dx_bf16) B2S_RLB2(T, NS_, true, bf16_t); else B2S_RLB2(T, NS_, true, float); } \
+                             else { if (dx_bf16) B2S_RLB2(T, NS_, false, bf16_t); else B2S_RLB2(T, NS_, false, float); } } while (0)
     if (slab_bf16) B2S_RLB(bf16_t, 8); else B2S_RLB(float, 8);
+#undef B2S_RLB2
 #undef B2S_RLB
     B2S_LAUNCH_CHECK();
     *nblk = grid;

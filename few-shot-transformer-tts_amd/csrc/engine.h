@@ -158,6 +158,10 @@ struct b2s_model {
     // ordered before the encoder backward through enc_wT_ev.
     bool enc_fused = false;
     int enc_slab_bf16 = 0;
+    // bf16 mode, hidden sizes 512 / 768: the residual gradient that the LayerNorm backward kernels read, add to and write back (3 per decoder
+    // layer, 2 per encoder layer) is held in bf16 -- 12 instead of 16 bytes per element and launch for kernels that run at the rate of their
+    // read / write mix (B2S_DX_BF16=0: fp32)
+    int dx_bf16 = 0;
     std::vector<void*> enc_wT;
     mutable hipEvent_t enc_wT_ev = nullptr;
     mutable LnReduceBatch ln_jobs = {};                       // LayerNorm parameter-gradient reductions queued for the stage's single launch

@@ -671,6 +671,9 @@ extern "C" int b2s_model_create(const b2s_config* cfg, b2s_model** out) {
         m->enc_fused = m->dtype == 1 && !no_fused && c.n_encoder_layer > 0 && c.n_encoder_layer * 4 <= 24 &&
                        b2s_encf_supported(c.encoder_hidden, c.n_attention_head, 4 * c.encoder_hidden, 1);
         m->enc_slab_bf16 = slab_bf16;
+        static const bool no_dx16 = getenv("B2S_DX_BF16") && atoi(getenv("B2S_DX_BF16")) == 0;
+        auto fast_ln = [](int d) { return d == 512 || d == 768; };
+        m->dx_bf16 = m->dtype == 1 && !no_dx16 && !getenv("B2S_LN_GENERIC") && fast_ln(c.encoder_hidden) && fast_ln(c.decoder_hidden);
     }
     build_layout(m);
     const size_t n = m->tinfo.size();
@@ -1091,6 +1094,7 @@ int take_dy(b2s_model* m, hipStream_t st, Scratch& sc, long M, int D, const Drop
     *dy = sc.dx;
     sc.dyT = Scratch::rot(sc.r_dyT, sc.i_dyT);
     B2S_TRY(guard_write(m, sc.dyT, st));
+    B2S_CHECK(!m->dx_bf16, "internal: a bf16 residual gradient always comes with the next sublayer's dY operand");
     if (m->dtype || dres.thresh) { B2S_TRY(ro_cast_drop(m->dtype, sc.dx, D, sc.dyT, D, (int)M, D, dres, st)); *dy = sc.dyT; }
     return 0;
 }
@@ -1115,7 +1119,7 @@ int ln_bwd_exit(b2s_model* m, hipStream_t st, Scratch& sc, const void* dh, int d
     LnReduceJob& jb = m->ln_jobs.j[m->ln_jobs.n];
     jb.ws = m->dw_group ? sc.r_lnws[(size_t)sc.i_lnws++ % sc.r_lnws.size()] : sc.r_lnws[m->ln_jobs.n]; jb.D = D; jb.dgamma = m->G(lnp + ".weight"); jb.dbeta = m->G(lnp + ".bias");
     B2S_TRY(ro_layernorm_bwd(m->dtype, dh, dh_fp32, lddh, x_in, m->P(lnp + ".weight"), mean, rstd, sc.dx, accumulate,
-                             jb.dgamma, jb.dbeta, (int)M, D, row_len, rpb, st, const_cast<float*>(jb.ws), dy2, nd, &jb.nblk));
+                             jb.dgamma, jb.dbeta, (int)M, D, row_len, rpb, st, const_cast<float*>(jb.ws), dy2, nd, &jb.nblk, m->dx_bf16));
     ++m->ln_jobs.n;
     sc.dy_ready = dy2 != nullptr;
     return 0;
@@ -1222,7 +1226,7 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
             jb.ws = m->dw_group ? sc.r_lnws[(size_t)sc.i_lnws++ % sc.r_lnws.size()] : sc.r_lnws[m->ln_jobs.n];
             jb.D = D; jb.dgamma = m->G(lnp + ".weight"); jb.dbeta = m->G(lnp + ".bias");
             B2S_TRY(b2s_encf_reduce_ln_bwd(sc.slabs, ns, sb, x_in, m->P(lnp + ".weight"), mean, rstd, sc.dx, const_cast<float*>(jb.ws), &jb.nblk, dy2, ndc,
-                                           (int)M, st));
+                                           (int)M, st, m->dx_bf16));
             ++m->ln_jobs.n;
             sc.dy_ready = dy2 != nullptr;
             return 0;
@@ -1285,7 +1289,7 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
         B2S_TRY(end_stage(m, st, 4 + cf.n_decoder_layer + (cf.n_encoder_layer - 1 - l), false));
     }
     B2S_TRY(ro_embed_prep_bwd(sc.dx, (const long*)c->ids, c->in_len, m->pe_enc, m->G("encoder.embed.weight"), m->G(p + "pe_scale"),
-                              B, S, D, make_drop(pt, c->seed, opid(1, 0, 1)), st));
+                              B, S, D, make_drop(pt, c->seed, opid(1, 0, 1)), st, m->dx_bf16));
     B2S_TRY(end_stage(m, st, 4 + cf.n_decoder_layer + cf.n_encoder_layer, true));
     return 0;
 }
@@ -1568,7 +1572,7 @@ extern "C" int b2s_decoder_backward_ev(b2s_model* m, b2s_ctx* c, const float* d_
         B2S_TRY(end_stage(m, st, 2 + (cf.n_decoder_layer - 1 - l), false));
     }
     B2S_TRY(finish_dmem());                                  // (no decoder layers)
-    B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, opid(2, 0, 3)), st));
+    B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, opid(2, 0, 3)), st, m->dx_bf16));
     // prenet backward
     DropCfg d1 = make_drop(pd, c->seed, opid(2, 0, 1)), d2 = make_drop(pd, c->seed, opid(2, 0, 2));
     B2S_TRY(linear_dw(m, st, sc.da3, D, c->a2, HP, (int)M, D, HP, m->G("decoder.prenet.dense_final.weight")));

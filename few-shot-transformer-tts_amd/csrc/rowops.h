@@ -8,7 +8,7 @@
 int ro_embed_prep_fwd(const long* ids, const int* lens, const float* embed, const float* pe, const float* pe_scale,
                       float* x, int B, int S, int D, DropCfg drop, hipStream_t st);
 int ro_embed_prep_bwd(const float* dx, const long* ids, const int* lens, const float* pe, float* d_embed,
-                      float* d_pe_scale, int B, int S, int D, DropCfg drop, hipStream_t st);
+                      float* d_pe_scale, int B, int S, int D, DropCfg drop, hipStream_t st, int dx_bf16 = 0);      // dx_bf16: dx holds bf16
 
 // y = LN(x) (eps), rows of width D; y (T) with leading dim ldy; optional fp32 copy y32 (ld ldy32);
 // optional row mask (rows t >= row_len[b] -> 0)                                    (modules.py:36-47,88-106)
@@ -19,7 +19,8 @@ int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float*
 int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const float* x, const float* gamma,
                      const float* mean, const float* rstd, float* dx, int accumulate, float* dgamma, float* dbeta,
                      int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws = nullptr,
-                     void* dy2 = nullptr, DropCfg drop2 = DropCfg{0, 0, 1.f}, int* defer_nblk = nullptr);
+                     void* dy2 = nullptr, DropCfg drop2 = DropCfg{0, 0, 1.f}, int* defer_nblk = nullptr, int dx_bf16 = 0);
+// dx_bf16: the residual gradient dx is held in bf16 (D = 512 / 768 only)
 // ws (optional): RO_LN_WS_ROWS * 2 * D floats of scratch for the parameter-gradient partials (avoids global atomics)
 // defer_nblk (with ws): the partial-sum reduction into dgamma / dbeta is NOT launched; *defer_nblk receives the number of
 // partial rows and the caller reduces several LayerNorms' partials in one launch (ro_ln_param_reduce_batch)
@@ -51,7 +52,7 @@ int ro_cast_back(int dtype, const void* in, float* out, long n, hipStream_t st);
 int ro_shift_pe_fwd(const float* a, const int* lens, const float* pe, const float* pe_scale, float* x, int B, int T,
                     int D, DropCfg drop, hipStream_t st);
 int ro_shift_pe_bwd(int dtype, const float* dx, const int* lens, const float* pe, void* da, float* d_pe_scale, int B,
-                    int T, int D, DropCfg drop, hipStream_t st);
+                    int T, int D, DropCfg drop, hipStream_t st, int dx_bf16 = 0);
 
 // speaker / language embeddings (tacotron.py:21-31), written into memory[:, :, col0 : col0+E] for all S
 int ro_spk_embed_fwd(const long* spk_ids, const float* table, const float* W, const float* b, float* e_raw,

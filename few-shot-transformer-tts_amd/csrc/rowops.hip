@@ -55,7 +55,8 @@ __global__ void k_embed_prep_fwd(const long* ids, const int* lens, const float* 
         st4(x + (long)row * D + c, drop4(v, drop, (uint32_t)((long)row * D + c)));
     }
 }
-__global__ void k_embed_prep_bwd(const float* dx, const long* ids, const int* lens, const float* pe, float* d_embed,
+template <typename TX>
+__global__ void k_embed_prep_bwd(const TX* dx, const long* ids, const int* lens, const float* pe, float* d_embed,
                                  float* d_pe_scale, int S, int D, DropCfg drop) {
     __shared__ float sh[4];
     const int row = blockIdx.x, b = row / S, s = row - b * S;
@@ -200,8 +201,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const TD* dy, int lddy, const fl
 // branch around its loads, and hipcc waits vmcnt(0) at the join of every such block -- a row became ~8 dependent memory round trips.
 // Here a wave issues all loads of its NEXT row before it reduces the current one (two rows in flight per wave).
 template <int NCH> struct LnRow { float4 d[NCH], xv[NCH], pv[NCH]; float mu, rs; };
-template <typename TD, int NCH, bool ACC>
-__device__ __forceinline__ void ln_row_load(LnRow<NCH>& r, const TD* __restrict__ dy, int lddy, const float* __restrict__ x, const float* dx,
+template <typename TD, int NCH, bool ACC, typename TX>
+__device__ __forceinline__ void ln_row_load(LnRow<NCH>& r, const TD* __restrict__ dy, int lddy, const float* __restrict__ x, const TX* dx,
                                             const float* __restrict__ mean, const float* __restrict__ rstd, int row, int lane) {
     constexpr int D = NCH * 256;
 #pragma unroll
@@ -216,9 +217,11 @@ __device__ __forceinline__ void ln_row_load(LnRow<NCH>& r, const TD* __restrict_
 #ifndef B2S_LN_BWD_WAVES
 #define B2S_LN_BWD_WAVES 3      // waves per SIMD the backward kernel is compiled for (4 = 128 VGPRs spills 12 dwords: 8.59 vs 8.50 ms per step)
 #endif
-template <typename TD, int NCH, bool ACC, bool DY2>
+// TX: type of the residual gradient dx (fp32, or bf16: 12 instead of 16 bytes per element and launch -- the kernel runs at the rate of
+// its read / write mix, tools/mix_lab.hip)
+template <typename TD, int NCH, bool ACC, bool DY2, typename TX>
 __global__ __launch_bounds__(256, B2S_LN_BWD_WAVES) void k_ln_bwd_fast(const TD* __restrict__ dy, int lddy, const float* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ mean, const float* __restrict__ rstd, float* dx, int M,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, TX* dx, int M,
                                                      const int* __restrict__ row_len, int rpb, float* __restrict__ ws, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, bf16_t* __restrict__ dy2, DropCfg drop2) {
     constexpr int D = NCH * 256;
@@ -230,9 +233,9 @@ __global__ __launch_bounds__(256, B2S_LN_BWD_WAVES) void k_ln_bwd_fast(const TD*
     const int nw = gridDim.x * 4;
     int row = blockIdx.x * 4 + wave;
     LnRow<NCH> cur, nxt;
-    ln_row_load<TD, NCH, ACC>(cur, dy, lddy, x, dx, mean, rstd, min(row, M - 1), lane);
+    ln_row_load<TD, NCH, ACC, TX>(cur, dy, lddy, x, dx, mean, rstd, min(row, M - 1), lane);
     for (; row < M; row += nw) {
-        ln_row_load<TD, NCH, ACC>(nxt, dy, lddy, x, dx, mean, rstd, min(row + nw, M - 1), lane);      // (past the end: the last row again, unused)
+        ln_row_load<TD, NCH, ACC, TX>(nxt, dy, lddy, x, dx, mean, rstd, min(row + nw, M - 1), lane);      // (past the end: the last row again, unused)
         bool zero = false;
         if (row_len) { const int b = row / rpb; zero = (row - b * rpb) >= row_len[b]; }
         const float mu = cur.mu, rs = cur.rs;
@@ -478,8 +481,8 @@ __global__ void k_shift_pe_fwd(const float* a, const int* lens, const float* pe,
         st4(x + (long)row * D + c, drop4(v, drop, (uint32_t)((long)row * D + c)));
     }
 }
-template <typename T_>
-__global__ __launch_bounds__(512) void k_shift_pe_bwd(const float* dx, const int* lens, const float* pe, T_* da, float* d_pe_scale, int T,
+template <typename T_, typename TX>
+__global__ __launch_bounds__(512) void k_shift_pe_bwd(const TX* dx, const int* lens, const float* pe, T_* da, float* d_pe_scale, int T,
                                                       int D, DropCfg drop, int rows) {
     // A wave takes two rows per pass (every load of both issued before the first is used).  At most 256 workgroups: the kernel ends
     // with one float atomic per workgroup on d_pe_scale, and same-address atomics retire at ~7 ns each (2048 workgroups: 35 us of
@@ -1202,8 +1205,9 @@ int ro_embed_prep_fwd(const long* ids, const int* lens, const float* embed, cons
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_embed_prep_bwd(const float* dx, const long* ids, const int* lens, const float* pe, float* d_embed,
-                      float* d_pe_scale, int B, int S, int D, DropCfg drop, hipStream_t st) {
-    hipLaunchKernelGGL(k_embed_prep_bwd, dim3(B * S), dim3(128), 0, st, dx, ids, lens, pe, d_embed, d_pe_scale, S, D, drop);
+                      float* d_pe_scale, int B, int S, int D, DropCfg drop, hipStream_t st, int dx_bf16) {
+    if (dx_bf16) hipLaunchKernelGGL(k_embed_prep_bwd<bf16_t>, dim3(B * S), dim3(128), 0, st, (const bf16_t*)dx, ids, lens, pe, d_embed, d_pe_scale, S, D, drop);
+    else hipLaunchKernelGGL(k_embed_prep_bwd<float>, dim3(B * S), dim3(128), 0, st, dx, ids, lens, pe, d_embed, d_pe_scale, S, D, drop);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float* beta, void* y, int ldy, float* y32,
@@ -1225,8 +1229,9 @@ int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float*
 int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const float* x, const float* gamma,
                      const float* mean, const float* rstd, float* dx, int accumulate, float* dgamma, float* dbeta,
                      int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws, void* dy2, DropCfg drop2,
-                     int* defer_nblk) {
+                     int* defer_nblk, int dx_bf16) {
     B2S_CHECK(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
+    B2S_CHECK(!dx_bf16 || ((D == 768 || D == 512) && (lddy & 3) == 0 && !getenv("B2S_LN_GENERIC")), "layernorm backward: a bf16 residual gradient needs the D = 512 / 768 kernels");
     int grid = cdiv(M, 4); if (grid > (ws ? RO_LN_WS_ROWS : 512)) grid = ws ? RO_LN_WS_ROWS : 512;
     static const bool no_fast = getenv("B2S_LN_GENERIC") != nullptr;             // A/B switch
     const bool f32 = dy_fp32 || !dtype;
@@ -1234,8 +1239,10 @@ int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const flo
         // ~3 rows per wave (the next row's loads fly under the current row's reductions); at most RO_LN_WS_ROWS partial rows
         static const int rows_per_wg = getenv("B2S_LN_BWD_ROWS") ? atoi(getenv("B2S_LN_BWD_ROWS")) : 12;
         grid = std::max(1, std::min(cdiv(M, rows_per_wg), ws ? RO_LN_WS_ROWS : 512));
-#define B2S_LN_FAST(TD, NCH, ACC, DY2) hipLaunchKernelGGL((k_ln_bwd_fast<TD, NCH, ACC, DY2>), dim3(grid), dim3(256), 0, st, (const TD*)dy, lddy, x, \
-            gamma, mean, rstd, dx, M, row_len, rows_per_batch, ws, dgamma, dbeta, (bf16_t*)dy2, drop2)
+#define B2S_LN_FAST(TD, NCH, ACC, DY2) do { if (dx_bf16) hipLaunchKernelGGL((k_ln_bwd_fast<TD, NCH, ACC, DY2, bf16_t>), dim3(grid), dim3(256), 0, st, (const TD*)dy, lddy, x, \
+            gamma, mean, rstd, (bf16_t*)dx, M, row_len, rows_per_batch, ws, dgamma, dbeta, (bf16_t*)dy2, drop2); \
+        else hipLaunchKernelGGL((k_ln_bwd_fast<TD, NCH, ACC, DY2, float>), dim3(grid), dim3(256), 0, st, (const TD*)dy, lddy, x, \
+            gamma, mean, rstd, dx, M, row_len, rows_per_batch, ws, dgamma, dbeta, (bf16_t*)dy2, drop2); } while (0)
 #define B2S_LN_FAST_AD(TD, NCH) do { if (accumulate) { if (dy2) B2S_LN_FAST(TD, NCH, true, true); else B2S_LN_FAST(TD, NCH, true, false); } \
                                      else { if (dy2) B2S_LN_FAST(TD, NCH, false, true); else B2S_LN_FAST(TD, NCH, false, false); } } while (0)
         if (D == 768) { if (f32) B2S_LN_FAST_AD(float, 3); else B2S_LN_FAST_AD(bf16_t, 3); }
@@ -1313,8 +1320,10 @@ int ro_shift_pe_fwd(const float* a, const int* lens, const float* pe, const floa
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_shift_pe_bwd(int dtype, const float* dx, const int* lens, const float* pe, void* da, float* d_pe_scale, int B,
-                    int T, int D, DropCfg drop, hipStream_t st) {
-    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_shift_pe_bwd<TY>), dim3(std::min(cdiv(B * T, 8), 256)), dim3(512), 0, st, dx, lens, pe, (TY*)da,
+                    int T, int D, DropCfg drop, hipStream_t st, int dx_bf16) {
+    if (dx_bf16) RO_DISPATCH(dtype, hipLaunchKernelGGL((k_shift_pe_bwd<TY, bf16_t>), dim3(std::min(cdiv(B * T, 8), 256)), dim3(512), 0, st, (const bf16_t*)dx, lens,
+                                                       pe, (TY*)da, d_pe_scale, T, D, drop, B * T));
+    else RO_DISPATCH(dtype, hipLaunchKernelGGL((k_shift_pe_bwd<TY, float>), dim3(std::min(cdiv(B * T, 8), 256)), dim3(512), 0, st, dx, lens, pe, (TY*)da,
                                           d_pe_scale, T, D, drop, B * T));
     B2S_LAUNCH_CHECK(); return 0;
 }
