@@ -75,10 +75,11 @@ def cpu_baseline_train(budget_s=25.0):
             "seconds_per_step": round(best, 3)}
 
 
-def _sub_bench(extra):
+def _sub_bench(extra, env=None):
     """Run another bench mode in a child process and return the fields of its JSON line that matter on the parent's line."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1"] + extra, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1"] + extra, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, **env) if env else None)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"error": (r.stderr or r.stdout)[-400:]}
@@ -351,6 +352,16 @@ def main():
         out["finetune"] = _sub_bench(["--mode", "finetune", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
                                       "--no-roofline-pass"])
         out["fp32_mode"] = _sub_bench(["--dtype", "fp32", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-roofline-pass"])
+        # the headline step with the data-parallel exchange path switched on (1-rank RCCL group: stage hooks, buckets, bf16 pack, all-reduce
+        # calls, waits, Adam reading the wire buffer -- everything but the wire itself): what one rank of an N-GPU run pays on top
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            dp_port = sk.getsockname()[1]
+        dp = _sub_bench(["--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-roofline-pass", "--no-extras"],
+                        env={"B2S_FORCE_DP": "1", "B2S_GRAD_PAYLOAD": "bf16", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(dp_port), "RANK": "0",
+                             "WORLD_SIZE": "1"})
+        out["dp_path_ms_per_step"] = dp.get("ms_per_step", dp.get("error"))
     if world > 1 or force_dp:
         torch.distributed.destroy_process_group()
     if rank == 0:

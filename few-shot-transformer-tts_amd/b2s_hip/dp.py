@@ -32,7 +32,7 @@ class GradBucketer(object):
     must tile the flat buffer in that order (HipEngine lays gradients out that way)."""
 
     def __init__(self, flat, stage_ranges, n_stages, bucket_elems, group=None, dist=None, payload="fp32", pack=None, unpack=None,
-                 stream=None):
+                 stream=None, consume_wire=False):
         """payload "bf16": every bucket is converted to a bf16 wire buffer before its all-reduce and back afterwards -- half the
         bytes over xGMI (167 MB instead of 334 MB per step at the default sizes); the sum over ranks is then taken in bf16,
         everything inside a rank (accumulation, Adam moments, masters) stays fp32.  pack(src_f32, dst_bf16) / unpack(src_bf16,
@@ -50,6 +50,9 @@ class GradBucketer(object):
         self.pack = pack or (lambda src, dst: dst.copy_(src))
         self.unpack = unpack or (lambda src, dst: dst.copy_(src))
         self.stream = stream
+        # consume_wire (bf16 payload): the optimizer reads the all-reduced gradients from the wire buffer itself (b2s_adam_set_grad_wire);
+        # finish() then skips the unpack pass and the fp32 buffer keeps this rank's local gradients
+        self.consume_wire = bool(consume_wire) and self.wire is not None
         self._pending = None
         self._works = []
         self.launched = []                       # (lo, hi) of every all-reduce of the current step, for tests / logs
@@ -99,7 +102,7 @@ class GradBucketer(object):
             self._launch()
         for w, lo, hi in self._works:
             w.wait()
-            if self.wire is not None:
+            if self.wire is not None and not self.consume_wire:
                 self.unpack(self.wire[lo:hi], self.flat[lo:hi])
         self._works = []
         if expect_all:
@@ -111,6 +114,12 @@ class GradBucketer(object):
             if pos != self.flat.numel():
                 raise RuntimeError("gradient exchange covered [0, %d) of %d elements (ranges %s): a backward stage did not report"
                                    % (pos, self.flat.numel(), self.launched[:4]))
+
+    def unpack_all(self):
+        """consume_wire: write the reduced gradients of the last step back into the fp32 buffer (tests / diagnostics)."""
+        if self.wire is not None:
+            for lo, hi in self.launched:
+                self.unpack(self.wire[lo:hi], self.flat[lo:hi])
 
     def abort(self):
         """Wait for what was launched and drop the rest (a stage hook failed; the step is being abandoned)."""

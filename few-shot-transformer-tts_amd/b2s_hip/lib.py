@@ -109,12 +109,14 @@ _PROTOS = {
     "b2s_decode_alignment": (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "b2s_decode_end": (None, [P]),
     "b2s_model_set_stage_hook_stream": (C.c_int, [P, P]),
+    "b2s_model_second_stream": (C.c_void_p, [P]),
     "b2s_gemm_set_tile_policy": (C.c_int, [C.c_int]),
     "b2s_model_backward_abort": (C.c_int, [P, P]),
     "b2s_model_set_stage_hook": (C.c_int, [P, P, P]),
     "b2s_prof_enable": (None, [C.c_int]),
     "b2s_adam_step_ex": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, P]),
     "b2s_adam_wait": (C.c_int, [P, P]),
+    "b2s_adam_set_grad_wire": (C.c_int, [P, P, P]),
     "b2s_adam_step_groups": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, P]),
     "b2s_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "b2s_dropout_mask": (C.c_int, [C.c_float, C.c_uint64, C.c_uint32, P, C.c_int64, P]),

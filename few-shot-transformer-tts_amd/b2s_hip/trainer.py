@@ -42,7 +42,7 @@ class _SchedView(object):
 
 
 class HipTrainer(object):
-    def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0, overlap_adam=False, grad_payload=None):
+    def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0, overlap_adam=False, grad_payload=None, dist=None):
         from transformer.tacotron import learning_rate_schedule
         self.model, self.hp = model, hp
         # overlap_adam: the optimizer step runs on the engine's second stream while the next step's forward pass starts
@@ -81,11 +81,17 @@ class HipTrainer(object):
         # the fused optimizer's pointer table against the new tensors (b2s_model_bind), the moments stay these buffers
         self.eng._trainer = weakref.ref(self)
         self._hook_error = None
+        self.grad_probe = None          # test aid: called as grad_probe(flat_fp32_gradients, bf16_wire_or_None) right before the optimizer step
         self.global_step = 0
         self.freeze_encoder = bool(self.eng.cfg.freeze_encoder)
         self._one = torch.ones(1, dtype=torch.float32, device=g.device)
         self.last_ga_loss = None
-        self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
+        # dist: an object with torch.distributed's interface (get_world_size / broadcast / all_reduce(async_op=True) -> work.wait());
+        # default: torch.distributed when a process group is initialised.  (tests/test_gpu_dp_race.py passes an asynchronous stand-in.)
+        if dist is not None:
+            self.dist = dist
+        else:
+            self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.bucketer = None
         self._hook = _HOOK_T(self._on_stage)      # keep a reference: ctypes callbacks must outlive their use
@@ -108,10 +114,31 @@ class HipTrainer(object):
             on_gpu = self.eng._gflat.is_cuda
             # the collectives are launched from a stream of their own: the engine orders it behind each stage's gradient work,
             # the backward pass itself never waits for the second stream on their account
-            self._hook_stream = torch.cuda.Stream(device=self.eng._gflat.device) if on_gpu else None
+            # -- the engine's own second stream: a stage's gradients are complete exactly there (its weight-gradient group is the stage's last
+            # work), so the pack kernel and the collective's launch need no extra ordering, and the process stays at four active streams
+            # (main, second, encoder, RCCL's).  A fifth one (B2S_HOOK_STREAM=own: the round-3 layout) oversubscribes the hardware queues:
+            # 12.6 ms per step instead of 7.9 with the encoder on its own stream (profiles/NOTES_r04.md)
+            self._hook_stream = None
+            if on_gpu:
+                aux = self.lib.b2s_model_second_stream(self.eng.handle)
+                if aux and os.environ.get("B2S_HOOK_STREAM", "second") != "own":
+                    self._hook_stream = torch.cuda.ExternalStream(aux, device=self.eng._gflat.device)
+                else:
+                    self._hook_stream = torch.cuda.Stream(device=self.eng._gflat.device)
+            # bf16 payload: the fused Adam reads the all-reduced gradients straight from the wire buffer (no unpack kernel, no fp32 re-read of
+            # 334 MB: ~0.15 ms per step at N > 1); B2S_ADAM_FROM_WIRE=0 restores unpack + fp32 read
+            consume = payload == "bf16" and on_gpu and os.environ.get("B2S_ADAM_FROM_WIRE", "1") != "0" and not self.split_adam
             self.bucketer = GradBucketer(self.eng._gflat, self.eng.stage_ranges, self.eng.n_stages(),
                                          bucket_mb * 1024 * 1024 / 4, dist=self.dist, payload=payload,
-                                         pack=pack if on_gpu else None, unpack=unpack if on_gpu else None, stream=self._hook_stream)
+                                         pack=pack if on_gpu else None, unpack=unpack if on_gpu else None, stream=self._hook_stream,
+                                         consume_wire=consume)
+            if consume:
+                L.check(self.lib.b2s_adam_set_grad_wire(self.eng.handle, self.bucketer.wire.data_ptr(), self.eng._gflat.data_ptr()))
+            if self.world > 1 and self.dist.get_rank() == 0:
+                import sys
+                print("[b2s] data-parallel gradient payload: %s%s (HipTrainer(grad_payload=...) / B2S_GRAD_PAYLOAD; fp32 = the reference's exact "
+                      "mean of the rank gradients, train.py:125)" % (payload, ", consumed by the optimizer from the wire buffer" if consume else ""),
+                      file=sys.stderr)
             L.check(self.lib.b2s_model_set_stage_hook(self.eng.handle, C.cast(self._hook, L.P), None))
             if self._hook_stream is not None:
                 L.check(self.lib.b2s_model_set_stage_hook_stream(self.eng.handle, self._hook_stream.cuda_stream))
@@ -215,6 +242,7 @@ class HipTrainer(object):
         cur = torch.cuda.current_stream()
         ovl = self.overlap_encoder and not self.split_adam
         if ovl and self._enc_stream is None:
+            self._lab_skipped = [torch.cuda.Stream(device=eng._gflat.device) for _ in range(int(os.environ.get('B2S_LAB_SKIP_STREAMS', '0')))]
             self._enc_stream = torch.cuda.Stream(device=eng._gflat.device)
         enc_s = self._enc_stream if ovl else None
         if enc_s is not None:
@@ -298,6 +326,8 @@ class HipTrainer(object):
             raise RuntimeError("gradient exchange failed in the backward stage hook; the optimizer step was NOT applied") from err
         if self.bucketer is not None:
             self.bucketer.finish(expect_all=not self.freeze_encoder)
+        if self.grad_probe is not None:
+            self.grad_probe(eng._gflat, self.bucketer.wire if (self.bucketer is not None and self.bucketer.consume_wire) else None)
         self.global_step = step_no
         if split:
             L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 1, 0, L.stream()))

@@ -307,11 +307,15 @@ int flush_ln_jobs(const b2s_model* m, hipStream_t st);
 // Ordering for the stage hook.  The hook launches a collective on gradients that the second stream completes: the stream the hook
 // works on must wait for that.  With a dedicated hook stream the backward's own stream never waits for the second stream here (it
 // used to, at every stage -- 0.45 ms per step in data-parallel runs).
+// (B2S_LAB_NO_HOOK_ORDER: drops these waits -- only to show that tests/test_gpu_dp_race.py fails without them)
+static const bool g_lab_no_hook_order = getenv("B2S_LAB_NO_HOOK_ORDER") != nullptr;
 int hook_after_event(const b2s_model* m, hipStream_t st, hipEvent_t ev) {      // ev: second-stream event after the stage's last gradient work
+    if (g_lab_no_hook_order) return 0;
     if (ev) B2S_HIP(hipStreamWaitEvent(m->hook_stream ? m->hook_stream : st, ev, 0));
     return 0;
 }
 int hook_after_stream(const b2s_model* m, hipStream_t st) {                    // the stage's gradients are complete at this point of `st`
+    if (g_lab_no_hook_order) return 0;
     if (m->stage_hook && m->hook_stream && m->hook_stream != st) {
         hipEvent_t e = m->next_event();
         B2S_HIP(hipEventRecord(e, st));
@@ -893,6 +897,7 @@ extern "C" int b2s_model_sync_weights_ex(b2s_model* m, void* stream, int shadows
 }
 
 extern "C" void b2s_ctx_free(b2s_ctx* ctx) { delete ctx; }
+extern "C" void* b2s_model_second_stream(b2s_model* m) { return (m && m->bound) ? (void*)m->aux : nullptr; }
 extern "C" int b2s_model_set_stage_hook_stream(b2s_model* m, void* stream) {
     B2S_CHECK(m, "null model");
     m->hook_stream = (hipStream_t)stream;
@@ -1817,6 +1822,12 @@ extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, floa
                              void* stream) {
     return b2s_adam_step_ex(m, lr, step, beta1, beta2, eps, l2, grad_scale, 0, stream);
 }
+extern "C" int b2s_adam_set_grad_wire(b2s_model* m, const void* wire_bf16, const float* grad_base) {
+    B2S_CHECK(m && (!wire_bf16 || grad_base), "null argument");
+    B2S_CHECK(!wire_bf16 || (((size_t)wire_bf16 & 15) == 0 && ((size_t)grad_base & 15) == 0), "wire / gradient buffers must be 16-byte aligned");
+    m->adam_wire = wire_bf16; m->adam_gbase = wire_bf16 ? grad_base : nullptr;
+    return 0;
+}
 extern "C" int b2s_adam_wait(b2s_model* m, void* stream) {
     B2S_CHECK(m, "null model");
     return wait_adam(m, S_(stream), 7);
@@ -1840,7 +1851,7 @@ extern "C" int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, f
         for (int k = 0; k < 3; ++k) {
             const int g = order[k], lo = m->adam_grp[g], n = m->adam_grp[g + 1] - lo;
             if (n <= 0) continue;
-            B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, m->aux));
+            B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, m->aux, m->adam_wire, m->adam_gbase));
             if (g == 2 && m->dtype == 0) B2S_TRY(relayout_convs(m, m->aux));     // fp32: the conv GEMM images follow the masters
             if (!m->adam_ev[g]) B2S_HIP(hipEventCreateWithFlags(&m->adam_ev[g], hipEventDisableTiming));
             B2S_HIP(hipEventRecord(m->adam_ev[g], m->aux));
@@ -1855,7 +1866,7 @@ extern "C" int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, f
     // l2 is applied to the L2 member set only (chunk flag), i.e. g = grad*grad_scale + l2*p for members
     // the partial sums cover the L2 regulariser only if every member is in the chunk table (not with a frozen encoder)
     const bool cover = !m->cfg.freeze_encoder;
-    B2S_TRY(ro_mt_adam(m->adam_chunks, m->n_adam_chunks, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part : nullptr, st));
+    B2S_TRY(ro_mt_adam(m->adam_chunks, m->n_adam_chunks, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part : nullptr, st, m->adam_wire, m->adam_gbase));
     // fp32 (parity) mode: the Adam kernel does not write the conv GEMM images (in bf16 mode it does); refresh them here so that
     // an eval / synthesis forward between two training steps sees the weights the step just produced
     if (m->dtype == 0) B2S_TRY(relayout_convs(m, st));
@@ -1866,6 +1877,7 @@ extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta
                                     int groups, int on_aux, void* stream) {
     B2S_TRY(check_bound(m));
     B2S_CHECK(m->adam_chunks && step >= 1 && groups > 0 && groups < 8, "Adam state not bound, bad step or bad group mask");
+    B2S_CHECK(!(m->adam_wire && on_aux), "the narrow optimizer launch beside the backward pass does not read a bf16 gradient wire buffer");
     if (step != m->adam_step_no) { m->adam_step_no = step; m->adam_step_mask = 0; }
     B2S_CHECK((m->adam_step_mask & groups) == 0, "parameter group mask %d was already updated in step %d", groups & m->adam_step_mask, step);
     hipStream_t st = S_(stream);
@@ -1897,7 +1909,7 @@ extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta
         if (run != st && narrow > 0)
             B2S_TRY(ro_mt_adam_narrow(m->adam_chunks + lo, n, narrow, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, run));
         else
-            B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, run));
+            B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, run, m->adam_wire, m->adam_gbase));
         if (g == 2 && m->dtype == 0) B2S_TRY(relayout_convs(m, run));
         if (run != st) {
             if (!m->adam_ev[g]) B2S_HIP(hipEventCreateWithFlags(&m->adam_ev[g], hipEventDisableTiming));

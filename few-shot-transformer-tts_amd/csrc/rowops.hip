@@ -1063,17 +1063,26 @@ __device__ __forceinline__ void adam_store_shadow(const MtChunk& c, int i4, f4v 
         }
     }
 }
-template <int KIND>
-__device__ __forceinline__ float adam_chunk(const MtChunk& c, float gs, float l2p, float b1, float b2, float step, float sbc2, float eps) {
+// gradient of 4 consecutive elements: the fp32 gradient buffer, or (gw != null) the bf16 wire buffer of the gradient exchange at the same
+// element offsets -- the all-reduced sum is consumed where RCCL left it, no unpack pass and no fp32 re-read (b2s_adam_set_grad_wire)
+template <bool W16>
+__device__ __forceinline__ f4v adam_grad4(const f4v* G, const uint2* GW, int i4) {
+    if (!W16) return __builtin_nontemporal_load(G + i4);
+    const uint2 u = GW[i4];
+    return (f4v){bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16))};
+}
+template <int KIND, bool W16>
+__device__ __forceinline__ float adam_chunk(const MtChunk& c, const bf16_t* gw, float gs, float l2p, float b1, float b2, float step, float sbc2, float eps) {
     float ss = 0.f;
     const int n4 = c.n >> 2;
     f4v* P = reinterpret_cast<f4v*>(c.a); f4v* M = reinterpret_cast<f4v*>(c.c); f4v* V = reinterpret_cast<f4v*>(c.d);
     const f4v* G = reinterpret_cast<const f4v*>(c.b);
+    const uint2* GW = reinterpret_cast<const uint2*>(gw);
     int i = threadIdx.x;
     for (; i + 768 < n4; i += 1024) {
         f4v p[4], g[4], m[4], v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { p[u] = P[i + u * 256]; g[u] = __builtin_nontemporal_load(G + i + u * 256); m[u] = M[i + u * 256]; v[u] = V[i + u * 256]; }
+        for (int u = 0; u < 4; ++u) { p[u] = P[i + u * 256]; g[u] = adam_grad4<W16>(G, GW, i + u * 256); m[u] = M[i + u * 256]; v[u] = V[i + u * 256]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -1083,7 +1092,7 @@ __device__ __forceinline__ float adam_chunk(const MtChunk& c, float gs, float l2
         }
     }
     for (; i < n4; i += 256) {
-        f4v p = P[i], g = G[i], m = M[i], v = V[i];
+        f4v p = P[i], g = adam_grad4<W16>(G, GW, i), m = M[i], v = V[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { float pe = p[e], me = m[e], ve = v[e]; ss += adam_elem(pe, g[e], me, ve, gs, l2p, b1, b2, step, sbc2, eps); p[e] = pe; m[e] = me; v[e] = ve; }
         M[i] = m; V[i] = v; P[i] = p;
@@ -1091,24 +1100,26 @@ __device__ __forceinline__ float adam_chunk(const MtChunk& c, float gs, float l2
     }
     return ss;
 }
+template <bool W16>
 __global__ __launch_bounds__(256) void k_mt_adam2(const MtChunk* __restrict__ ch, const float* __restrict__ hp, float b1, float b2, float eps,
-                                                  float l2, float gs, float* sumsq_part) {
+                                                  float l2, float gs, float* sumsq_part, const bf16_t* __restrict__ wire, const float* gbase) {
     __shared__ float sh[4];
     const MtChunk c = ch[blockIdx.x];
+    const bf16_t* gw = W16 ? wire + (c.b - gbase) : nullptr;
     const float lr = hp[0], bc1 = hp[1], sbc2 = hp[2];
     const float step = lr / bc1, l2p = c.pad ? l2 : 0.f;
     float ss = 0.f;
     int i0 = 0;
-    const bool vec = ((((size_t)c.a | (size_t)c.b | (size_t)c.c | (size_t)c.d) & 15) == 0) && (c.cin || ((size_t)c.s & 7) == 0);
+    const bool vec = ((((size_t)c.a | (size_t)c.b | (size_t)c.c | (size_t)c.d) & 15) == 0) && (c.cin || ((size_t)c.s & 7) == 0) && (!W16 || ((size_t)gw & 7) == 0);
     if (vec) {
-        if (c.cin) ss = adam_chunk<2>(c, gs, l2p, b1, b2, step, sbc2, eps);
-        else if (c.s) ss = adam_chunk<1>(c, gs, l2p, b1, b2, step, sbc2, eps);
-        else ss = adam_chunk<0>(c, gs, l2p, b1, b2, step, sbc2, eps);
+        if (c.cin) ss = adam_chunk<2, W16>(c, gw, gs, l2p, b1, b2, step, sbc2, eps);
+        else if (c.s) ss = adam_chunk<1, W16>(c, gw, gs, l2p, b1, b2, step, sbc2, eps);
+        else ss = adam_chunk<0, W16>(c, gw, gs, l2p, b1, b2, step, sbc2, eps);
         i0 = (c.n >> 2) << 2;
     }
     for (int i = i0 + threadIdx.x; i < c.n; i += 256) {       // unaligned tensors and the last 0-3 elements of a chunk
         float p = c.a[i], m = c.c[i], v = c.d[i];
-        ss += adam_elem(p, c.b[i], m, v, gs, l2p, b1, b2, step, sbc2, eps);
+        ss += adam_elem(p, W16 ? bf2f(gw[i]) : c.b[i], m, v, gs, l2p, b1, b2, step, sbc2, eps);
         c.c[i] = m; c.d[i] = v;
         c.a[i] = p;
         if (c.cin) {
@@ -1491,12 +1502,15 @@ int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gsc
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1, float beta2, float eps, float l2,
-               float grad_scale, float* sumsq_part, hipStream_t st) {
+               float grad_scale, float* sumsq_part, hipStream_t st, const void* wire, const float* gbase) {
     static const bool v1 = getenv("B2S_ADAM_V1") != nullptr;
-    if (nchunks > 0 && v1)
+    if (nchunks > 0 && wire)
+        hipLaunchKernelGGL(k_mt_adam2<true>, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part, (const bf16_t*)wire, gbase);
+    else if (nchunks > 0 && v1)
         hipLaunchKernelGGL(k_mt_adam, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part);
     else if (nchunks > 0)
-        hipLaunchKernelGGL(k_mt_adam2, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part);
+        hipLaunchKernelGGL(k_mt_adam2<false>, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part, (const bf16_t*)nullptr,
+                           (const float*)nullptr);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_mt_adam_narrow(const MtChunk* chunks, int nchunks, int nwg, const float* hp, float beta1, float beta2, float eps, float l2,

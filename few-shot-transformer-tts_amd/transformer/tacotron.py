@@ -191,6 +191,13 @@ class Tacotron(nn.Module):
 
     def forward(self, inputs, input_lengths, mel_targets, target_lengths, input_spk_ids, input_language_vecs, **kwargs):
         """tacotron.py:126-133: kwargs are the dataloader batch dict (unknown keys such as `names` are ignored)."""
+        if getattr(self, "_is_replica", False):
+            # nn.DataParallel over several devices (train.py:126-127 without --ddp) replicates the module per device and per step; the HIP
+            # engine is bound to ONE device's parameters, gradient buffer and streams.  One process per GPU is the supported layout.
+            from b2s_hip.lib import B2SError
+            raise B2SError("nn.DataParallel over more than one device is not supported by the HIP engine (it is bound to one device); run one "
+                           "process per GPU -- torch.distributed.run + DistributedDataParallel (train.py --ddp) or b2s_hip.trainer.HipTrainer -- "
+                           "or restrict the wrapper: nn.DataParallel(m, device_ids=[0])")
         enc_outputs = self.encoder(inputs, input_lengths, input_spk_ids, input_language_vecs)
         mel_bef, stop_logits, alignments = self.decoder(enc_outputs, input_lengths, mel_targets, target_lengths)
         mel_aft = self.postnet(mel_bef, target_lengths, _fuse_add=True)          # mel_bef + postnet(mel_bef), fused

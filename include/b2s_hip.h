@@ -148,6 +148,11 @@ int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int stage, void* user), 
  * that stream waits, the backward pass is not held up (the hook must launch its work on it; the final optimizer step has to
  * wait for the collectives as before). */
 int b2s_model_set_stage_hook_stream(b2s_model* m, void* stream);
+/* The engine's second stream (hipStream_t; NULL before b2s_model_bind or when the model runs single-stream): the stream its weight-gradient
+ * work runs on.  A data-parallel caller passes it to b2s_model_set_stage_hook_stream, so that the gradient exchange is launched from the
+ * stream that completes the gradients instead of a fifth stream: more than four concurrently ACTIVE HIP streams (main, second, encoder,
+ * exchange, RCCL's own) were measured at 12.6 ms per step against 7.9 with four (MI355X, profiles/NOTES_r04.md). */
+void* b2s_model_second_stream(b2s_model* m);
 /* Give up a backward pass between its entry points (after a failed call, or when the caller will not make the joining call that
  * B2S_POST_BWD_DEFER_JOIN / B2S_DEC_BWD_DEFER_JOIN promised): queued weight-gradient work, reductions and stage hooks are dropped
  * unlaunched / unfired, `stream` waits for what the second stream is already running.  Call before freeing the contexts.  The gradient
@@ -205,6 +210,11 @@ int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, fl
 int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
                      int overlap, void* stream);
 int b2s_adam_wait(b2s_model* m, void* stream);
+/* Data-parallel runs with a bf16 gradient payload: `wire_bf16` is the exchange's wire buffer -- bf16, element i = gradient element i of the
+ * flat fp32 gradient buffer that starts at `grad_base` (the bound gradient tensors are slices of it).  From now on every b2s_adam_step*
+ * reads its gradients from the wire buffer, i.e. consumes the all-reduced sum where the collective left it: no unpack pass, no fp32
+ * re-read (train.py:125,130-131: DDP's averaged gradient feeding optim.step()).  NULL restores the fp32 gradient buffers. */
+int b2s_adam_set_grad_wire(b2s_model* m, const void* wire_bf16, const float* grad_base);
 /* One optimizer step applied in pieces: `groups` is a mask of parameter groups (B2S_ADAM_ENCODER | _DECODER | _POSTNET)
  * whose gradients are final.  on_aux = 1: those groups are updated on the model's second stream, ordered after everything
  * already enqueued on `stream`, and the call returns with `stream` free to go on -- the fused trainer updates the decoder

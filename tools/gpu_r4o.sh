@@ -1,0 +1,11 @@
+#!/bin/bash
+export MASTER_ADDR=127.0.0.1 RANK=0 WORLD_SIZE=1 B2S_FORCE_DP=1
+p=29900
+for arm in "-" "B2S_HOOK_STREAM=own" "B2S_ENC_OVERLAP=0" "B2S_ENC_OVERLAP=0 B2S_HOOK_STREAM=own" "B2S_ADAM_FROM_WIRE=0"; do
+  p=$((p+1)); envs="MASTER_PORT=$p"; [ "$arm" != "-" ] && envs="$envs $arm"
+  ms=$(env $envs python bench.py --no-cpu-baseline --no-roofline-pass --no-extras --steps 30 --warmup 6 2>/dev/null | python -c "import sys,json; print(json.loads([l for l in sys.stdin if l.startswith('{')][-1])['ms_per_step'])")
+  echo "[$arm] $ms"
+done
+unset B2S_FORCE_DP
+ms=$(python bench.py --no-cpu-baseline --no-roofline-pass --no-extras --steps 30 --warmup 6 2>/dev/null | python -c "import sys,json; print(json.loads([l for l in sys.stdin if l.startswith('{')][-1])['ms_per_step'])")
+echo "[no DP] $ms"

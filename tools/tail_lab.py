@@ -11,6 +11,10 @@ from benchdata import synthetic_batch
 hp.parse("compute_dtype=bf16")
 if os.environ.get("B2S_LAB_HP"):                     # e.g. "freeze_encoder=true,guided_attention_weight=1.0"
     hp.parse(os.environ["B2S_LAB_HP"])
+if os.environ.get("B2S_FORCE_DP"):                 # the exchange path on a 1-rank RCCL group
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    torch.distributed.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", 0))
 torch.manual_seed(0)
 m = Tacotron(hp); initialize_variables(m); m = m.to("cuda").train()
 tr = HipTrainer(m, hp)
