@@ -285,6 +285,18 @@ def test_dropout_rng_statistics():
         assert abs(c - (1 - p) ** 2) < 5e-3, c
 
 
+def test_dropout_mask_matches_host_restatement():
+    """Device masks == oracle/rng.py (the restatement whose statistics tests/test_host_logic.py checks), bit for bit, incl. odd starts."""
+    from oracle import rng
+    ops, lib = _ops()
+    l = lib.load()
+    for p, seed, op, n in ((0.1, 1234, 5, 200003), (0.5, (7 << 40) + 3, 4099, 65536), (0.9999, 1, 2, 4097), (1e-6, 1, 2, 4097)):
+        m = torch.empty(n, dtype=torch.uint8, device=DEV)
+        lib.check(l.b2s_dropout_mask(p, seed, op, lib.ptr(m), n, lib.stream()))
+        torch.cuda.synchronize()
+        assert np.array_equal(m.cpu().numpy().astype(bool), rng.keep_mask(p, seed, op, n)), (p, seed, op)
+
+
 @pytest.mark.parametrize("nb", ["3", "4"])
 def test_gemm_256_tile_kernel_all_forms(nb):
     """The 256x128 / 256x96 tile kernel (gemm_glds256.hip) is normally chosen for M > 128 with a shape-dependent tile width;

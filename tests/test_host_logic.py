@@ -270,3 +270,31 @@ def test_grad_bucketer_reports_missing_stage():
     for s in (0, 1, 2):
         bk.stage_done(s)
     bk.finish(expect_all=False)                           # frozen encoder: the tail of the buffer is never exchanged
+
+
+def test_dropout_hash_statistics():
+    """The counter RNG behind every dropout mask (csrc/b2s_common.h: b2s_keep = lowbias32(idx * golden + key) >= p * 2^32, restated in
+    oracle/rng.py and pinned bit for bit to the device by tests/test_gpu_ops.py): avalanche of the hash, keep-rate, independence of
+    neighbouring elements, of rows and diagonals of an attention-shaped [rows, 582] mask, binomial row / column sums, independent ops."""
+    import numpy as np
+    from oracle import rng
+    g = np.random.default_rng(1)
+    x = g.integers(0, 1 << 26, 1 << 14, dtype=np.uint64)
+    for key in (0x1234567, 0xdeadbeef):
+        h0 = rng.rand32(x, key)
+        for i in range(26):
+            d = h0 ^ rng.rand32(x ^ np.uint64(1 << i), key)
+            flips = np.array([((d >> np.uint64(o)) & np.uint64(1)).mean() for o in range(32)])
+            assert flips.min() > 0.46 and flips.max() < 0.54, (key, i, flips.min(), flips.max())
+    rows, Lk = 2048, 582
+    for p, seed, op in ((0.1, 1234, 5), (0.5, 99, 77)):
+        keep = rng.keep_mask(p, seed, op, rows * Lk).reshape(rows, Lk).astype(np.float64)
+        assert abs((1 - keep.mean()) - p) < 4 * (p * (1 - p) / keep.size) ** 0.5 + 2e-5
+        k = keep - keep.mean()
+        var = k.var()
+        corr = lambda a, b: abs(float((a * b).mean() / var))
+        assert corr(k[:, :-1], k[:, 1:]) < 4e-3 and corr(k[:, :-2], k[:, 2:]) < 4e-3
+        assert corr(k[:-1], k[1:]) < 4e-3 and corr(k[:-1, :-1], k[1:, 1:]) < 4e-3
+        assert 0.9 < keep.sum(1).var() / (Lk * p * (1 - p)) < 1.1 and 0.85 < keep.sum(0).var() / (rows * p * (1 - p)) < 1.15
+        other = rng.keep_mask(p, seed, op + 1, rows * Lk).reshape(rows, Lk)
+        assert abs((keep.astype(bool) == other).mean() - ((1 - p) ** 2 + p ** 2)) < 3e-3
