@@ -78,6 +78,7 @@ _PROTOS = {
     "b2s_adam_bind": (C.c_int, [P, C.POINTER(P), C.POINTER(P), C.c_int]),
     "b2s_adam_step": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, P]),
     "b2s_zero_grads": (C.c_int, [P, P]),
+    "b2s_zero_grads_ex": (C.c_int, [P, P, C.c_int]),
     "b2s_model_set_grad_slot_padding": (C.c_int, [P, C.c_int]),
     "b2s_gemm": (C.c_int, [C.POINTER(GemmDesc), P, P, P, P, P, P, P, P]),
     "b2s_gemm_splitk": (C.c_int, [C.POINTER(GemmDesc), C.c_int, P, P, P, P, C.c_size_t, P]),

@@ -262,7 +262,8 @@ class HipTrainer(object):
         guided = eng.guided_enabled()
         if guided:
             self.last_ga_loss = eng.guided_loss(c_dec, add_to=vals)       # vals[0] (total loss) += weight * guided loss
-        L.check(lib.b2s_zero_grads(eng.handle, L.stream()))        # (on a stream of its own under the forward pass: measured, no gain)
+        # (1 = B2S_ZERO_GRADS_OVERWRITE_DW: this step runs every backward segment exactly once)
+        L.check(lib.b2s_zero_grads_ex(eng.handle, L.stream(), 1))
         eng._needs_zero = False
         if self.bucketer is not None:
             self.bucketer.begin_step()

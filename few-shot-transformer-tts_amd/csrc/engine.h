@@ -1,6 +1,7 @@
 // Internal model / context structures of libb2s_hip (see engine.hip).
 #pragma once
 #include <map>
+#include <set>
 #include <string>
 #include <functional>
 #include <vector>
@@ -130,6 +131,16 @@ struct b2s_model {
     // The stage hook of stage s then fires one stage late (when stage s+1 has been enqueued), so the host never stalls
     // the main stream on the group it has just launched.
     mutable bool dw_group = false;
+    // Overwrite mode of a backward pass (b2s_zero_grads_ex, flag B2S_ZERO_GRADS_OVERWRITE_DW): the weight gradients that are written exactly
+    // once per pass by a grouped launch (dw_ow: the GEMM weights of the encoder / decoder layers whose stage has >= 32 output tiles) are
+    // STORED instead of accumulated, and only the other gradients (zero_chunks: biases, LayerNorm / BatchNorm, embeddings, conv weights,
+    // prenet / heads -- everything that accumulates through atomics, split-K slabs or several launches) are cleared, by one kernel
+    // instead of a 334 MB memset; the stores also take the GEMM's 16-byte fast epilogue and read nothing.
+    std::vector<char> dw_ow;                                   // per tensor
+    std::set<const float*> dw_ow_ptrs;                          // their gradient pointers
+    mutable bool dw_overwrite_pass = false;
+    MtChunk* zero_chunks = nullptr;
+    int n_zero_chunks = 0;
     mutable std::vector<GemmArgs> dw_pending;
     mutable int dw_stages_pending = 0;                        // backward stages whose weight-gradient GEMMs are queued in dw_pending
     // Tail policy of the decoder backward when the encoder backward runs beside its end (b2s_decoder_backward_ev + B2S_DEC_BWD_FLUSH_TAIL):

@@ -231,7 +231,9 @@ int linear_dw(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
     g.A.p = dY; g.A.ld = lddy; g.A.R = M; g.A.C = Nout;
     g.B.p = X; g.B.ld = ldx; g.B.R = M; g.B.C = Kin;
     g.M = Nout; g.N = Kin; g.K = M; g.C = dW; g.c_fp32 = 1; g.ldc = Kin;
-    g.epi.accumulate = 1;          // parameter gradients accumulate; the host zeroes them once per backward pass
+    // parameter gradients accumulate (the host zeroes them once per backward pass) -- except, in an overwrite pass (engine.h: dw_ow), the
+    // layer weights that one grouped launch writes exactly once: those are stored
+    g.epi.accumulate = (m->dw_overwrite_pass && m->dw_group && m->dw_ow_ptrs.count(dW)) ? 0 : 1;
     if (m->dw_group) { m->dw_pending.push_back(g); return 0; }      // launched by end_stage() as part of the stage's group
     g.splitk = pick_splitk(Nout, Kin, M, m->dtype);
     m->set_ws(g, m->aux ? m->aux : st);
@@ -272,6 +274,7 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
     for (const GemmArgs& g : q) tiles += b2s_gemm_glds256_tiles(g);
     if (tiles < 32) {
         for (GemmArgs g : q) {
+            B2S_CHECK(g.epi.accumulate, "internal: an overwriting weight gradient reached the split-K path");
             g.splitk = pick_splitk(g.M, g.N, g.K, m->dtype);
             m->set_ws(g, m->aux);
             B2S_TRY(b2s_gemm_launch(g, m->dtype, true, true, m->aux));
@@ -766,6 +769,62 @@ int build_chunks(b2s_model* m, bool l2only, bool with_state, MtChunk** out, int*
     }
     return 0;
 }
+// overwrite mode (engine.h: dw_ow): which weight gradients a grouped launch writes exactly once per backward pass, and the chunk table
+// of everything else (cleared by ro_mt_zero)
+int build_zero_table(b2s_model* m) {
+    const size_t n = m->tinfo.size();
+    m->dw_ow.assign(n, 0);
+    m->dw_ow_ptrs.clear();
+    static const bool off = (getenv("B2S_DW_OVERWRITE") && atoi(getenv("B2S_DW_OVERWRITE")) == 0) || (getenv("B2S_DW_SPLIT") && atoi(getenv("B2S_DW_SPLIT")) > 1);
+    if (m->dtype == 1 && m->dw_group && !off) {
+        auto tiles = [&](const TensorInfo& t) { return (long)cdiv(t.shape[0], 256) * cdiv(t.shape[1], 128); };
+        auto layer_key = [](const std::string& nme, std::string& key) {          // "encoder.encoder.<list>.<i>.<leaf>" -> stack + layer index
+            for (const char* lst : {".self_attentions.", ".encdec_attentions.", ".ffn_layers."}) {
+                const size_t p = nme.find(lst);
+                if (p == std::string::npos) continue;
+                const size_t q = p + strlen(lst), e = nme.find('.', q);
+                key = nme.substr(0, nme.find('.')) + ":" + nme.substr(q, e - q);
+                return true;
+            }
+            return false;
+        };
+        std::map<std::string, long> stage_tiles;
+        std::string key;
+        for (size_t i = 0; i < n; ++i)
+            if (m->tinfo[i].gemm_weight && m->tinfo[i].shape.size() == 2 && m->grad[i] && layer_key(m->tinfo[i].name, key)) stage_tiles[key] += tiles(m->tinfo[i]);
+        for (size_t i = 0; i < n; ++i) {
+            const TensorInfo& t = m->tinfo[i];
+            if (t.gemm_weight && t.shape.size() == 2 && m->grad[i] && layer_key(t.name, key) && stage_tiles[key] >= 32 &&
+                !(m->cfg.freeze_encoder && t.name.compare(0, 8, "encoder.") == 0)) {
+                m->dw_ow[i] = 1; m->dw_ow_ptrs.insert((const float*)m->grad[i]);
+            }
+        }
+    }
+    std::vector<MtChunk> h;
+    const int CH = 16384;
+    for (size_t i = 0; i < n; ++i) {
+        const TensorInfo& t = m->tinfo[i];
+        if (t.kind != 1 || !m->grad[i] || m->dw_ow[i]) continue;
+        for (long o = 0; o < t.numel; o += CH) {
+            MtChunk c = {};
+            c.a = (float*)m->grad[i] + o; c.n = (int)std::min<long>(CH, t.numel - o);
+            h.push_back(c);
+        }
+    }
+    if (m->zero_chunks) {
+        auto it = std::find(m->owned.begin(), m->owned.end(), (void*)m->zero_chunks);
+        if (it != m->owned.end()) m->owned.erase(it);
+        (void)hipFree(m->zero_chunks);
+        m->zero_chunks = nullptr;
+    }
+    m->n_zero_chunks = (int)h.size();
+    if (!h.empty()) {
+        B2S_HIP(hipMalloc(&m->zero_chunks, h.size() * sizeof(MtChunk)));
+        B2S_HIP(hipMemcpy(m->zero_chunks, h.data(), h.size() * sizeof(MtChunk), hipMemcpyHostToDevice));
+        m->owned.push_back(m->zero_chunks);
+    }
+    return 0;
+}
 int rebuild_adam_chunks(b2s_model* m) {
     const int before = m->n_adam_chunks;
     B2S_TRY(build_chunks(m, false, true, &m->adam_chunks, &m->n_adam_chunks));
@@ -872,6 +931,7 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
     B2S_TRY(ensure_pe(m, 2048));
     m->l2_fresh = false;
     B2S_TRY(build_chunks(m, true, false, &m->l2_chunks, &m->n_l2_chunks));
+    B2S_TRY(build_zero_table(m));
     m->bound = true;
     // A fused optimizer bound earlier (b2s_adam_bind) holds the OLD parameter / gradient pointers in its chunk table: rebuild
     // it against the new ones (the moment buffers belong to the caller and are still the ones it registered), so the step
@@ -1943,12 +2003,20 @@ extern "C" int b2s_model_set_grad_slot_padding(b2s_model* m, int bytes) {
     m->grad_pad_bytes = (size_t)bytes;
     return 0;
 }
-extern "C" int b2s_zero_grads(b2s_model* m, void* stream) {
+extern "C" int b2s_zero_grads(b2s_model* m, void* stream) { return b2s_zero_grads_ex(m, stream, 0); }
+extern "C" int b2s_zero_grads_ex(b2s_model* m, void* stream, int flags) {
     B2S_TRY(check_bound(m));
     B2S_TRY(wait_adam(m, S_(stream), 7));
     // a new backward pass starts here: nothing of an earlier one may still be queued (it would run on freed contexts)
     if (!m->dw_pending.empty() || !m->aux_jobs.empty() || m->ln_jobs.n > 0 || !m->pending_stages.empty() || !m->unflushed_stages.empty())
         B2S_TRY(b2s_model_backward_abort(m, stream));
+    m->dw_overwrite_pass = false;
+    if ((flags & B2S_ZERO_GRADS_OVERWRITE_DW) && m->dw_group && !m->dw_ow_ptrs.empty()) {
+        // the caller runs the WHOLE backward pass (every segment, once): layer weight gradients are stored by their grouped launch, only
+        // the accumulating rest is cleared
+        m->dw_overwrite_pass = true;
+        return ro_mt_zero(m->zero_chunks, m->n_zero_chunks, S_(stream));
+    }
     // coalesce adjacent gradient buffers (the host normally binds one flat buffer) into few memsets
     std::vector<std::pair<char*, size_t>> r;
     for (size_t i = 0; i < m->tinfo.size(); ++i)

@@ -511,12 +511,13 @@ int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* 
     const long deep = makespan(true), shallow = makespan(false);
     if (deep <= shallow) makespan(true);               // (leaves `order` as chosen)
     int tiles = 0;
+    static const int split = getenv("B2S_DW_SPLIT") ? std::max(1, std::min(atoi(getenv("B2S_DW_SPLIT")), 4)) : 1;
     for (int k = 0; k < n; ++k) {
         const GemmArgs& g = probs[order[k]];
-        B2S_CHECK(g.batch == 1 && g.c_fp32 && g.epi.accumulate && g.A.g_cin == 0 && g.B.g_cin == 0, "grouped GEMM: problem %d is not a plain fp32-accumulate dW", order[k]);
+        B2S_CHECK(g.batch == 1 && g.c_fp32 && g.A.g_cin == 0 && g.B.g_cin == 0, "grouped GEMM: problem %d is not a plain fp32 dW", order[k]);
+        B2S_CHECK(g.epi.accumulate || split == 1, "grouped GEMM: split K needs an accumulating output (problem %d overwrites)", order[k]);
         // B2S_DW_SPLIT = 2: every tile's K walk in two halves.  The weight-gradient groups share the chip with the backward's main-stream
         // kernels; ~290 tiles of 127 K steps each on fewer than 256 free CUs need a second full-length round, half-length units pack better.
-        static const int split = getenv("B2S_DW_SPLIT") ? std::max(1, std::min(atoi(getenv("B2S_DW_SPLIT")), 4)) : 1;
         grp.p[k] = g; grp.p[k].splitk = (split > 1 && g.K >= 4 * split * t256::BK) ? split : 1;
         grp.tile0[k] = tiles;
         tiles += cdiv(g.M, t256::BM) * cdiv(g.N, 128) * grp.p[k].splitk;

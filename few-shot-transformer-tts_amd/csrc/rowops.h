@@ -108,7 +108,8 @@ struct MtChunk {            // pad: 1 = member of the L2 set; s: bf16 shadow (or
     // s = forward image, s2 = backward-data image; off = index of the chunk's first element in the [Cout][Cin][5] master
     bf16_t* s2; int cin, cout; long off;
 };
-int ro_mt_sumsq(const MtChunk* chunks, int nchunks, float* out, float scale, hipStream_t st);         // out += scale*sum a^2
+int ro_mt_sumsq(const MtChunk* chunks, int nchunks, float* out, float scale, hipStream_t st);
+int ro_mt_zero(const MtChunk* chunks, int nchunks, hipStream_t st);                                        // a[0..n) = 0 for every chunk         // out += scale*sum a^2
 int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gscale, hipStream_t st);  // b += alpha*gscale*a
 // Adam: a=param b=grad c=m d=v ; lr and step read from device (hp[0]=lr, hp[1]=bias_corr1, hp[2]=bias_corr2)
 // wire (optional): bf16 array laid out like the fp32 gradient buffer that starts at gbase -- the gradients are read from there instead

@@ -1551,6 +1551,23 @@ int ro_add(const float* a, const float* b, float* out, long n, hipStream_t st) {
     hipLaunchKernelGGL(k_add, dim3(ew_grid(n)), dim3(256), 0, st, a, b, out, n);
     B2S_LAUNCH_CHECK(); return 0;
 }
+// out-of-line: zero the `a` ranges of a chunk table (a, n) in one launch (the gradient ranges that still accumulate: a memset per range would
+// be ~40 fill kernels of 3-5 us)
+__global__ __launch_bounds__(256) void k_mt_zero(const MtChunk* __restrict__ ch) {
+    const MtChunk c = ch[blockIdx.x];
+    const bool vec = (((size_t)c.a) & 15) == 0;
+    int i0 = 0;
+    if (vec) {
+        float4* p = reinterpret_cast<float4*>(c.a);
+        for (int i = threadIdx.x; i < (c.n >> 2); i += 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        i0 = (c.n >> 2) << 2;
+    }
+    for (int i = i0 + threadIdx.x; i < c.n; i += 256) c.a[i] = 0.f;
+}
+int ro_mt_zero(const MtChunk* chunks, int nchunks, hipStream_t st) {
+    if (nchunks > 0) hipLaunchKernelGGL(k_mt_zero, dim3(nchunks), dim3(256), 0, st, chunks);
+    B2S_LAUNCH_CHECK(); return 0;
+}
 int ro_fill(float* p, float v, long n, hipStream_t st) {
     hipLaunchKernelGGL(k_fill, dim3(ew_grid(n)), dim3(256), 0, st, p, v, n);
     B2S_LAUNCH_CHECK(); return 0;

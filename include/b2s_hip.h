@@ -229,6 +229,13 @@ int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta1, float be
 /* Zero every bound parameter gradient.  Every *_backward entry point ACCUMULATES into the bound gradient
  * buffers (several use atomics), so the host calls this once at the start of each backward pass. */
 int b2s_zero_grads(b2s_model* m, void* stream);
+/* flags = B2S_ZERO_GRADS_OVERWRITE_DW: the caller is about to run ONE complete backward pass (postnet, decoder, encoder -- every segment
+ * exactly once, as b2s_hip.trainer.HipTrainer does).  bf16 mode: the weight gradients of the encoder / decoder layers are then STORED by
+ * their grouped weight-gradient launch instead of accumulated, and only the remaining gradients (biases, LayerNorm / BatchNorm, embeddings,
+ * convolutions, prenet, heads) are cleared -- one small kernel instead of a 334 MB memset, and no read-modify-write in the weight-gradient
+ * epilogues.  Without the flag (or in fp32 mode) this is b2s_zero_grads. */
+#define B2S_ZERO_GRADS_OVERWRITE_DW 1
+int b2s_zero_grads_ex(b2s_model* m, void* stream, int flags);
 /* Gradient tensors bound as slots of ONE flat buffer with up to `bytes` of alignment padding between them (the Python engine: 256):
  * b2s_zero_grads then clears the padding along with the slots (one memset).  Default 0: separately bound gradient tensors are cleared
  * range by range and nothing between them is touched. */
