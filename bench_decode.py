@@ -14,15 +14,33 @@ import torch
 PEAK_HBM_GBS = 8000.0
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources (csrc/*.hip, *.h in name order): stamped into every PMC summary, so that a bench
+    line can say whether the counters it quotes were collected on the kernels it is timing (the GPU box has no .git to ask)."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "few-shot-transformer-tts_amd", "csrc")
+    h = hashlib.sha256()
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".h")):
+            h.update(n.encode()); h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc(suffix):
-    """Newest committed PMC summary profiles/rNN_<suffix> -> (file name, commit it was collected at, rows); (None, None, []) if none."""
+    """Newest committed PMC summary profiles/rNN_<suffix> -> (file name, commit it was collected at [+ whether the kernel sources changed
+    since], rows); (None, None, []) if none."""
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     names = sorted(n for n in (os.listdir(pdir) if os.path.isdir(pdir) else []) if n.endswith(suffix) and n[0] == "r" and n[1:3].isdigit())
     if not names:
         return None, None, []
     d = json.load(open(os.path.join(pdir, names[-1])))
     if isinstance(d, dict):
-        return names[-1], d.get("commit", "unknown"), d["rows"]
+        stamp = d.get("commit", "unknown")
+        if d.get("csrc_sha16"):
+            stamp += "; kernel sources unchanged since" if d["csrc_sha16"] == csrc_sha16() else "; KERNEL SOURCES CHANGED since that collection"
+        else:
+            stamp += "; collected before the source stamp existed (kernel sources have changed since)"
+        return names[-1], stamp, d["rows"]
     return names[-1], "unrecorded (round-2 file)", d
 
 

@@ -46,7 +46,9 @@ def main():
     rows.sort(key=lambda r: -r["total_fetch_MB_corrected"])
     import os
     # the tree the counters were collected on (B2S_COMMIT: the GPU box has no .git) -- bench.py copies it into roofline.traffic_source
-    json.dump({"commit": os.environ.get("B2S_COMMIT", "unknown"), "tool": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench_decode import csrc_sha16
+    json.dump({"commit": os.environ.get("B2S_COMMIT", "unknown"), "csrc_sha16": csrc_sha16(), "tool": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, "
                "separate passes (tools/gpu_pmc.sh)", "rows": rows}, open(out, "w"), indent=1)
     for r in rows[:12]:
         print("%-60s launches %5d  fetch %9.2f MB/launch  write %9.2f MB/launch  mfma_util %s" % (
