@@ -113,6 +113,7 @@ _PROTOS = {
     "b2s_model_second_stream": (C.c_void_p, [P]),
     "b2s_gemm_set_tile_policy": (C.c_int, [C.c_int]),
     "b2s_model_backward_abort": (C.c_int, [P, P]),
+    "b2s_model_mark_grads_ready": (C.c_int, [P]),
     "b2s_model_set_stage_hook": (C.c_int, [P, P, P]),
     "b2s_prof_enable": (None, [C.c_int]),
     "b2s_adam_step_ex": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, P]),

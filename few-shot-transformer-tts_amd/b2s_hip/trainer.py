@@ -55,6 +55,10 @@ class HipTrainer(object):
         # them CUs but its HBM stream raises memory latency and the latency-bound encoder kernels run 1.6x slower while it
         # lasts; a CU-masked stream serialised the two queues.  Off by default, kept as an option (B2S_SPLIT_ADAM=1).
         self.split_adam = os.environ.get("B2S_SPLIT_ADAM", "0") == "1"
+        # tail_adam: with the encoder backward on its own stream, this stream is idle from the end of the decoder backward until the
+        # encoder's last weight gradients are done (~0.9 ms); the decoder / postnet update (HBM-bound) runs there, behind the second
+        # stream's last decoder weight-gradient group, and only the encoder group's update follows the encoder backward
+        self.tail_adam = os.environ.get("B2S_TAIL_ADAM", "1") != "0"
         # overlap_encoder: the encoder is 5 % of the step's FLOPs in ~55 launches per pass of 78..208 workgroups -- a fifth of the step on
         # a quarter of the chip.  Its forward runs on a stream of its own beside the decoder's prenet and first self-attention (which
         # do not read the encoder output), its backward starts as soon as d(memory) is complete, beside the first decoder layer's
@@ -243,7 +247,7 @@ class HipTrainer(object):
         ovl = self.overlap_encoder and not self.split_adam
         if ovl and self._enc_stream is None:
             self._lab_skipped = [torch.cuda.Stream(device=eng._gflat.device) for _ in range(int(os.environ.get('B2S_LAB_SKIP_STREAMS', '0')))]
-            self._enc_stream = torch.cuda.Stream(device=eng._gflat.device)
+            self._enc_stream = torch.cuda.Stream(device=eng._gflat.device, priority=int(os.environ.get("B2S_ENC_PRIO", "0")))
         enc_s = self._enc_stream if ovl else None
         if enc_s is not None:
             enc_s.wait_stream(cur)                         # (weights synced above; the previous step's optimizer update)
@@ -290,13 +294,20 @@ class HipTrainer(object):
             lr = self.hp.max_lr * self.lr_lambda(self.global_step)
             step_no = self.global_step + 1
             adam = (lr, step_no, self.beta1, self.beta2, self.hp.adam_eps, self.hp.reg_weight, 1.0 / self.world)
+            tail = (self.tail_adam and enc_bwd_s is not None and self.bucketer is None and not self.overlap_adam and not split)
             if split:
                 L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 1, L.stream()))
+            elif tail:
+                L.check(lib.b2s_model_mark_grads_ready(eng.handle))     # decoder / postnet gradients are final behind this point of the second stream
             if not self.freeze_encoder:
                 if enc_bwd_s is not None:
                     enc_bwd_s.wait_event(dmem_done)            # d(memory) only: the rest of the decoder backward runs beside the encoder's
                     with torch.cuda.stream(enc_bwd_s):
                         eng.encoder_backward(c_enc, dmem)
+                    if tail:
+                        # issued only now (a failure in the encoder backward call above leaves the step unapplied), but ordered behind the
+                        # mark only: on the device it runs beside the encoder backward
+                        L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 2, L.stream()))
                     cur.wait_stream(enc_bwd_s)                 # (its last stage joined the engine's second stream)
                 else:
                     eng.encoder_backward(c_enc, dmem)
@@ -330,7 +341,7 @@ class HipTrainer(object):
         if self.grad_probe is not None:
             self.grad_probe(eng._gflat, self.bucketer.wire if (self.bucketer is not None and self.bucketer.consume_wire) else None)
         self.global_step = step_no
-        if split:
+        if split or tail:
             L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 1, 0, L.stream()))
             # order this stream behind the second-stream update (done long before the encoder backward ends): plain torch
             # code that reads parameters right after train_step needs no explicit sync()

@@ -919,7 +919,8 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
     if (!m->aux && !getenv("B2S_NO_AUX")) {
         // (a lowest-priority second stream was measured: no change -- a weight-gradient workgroup holds its CU for ~110 us once it
         // has started, whatever the queue priorities say)
-        B2S_HIP(hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking));
+        if (getenv("B2S_AUX_PRIO")) B2S_HIP(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, atoi(getenv("B2S_AUX_PRIO"))));
+        else B2S_HIP(hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking));
         m->ev_pool.resize(256);
         for (auto& ev : m->ev_pool) B2S_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
@@ -1936,7 +1937,7 @@ extern "C" int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, f
 extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
                                     int groups, int on_aux, void* stream) {
     B2S_TRY(check_bound(m));
-    B2S_CHECK(m->adam_chunks && step >= 1 && groups > 0 && groups < 8, "Adam state not bound, bad step or bad group mask");
+    B2S_CHECK(m->adam_chunks && step >= 1 && groups > 0 && groups < 8 && on_aux >= 0 && on_aux <= 2, "Adam state not bound, bad step, group mask or placement");
     B2S_CHECK(!(m->adam_wire && on_aux), "the narrow optimizer launch beside the backward pass does not read a bf16 gradient wire buffer");
     if (step != m->adam_step_no) { m->adam_step_no = step; m->adam_step_mask = 0; }
     B2S_CHECK((m->adam_step_mask & groups) == 0, "parameter group mask %d was already updated in step %d", groups & m->adam_step_mask, step);
@@ -1953,23 +1954,38 @@ extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta
     B2S_CHECK(m->dw_pending.empty() && m->aux_jobs.empty() && m->ln_jobs.n == 0 && m->dw_stages_pending == 0 && m->unflushed_stages.empty(),
               "b2s_adam_step_groups: gradient work of the last backward stages is still queued (the preceding backward call deferred its "
               "join): call it without B2S_DEC_BWD_DEFER_JOIN / B2S_POST_BWD_DEFER_JOIN before a partial optimizer step");
-    if (on_aux && m->aux) {
+    if (on_aux == 1 && m->aux) {
         hipEvent_t ready = m->next_event();
         B2S_HIP(hipEventRecord(ready, st));                    // gradients of `groups` (and their all-reduce) are complete here
         B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
         run = m->aux;
+    } else if (on_aux == 2) {
+        // on the caller's stream, behind the mark only (b2s_model_mark_grads_ready): whatever the second stream was given after the
+        // mark -- the encoder's weight-gradient groups -- belongs to groups that are not in `groups`
+        B2S_CHECK(m->grads_marked, "b2s_adam_step_groups(on_aux = 2) needs b2s_model_mark_grads_ready after the last backward call of these groups");
+        B2S_CHECK(!(groups & B2S_ADAM_ENCODER), "on_aux = 2 is for the groups whose gradients were complete at the mark");
+        B2S_HIP(hipStreamWaitEvent(st, m->grads_mark_ev, 0));
+        m->grads_marked = false;
+    } else {
+        // on the caller's stream: the weight-gradient groups a backward entry point handed to the second stream without joining it
+        // (B2S_DEC_BWD_FLUSH_TAIL) must have landed first
+        B2S_TRY(join_aux(m, st));
     }
     // beside the backward pass: a narrow launch (see k_mt_adam_narrow); B2S_ADAM_CUS = number of its workgroups, 0 = wide launch
     // (measured, MI355X: a CU-masked stream made the two queues run one after the other instead of side by side)
     static const int narrow = getenv("B2S_ADAM_CUS") ? atoi(getenv("B2S_ADAM_CUS")) : 64;
     static const int order[3] = {1, 2, 0};                     // decoder, postnet, encoder
+    // on_aux = 2 runs beside the encoder backward (on its own stream) and the last weight-gradient groups: a capped grid -- the full one
+    // saturates HBM and the latency-bound encoder kernels take 3-4x as long while it runs (measured, profiles/NOTES_r04.md)
+    static const int tail_wg = getenv("B2S_TAIL_ADAM_WG") ? atoi(getenv("B2S_TAIL_ADAM_WG")) : 512;
     for (int k = 0; k < 3; ++k) {
         const int g = order[k], lo = m->adam_grp[g], n = m->adam_grp[g + 1] - lo;
         if (!(groups >> g & 1) || n <= 0) continue;
         if (run != st && narrow > 0)
             B2S_TRY(ro_mt_adam_narrow(m->adam_chunks + lo, n, narrow, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, run));
         else
-            B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, run, m->adam_wire, m->adam_gbase));
+            B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, run, m->adam_wire, m->adam_gbase,
+                               on_aux == 2 ? tail_wg : 0));
         if (g == 2 && m->dtype == 0) B2S_TRY(relayout_convs(m, run));
         if (run != st) {
             if (!m->adam_ev[g]) B2S_HIP(hipEventCreateWithFlags(&m->adam_ev[g], hipEventDisableTiming));
@@ -1981,6 +1997,20 @@ extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta
     // the per-chunk sums of squares cover the regulariser once every group has been stepped (groups whose chunk range is
     // empty -- a frozen encoder -- never are: `cover` is false then)
     m->l2_fresh = cover && m->adam_step_mask == 7;
+    return 0;
+}
+// Marks the point of the second stream behind all gradient work handed to it so far (a decoder backward called with
+// B2S_DEC_BWD_FLUSH_TAIL leaves its last weight-gradient groups running there).  b2s_adam_step_groups(on_aux = 2) waits for the mark
+// instead of joining the second stream -- the caller may enqueue the encoder backward (on another stream) in between, so that a
+// failure there still finds no part of the optimizer step applied.
+extern "C" int b2s_model_mark_grads_ready(b2s_model* m) {
+    B2S_TRY(check_bound(m));
+    B2S_CHECK(m->aux, "no second stream");
+    B2S_CHECK(m->dw_pending.empty() && m->aux_jobs.empty() && m->ln_jobs.n == 0 && m->dw_stages_pending == 0,
+              "b2s_model_mark_grads_ready: gradient work is still queued on the host side (call the backward entry point with B2S_DEC_BWD_FLUSH_TAIL)");
+    if (!m->grads_mark_ev) B2S_HIP(hipEventCreateWithFlags(&m->grads_mark_ev, hipEventDisableTiming));
+    B2S_HIP(hipEventRecord(m->grads_mark_ev, m->aux));
+    m->grads_marked = true;
     return 0;
 }
 // A backward pass that was given up between entry points (a failed call, an exception in the caller between postnet / decoder / encoder
@@ -1995,6 +2025,7 @@ extern "C" int b2s_model_backward_abort(b2s_model* m, void* stream) {
     m->pending_stages.clear(); m->unflushed_stages.clear();
     m->pending_ev = nullptr;
     m->dw_hold_from = -1; m->dw_tail_cap = 0; m->dw_flush_capped = false;      // (a decoder backward that failed mid-call leaves its tail policy set)
+    m->grads_marked = false;
     if (m->aux) { m->aux_dirty = true; B2S_TRY(join_aux(m, S_(stream))); }
     return 0;
 }

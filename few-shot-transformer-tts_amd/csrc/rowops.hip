@@ -1101,38 +1101,41 @@ __device__ __forceinline__ float adam_chunk(const MtChunk& c, const bf16_t* gw, 
     return ss;
 }
 template <bool W16>
-__global__ __launch_bounds__(256) void k_mt_adam2(const MtChunk* __restrict__ ch, const float* __restrict__ hp, float b1, float b2, float eps,
+__global__ __launch_bounds__(256) void k_mt_adam2(const MtChunk* __restrict__ ch, int nchunks, const float* __restrict__ hp, float b1, float b2, float eps,
                                                   float l2, float gs, float* sumsq_part, const bf16_t* __restrict__ wire, const float* gbase) {
     __shared__ float sh[4];
-    const MtChunk c = ch[blockIdx.x];
-    const bf16_t* gw = W16 ? wire + (c.b - gbase) : nullptr;
     const float lr = hp[0], bc1 = hp[1], sbc2 = hp[2];
-    const float step = lr / bc1, l2p = c.pad ? l2 : 0.f;
-    float ss = 0.f;
-    int i0 = 0;
-    const bool vec = ((((size_t)c.a | (size_t)c.b | (size_t)c.c | (size_t)c.d) & 15) == 0) && (c.cin || ((size_t)c.s & 7) == 0) && (!W16 || ((size_t)gw & 7) == 0);
-    if (vec) {
-        if (c.cin) ss = adam_chunk<2, W16>(c, gw, gs, l2p, b1, b2, step, sbc2, eps);
-        else if (c.s) ss = adam_chunk<1, W16>(c, gw, gs, l2p, b1, b2, step, sbc2, eps);
-        else ss = adam_chunk<0, W16>(c, gw, gs, l2p, b1, b2, step, sbc2, eps);
-        i0 = (c.n >> 2) << 2;
-    }
-    for (int i = i0 + threadIdx.x; i < c.n; i += 256) {       // unaligned tensors and the last 0-3 elements of a chunk
-        float p = c.a[i], m = c.c[i], v = c.d[i];
-        ss += adam_elem(p, W16 ? bf2f(gw[i]) : c.b[i], m, v, gs, l2p, b1, b2, step, sbc2, eps);
-        c.c[i] = m; c.d[i] = v;
-        c.a[i] = p;
-        if (c.cin) {
-            const long gi = c.off + i, r = gi / 5;
-            const int j = (int)(gi - r * 5), co = (int)(r / c.cin), ci = (int)(r - (long)co * c.cin);
-            const bf16_t pb = f2bf(p);
-            c.s[(long)co * 5 * c.cin + (long)j * c.cin + ci] = pb;
-            c.s2[(long)ci * 5 * c.cout + (long)(4 - j) * c.cout + co] = pb;
-        } else if (c.s) c.s[i] = f2bf(p);
-    }
-    if (sumsq_part) {
-        ss = block_sum_256(ss, sh);
-        if (threadIdx.x == 0) sumsq_part[blockIdx.x] = c.pad ? ss : 0.f;
+    // one chunk per workgroup, or (a capped grid: ro_mt_adam's max_wg) every gridDim.x-th chunk
+    for (int cix = blockIdx.x; cix < nchunks; cix += gridDim.x) {
+        const MtChunk c = ch[cix];
+        const bf16_t* gw = W16 ? wire + (c.b - gbase) : nullptr;
+        const float step = lr / bc1, l2p = c.pad ? l2 : 0.f;
+        float ss = 0.f;
+        int i0 = 0;
+        const bool vec = ((((size_t)c.a | (size_t)c.b | (size_t)c.c | (size_t)c.d) & 15) == 0) && (c.cin || ((size_t)c.s & 7) == 0) && (!W16 || ((size_t)gw & 7) == 0);
+        if (vec) {
+            if (c.cin) ss = adam_chunk<2, W16>(c, gw, gs, l2p, b1, b2, step, sbc2, eps);
+            else if (c.s) ss = adam_chunk<1, W16>(c, gw, gs, l2p, b1, b2, step, sbc2, eps);
+            else ss = adam_chunk<0, W16>(c, gw, gs, l2p, b1, b2, step, sbc2, eps);
+            i0 = (c.n >> 2) << 2;
+        }
+        for (int i = i0 + threadIdx.x; i < c.n; i += 256) {       // unaligned tensors and the last 0-3 elements of a chunk
+            float p = c.a[i], m = c.c[i], v = c.d[i];
+            ss += adam_elem(p, W16 ? bf2f(gw[i]) : c.b[i], m, v, gs, l2p, b1, b2, step, sbc2, eps);
+            c.c[i] = m; c.d[i] = v;
+            c.a[i] = p;
+            if (c.cin) {
+                const long gi = c.off + i, r = gi / 5;
+                const int j = (int)(gi - r * 5), co = (int)(r / c.cin), ci = (int)(r - (long)co * c.cin);
+                const bf16_t pb = f2bf(p);
+                c.s[(long)co * 5 * c.cin + (long)j * c.cin + ci] = pb;
+                c.s2[(long)ci * 5 * c.cout + (long)(4 - j) * c.cout + co] = pb;
+            } else if (c.s) c.s[i] = f2bf(p);
+        }
+        if (sumsq_part) {
+            ss = block_sum_256(ss, sh);
+            if (threadIdx.x == 0) sumsq_part[cix] = c.pad ? ss : 0.f;
+        }
     }
 }
 // The same update from a NARROW grid: gridDim.x workgroups of 1024 threads walk the chunk list.  For the optimizer update that
@@ -1502,14 +1505,15 @@ int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gsc
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1, float beta2, float eps, float l2,
-               float grad_scale, float* sumsq_part, hipStream_t st, const void* wire, const float* gbase) {
+               float grad_scale, float* sumsq_part, hipStream_t st, const void* wire, const float* gbase, int max_wg) {
     static const bool v1 = getenv("B2S_ADAM_V1") != nullptr;
+    const int grid = max_wg > 0 ? std::min(max_wg, nchunks) : nchunks;
     if (nchunks > 0 && wire)
-        hipLaunchKernelGGL(k_mt_adam2<true>, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part, (const bf16_t*)wire, gbase);
+        hipLaunchKernelGGL(k_mt_adam2<true>, dim3(grid), dim3(256), 0, st, chunks, nchunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part, (const bf16_t*)wire, gbase);
     else if (nchunks > 0 && v1)
         hipLaunchKernelGGL(k_mt_adam, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part);
     else if (nchunks > 0)
-        hipLaunchKernelGGL(k_mt_adam2<false>, dim3(nchunks), dim3(256), 0, st, chunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part, (const bf16_t*)nullptr,
+        hipLaunchKernelGGL(k_mt_adam2<false>, dim3(grid), dim3(256), 0, st, chunks, nchunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part, (const bf16_t*)nullptr,
                            (const float*)nullptr);
     B2S_LAUNCH_CHECK(); return 0;
 }

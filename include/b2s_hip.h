@@ -220,12 +220,17 @@ int b2s_adam_set_grad_wire(b2s_model* m, const void* wire_bf16, const float* gra
  * already enqueued on `stream`, and the call returns with `stream` free to go on -- the fused trainer updates the decoder
  * and postnet parameters this way while the encoder backward (small kernels that leave most CUs idle) still runs, then the
  * encoder group on `stream` itself.  Every group must be stepped exactly once per `step`; entry points wait for the groups
- * they read (as with b2s_adam_step_ex). */
+ * they read (as with b2s_adam_step_ex).
+ * on_aux = 2: the groups are updated on `stream` itself by a capped grid, behind the mark b2s_model_mark_grads_ready left on the second
+ * stream (and nothing later): the trainer marks after the decoder backward, enqueues the encoder backward on its own stream, and only
+ * then issues the decoder / postnet update -- which runs beside the encoder backward on the device, while a host-side failure in the
+ * encoder backward still finds no part of the step applied. */
 #define B2S_ADAM_ENCODER 1
 #define B2S_ADAM_DECODER 2
 #define B2S_ADAM_POSTNET 4
 int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
                          int groups, int on_aux, void* stream);
+int b2s_model_mark_grads_ready(b2s_model* m);
 /* Zero every bound parameter gradient.  Every *_backward entry point ACCUMULATES into the bound gradient
  * buffers (several use atomics), so the host calls this once at the start of each backward pass. */
 int b2s_zero_grads(b2s_model* m, void* stream);

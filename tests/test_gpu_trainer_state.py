@@ -163,6 +163,29 @@ def test_split_optimizer_step_matches_single_launch(monkeypatch, extra):
     assert abs(res[0][1][0] - res[1][1][0]) < 2e-2 * abs(res[0][1][0])
 
 
+def test_tail_optimizer_step_matches_single_launch(monkeypatch):
+    """Default schedule (B2S_TAIL_ADAM): the decoder / postnet update runs on the trainer's stream behind b2s_model_mark_grads_ready,
+    beside the encoder backward on its own stream, the encoder group after it.  Same arithmetic as the single launch after the whole
+    backward pass: fp32 mode (no atomics in the compared path beyond the column sums), identical losses and parameters after 3 steps."""
+    from b2s_hip.trainer import HipTrainer
+    res = []
+    for tail in ("0", "1"):
+        monkeypatch.setenv("B2S_TAIL_ADAM", tail)
+        m, cfg, _, hp = build(TINY96, compute_dtype="bf16")
+        _, b = _batch(cfg)
+        m.train()
+        tr = HipTrainer(m, hp)
+        assert tr.tail_adam == (tail == "1") and tr.overlap_encoder
+        for _ in range(3):
+            v = tr.train_step(b)
+        torch.cuda.synchronize()
+        res.append(({k: t.detach().clone() for k, t in m.state_dict().items()}, v.cpu().numpy()))
+    for k, t in res[0][0].items():
+        d = float((t.double() - res[1][0][k].double()).abs().max())
+        assert d <= 2e-2 * (1.0 + float(t.double().abs().max())), (k, d)           # bf16 + atomics: runs are not bit-reproducible
+    assert abs(res[0][1][0] - res[1][1][0]) < 2e-2 * abs(res[0][1][0])
+
+
 @pytest.mark.parametrize("where", ["decoder_backward", "encoder_backward"])
 def test_failed_backward_is_abandoned_cleanly(where):
     """An exception between the backward entry points (which hand queued weight-gradient work to each other: deferred joins) must not
