@@ -68,7 +68,7 @@ int b2s_gemm_glds256_launch(const GemmArgs& g, bool ta, bool tb, const bf16_t* z
 int b2s_splitk_reduce_launch(const float* ws, float* dst, int M, int N, int ldc, int splitk, int conv_dw_cin, hipStream_t stream);
 // up to B2S_MAX_GROUP weight-gradient problems (TN form, fp32 accumulate, no split-K) in one launch
 #define B2S_MAX_GROUP 8
-struct b2s_gemm_group { int n; int tile0[B2S_MAX_GROUP + 1]; GemmArgs p[B2S_MAX_GROUP]; };
+struct b2s_gemm_group { int n; int order; int tile0[B2S_MAX_GROUP + 1]; GemmArgs p[B2S_MAX_GROUP]; };      // order: 1 = XCD-contiguous over the whole list
 int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* zero, hipStream_t stream);
 // 256 zero bytes in device memory, written once at first use and immutable afterwards (source of the out-of-bounds chunks of
 // the LDS-DMA loads); the only process-wide device object of the GEMM layer

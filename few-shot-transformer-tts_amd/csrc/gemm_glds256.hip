@@ -407,21 +407,37 @@ __global__ __launch_bounds__(nthreads_of(false), 1) void gemm_glds256_grouped_ke
     // 36 long tiles to each of the other seven (32 CUs each): a second round of 8148-deep tiles, 213 us instead of ~120.
     // Inside a problem the ids that land on one XCD are mapped to a contiguous piece of its row-major tile list (shared
     // A / B panels stay in that XCD's L2).
-    const int i = blockIdx.x;
-    int p = 0;
-    while (p + 1 < grp.n && i >= grp.tile0[p + 1]) ++p;
-    const int s0 = grp.tile0[p], cnt = grp.tile0[p + 1] - s0, xcd = i & 7;
-    int before = 0;                                     // tiles of this problem on lower-numbered XCDs
-    for (int x = 0; x < xcd; ++x) {
-        const int first = s0 + ((x - s0) & 7);          // smallest id >= s0 on XCD x
-        before += first < s0 + cnt ? (s0 + cnt - 1 - first) / 8 + 1 : 0;
+    const int i = blockIdx.x, xcd = i & 7;
+    int p = 0, local;
+    if (grp.order == 1) {
+        // One launch holds problems of ONE depth class (engine: flush_dw), so a globally XCD-contiguous order is balanced: XCD x takes
+        // the x-th eighth of the whole tile list -- ~32 neighbouring tiles, mostly of one problem, i.e. ~5 A panels + 6 B panels per XCD
+        // instead of an eighth of EVERY problem's tiles (1-2 A panels + up to 10 B panels of each of the 6-7 problems)
+        const int T = grp.tile0[grp.n];
+        int start = 0;
+        for (int x = 0; x < xcd; ++x) start += (T - x + 7) >> 3;        // ids x, x + 8, ... < T
+        const int g = start + (i >> 3);
+        while (p + 1 < grp.n && g >= grp.tile0[p + 1]) ++p;
+        local = g - grp.tile0[p];
+    } else {
+        while (p + 1 < grp.n && i >= grp.tile0[p + 1]) ++p;
+        const int s0 = grp.tile0[p], cnt = grp.tile0[p + 1] - s0;
+        int before = 0;                                     // tiles of this problem on lower-numbered XCDs
+        for (int x = 0; x < xcd; ++x) {
+            const int first = s0 + ((x - s0) & 7);          // smallest id >= s0 on XCD x
+            before += first < s0 + cnt ? (s0 + cnt - 1 - first) / 8 + 1 : 0;
+        }
+        local = before + (i - (s0 + ((xcd - s0) & 7))) / 8;
     }
-    const int local = before + (i - (s0 + ((xcd - s0) & 7))) / 8;
-    const int tiles_n = (grp.p[p].N + NB * 32 - 1) / (NB * 32);
+    const int tiles_n = (grp.p[p].N + NB * 32 - 1) / (NB * 32), tiles_m = (grp.p[p].M + BM - 1) / BM;
     // K split over `splitk` workgroups per output tile (fp32 atomic accumulate; with two halves added to a zeroed gradient the result does
     // not depend on their order): the K parts of a tile are adjacent in the XCD's list, so they share its A / B panels' neighbours in L2
     const int sk = grp.p[p].splitk, t = local / sk, bz = local - t * sk;
-    const int by = t / tiles_n, bx = t - by * tiles_n;
+    int by, bx;
+    // wide outputs (tiles_n > 8: W2's 3 x 24 tiles) are walked column by column: a run of 32 tiles is then 3 A panels x 11 B panels
+    // instead of 2 x 24
+    if (grp.order == 1 && tiles_n > 8) { bx = t / tiles_m; by = t - bx * tiles_m; }
+    else { by = t / tiles_n; bx = t - by * tiles_n; }
     gemm256_body<true, true, 0, NB>(grp.p[p], zero, nullptr, bx, by, bz);
 }
 
@@ -486,6 +502,8 @@ int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* 
     B2S_CHECK(n >= 1 && n <= B2S_MAX_GROUP, "grouped GEMM: %d problems (max %d)", n, B2S_MAX_GROUP);
     b2s_gemm_group grp;
     grp.n = n;
+    static const int xcd_order = getenv("B2S_DW_XCD_ORDER") ? atoi(getenv("B2S_DW_XCD_ORDER")) : 1;
+    grp.order = xcd_order;
     // Launch order = dispatch order.  Tiles cost ~K; with one workgroup per CU the makespan of "deepest first" against
     // "shallowest first" is decided by list scheduling on the CU count (288 tiles of a decoder layer: 252 deep + 36 shallow --
     // shallow first lets the 36 early finishers take the last 32 deep tiles, deep first leaves 32 shallow tiles to 4 CUs)
