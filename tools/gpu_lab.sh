@@ -1,12 +1,10 @@
 #!/bin/bash
-# scratch GPU lab call (edited per experiment)
+# One gpurun call = an optional pytest selection + an interleaved A/B of environment switches on the training-step benchmark.
+# usage (through gpurun): bash tools/gpu_lab.sh <tag> "<pytest arguments or ->" <rounds> "ENV=a" "ENV=b ENV2=c" "-" ...
+#   e.g. gpurun -- 'bash tools/gpu_lab.sh tail "tests/test_gpu_trainer_state.py -q" 3 "B2S_TAIL_ADAM=0" "-"'
+# (A/B arms always inside ONE call: boxes differ by 2-3 %.  Traces: tools/gpu_trace.sh; counters: tools/gpu_pmc.sh; the round's
+# profile set: tools/gpu_round_profiles.sh.)
+tag=$1; sel=$2; rounds=$3; shift 3
 mkdir -p gpurun_out
-repo=$PWD; out=$repo/gpurun_out
-export TMPDIR=/tmp
-cd /tmp
-for arm in 0 1; do
-B2S_RESIDUAL_BF16=$arm rocprofv3 --kernel-trace --stats --output-format csv -d $out/lab_x$arm -o t -- python $repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass --no-extras > $out/lab_x$arm.log 2>&1
-find $out/lab_x$arm -name "*kernel_trace.csv" -delete; find $out/lab_x$arm -name "*.db" -delete
-done
-cd $repo
-bash tools/gpu_ab.sh lab 4 "B2S_RESIDUAL_BF16=0" "-"
+if [ "$sel" != "-" ]; then python -m pytest $sel 2>&1 | tail -15 > gpurun_out/${tag}_tests.log; tail -3 gpurun_out/${tag}_tests.log; fi
+[ "$rounds" -gt 0 ] && bash tools/gpu_ab.sh $tag $rounds "$@"
