@@ -327,6 +327,11 @@ class HipEngine(object):
         L.check(self.lib.b2s_add(L.ptr(a.contiguous()), L.ptr(b.contiguous()), L.ptr(out), a.numel(), L.stream()))
         return out
 
+    def add3(self, a, b, c):
+        out = torch.empty_like(a)
+        L.check(self.lib.b2s_add3(L.ptr(a.contiguous()), L.ptr(b.contiguous()), L.ptr(c.contiguous()), L.ptr(out), a.numel(), L.stream()))
+        return out
+
     def loss_forward(self, bef, aft, stop, tgt, len32):
         dev = self.ensure_bound()
         B, T, _ = tgt.shape

@@ -98,6 +98,7 @@ _PROTOS = {
                                             P]),
     "b2s_align_from_probs": (C.c_int, [C.c_int, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P]),
     "b2s_add": (C.c_int, [P, P, P, C.c_int64, P]),
+    "b2s_add3": (C.c_int, [P, P, P, P, C.c_int64, P]),
     "b2s_pack_bf16": (C.c_int, [P, P, C.c_int64, P]),
     "b2s_unpack_bf16": (C.c_int, [P, P, C.c_int64, P]),
     "b2s_cast": (C.c_int, [C.c_int, P, P, C.c_int64, P]),

@@ -110,6 +110,7 @@ class HipTrainer(object):
             # CUs for a whole round (b2s_gemm_set_tile_policy; measured with tools/cu_loss.py, profiles/NOTES_r03.md)
             if self.world > 1:
                 L.check(self.lib.b2s_gemm_set_tile_policy(4))
+                self._set_tile_policy = True               # (process-wide switch: close() restores the per-shape choice)
             lib = self.lib
             def pack(src, dst):
                 L.check(lib.b2s_pack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()))
@@ -165,6 +166,12 @@ class HipTrainer(object):
     def sync(self):
         """Make the current torch stream wait for an overlapped optimizer step (no-op otherwise)."""
         L.check(self.lib.b2s_adam_wait(self.eng.handle, L.stream()))
+
+    def close(self):
+        """Undo the process-wide settings this trainer made (the data-parallel GEMM tile policy); the trainer stays usable."""
+        if getattr(self, "_set_tile_policy", False):
+            L.check(self.lib.b2s_gemm_set_tile_policy(0))
+            self._set_tile_policy = False
 
     def state_dict(self):
         """Optimizer state in torch.optim.Adam.state_dict() layout (what train.py:130 + checkpoint.py:27 write), so a
@@ -275,7 +282,7 @@ class HipTrainer(object):
         try:
             dbef, daft, dstop = eng.loss_backward(mels, aft, stop, batch["mel_targets"], tgt32, None)
             din = eng.postnet_backward(c_post, daft, defer_join=True)           # (the decoder backward below takes over the second stream's join)
-            dmel = eng.add(eng.add(din, daft), dbef)
+            dmel = eng.add3(din, daft, dbef)                  # (same order of additions as two b2s_add calls)
             # split: the decoder / postnet gradients (78 % of the parameters) get their optimizer update (HBM-bound, no LDS) on the
             # engine's second stream under the encoder backward, whose GEMMs are 78..208 workgroups on 256 CUs; the encoder group
             # follows on this stream.  Data parallel: those gradients' all-reduce must be complete first, so the split is used only

@@ -141,6 +141,10 @@ extern "C" int b2s_add(const float* a, const float* b, float* out, int64_t n, vo
     B2S_CHECK(a && b && out, "null argument");
     return ro_add(a, b, out, n, S_(stream));
 }
+extern "C" int b2s_add3(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream) {
+    B2S_CHECK(a && b && c && out, "null argument");
+    return ro_add3(a, b, c, out, n, S_(stream));
+}
 extern "C" int b2s_cast(int dtype, const float* in, void* out, int64_t n, void* stream) {
     B2S_CHECK(in && out, "null argument");
     return ro_cast(dtype, in, out, n, S_(stream));

@@ -1564,6 +1564,9 @@ extern "C" int b2s_decoder_backward_ev(b2s_model* m, b2s_ctx* c, const float* d_
     static const int tail_layers = getenv("B2S_DW_TAIL_LAYERS") ? atoi(getenv("B2S_DW_TAIL_LAYERS")) : 2;
     static const int tail_cap = getenv("B2S_DW_TAIL_CAP") ? atoi(getenv("B2S_DW_TAIL_CAP")) : 200;
     m->dw_hold_from = -1; m->dw_tail_cap = 0;
+    // (whatever way this call is left -- a failing B2S_TRY included -- the tail policy does not outlive it: a following stand-alone
+    // b2s_encoder_backward must not find its stages held)
+    struct TailPolicyReset { b2s_model* m; ~TailPolicyReset() { m->dw_hold_from = -1; m->dw_tail_cap = 0; m->dw_flush_capped = false; } } tail_policy_reset{m};
     if ((flags & B2S_DEC_BWD_FLUSH_TAIL) && m->dw_group && tail_layers > 0 && tail_cap > 0 && dt == 1) {
         m->dw_hold_from = 2 + std::max(0, cf.n_decoder_layer - tail_layers);      // stage 1 = heads, 2 + k = decoder layer L-1-k
         m->dw_tail_cap = tail_cap;

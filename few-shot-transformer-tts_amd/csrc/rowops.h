@@ -126,4 +126,5 @@ int ro_sum_scaled(const float* part, int n, float scale, float* out, hipStream_t
 // conv weight relayouts (fp32 master [Cout][Cin][5] -> T):  fwd[co][j*Cin+ci] ; bwd[ci][j*Cout+co] = w[co][ci][4-j]
 int ro_conv_w_relayout(int dtype, const float* w, void* wf, void* wb, int Cout, int Cin, hipStream_t st);
 int ro_add(const float* a, const float* b, float* out, long n, hipStream_t st);
+int ro_add3(const float* a, const float* b, const float* c, float* out, long n, hipStream_t st);     // out = (a + b) + c
 int ro_fill(float* p, float v, long n, hipStream_t st);

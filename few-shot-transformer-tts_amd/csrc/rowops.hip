@@ -1203,6 +1203,9 @@ __global__ void k_conv_w_relayout(const float* w, T* wf, T* wb, int Cout, int Ci
 __global__ void k_add(const float* a, const float* b, float* o, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) o[i] = a[i] + b[i];
 }
+__global__ void k_add3(const float* a, const float* b, const float* c, float* o, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) o[i] = (a[i] + b[i]) + c[i];
+}
 __global__ void k_fill(float* p, float v, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -1549,6 +1552,10 @@ int ro_im2col5(int dtype, const void* x, const int* lens, int T, int cin, void* 
 int ro_conv_w_relayout(int dtype, const float* w, void* wf, void* wb, int Cout, int Cin, hipStream_t st) {
     RO_DISPATCH(dtype, hipLaunchKernelGGL((k_conv_w_relayout<TY>), dim3(ew_grid((long)Cout * Cin * 5)), dim3(256), 0, st, w,
                                           (TY*)wf, (TY*)wb, Cout, Cin));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_add3(const float* a, const float* b, const float* c, float* out, long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_add3, dim3(ew_grid(n)), dim3(256), 0, st, a, b, c, out, n);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_add(const float* a, const float* b, float* out, long n, hipStream_t st) {

@@ -301,6 +301,9 @@ int b2s_flash_attention_align(int dtype, const void* q, int ldq, const void* k, 
 int b2s_align_from_probs(int dtype, const void* P, float* align, int B, int H, int Lq, int Lk, void* stream);
 /* out = a + b (fp32, n elements) */
 int b2s_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* out = (a + b) + c: the three contributions to d(mel_before) -- postnet input gradient, d(mel_after) routed around it and the direct loss
+ * term (tacotron.py:126-133 + autograd) -- in one launch */
+int b2s_add3(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream);
 /* Gradient payload conversion for the data-parallel exchange (b2s_hip/dp.py): fp32 gradients -> bf16 wire buffer and back (half
  * the bytes per all-reduce over xGMI; parameters, Adam moments and the accumulation inside a rank stay fp32). */
 int b2s_pack_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);

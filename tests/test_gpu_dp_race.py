@@ -106,7 +106,8 @@ def test_exchange_ordering_bf16_wire_is_exact(spin):
                     d = float((tr.exp_avg[off:off + cnt] - ref).abs().max())
                     assert d <= 1e-6 * float(ref.abs().max()) + 1e-12, (i, n, d)
     finally:
-        L.check(L.load().b2s_gemm_set_tile_policy(0))                     # (the world-2 trainer selected the data-parallel tile policy process-wide)
+        tr.close()                                                         # (the world-2 trainer selected the data-parallel tile policy process-wide)
+        assert not tr._set_tile_policy
 
 
 @pytest.mark.parametrize("spin", [0, 400000])

@@ -186,6 +186,41 @@ def test_tail_optimizer_step_matches_single_launch(monkeypatch):
     assert abs(res[0][1][0] - res[1][1][0]) < 2e-2 * abs(res[0][1][0])
 
 
+def test_tail_update_protocol_is_checked():
+    """b2s_adam_step_groups(on_aux = 2) is only valid behind b2s_model_mark_grads_ready, never for the encoder group, and a group is
+    stepped once per step: each misuse is an error code with a message, not a silent partial update.  b2s_add3 == two b2s_add calls."""
+    from b2s_hip.trainer import HipTrainer
+    from b2s_hip import lib as L
+    m, cfg, _, hp = build(TINY96, compute_dtype="bf16")
+    _, b = _batch(cfg)
+    m.train()
+    tr = HipTrainer(m, hp)
+    tr.train_step(b)
+    torch.cuda.synchronize()
+    lib, h = tr.lib, tr.eng.handle
+    adam = (1e-3, 2, 0.9, 0.999, 1e-6, 0.0, 1.0)
+    with pytest.raises(L.B2SError, match="mark_grads_ready"):
+        L.check(lib.b2s_adam_step_groups(h, *adam, 2 | 4, 2, L.stream()))           # no mark
+    L.check(lib.b2s_model_mark_grads_ready(h))
+    with pytest.raises(L.B2SError, match="complete at the mark"):
+        L.check(lib.b2s_adam_step_groups(h, *adam, 1 | 2, 2, L.stream()))           # encoder group behind a decoder mark
+    with pytest.raises(L.B2SError, match="placement"):
+        L.check(lib.b2s_adam_step_groups(h, *adam, 2, 3, L.stream()))
+    before = {k: v.detach().clone() for k, v in m.state_dict().items() if v.is_floating_point()}
+    torch.cuda.synchronize()
+    for k, v in m.state_dict().items():
+        if k in before:
+            assert torch.equal(v, before[k]), k                                         # nothing was applied by the refused calls
+    lib.b2s_model_backward_abort(h, L.stream())                                         # (drops the mark)
+    with pytest.raises(L.B2SError, match="mark_grads_ready"):
+        L.check(lib.b2s_adam_step_groups(h, *adam, 2 | 4, 2, L.stream()))
+    x, y, z = (torch.randn(1000, 80, device=DEV) for _ in range(3))
+    assert torch.equal(tr.eng.add3(x, y, z), tr.eng.add(tr.eng.add(x, y), z))
+    tr.train_step(b)                                                                    # the trainer is still usable
+    torch.cuda.synchronize()
+    assert tr.global_step == 2
+
+
 @pytest.mark.parametrize("where", ["decoder_backward", "encoder_backward"])
 def test_failed_backward_is_abandoned_cleanly(where):
     """An exception between the backward entry points (which hand queued weight-gradient work to each other: deferred joins) must not
