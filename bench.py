@@ -21,6 +21,10 @@ import time
 # second stream landed on the main stream's hardware queue and the two serialised (single-rank RCCL run: 10.9 ms per step
 # against 9.98 with 8 queues; no effect without RCCL).  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (b2s_hip/lib.py makes the same choice at import; here the process group is created before that import) data-parallel runs: cap RCCL's
+# channel count -- every channel holds a CU while a collective runs (profiles/r03_cu_loss.txt) and the exchange needs 22 GB/s per GPU
+if int(os.environ.get("WORLD_SIZE", "1") or "1") > 1:
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "few-shot-transformer-tts_amd")
 for p in (ROOT, PKG):

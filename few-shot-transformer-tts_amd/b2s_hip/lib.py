@@ -11,6 +11,12 @@ import os
 # (+10 % step time).  Effective only if the HIP runtime has not initialised yet -- importing this package before the first
 # torch.cuda call is enough; launchers can also export it.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Data-parallel runs (a launcher exported WORLD_SIZE > 1): every RCCL channel is a workgroup that holds a CU while the collective runs, and
+# the step loses 4-5 % with 8-32 CUs held, 10.6 % with 64 (profiles/r03_cu_loss.txt) -- while the exchange moves 167 MB per ~7.5 ms step
+# (22 GB/s per GPU), a fraction of what a handful of channels carry.  Cap the channel count unless the launcher chose one itself.
+# Effective only before the process group is created.
+if int(os.environ.get("WORLD_SIZE", "1") or "1") > 1:
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
 
 import torch  # noqa: E402
 
