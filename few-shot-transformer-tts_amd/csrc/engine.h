@@ -161,6 +161,7 @@ struct b2s_model {
     const void* adam_wire = nullptr;                           // b2s_adam_set_grad_wire: bf16 gradients (the exchange's wire buffer) laid out like the
     const float* adam_gbase = nullptr;                         // fp32 gradient buffer that starts at adam_gbase
     int adam_step_no = 0, adam_step_mask = 0;                  // b2s_adam_step_groups: groups already updated in step adam_step_no
+    mutable bool dw_flush_exposed = false;                     // end_stage -> flush_dw: this hand-over is the entry point's drain (nothing overlaps it)
     mutable hipEvent_t grads_mark_ev = nullptr;                // b2s_model_mark_grads_ready: second-stream event behind the gradient work queued so far
     mutable bool grads_marked = false;
     // bf16 mode: the compute-dtype copies of the L encoder-decoder kv_transform weights are one slab [L*2D][D], so that the

@@ -280,20 +280,51 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
             B2S_TRY(b2s_gemm_launch(g, m->dtype, true, true, m->aux));
         }
     } else {
-        // one grouped launch per depth class (q is sorted by K): a decoder layer is 252 tiles over all 8148 tokens + 36 tiles
-        // over the 1596 memory rows; launched together the 288 tiles need a second round of deep tiles on 32 CUs (172 us),
-        // apart they take 129 + 20 us
-        // tail policy (engine.h: dw_hold_from): launches of at most dw_tail_cap tiles, one after the other -- the second stream then never
-        // holds more than that many CUs at a time and the encoder chain on the caller's other stream keeps finding free ones
+        // Launches are packed per depth class (q is sorted by K; a class = K within 2x: a decoder layer is 252 tiles over all 8148 tokens + 36
+        // tiles over the 1596 memory rows -- launched together the 288 tiles need a second round of deep tiles on 32 CUs, 172 us; apart
+        // 129 + 20 us) and, inside a class, first-fit-decreasing by tile count into launches of at most B2S_MAX_GROUP problems and at most
+        // ONE ROUND of tiles (256, one workgroup per CU): two stages handed over together used to go out as 8 + 6 problems = 396 + 108 tiles
+        // = three rounds of 8148-deep tiles (278 + 124 us) where 252 + 252 is two (2 x 125 us), and heads + layer as 258 tiles (265 us)
+        // where 252 + a 6-tile rest is one.
+        // tail policy (engine.h: dw_hold_from): at most dw_tail_cap tiles per launch instead -- the second stream then never holds more than
+        // that many CUs at a time and the encoder chain on the caller's other stream keeps finding free ones
+        // ... for a hand-over that nothing else overlaps (dw_flush_exposed: the drain at the end of a backward entry point -- the fine-tune
+        // step's last groups, 7.34 -> 7.24 ms).  Beside the main stream's GEMMs the same packing LOSES (7.43 -> 7.55 ms per step): a
+        // 252-tile launch takes every CU for a whole round and the main stream's one-round GEMMs stall behind it, while the CU time
+        // (tiles x time per tile) is the same either way -- there the launches stay contiguous runs of up to B2S_MAX_GROUP problems.
+        static const int round_env = getenv("B2S_DW_ROUND_TILES") ? atoi(getenv("B2S_DW_ROUND_TILES")) : 256;       // (0: never)
+        const int round_tiles = m->dw_flush_exposed ? round_env : 0;
         const bool capped = m->dw_flush_capped && m->dw_tail_cap > 0;
+        const long cap = capped ? m->dw_tail_cap : (round_tiles > 0 ? round_tiles : (1L << 30));
         size_t i = 0;
         while (i < q.size()) {
-            size_t j = i + 1;
-            long t = b2s_gemm_glds256_tiles(q[i]);
-            while (j < q.size() && j - i < B2S_MAX_GROUP && q[j].K * 2 > q[i].K &&
-                   (!capped || t + b2s_gemm_glds256_tiles(q[j]) <= m->dw_tail_cap)) { t += b2s_gemm_glds256_tiles(q[j]); ++j; }
-            B2S_TRY(b2s_gemm_grouped_launch(q.data() + i, (int)(j - i), m->aux));
-            i = j;
+            size_t ce = i + 1;
+            while (ce < q.size() && q[ce].K * 2 > q[i].K) ++ce;
+            if (round_tiles > 0)
+                std::stable_sort(q.begin() + i, q.begin() + ce, [](const GemmArgs& a, const GemmArgs& b) { return b2s_gemm_glds256_tiles(a) > b2s_gemm_glds256_tiles(b); });
+            std::vector<char> used(ce - i, 0);
+            for (;;) {
+                GemmArgs grp[B2S_MAX_GROUP];
+                int n = 0; long t = 0; bool acc_all = true;
+                for (size_t k = i; k < ce && n < B2S_MAX_GROUP; ++k) {
+                    const long tk = b2s_gemm_glds256_tiles(q[k]);
+                    if (used[k - i] || (n > 0 && t + tk > cap)) { if (round_tiles <= 0 && !used[k - i]) break; continue; }     // (old packing: contiguous runs only)
+                    grp[n++] = q[k]; t += tk; used[k - i] = 1; acc_all = acc_all && q[k].epi.accumulate;
+                }
+                if (!n) break;
+                // a launch of a few tiles (the rest of a class: the prenet's 256 x 80 dense0 gradient alone was ONE workgroup walking all 8148
+                // tokens, 99 us at the end of the fine-tune step) splits K over workgroups instead
+                if (t < 32 && acc_all) {
+                    for (int k = 0; k < n; ++k) {
+                        GemmArgs g = grp[k];
+                        g.splitk = pick_splitk(g.M, g.N, g.K, m->dtype);
+                        m->set_ws(g, m->aux);
+                        B2S_TRY(b2s_gemm_launch(g, m->dtype, true, true, m->aux));
+                    }
+                } else
+                    B2S_TRY(b2s_gemm_grouped_launch(grp, n, m->aux));
+            }
+            i = ce;
         }
     }
     hipEvent_t done = m->next_event();
@@ -357,7 +388,10 @@ int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain, bool fo
     if (serial || m->dw_pending.empty()) B2S_TRY(flush_ln_jobs(m, st));
     hipEvent_t prev_ev = m->pending_ev;
     m->pending_ev = nullptr;
-    B2S_TRY(flush_dw(m, st));                          // sets pending_ev when it launched something
+    m->dw_flush_exposed = drain && !m->dw_flush_capped;      // (flush_dw: one round of tiles per launch when nothing overlaps the hand-over)
+    const int rc_flush = flush_dw(m, st);                 // sets pending_ev when it launched something
+    m->dw_flush_exposed = false;
+    B2S_TRY(rc_flush);
     if (m->stage_hook && !m->pending_stages.empty()) {
         if (prev_ev) B2S_TRY(hook_after_event(m, st, prev_ev));        // (the event implies the main stream's part of those stages: the group waited for it)
         else B2S_TRY(hook_after_stream(m, st));                        // stages without second-stream work
