@@ -235,3 +235,48 @@ def test_transpose_bf16():
         L.check(lib.b2s_transpose_bf16(src.data_ptr(), dst.data_ptr(), R, Cc, None))
         torch.cuda.synchronize()
         assert torch.equal(dst, src.t().contiguous())
+
+
+def test_fused_encoder_is_bit_reproducible():
+    """The fused sublayers leave partial slabs that a row kernel sums in FIXED order (no atomics): two runs of the engine's encoder segment on
+    the same inputs and seed (dropout on, default model sizes, bf16, S = 114 -> the fused path) give bit-identical memory, and the backward's
+    stored layer weight gradients (grouped GEMM, overwrite mode off here: accumulated into a zeroed buffer) are bit-identical as well."""
+    import numpy as np
+    import hyperparams
+    from hyperparams import hparams as hp
+    from transformer.tacotron import Tacotron
+    from b2s_hip.trainer import HipTrainer
+    from oracle import synth, make_config
+    hp.override_from_dict(hyperparams.DEFAULTS)
+    hp.parse("compute_dtype=bf16")
+    cfg = make_config("")
+    st = synth.synthetic_state(cfg, 5)
+    m = Tacotron(hp)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()})
+    m = m.to(DEV).train()
+    tr = HipTrainer(m, hp)
+    eng = tr.eng
+    nb = synth.synthetic_batch(cfg, 6, 114, 64, seed=3, in_lens=[114, 100, 77, 50, 17, 1], n_spk=1, n_lang=1)
+    inputs = torch.from_numpy(np.asarray(nb["inputs"])).to(DEV)
+    in32 = torch.from_numpy(np.asarray(nb["input_lengths"])).to(DEV).to(torch.int32)
+    spk = torch.from_numpy(np.asarray(nb["input_spk_ids"])).to(DEV) if nb.get("input_spk_ids") is not None else None
+    lang = torch.from_numpy(np.asarray(nb["input_language_vecs"])).to(DEV) if nb.get("input_language_vecs") is not None else None
+    names = [n for n, _ in m.named_parameters() if n.startswith("encoder.encoder.") and n.endswith("transform.weight") or n.startswith("encoder.encoder.ffn_layers") and n.endswith("_layer.weight")]
+    assert len(names) >= 24
+    g = torch.Generator(device="cpu").manual_seed(1)
+    runs = []
+    for _ in range(2):
+        mem, ctx = eng.encoder_forward(inputs, in32, spk, lang, True, 1234, True)
+        dmem = torch.randn(mem.shape, generator=g.manual_seed(1)).to(DEV)
+        eng._gflat.zero_()
+        eng._needs_zero = False
+        eng.encoder_backward(ctx, dmem)
+        torch.cuda.synchronize()
+        grads = {n: eng._gflat[eng.param_offsets[n][0]:eng.param_offsets[n][0] + eng.param_offsets[n][1]].clone() for n in names}
+        runs.append((mem.clone(), grads))
+        ctx.free()
+    assert torch.equal(runs[0][0], runs[1][0]), "encoder memory differs between two identical runs"
+    assert float(runs[0][0].abs().max()) > 0
+    for n in names:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+        assert float(runs[0][1][n].abs().max()) > 0, n
