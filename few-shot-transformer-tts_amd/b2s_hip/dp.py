@@ -56,6 +56,9 @@ class GradBucketer(object):
         self._pending = None
         self._works = []
         self.launched = []                       # (lo, hi) of every all-reduce of the current step, for tests / logs
+        # split (element index, or None): a bucket never straddles it -- the trainer updates the parameters below it (decoder + postnet)
+        # as soon as THEIR all-reduces are complete (wait_prefix), beside the encoder backward
+        self.split = None
 
     def begin_step(self):
         self._pending, self._works, self.launched = None, [], []
@@ -91,8 +94,30 @@ class GradBucketer(object):
                 assert rng[0] == self._pending[1], "stage ranges must be contiguous in backward order"
                 self._pending = (self._pending[0], rng[1])
         if self._pending is not None and (self._pending[1] - self._pending[0] >= self.bucket_elems or
-                                          stage == self.n_stages - 1):
+                                          stage == self.n_stages - 1 or self._pending[1] == self.split):
             self._launch()
+
+    def wait_prefix(self, limit):
+        """Make the current stream wait for every all-reduce launched so far that lies below element `limit` (and, unless the optimizer
+        consumes the wire buffer, unpack it).  Returns True if those ranges tile [0, limit) exactly -- i.e. the gradients below `limit`
+        are final on the current stream; False (nothing waited for) if a stage below `limit` has not reported yet."""
+        pos = 0
+        for lo, hi in self.launched:
+            if lo != pos or hi > limit:
+                break
+            pos = hi
+        if pos != limit:
+            return False
+        rest = []
+        for w, lo, hi in self._works:
+            if hi <= limit:
+                w.wait()
+                if self.wire is not None and not self.consume_wire:
+                    self.unpack(self.wire[lo:hi], self.flat[lo:hi])
+            else:
+                rest.append((w, lo, hi))
+        self._works = rest
+        return True
 
     def finish(self, expect_all=True):
         """Launch what is still pending, wait for every all-reduce and (expect_all) check that the launched ranges tile the

@@ -137,6 +137,9 @@ class HipTrainer(object):
                                          bucket_mb * 1024 * 1024 / 4, dist=self.dist, payload=payload,
                                          pack=pack if on_gpu else None, unpack=unpack if on_gpu else None, stream=self._hook_stream,
                                          consume_wire=consume)
+            enc0 = self.eng.stage_ranges.get(3 + self.eng.cfg.n_decoder_layer)            # first encoder stage: the flat buffer's decoder | encoder boundary
+            if self.tail_adam and not self.freeze_encoder and enc0 is not None and enc0[0] > 0:
+                self.bucketer.split = enc0[0]
             if consume:
                 L.check(self.lib.b2s_adam_set_grad_wire(self.eng.handle, self.bucketer.wire.data_ptr(), self.eng._gflat.data_ptr()))
             if self.world > 1 and self.dist.get_rank() == 0:
@@ -301,7 +304,10 @@ class HipTrainer(object):
             lr = self.hp.max_lr * self.lr_lambda(self.global_step)
             step_no = self.global_step + 1
             adam = (lr, step_no, self.beta1, self.beta2, self.hp.adam_eps, self.hp.reg_weight, 1.0 / self.world)
-            tail = (self.tail_adam and enc_bwd_s is not None and self.bucketer is None and not self.overlap_adam and not split)
+            # (data parallel: the same schedule once the decoder / postnet buckets' all-reduces are complete -- GradBucketer.split keeps a
+            # bucket from straddling the group boundary, wait_prefix orders this stream behind exactly those collectives)
+            tail = (self.tail_adam and enc_bwd_s is not None and not self.overlap_adam and not split and
+                    (self.bucketer is None or self.bucketer.split is not None))
             if split:
                 L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 1, L.stream()))
             elif tail:
@@ -311,6 +317,10 @@ class HipTrainer(object):
                     enc_bwd_s.wait_event(dmem_done)            # d(memory) only: the rest of the decoder backward runs beside the encoder's
                     with torch.cuda.stream(enc_bwd_s):
                         eng.encoder_backward(c_enc, dmem)
+                    if tail and self.bucketer is not None:
+                        # every decoder / postnet stage has reported by now (their hooks fire at the encoder backward's first hand-over);
+                        # a hook that failed, or a stage that has not reported, falls back to the single update after the whole exchange
+                        tail = self._hook_error is None and self.bucketer.wait_prefix(self.bucketer.split)
                     if tail:
                         # issued only now (a failure in the encoder backward call above leaves the step unapplied), but ordered behind the
                         # mark only: on the device it runs beside the encoder backward
@@ -348,6 +358,7 @@ class HipTrainer(object):
         if self.grad_probe is not None:
             self.grad_probe(eng._gflat, self.bucketer.wire if (self.bucketer is not None and self.bucketer.consume_wire) else None)
         self.global_step = step_no
+        self.last_step_tail_update = bool(tail)            # (tests: which optimizer schedule the step took)
         if split or tail:
             L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 1, 0, L.stream()))
             # order this stream behind the second-stream update (done long before the encoder backward ends): plain torch

@@ -1975,7 +1975,7 @@ extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta
                                     int groups, int on_aux, void* stream) {
     B2S_TRY(check_bound(m));
     B2S_CHECK(m->adam_chunks && step >= 1 && groups > 0 && groups < 8 && on_aux >= 0 && on_aux <= 2, "Adam state not bound, bad step, group mask or placement");
-    B2S_CHECK(!(m->adam_wire && on_aux), "the narrow optimizer launch beside the backward pass does not read a bf16 gradient wire buffer");
+    B2S_CHECK(!(m->adam_wire && on_aux == 1), "the narrow optimizer launch on the second stream does not read a bf16 gradient wire buffer");
     if (step != m->adam_step_no) { m->adam_step_no = step; m->adam_step_mask = 0; }
     B2S_CHECK((m->adam_step_mask & groups) == 0, "parameter group mask %d was already updated in step %d", groups & m->adam_step_mask, step);
     hipStream_t st = S_(stream);

@@ -93,6 +93,7 @@ def test_exchange_ordering_bf16_wire_is_exact(spin):
             m_before = tr.exp_avg.clone()
             tr.train_step({k: (torch.from_numpy(np.asarray(v)).to(DEV) if not isinstance(v, list) else v) for k, v in nb.items()})
             torch.cuda.synchronize()
+            assert tr.last_step_tail_update and tr.bucketer.launched[0][0] == 0 and any(hi == tr.bucketer.split for _, hi in tr.bucketer.launched)     # decoder / postnet update beside the encoder backward, behind ITS buckets only
             flat, wire = seen[-1]
             assert fd.calls >= 4 * (i + 1)
             want = (flat.to(torch.bfloat16).float() * 2).to(torch.bfloat16)

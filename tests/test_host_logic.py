@@ -240,6 +240,48 @@ def test_gemm_tile_maps_are_bijections():
             assert max(share) - min(share) <= 1
 
 
+def test_grad_bucketer_split_and_prefix_wait():
+    """GradBucketer.split: no bucket straddles the decoder | encoder boundary of the flat gradient buffer, and wait_prefix(limit) waits for
+    exactly the all-reduces below it once they tile [0, limit) -- what lets the trainer update the decoder / postnet parameters while the
+    encoder's gradients are still being produced and exchanged.  bf16 payload without consume_wire: the prefix is unpacked as well."""
+    from b2s_hip.dp import GradBucketer
+
+    class Work(object):
+        def __init__(self, log, rng): self.log, self.rng = log, rng
+        def wait(self): self.log.append(self.rng)
+
+    class FakeDist(object):
+        def __init__(self): self.waited = []; self.n = 0
+        def all_reduce(self, t, group=None, async_op=False):
+            self.n += 1
+            t.mul_(2)
+            return Work(self.waited, t.numel())
+    flat = torch.arange(100, dtype=torch.float32)
+    ranges = {0: (0, 30), 1: (30, 30), 2: (30, 60), 3: (60, 70), 4: (70, 100)}
+    d = FakeDist()
+    bk = GradBucketer(flat.clone(), ranges, 5, bucket_elems=50, dist=d, payload="bf16")
+    bk.split = 60
+    bk.begin_step()
+    bk.stage_done(0)
+    assert not bk.wait_prefix(60) and d.waited == []           # stage 2 has not reported: nothing waited for
+    bk.stage_done(1); bk.stage_done(2)
+    assert bk.launched == [(0, 60)]                             # closed AT the split although a 50-element bucket was already full at 60 only
+    bk.stage_done(3)
+    assert bk.launched == [(0, 60)]                             # (60, 70) is pending: below the bucket size
+    assert bk.wait_prefix(60) and d.waited == [60]
+    assert torch.equal(bk.flat[:60], (flat[:60].to(torch.bfloat16) * 2).float()) and torch.equal(bk.flat[60:], flat[60:])     # prefix unpacked only
+    bk.stage_done(4)
+    bk.finish()
+    assert bk.launched == [(0, 60), (60, 100)] and d.waited == [60, 40]
+    # without the split the same stages merge across the boundary
+    bk2 = GradBucketer(flat.clone(), ranges, 5, bucket_elems=65, dist=FakeDist())
+    bk2.begin_step()
+    for s in range(5):
+        bk2.stage_done(s)
+    bk2.finish()
+    assert bk2.launched == [(0, 70), (70, 100)]
+
+
 def test_grad_bucketer_reports_missing_stage():
     """finish() verifies that the launched all-reduce ranges tile the flat gradient buffer: a backward stage that never
     reported (e.g. its hook raised) must not pass silently as 'reduced'."""
