@@ -307,7 +307,7 @@ class HipTrainer(object):
             # (data parallel: the same schedule once the decoder / postnet buckets' all-reduces are complete -- GradBucketer.split keeps a
             # bucket from straddling the group boundary, wait_prefix orders this stream behind exactly those collectives)
             tail = (self.tail_adam and enc_bwd_s is not None and not self.overlap_adam and not split and
-                    (self.bucketer is None or self.bucketer.split is not None))
+                    (self.bucketer is None or getattr(self.bucketer, "split", None) is not None))
             if split:
                 L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 1, L.stream()))
             elif tail:

@@ -85,7 +85,10 @@ def test_fp32_step_then_eval_forward_uses_updated_conv_weights():
     assert float((res - rres).abs().max()) < 2e-4
 
 
-def test_stage_hook_exception_is_raised_before_the_optimizer_step():
+@pytest.mark.parametrize("with_split", [False, True])
+def test_stage_hook_exception_is_raised_before_the_optimizer_step(with_split):
+    """A stage hook that raises (a failed collective) abandons the step: no optimizer launch at all -- also with the data-parallel tail
+    schedule armed (GradBucketer.split set), whose decoder / postnet update would otherwise be issued before the error is looked at."""
     from b2s_hip.trainer import HipTrainer
     import ctypes as C
     from b2s_hip import lib as L
@@ -100,6 +103,9 @@ def test_stage_hook_exception_is_raised_before_the_optimizer_step():
         def stage_done(self, stage): raise ValueError("boom at stage %d" % stage)
         def finish(self, expect_all=True): raise AssertionError("finish must not run after a failed hook")
         def abort(self): self.aborted = True
+        def wait_prefix(self, limit): raise AssertionError("the tail update must not be attempted after a failed hook")
+    if with_split:
+        Boom.split = 1
     tr.bucketer = Boom()
     L.check(tr.lib.b2s_model_set_stage_hook(tr.eng.handle, C.cast(tr._hook, L.P), None))
     before = {n: p.detach().clone() for n, p in m.named_parameters()}
