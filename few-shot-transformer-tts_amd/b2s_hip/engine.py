@@ -95,6 +95,7 @@ class HipEngine(object):
         self._trainer = None              # weakref to an attached HipTrainer (its Adam moments mirror the flat gradient layout)
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
         self._calls = 0
+        self.seeds_used = {}
         self.index = {n_: i for i, n_ in enumerate(self.names)}
 
     def __del__(self):
@@ -205,9 +206,14 @@ class HipEngine(object):
             return 4 + Ld + Le
         return 4 + Ld + (Le - 1 - int(parts[3]))
 
-    def next_seed(self):
+    def next_seed(self, segment=None):
+        """Seed of the next segment call's dropout masks.  seeds_used[segment] keeps the last one handed out per segment ("encoder",
+        "decoder", "postnet", "decode"): with it and b2s_dropout_site a checker can regenerate every mask of the step."""
         self._calls += 1
-        return (self._seed * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        seed = (self._seed * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        if segment is not None:
+            self.seeds_used[segment] = seed
+        return seed
 
     def begin_backward(self):
         if self._needs_zero:
@@ -367,7 +373,7 @@ class EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, prefix, names, inputs, lens32, spk, lang, train, *params):
         need = any(ctx.needs_input_grad)          # grad mode is off inside forward(); this reflects the caller's mode
-        mem, c = eng.encoder_forward(inputs, lens32, spk, lang, train, eng.next_seed(), need)
+        mem, c = eng.encoder_forward(inputs, lens32, spk, lang, train, eng.next_seed("encoder"), need)
         ctx.eng, ctx.c, ctx.names, ctx.prefix = eng, c, names, prefix
         ctx.req = [p.requires_grad for p in params]
         return mem
@@ -386,7 +392,7 @@ class EncoderFn(torch.autograd.Function):
 class DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, prefix, names, memory, in32, targets, tgt32, train, holder, *params):
-        mels, stop, c = eng.decoder_forward(memory, in32, targets, tgt32, train, eng.next_seed(), True)
+        mels, stop, c = eng.decoder_forward(memory, in32, targets, tgt32, train, eng.next_seed("decoder"), True)
         holder.append(c)
         ctx.eng, ctx.c, ctx.names, ctx.prefix = eng, c, names, prefix
         ctx.req = [p.requires_grad for p in params]
@@ -412,7 +418,7 @@ class PostnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, prefix, names, inputs, len32, fuse_add, train, *params):
         need = any(ctx.needs_input_grad)
-        out, c = eng.postnet_forward(inputs, len32, inputs if fuse_add else None, train, eng.next_seed(), need)
+        out, c = eng.postnet_forward(inputs, len32, inputs if fuse_add else None, train, eng.next_seed("postnet"), need)
         ctx.eng, ctx.c, ctx.names, ctx.prefix, ctx.fuse = eng, c, names, prefix, fuse_add
         ctx.req = [p.requires_grad for p in params]
         return out

@@ -263,15 +263,15 @@ class HipTrainer(object):
             enc_s.wait_stream(cur)                         # (weights synced above; the previous step's optimizer update)
             with torch.cuda.stream(enc_s):
                 mem, c_enc = eng.encoder_forward(batch["inputs"], in32, batch.get("input_spk_ids"), batch.get("input_language_vecs"),
-                                                 True, eng.next_seed(), not self.freeze_encoder)
+                                                 True, eng.next_seed("encoder"), not self.freeze_encoder)
                 mem_ready = torch.cuda.Event()
                 mem_ready.record(enc_s)
-            mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed(), True, memory_ready=mem_ready, padded_unobserved=True)
+            mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed("decoder"), True, memory_ready=mem_ready, padded_unobserved=True)
         else:
             mem, c_enc = eng.encoder_forward(batch["inputs"], in32, batch.get("input_spk_ids"), batch.get("input_language_vecs"),
-                                             True, eng.next_seed(), not self.freeze_encoder)
-            mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed(), True, padded_unobserved=True)
-        aft, c_post = eng.postnet_forward(mels, tgt32, mels, True, eng.next_seed(), True)
+                                             True, eng.next_seed("encoder"), not self.freeze_encoder)
+            mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed("decoder"), True, padded_unobserved=True)
+        aft, c_post = eng.postnet_forward(mels, tgt32, mels, True, eng.next_seed("postnet"), True)
         vals, per = eng.loss_forward(mels, aft, stop, batch["mel_targets"], tgt32)
         guided = eng.guided_enabled()
         if guided:

@@ -12,6 +12,7 @@
 // self K/V cache read (Ld*2*B*t*Dd) + cross K/V read (Ld*2*B*S*Dd) + cache append.
 #include "engine.h"
 #include "decode_fused.h"
+#include "drop_sites.h"
 
 struct b2s_decode_state {
     int B = 0, S = 0, maxT = 0, train = 0;
@@ -331,7 +332,7 @@ int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
     pn.W0 = m->W("decoder.prenet.dense0.weight"); pn.W1 = s->Wd(m, "decoder.prenet.dense1.weight"); pn.Wf = s->Wd(m, "decoder.prenet.dense_final.weight");
     pn.b0 = m->P("decoder.prenet.dense0.bias"); pn.b1 = m->P("decoder.prenet.dense1.bias");
     pn.pe = m->pe_dec; pn.pe_scale = m->P(p + "pe_scale"); pn.lengths = s->lengths; pn.t = s->t; pn.X = s->Xpp[0];
-    pn.drop0 = make_drop(pd, s->seed, 9001); pn.drop1 = make_drop(pd, s->seed, 9002); pn.drop_x = make_drop(pt, s->seed, 9003);
+    pn.drop0 = make_drop(pd, s->seed, drop_op_decode(DS_DEC_PRENET0, 0)); pn.drop1 = make_drop(pd, s->seed, drop_op_decode(DS_DEC_PRENET1, 0)); pn.drop_x = make_drop(pt, s->seed, drop_op_decode(DS_DEC_EMBED, 0));
     B2S_TRY(b2s_df_prenet(dt, pn, st));
     int k = 0, np = 0;                           // sublayer index within the frame, slabs written by the previous kernel
     auto common = [&](const std::string& ln, DropCfg dres) {
@@ -345,27 +346,27 @@ int step_fused(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
         const std::string lna = p + "attn_layer_norms." + std::to_string(l), lnx = p + "encdec_layer_norms." + std::to_string(l),
                           lnf = p + "ffn_layer_norms." + std::to_string(l);
         DfAttn sa;
-        sa.c = common(lna, make_drop(pt, s->seed, 9020 + l));
+        sa.c = common(lna, make_drop(pt, s->seed, drop_op_decode(DS_DEC_SELF_RES, l)));
         sa.H = H; sa.dh = dh; sa.Wqkv = s->Wd(m, nm2(p, "self_attentions", l, "qkv_transform.weight"));
         sa.Wo = s->Wd(m, nm2(p, "self_attentions", l, "output_transform.weight"));
         sa.Kc = s->selfK[l]; sa.Vc = s->selfV[l]; sa.ldkv = dh; sa.kv_bstride = (long)maxT * D; sa.kv_hstride = (long)maxT * dh; sa.maxT = maxT;
         sa.probs = s->selfP[l]; sa.probs_rows = maxT; sa.probs_ld = maxT; sa.klen = nullptr; sa.nmax = maxT; sa.scale = scale;
-        sa.drop_attn = make_drop(pt, s->seed, 9010 + l);
+        sa.drop_attn = make_drop(pt, s->seed, drop_op_decode(DS_DEC_SELF_ATTN, l));
         B2S_TRY(b2s_df_attn(dt, true, sa, st));
         ++k; np = H;
         DfAttn xa;
-        xa.c = common(lnx, make_drop(pt, s->seed, 9040 + l));
+        xa.c = common(lnx, make_drop(pt, s->seed, drop_op_decode(DS_DEC_CROSS_RES, l)));
         xa.H = H; xa.dh = dh; xa.Wqkv = s->Wd(m, nm2(p, "encdec_attentions", l, "q_transform.weight"));
         xa.Wo = s->Wd(m, nm2(p, "encdec_attentions", l, "output_transform.weight"));
         xa.Kc = s->crossKV[l]; xa.Vc = (char*)s->crossKV[l] + (size_t)B * S * D * m->esz; xa.ldkv = dh; xa.kv_bstride = (long)S * D; xa.kv_hstride = (long)S * dh;
         xa.maxT = maxT; xa.probs = s->crossP[l]; xa.probs_rows = maxT; xa.probs_ld = S; xa.klen = s->in_len; xa.nmax = S; xa.scale = scale;
-        xa.drop_attn = make_drop(pt, s->seed, 9030 + l);
+        xa.drop_attn = make_drop(pt, s->seed, drop_op_decode(DS_DEC_CROSS_ATTN, l));
         B2S_TRY(b2s_df_attn(dt, false, xa, st));
         ++k; np = H;
         DfFfn ff;
-        ff.c = common(lnf, make_drop(pt, s->seed, 9060 + l));
+        ff.c = common(lnf, make_drop(pt, s->seed, drop_op_decode(DS_DEC_FFN_RES, l)));
         ff.F = 4 * D; ff.ns = s->ns_ffn; ff.W1 = s->Wd(m, nm2(p, "ffn_layers", l, "input_layer.weight")); ff.W2 = s->Wd(m, nm2(p, "ffn_layers", l, "output_layer.weight"));
-        ff.drop_hid = make_drop(pt, s->seed, 9050 + l);
+        ff.drop_hid = make_drop(pt, s->seed, drop_op_decode(DS_DEC_FFN_HID, l));
         B2S_TRY(b2s_df_ffn(dt, ff, st));
         ++k; np = s->ns_ffn;
     }
@@ -387,13 +388,13 @@ int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
     const float scale = 1.f / sqrtf((float)dh);
     const std::string p = "decoder.decoder.";
     hipLaunchKernelGGL((k_dec_prep<T>), dim3(B), dim3(128), 0, st, s->mels, s->t, (T*)s->tgt, maxT, NM);
-    GemmEpilogue e0; e0.bias = m->P("decoder.prenet.dense0.bias"); e0.relu = 1; e0.drop = make_drop(pd, s->seed, 9001); e0.drop_salt = s->t;
+    GemmEpilogue e0; e0.bias = m->P("decoder.prenet.dense0.bias"); e0.relu = 1; e0.drop = make_drop(pd, s->seed, drop_op_decode(DS_DEC_PRENET0, 0)); e0.drop_salt = s->t;
     B2S_TRY(lin(m, st, s->tgt, NM, m->W("decoder.prenet.dense0.weight"), B, HP, NM, s->a1, 0, HP, e0));
-    GemmEpilogue e1; e1.bias = m->P("decoder.prenet.dense1.bias"); e1.relu = 1; e1.drop = make_drop(pd, s->seed, 9002); e1.drop_salt = s->t;
+    GemmEpilogue e1; e1.bias = m->P("decoder.prenet.dense1.bias"); e1.relu = 1; e1.drop = make_drop(pd, s->seed, drop_op_decode(DS_DEC_PRENET1, 0)); e1.drop_salt = s->t;
     B2S_TRY(lin(m, st, s->a1, HP, m->W("decoder.prenet.dense1.weight"), B, HP, HP, s->a2, 0, HP, e1));
     B2S_TRY(lin(m, st, s->a2, HP, m->W("decoder.prenet.dense_final.weight"), B, D, HP, s->a3, 1, D, GemmEpilogue()));
     hipLaunchKernelGGL(k_dec_x0, dim3(B), dim3(256), 0, st, s->a3, s->lengths, m->pe_dec, m->P(p + "pe_scale"), s->t, s->x, D,
-                       make_drop(pt, s->seed, 9003));
+                       make_drop(pt, s->seed, drop_op_decode(DS_DEC_EMBED, 0)));
     const int ve = dt ? 8 : 4, Rr = 256 / (dh / ve);
     B2S_CHECK(dh <= 128 && dh % (4 * ve) == 0, "decode attention: head width %d (needs a multiple of %d, at most 128)", dh, 4 * ve);
     const size_t sh_self = (size_t)(dh + maxT + Rr * dh + 8) * 4, sh_cross = (size_t)(dh + S + Rr * dh + 8) * 4;
@@ -414,8 +415,8 @@ int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
             hipLaunchKernelGGL((k_dec_append<T>), dim3(B), dim3(256), 0, st, (const T*)s->qkv, s->t, (T*)s->selfK[l], (T*)s->selfV[l], maxT, D, dh);
         hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(256), sh_self, st, (const T*)s->qkv, 3 * D, (const T*)s->selfK[l],
                            (const T*)s->selfV[l], dh, (long)maxT * D, (long)maxT * dh, (T*)s->ctx, D, s->selfP[l], maxT, maxT, s->t, (const int*)nullptr, 1, H, dh,
-                           maxT, scale, make_drop(pt, s->seed, 9010 + l));
-        GemmEpilogue ea; ea.drop = make_drop(pt, s->seed, 9020 + l); ea.drop_salt = s->t; ea.residual = s->x; ea.ldr = D;
+                           maxT, scale, make_drop(pt, s->seed, drop_op_decode(DS_DEC_SELF_ATTN, l)));
+        GemmEpilogue ea; ea.drop = make_drop(pt, s->seed, drop_op_decode(DS_DEC_SELF_RES, l)); ea.drop_salt = s->t; ea.residual = s->x; ea.ldr = D;
         B2S_TRY(lin(m, st, s->ctx, D, m->W(nm2(p, "self_attentions", l, "output_transform.weight")), B, D, D, s->x, 1, D, ea));
         // encoder-decoder attention over the pre-projected memory K/V
         B2S_TRY(ro_layernorm_fwd(dt, s->x, m->P(lnx + ".weight"), m->P(lnx + ".bias"), s->h, D, nullptr, 0, s->mean, s->rstd, B, D, 1e-6f,
@@ -423,15 +424,15 @@ int step_t(b2s_model* m, b2s_decode_state* s, hipStream_t st) {
         B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "encdec_attentions", l, "q_transform.weight")), B, D, D, s->qkv, 0, D, GemmEpilogue()));
         hipLaunchKernelGGL((k_dec_attn<T>), dim3(B * H), dim3(256), sh_cross, st, (const T*)s->qkv, D, (const T*)s->crossKV[l],
                            (const T*)s->crossKV[l] + (long)B * S * D, dh, (long)S * D, (long)S * dh, (T*)s->ctx, D, s->crossP[l], maxT, S, s->t, s->in_len, 0, H, dh,
-                           S, scale, make_drop(pt, s->seed, 9030 + l));
-        GemmEpilogue ex; ex.drop = make_drop(pt, s->seed, 9040 + l); ex.drop_salt = s->t; ex.residual = s->x; ex.ldr = D;
+                           S, scale, make_drop(pt, s->seed, drop_op_decode(DS_DEC_CROSS_ATTN, l)));
+        GemmEpilogue ex; ex.drop = make_drop(pt, s->seed, drop_op_decode(DS_DEC_CROSS_RES, l)); ex.drop_salt = s->t; ex.residual = s->x; ex.ldr = D;
         B2S_TRY(lin(m, st, s->ctx, D, m->W(nm2(p, "encdec_attentions", l, "output_transform.weight")), B, D, D, s->x, 1, D, ex));
         // FFN
         B2S_TRY(ro_layernorm_fwd(dt, s->x, m->P(lnf + ".weight"), m->P(lnf + ".bias"), s->h, D, nullptr, 0, s->mean, s->rstd, B, D, 1e-6f,
                                  nullptr, 1, st));
-        GemmEpilogue f1; f1.relu = 1; f1.drop = make_drop(pt, s->seed, 9050 + l); f1.drop_salt = s->t;
+        GemmEpilogue f1; f1.relu = 1; f1.drop = make_drop(pt, s->seed, drop_op_decode(DS_DEC_FFN_HID, l)); f1.drop_salt = s->t;
         B2S_TRY(lin(m, st, s->h, D, m->W(nm2(p, "ffn_layers", l, "input_layer.weight")), B, 4 * D, D, s->f, 0, 4 * D, f1));
-        GemmEpilogue f2; f2.drop = make_drop(pt, s->seed, 9060 + l); f2.drop_salt = s->t; f2.residual = s->x; f2.ldr = D;
+        GemmEpilogue f2; f2.drop = make_drop(pt, s->seed, drop_op_decode(DS_DEC_FFN_RES, l)); f2.drop_salt = s->t; f2.residual = s->x; f2.ldr = D;
         B2S_TRY(lin(m, st, s->f, 4 * D, m->W(nm2(p, "ffn_layers", l, "output_layer.weight")), B, D, 4 * D, s->x, 1, D, f2));
     }
     B2S_TRY(ro_layernorm_fwd(dt, s->x, m->P(p + "output_layer_norm.weight"), m->P(p + "output_layer_norm.bias"), s->outT, D, nullptr, 0,

@@ -13,6 +13,7 @@
 #include "engine.h"
 #include "attention.h"
 #include "enc_fused.h"
+#include "drop_sites.h"
 
 thread_local char g_b2s_err[512] = "";
 int b2s_fail(const char* file, int line, const char* fmt, ...) {
@@ -32,7 +33,6 @@ namespace {
 
 inline int rup8(int x) { return (x + 7) & ~7; }
 inline hipStream_t S_(void* s) { return (hipStream_t)s; }
-inline uint32_t opid(int seg, int layer, int k) { return (uint32_t)(seg * 4096 + layer * 32 + k); }
 
 // ------------------------------------------------------------------------------------------------ layout
 void add_t(b2s_model* m, const std::string& name, std::vector<int64_t> shape, int kind, bool gw) {
@@ -992,6 +992,20 @@ extern "C" int b2s_model_sync_weights_ex(b2s_model* m, void* stream, int shadows
 }
 
 extern "C" void b2s_ctx_free(b2s_ctx* ctx) { delete ctx; }
+// the dropout-site table (drop_sites.h), read-only: what a checker needs to regenerate the mask of any dropout site of the model path
+extern "C" int b2s_dropout_site(const char* site, int layer, int decode, uint32_t* op_id_out, int* kind_out, int* salt_out) {
+    B2S_CHECK(site && op_id_out, "null argument");
+    B2S_CHECK(layer >= 0 && layer < 32, "layer %d out of range (op ids hold 32 layers per segment)", layer);
+    for (int i = 0; i < DS_COUNT; ++i) {
+        if (strcmp(site, g_drop_sites[i].name)) continue;
+        B2S_CHECK(!decode || g_drop_sites[i].decode_base > 0, "dropout site %s does not exist in the decode loop", site);
+        *op_id_out = decode ? drop_op_decode((DropSite)i, layer) : drop_op((DropSite)i, layer);
+        if (kind_out) *kind_out = g_drop_sites[i].kind;
+        if (salt_out) *salt_out = decode ? g_drop_sites[i].salt : B2S_SALT_NONE;
+        return 0;
+    }
+    return b2s_fail(__FILE__, __LINE__, "unknown dropout site %s", site);
+}
 extern "C" void* b2s_model_second_stream(b2s_model* m) { return (m && m->bound) ? (void*)m->aux : nullptr; }
 extern "C" int b2s_model_set_stage_hook_stream(b2s_model* m, void* stream) {
     B2S_CHECK(m, "null model");
@@ -1089,7 +1103,7 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
             if (want_wT) { B2S_TRY(transposes(m->aux)); B2S_HIP(hipEventRecord(m->enc_wT_ev, m->aux)); c->enc_wT_done = true; }
         }
         B2S_TRY(ro_embed_prep_fwd((const long*)inputs, input_lengths, m->P("encoder.embed.weight"), m->pe_enc,
-                                  m->P(p + "pe_scale"), xs[0], B, S, D, make_drop(pt, seed, opid(1, 0, 1)), st));
+                                  m->P(p + "pe_scale"), xs[0], B, S, D, make_drop(pt, seed, drop_op(DS_ENC_EMBED, 0)), st));
         if (fused) {
             // one kernel per sublayer + one row kernel (slab sum + residual + the NEXT LayerNorm) instead of 7 launches per layer (enc_fused.h)
             const int L = cf.n_encoder_layer, Dm = m->Dm, sb = m->enc_slab_bf16;
@@ -1100,8 +1114,8 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
             for (int l = 0; l < L && !lab_skip; ++l) {
                 AttnSave& s = c->self_attn[l];
                 FfnSave& f = c->ffn[l];
-                s.op_attn = opid(1, l, 2); s.op_res = opid(1, l, 3); s.mask_mode = 1;
-                f.op_hid = opid(1, l, 4); f.op_res = opid(1, l, 5);
+                s.op_attn = drop_op(DS_ENC_ATTN, l); s.op_res = drop_op(DS_ENC_ATTN_RES, l); s.mask_mode = 1;
+                f.op_hid = drop_op(DS_ENC_FFN_HID, l); f.op_res = drop_op(DS_ENC_FFN_RES, l);
                 EncfAttnFwd fa;
                 fa.hN = (const bf16_t*)s.h; fa.Wqkv = (const bf16_t*)m->W(nm(p, "self_attentions", l, "qkv_transform.weight"));
                 fa.Wo = (const bf16_t*)m->W(nm(p, "self_attentions", l, "output_transform.weight")); fa.klen = input_lengths; fa.B = B; fa.S = S;
@@ -1131,7 +1145,7 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
                                      (int)M, D, 1e-6f, nullptr, 1, st));
             B2S_TRY(linear(m, st, s.h, D, m->W(nm(p, "self_attentions", l, "qkv_transform.weight")), (int)M, 3 * D, D, s.qkv,
                            0, 3 * D, GemmEpilogue()));
-            s.op_attn = opid(1, l, 2); s.op_res = opid(1, l, 3);
+            s.op_attn = drop_op(DS_ENC_ATTN, l); s.op_res = drop_op(DS_ENC_ATTN_RES, l);
             const char* q = (const char*)s.qkv;
             B2S_TRY(attn_core_fwd(dt, st, q, 3 * D, q + (size_t)D * m->esz, 3 * D, q + (size_t)2 * D * m->esz, 3 * D, s.ctx, D,
                                   B, H, S, S, dh, 1, input_lengths, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd, s.lse));
@@ -1141,7 +1155,7 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
             const std::string lnf = p + "ffn_layer_norms." + std::to_string(l);
             B2S_TRY(ro_layernorm_fwd(dt, x1, m->P(lnf + ".weight"), m->P(lnf + ".bias"), f.h, D, nullptr, 0, f.mean, f.rstd,
                                      (int)M, D, 1e-6f, nullptr, 1, st));
-            f.op_hid = opid(1, l, 4); f.op_res = opid(1, l, 5);
+            f.op_hid = drop_op(DS_ENC_FFN_HID, l); f.op_res = drop_op(DS_ENC_FFN_RES, l);
             GemmEpilogue e1; e1.relu = 1; e1.drop = make_drop(pt, seed, f.op_hid);
             B2S_TRY(linear(m, st, f.h, D, m->W(nm(p, "ffn_layers", l, "input_layer.weight")), (int)M, 4 * D, D, f.f, 0, 4 * D, e1));
             GemmEpilogue e2; e2.drop = make_drop(pt, seed, f.op_res); e2.residual = x1; e2.ldr = D;
@@ -1389,7 +1403,7 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
         B2S_TRY(end_stage(m, st, 4 + cf.n_decoder_layer + (cf.n_encoder_layer - 1 - l), false));
     }
     B2S_TRY(ro_embed_prep_bwd(sc.dx, (const long*)c->ids, c->in_len, m->pe_enc, m->G("encoder.embed.weight"), m->G(p + "pe_scale"),
-                              B, S, D, make_drop(pt, c->seed, opid(1, 0, 1)), st, m->dx_bf16));
+                              B, S, D, make_drop(pt, c->seed, drop_op(DS_ENC_EMBED, 0)), st, m->dx_bf16));
     B2S_TRY(end_stage(m, st, 4 + cf.n_decoder_layer + cf.n_encoder_layer, true));
     return 0;
 }
@@ -1451,13 +1465,13 @@ extern "C" int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const i
         if (!memory_ready) B2S_TRY(need_memory());          // (single-stream callers keep the round-2 order)
         B2S_TRY(ro_cast(dt, targets, c->tgtT, M * NM, st));
         // prenet (tacotron.py:55-65)
-        GemmEpilogue e0; e0.bias = m->P("decoder.prenet.dense0.bias"); e0.relu = 1; e0.drop = make_drop(pd, seed, opid(2, 0, 1));
+        GemmEpilogue e0; e0.bias = m->P("decoder.prenet.dense0.bias"); e0.relu = 1; e0.drop = make_drop(pd, seed, drop_op(DS_DEC_PRENET0, 0));
         B2S_TRY(linear(m, st, c->tgtT, NM, m->W("decoder.prenet.dense0.weight"), (int)M, HP, NM, c->a1, 0, HP, e0));
-        GemmEpilogue e1; e1.bias = m->P("decoder.prenet.dense1.bias"); e1.relu = 1; e1.drop = make_drop(pd, seed, opid(2, 0, 2));
+        GemmEpilogue e1; e1.bias = m->P("decoder.prenet.dense1.bias"); e1.relu = 1; e1.drop = make_drop(pd, seed, drop_op(DS_DEC_PRENET1, 0));
         B2S_TRY(linear(m, st, c->a1, HP, m->W("decoder.prenet.dense1.weight"), (int)M, HP, HP, c->a2, 0, HP, e1));
         B2S_TRY(linear(m, st, c->a2, HP, m->W("decoder.prenet.dense_final.weight"), (int)M, D, HP, sc.a3, 1, D, GemmEpilogue()));
         B2S_TRY(ro_shift_pe_fwd(sc.a3, target_lengths, m->pe_dec, m->P(p + "pe_scale"), xs[0], B, T, D,
-                                make_drop(pt, seed, opid(2, 0, 3)), st));
+                                make_drop(pt, seed, drop_op(DS_DEC_EMBED, 0)), st));
         const bool guided = cf.guided_attention_weight > 0.f;
         // rows >= target_lengths[b] are padding: the heads mask them (row_len below) and the backward zeroes their gradient, and causal /
         // per-row sub-layers never let a valid row read them -- the attention kernels skip whole 64-row tiles of them (attention.h: qskip)
@@ -1477,7 +1491,7 @@ extern "C" int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const i
                                      1e-6f, nullptr, 1, st));
             B2S_TRY(linear(m, st, s.h, D, m->W(nm(p, "self_attentions", l, "qkv_transform.weight")), (int)M, 3 * D, D, s.qkv, 0, 3 * D,
                            GemmEpilogue()));
-            s.op_attn = opid(2, l, 4); s.op_res = opid(2, l, 5);
+            s.op_attn = drop_op(DS_DEC_SELF_ATTN, l); s.op_res = drop_op(DS_DEC_SELF_RES, l);
             const char* q = (const char*)s.qkv;
             B2S_TRY(attn_core_fwd(dt, st, q, 3 * D, q + (size_t)D * esz, 3 * D, q + (size_t)2 * D * esz, 3 * D, s.ctx, D, B, H, T, T, dh,
                                   2, nullptr, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd, s.lse, nullptr, qskip));
@@ -1493,7 +1507,7 @@ extern "C" int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const i
             if (!c->kvcat)
                 B2S_TRY(linear(m, st, c->memT, D, m->W(nm(p, "encdec_attentions", l, "kv_transform.weight")), (int)Mk, 2 * D, D, x.kv, 0, 2 * D,
                                GemmEpilogue()));
-            x.op_attn = opid(2, l, 6); x.op_res = opid(2, l, 7);
+            x.op_attn = drop_op(DS_DEC_CROSS_ATTN, l); x.op_res = drop_op(DS_DEC_CROSS_RES, l);
             const char* kv = (const char*)x.kv;
             GuidedArgs ga;
             if (guided) {
@@ -1509,7 +1523,7 @@ extern "C" int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const i
             const std::string lnf = p + "ffn_layer_norms." + std::to_string(l);
             B2S_TRY(ro_layernorm_fwd(dt, x2, m->P(lnf + ".weight"), m->P(lnf + ".bias"), f.h, D, nullptr, 0, f.mean, f.rstd, (int)M, D,
                                      1e-6f, nullptr, 1, st));
-            f.op_hid = opid(2, l, 8); f.op_res = opid(2, l, 9);
+            f.op_hid = drop_op(DS_DEC_FFN_HID, l); f.op_res = drop_op(DS_DEC_FFN_RES, l);
             GemmEpilogue f1; f1.relu = 1; f1.drop = make_drop(pt, seed, f.op_hid);
             B2S_TRY(linear(m, st, f.h, D, m->W(nm(p, "ffn_layers", l, "input_layer.weight")), (int)M, 4 * D, D, f.f, 0, 4 * D, f1));
             GemmEpilogue f2; f2.drop = make_drop(pt, seed, f.op_res); f2.residual = x2; f2.ldr = D;
@@ -1675,9 +1689,9 @@ extern "C" int b2s_decoder_backward_ev(b2s_model* m, b2s_ctx* c, const float* d_
         B2S_TRY(end_stage(m, st, 2 + (cf.n_decoder_layer - 1 - l), false));
     }
     B2S_TRY(finish_dmem());                                  // (no decoder layers)
-    B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, opid(2, 0, 3)), st, m->dx_bf16));
+    B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, drop_op(DS_DEC_EMBED, 0)), st, m->dx_bf16));
     // prenet backward
-    DropCfg d1 = make_drop(pd, c->seed, opid(2, 0, 1)), d2 = make_drop(pd, c->seed, opid(2, 0, 2));
+    DropCfg d1 = make_drop(pd, c->seed, drop_op(DS_DEC_PRENET0, 0)), d2 = make_drop(pd, c->seed, drop_op(DS_DEC_PRENET1, 0));
     B2S_TRY(linear_dw(m, st, sc.da3, D, c->a2, HP, (int)M, D, HP, m->G("decoder.prenet.dense_final.weight")));
     GemmEpilogue e2; e2.relu_aux = c->a2; e2.ld_aux = HP; e2.aux_scale = d2.scale;
     B2S_TRY(linear_dx(m, st, sc.da3, D, m->W("decoder.prenet.dense_final.weight"), (int)M, HP, D, sc.dz2, 0, HP, e2));
@@ -1764,7 +1778,7 @@ extern "C" int b2s_postnet_forward(b2s_model* m, const float* inputs, const int3
             g.M = (int)M; g.N = cout; g.K = 5 * cin; g.C = c->y[i]; g.c_fp32 = 1; g.ldc = cout;
             if (fused_stats) g.epi.colstat = sums;
             B2S_TRY(b2s_gemm_launch(g, dt, false, false, st));
-            DropCfg d = make_drop(pd, seed, opid(3, i, 1));
+            DropCfg d = make_drop(pd, seed, drop_op(DS_POST_CONV, i));
             const bool last = i == n - 1;
             if (fused_stats) {
                 B2S_TRY(ro_bn_apply_train(dt, c->y[i], sums, c->bn_mean[i], c->bn_rstd[i], 1e-5f, m->P(q + "running_mean"), m->P(q + "running_var"),
@@ -1816,7 +1830,7 @@ extern "C" int b2s_postnet_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
     for (int i = n - 1; i >= 0; --i) {
         const int cin = i == 0 ? cf.num_mels : cf.postnet_hidden, cout = i == n - 1 ? cf.num_mels : cf.postnet_hidden;
         const std::string q = "postnet.batchnorm_layers." + std::to_string(i) + ".";
-        DropCfg d = make_drop(pd, c->seed, opid(3, i, 1));
+        DropCfg d = make_drop(pd, c->seed, drop_op(DS_POST_CONV, i));
         const void* dout = i == n - 1 ? (const void*)d_out : ps.du[i + 1];
         void* dy = ps.dy[i];
         B2S_TRY(ro_bn_bwd(dt, dout, i == n - 1 ? 1 : 0, c->y[i], c->bn_mean[i], c->bn_rstd[i], m->P(q + "weight"), m->P(q + "bias"),

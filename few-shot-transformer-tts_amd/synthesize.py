@@ -96,7 +96,7 @@ def eval_batch(model_eval, data, use_bar=True, bar_interval=10, use_graph=True, 
             Ls.append(ln)
         try:
             for ln in Ls:
-                L.check(lib.b2s_decode_begin(eng.handle, L.ptr(ln.enc), L.ptr(ln.in32), ln.B, S, max_frames, int(train), eng.next_seed(),
+                L.check(lib.b2s_decode_begin(eng.handle, L.ptr(ln.enc), L.ptr(ln.in32), ln.B, S, max_frames, int(train), eng.next_seed("decode"),
                                              int(keep_self_alignments), L.ptr(ln.ws), ln.nbytes, ln.stream.cuda_stream, C.byref(ln.state)))
             shown = 0
             bar = None

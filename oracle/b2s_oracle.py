@@ -6,8 +6,12 @@ the reference's state_dict keys.  Each function cites the reference lines it fol
 Gradients come from torch autograd over these functions.
 
 Parity status: PINNED against reference-generated goldens (tests/golden/*.npz, made by
-tests/golden/make_goldens.py) for everything except dropout-on behaviour (RNG streams
-cannot match; statistical only) and initialize_variables (distributional only).
+tests/golden/make_goldens.py) for everything except dropout-on behaviour (the reference draws
+from torch's global generator; its streams cannot be reproduced) and initialize_variables
+(distributional only).  Dropout ON is checked the other way round: under `device_masks(...)`
+every F.dropout call below takes the mask the HIP engine's counter RNG draws at that site
+(oracle/rng.py: DeviceMasks), so forward, losses and every gradient of the dropout-on step
+the benchmark times can be compared element for element (tests/test_gpu_dropout_parity.py).
 """
 import math
 import numpy as np
@@ -62,8 +66,41 @@ def mask_reduce(loss, lengths, per_sample=False):
     return impute(loss, lengths).sum() / lengths.sum()
 
 
-def _drop(x, p, train):
-    return F.dropout(x, p, training=True) if (train and p > 0.0) else x
+_MASKS = None      # oracle/rng.py: DeviceMasks while a `device_masks` block is active, else None (torch's own generator)
+
+
+class device_masks:
+    """with device_masks(src): every dropout call below uses src.keep(site, layer, shape, p, frame_offset) -- the mask the HIP
+    engine applies at that site (same seed) -- instead of drawing from torch's generator."""
+
+    def __init__(self, src):
+        self.src = src
+
+    def __enter__(self):
+        global _MASKS
+        self.prev, _MASKS = _MASKS, self.src
+        return self.src
+
+    def __exit__(self, *a):
+        global _MASKS
+        _MASKS = self.prev
+
+
+def _drop(x, p, train, site=None, layer=0, channels_first=False, frame_offset=0):
+    """F.dropout(x, p) (modules.py:18 etc.).  site / layer name the reference call (csrc/drop_sites.h) for device_masks;
+    channels_first: x is [B, C, T] where the engine holds [B, T, C]; frame_offset: decode loop -- row r of x was produced by the
+    engine in frame r + frame_offset."""
+    if not (train and p > 0.0):
+        return x
+    if _MASKS is None:
+        return F.dropout(x, p, training=True)
+    shape = tuple(x.shape)
+    if channels_first:
+        shape = (shape[0], shape[2], shape[1])
+    keep = torch.from_numpy(_MASKS.keep(site, layer, shape, p, frame_offset))
+    if channels_first:
+        keep = keep.permute(0, 2, 1)
+    return x * (keep.to(x.dtype) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p))))
 
 
 def _ln(x, P, prefix):
@@ -71,7 +108,7 @@ def _ln(x, P, prefix):
 
 
 # --------------------------------------------------------------------------- attention
-def multihead_attention(P, prefix, queries, memories, bias, num_heads, p_drop=0.0, train=False):
+def multihead_attention(P, prefix, queries, memories, bias, num_heads, p_drop=0.0, train=False, site=None, layer=0):
     """attention.py:94-122 (A1-A4).  Returns (outputs [B,Lq,C], align [B,H,Lk,Lq])."""
     C = queries.shape[-1]
     if memories is None:                      # attention.py:62-64: fused q|k|v
@@ -94,15 +131,15 @@ def multihead_attention(P, prefix, queries, memories, bias, num_heads, p_drop=0.
         logits = logits + bias
     w = F.softmax(logits, dim=-1)
     align = w.permute(0, 1, 3, 2)             # attention.py:88 (pre-dropout)
-    w = _drop(w, p_drop, train)
+    w = _drop(w, p_drop, train, site, layer)
     ctx = (w @ v).permute(0, 2, 1, 3).reshape(B, Lq, C)   # attention.py:18-26
     return ctx @ P[prefix + ".output_transform.weight"].t(), align
 
 
-def ffn(P, prefix, x, p_drop=0.0, train=False):
+def ffn(P, prefix, x, p_drop=0.0, train=False, site=None, layer=0):
     """modules.py:15-20 (A5)."""
     h = F.relu(x @ P[prefix + ".input_layer.weight"].t())
-    h = _drop(h, p_drop, train)
+    h = _drop(h, p_drop, train, site, layer)
     return h @ P[prefix + ".output_layer.weight"].t()
 
 
@@ -114,14 +151,15 @@ def transformer_encoder(P, cfg, x, input_lengths, train=False, prefix="encoder.e
     x = x * mask.unsqueeze(-1)
     bias = attention_bias_masking(mask)
     x = x + sinusoid_table(x.shape[1], x.shape[2]) * P[prefix + ".pe_scale"]
-    x = _drop(x, p, train)
+    x = _drop(x, p, train, "encoder.embed")
     for i in range(cfg.n_encoder_layer):
         y, _ = multihead_attention(P, "%s.self_attentions.%d" % (prefix, i),
                                    _ln(x, P, "%s.attn_layer_norms.%d" % (prefix, i)), None, bias,
-                                   cfg.n_attention_head, p, train)
-        x = x + _drop(y, p, train)
-        y = ffn(P, "%s.ffn_layers.%d" % (prefix, i), _ln(x, P, "%s.ffn_layer_norms.%d" % (prefix, i)), p, train)
-        x = x + _drop(y, p, train)
+                                   cfg.n_attention_head, p, train, "encoder.attn", i)
+        x = x + _drop(y, p, train, "encoder.attn_res", i)
+        y = ffn(P, "%s.ffn_layers.%d" % (prefix, i), _ln(x, P, "%s.ffn_layer_norms.%d" % (prefix, i)), p, train,
+                "encoder.ffn_hidden", i)
+        x = x + _drop(y, p, train, "encoder.ffn_res", i)
     return _ln(x, P, prefix + ".output_layer_norm")
 
 
@@ -145,8 +183,9 @@ def encoder_forward(P, cfg, inputs, input_lengths, input_spk_ids=None, input_lan
 def prenet(P, cfg, x, train=False, prefix="decoder.prenet"):
     """tacotron.py:55-65 (A10)."""
     p = cfg.decoder_dropout_rate
-    x = _drop(F.relu(x @ P[prefix + ".dense0.weight"].t() + P[prefix + ".dense0.bias"]), p, train)
-    x = _drop(F.relu(x @ P[prefix + ".dense1.weight"].t() + P[prefix + ".dense1.bias"]), p, train)
+    # (decode loop: row r of the loop's decoder input is the previous frame, the engine computes its prenet in frame r + 1)
+    x = _drop(F.relu(x @ P[prefix + ".dense0.weight"].t() + P[prefix + ".dense0.bias"]), p, train, "decoder.prenet0", frame_offset=1)
+    x = _drop(F.relu(x @ P[prefix + ".dense1.weight"].t() + P[prefix + ".dense1.bias"]), p, train, "decoder.prenet1", frame_offset=1)
     return x @ P[prefix + ".dense_final.weight"].t()
 
 
@@ -159,21 +198,22 @@ def transformer_decoder(P, cfg, memory, targets, input_lengths, target_lengths, 
     x = impute(targets, target_lengths)
     x = torch.cat([torch.zeros_like(x[:, :1]), x], dim=1)[:, :-1]       # shift right (modules.py:115-116)
     x = x + sinusoid_table(x.shape[1], x.shape[2]) * P[prefix + ".pe_scale"]
-    x = _drop(x, p, train)
+    x = _drop(x, p, train, "decoder.embed")
     a_self, a_cross = [], []
     for i in range(cfg.n_decoder_layer):
         y, al = multihead_attention(P, "%s.self_attentions.%d" % (prefix, i),
                                     _ln(x, P, "%s.attn_layer_norms.%d" % (prefix, i)), None, dec_bias,
-                                    cfg.n_attention_head, p, train)
+                                    cfg.n_attention_head, p, train, "decoder.self_attn", i)
         a_self.append(al)
-        x = x + _drop(y, p, train)
+        x = x + _drop(y, p, train, "decoder.self_res", i)
         y, al = multihead_attention(P, "%s.encdec_attentions.%d" % (prefix, i),
                                     _ln(x, P, "%s.encdec_layer_norms.%d" % (prefix, i)), memory, enc_bias,
-                                    cfg.n_attention_head, p, train)
+                                    cfg.n_attention_head, p, train, "decoder.cross_attn", i)
         a_cross.append(al)
-        x = x + _drop(y, p, train)
-        y = ffn(P, "%s.ffn_layers.%d" % (prefix, i), _ln(x, P, "%s.ffn_layer_norms.%d" % (prefix, i)), p, train)
-        x = x + _drop(y, p, train)
+        x = x + _drop(y, p, train, "decoder.cross_res", i)
+        y = ffn(P, "%s.ffn_layers.%d" % (prefix, i), _ln(x, P, "%s.ffn_layer_norms.%d" % (prefix, i)), p, train,
+                "decoder.ffn_hidden", i)
+        x = x + _drop(y, p, train, "decoder.ffn_res", i)
     out = impute(_ln(x, P, prefix + ".output_layer_norm"), target_lengths)
     return out, {"self": a_self, "encdec": a_cross}
 
@@ -219,7 +259,7 @@ def postnet_forward(P, cfg, inputs, input_lengths, train=False, bn_state=None):
         x = x * P[q + "weight"][None, :, None] + P[q + "bias"][None, :, None]
         if i != n - 1:
             x = torch.tanh(x)
-        x = _drop(x, p, train)
+        x = _drop(x, p, train, "postnet.conv", i, channels_first=True)
     return x.transpose(2, 1)
 
 

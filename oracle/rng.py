@@ -39,3 +39,57 @@ def keep_mask(p, seed, op_id, n):
         return np.ones(n, dtype=bool)
     idx = np.arange(n, dtype=np.uint64)
     return rand32(idx, drop_key(seed, op_id)) >= np.uint64(drop_thresh(p))
+
+
+def _salt(rule, t):
+    """Frame salt of the decode loop (csrc/drop_sites.h: B2S_SALT_*), XORed into the key of frame t."""
+    t = np.uint64(int(t))
+    if rule == 1:
+        return int(_hash32(_u(t * np.uint64(2246822519) + np.uint64(3266489917))))
+    if rule == 2:
+        return int(_hash32(_u(t + np.uint64(0x9e3779b9))))
+    if rule == 3:
+        return int(_hash32(_u(t * np.uint64(2654435761) + np.uint64(77))))
+    return 0
+
+
+class DeviceMasks:
+    """The masks the HIP engine draws at every dropout site of the model path (include/b2s_hip.h: b2s_dropout_site), for
+    oracle.b2s_oracle.device_masks.
+
+    seeds: {"encoder": s, "decoder": s, "postnet": s} -- the `seed` argument of the engine's segment calls (decode loop: the seed
+    of b2s_decode_begin under "decoder").  site_info(site, layer, decode) -> (op_id, kind, salt_rule): the library's own table,
+    queried by the test through the C ABI (nothing about op ids is restated here).  The index rules (kind) and the hash are the
+    documented convention of that query.  decode: the autoregressive loop -- row r of a [B, rows, C] tensor (or query row r of
+    attention weights) was drawn in frame r + frame_offset with a frame-salted key and the per-frame index rules.
+    overrides: {(site, layer): op_id} -- deliberately wrong ids, for the test that shows the comparison notices."""
+
+    def __init__(self, seeds, site_info, decode=False, overrides=None):
+        self.seeds, self.site_info, self.decode, self.overrides = seeds, site_info, decode, overrides or {}
+        self.calls = []
+
+    def keep(self, site, layer, shape, p, frame_offset=0):
+        assert site is not None, "dropout call without a site name under device_masks"
+        op, kind, salt = self.site_info(site, layer, self.decode)
+        op = self.overrides.get((site, layer), op)
+        seed = self.seeds[site.split(".")[0]]
+        key = drop_key(seed, op)
+        th = np.uint64(drop_thresh(p))
+        self.calls.append((site, layer, tuple(shape)))
+        n = int(np.prod(shape))
+        if not self.decode:
+            assert n < 2 ** 32, "element index would wrap"
+            return (rand32(np.arange(n, dtype=np.uint64), key) >= th).reshape(shape)
+        out = np.empty(shape, dtype=bool)
+        if kind == 0:                               # rows [B, R, C]: frame r + offset, idx = b * C + c
+            B, R, C = shape
+            idx = (np.arange(B, dtype=np.uint64)[:, None] * np.uint64(C) + np.arange(C, dtype=np.uint64)[None, :])
+            for r in range(R):
+                out[:, r, :] = rand32(idx, key ^ _salt(salt, r + frame_offset)) >= th
+        else:                                       # weights [B, H, Lq, Lk]: frame q, idx = (b * H + h) * 4096 + k
+            B, H, Lq, Lk = shape
+            zh = (np.arange(B * H, dtype=np.uint64) * np.uint64(4096)).reshape(B, H, 1)
+            idx = zh + np.arange(Lk, dtype=np.uint64)[None, None, :]
+            for q in range(Lq):
+                out[:, :, q, :] = rand32(idx, key ^ _salt(salt, q + frame_offset)) >= th
+        return out

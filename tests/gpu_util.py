@@ -35,18 +35,21 @@ def report(name, a, b):
                                                         float(d.max() / (b.abs().max() + 1e-12)))
 
 
+DRIFT_FILE = "r05_bf16_drift.json"
+
+
 def record_drift(key, value):
-    """bf16 drift measured by a GPU test -> gpurun_out/r04_bf16_drift.json (merged back by gpurun; the committed copy lives in
-    profiles/r04_bf16_drift.json and is what the gates below are derived from: gate = 2 x the committed measurement).
-    Round 4 re-measured the file after two deliberate arithmetic changes of the bf16 mode (bf16 partial-sum slabs of the fused encoder
-    sublayers, bf16 residual gradient between the LayerNorm-backward kernels): profiles/NOTES_r04.md has the before / after values."""
+    """bf16 drift measured by a GPU test -> gpurun_out/r05_bf16_drift.json (merged back by gpurun; the committed copy lives in
+    profiles/ and is what the gates below are derived from).  Rounds 3 / 4 are kept beside it (profiles/r03_*, r04_*): round 4
+    re-measured after two deliberate arithmetic changes of the bf16 mode (bf16 partial-sum slabs of the fused encoder sublayers,
+    bf16 residual gradient between the LayerNorm-backward kernels), profiles/NOTES_r04.md has the before / after values."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = os.path.join(root, "gpurun_out")
     try:
         os.makedirs(d, exist_ok=True)
-        path = os.path.join(d, "r04_bf16_drift.json")
+        path = os.path.join(d, DRIFT_FILE)
         data = json.load(open(path)) if os.path.exists(path) else {}
         data[key] = float(value)
         json.dump(data, open(path, "w"), indent=1, sort_keys=True)
@@ -54,15 +57,18 @@ def record_drift(key, value):
         pass
 
 
-def drift_gate(key, fallback, floor=0.0):
-    """2 x the committed measurement of `key` (profiles/r04_bf16_drift.json), not below `floor` (run-to-run spread of a bf16 step with
-    fp32 atomics); `fallback` when it has not been measured yet."""
+def drift_gate(key, ceiling, floor=0.0):
+    """min(`ceiling`, max(2 x the committed measurement of `key`, `floor`)).  `ceiling` is a FIXED absolute bound against the fp32
+    oracle written in the test -- the gate can tighten with the committed measurement (profiles/r05_bf16_drift.json, else the
+    round-4 file) but a re-measurement can never move it past the ceiling, so a numerical regression cannot be waved through by
+    re-recording the drift file.  `floor`: run-to-run spread of a bf16 step with fp32 atomics."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "profiles", "r04_bf16_drift.json")
-    if os.path.exists(path):
-        v = json.load(open(path)).get(key)
-        if v is not None:
-            return max(2.0 * float(v), floor)
-    return fallback
+    for name in (DRIFT_FILE, "r04_bf16_drift.json"):
+        path = os.path.join(root, "profiles", name)
+        if os.path.exists(path):
+            v = json.load(open(path)).get(key)
+            if v is not None:
+                return min(float(ceiling), max(2.0 * float(v), floor))
+    return float(ceiling)
