@@ -4,11 +4,15 @@
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
 
 A "step" is one full training step (forward + loss + backward + gradient all-reduce + Adam) of the default
-83.5 M-parameter model on one LJSpeech-shaped packed batch per GPU (B=14, S=114, T=582: the mean batch the
-reference's packer produces), bf16 MFMA operands with fp32 accumulate / residual /
+83.5 M-parameter model on one packed batch per GPU, bf16 MFMA operands with fp32 accumulate / residual /
 optimizer, dropout ON at the reference rates, synthetic data, TF-style random init.  Metric: padded mel
-frames per second over the whole job.  --mode decode benchmarks the autoregressive loop instead.
-One JSON line is printed by rank 0.
+frames per second over the whole job.  Workloads:
+  lj  BASELINE configs[1]: the LJSpeech-shaped batch B=14, S=114, T=582 (the mean batch the reference's packer produces),
+      one speaker / language -- the default at --gpus 1;
+  c3  BASELINE configs[2]: the 38-language byte2speech batch per rank, B=14, S=256 (multi-byte scripts), T=582, 572 speakers,
+      identical shapes on every rank, different seeds -- the default at --gpus N > 1 (and a `c3` leg of the N = 1 line,
+      through the data-parallel exchange path on a 1-rank RCCL group).
+--mode decode benchmarks the autoregressive loop instead.  One JSON line is printed by rank 0.
 """
 import argparse
 import ctypes as C
@@ -21,9 +25,9 @@ import time
 # second stream landed on the main stream's hardware queue and the two serialised (single-rank RCCL run: 10.9 ms per step
 # against 9.98 with 8 queues; no effect without RCCL).  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# (b2s_hip/lib.py makes the same choice at import; here the process group is created before that import) data-parallel runs: cap RCCL's
-# channel count -- every channel holds a CU while a collective runs (profiles/r03_cu_loss.txt) and the exchange needs 22 GB/s per GPU
-if int(os.environ.get("WORLD_SIZE", "1") or "1") > 1:
+# The launcher's choice (the package itself never touches NCCL_*), data-parallel runs: cap RCCL's channel count -- every channel holds a CU
+# while a collective runs (profiles/r03_cu_loss.txt) and the exchange needs 22-45 GB/s per GPU.  Must precede the process group.
+if os.environ.get("WORLD_SIZE", "1").strip().isdigit() and int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "few-shot-transformer-tts_amd")
@@ -47,9 +51,9 @@ def fwd_flops(B, S, T, De=512, Fe=2048, Dd=768, Fd=3072, Le=6, Ld=6):
             + 10 * B * T * (80 * 512 + 3 * 512 * 512 + 512 * 80) + 2 * B * (2 * 128 * 128 + 100 * 128))
 
 
-def make_batch(cfg, B, S, T, seed, device):
+def make_batch(cfg, B, S, T, seed, device, n_spk=1, n_lang=1):
     from benchdata import synthetic_batch
-    nb = synthetic_batch(cfg, B, S, T, seed=seed, n_spk=1, n_lang=1)      # LJSpeech: one speaker, en-us
+    nb = synthetic_batch(cfg, B, S, T, seed=seed, n_spk=n_spk, n_lang=n_lang)      # (1, 1) = LJSpeech: one speaker, en-us; (572, 38) = C3
     return {k: (torch.from_numpy(np.asarray(v)).to(device) if not isinstance(v, list) else v) for k, v in nb.items()}
 
 
@@ -88,7 +92,7 @@ def _sub_bench(extra, env=None):
     if r.returncode != 0 or not lines:
         return {"error": (r.stderr or r.stdout)[-400:]}
     d = json.loads(lines[-1])
-    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "final_loss", "config", "roofline", "roofline_step",
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "final_loss", "config", "roofline", "roofline_step", "rccl_ranks",
             "cpu_baseline", "value_incl_host_copy", "ms_per_step_incl_host_copy", "valid_frames_per_s")
     d = {k: d[k] for k in keep if k in d}
     if isinstance(d.get("roofline"), dict):
@@ -105,8 +109,11 @@ def main():
                     help="train: BASELINE configs[1-2]; decode: configs[3]; finetune: configs[4] (frozen encoder, guided "
                          "attention on, batches of B drawn from a 30-utterance pool)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default=None, choices=["lj", "c3"],
+                    help="lj: BASELINE configs[1] (B=14, S=114, T=582, one speaker / language; default at --gpus 1); c3: configs[2], the "
+                         "per-rank 38-language batch (B=14, S=256, T=582, 572 speakers; default at --gpus N > 1)")
     ap.add_argument("--batch", type=int, default=14)
-    ap.add_argument("--S", type=int, default=114)
+    ap.add_argument("--S", type=int, default=None)
     ap.add_argument("--T", type=int, default=582)
     ap.add_argument("--hparams", default="", help="extra hparams overrides (experiments), e.g. transformer_dropout_rate=0.0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -114,6 +121,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="train mode, 1 GPU: skip the decode / finetune / fp32_mode sub-benchmarks added to the JSON line")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "c3" if (args.gpus > 1 and args.mode == "train") else "lj"
+    if args.S is None:
+        args.S = 256 if args.workload == "c3" else 114
+    n_spk, n_lang = (572, 38) if args.workload == "c3" else (1, 1)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start N ranks ourselves (one process per GPU, RCCL rendezvous on
@@ -161,15 +173,16 @@ def main():
     model = Tacotron(hp)
     initialize_variables(model)
     model = model.to(device).train()
-    # B2S_ADAM_OVERLAP=1: optimizer step on the second stream under the next forward pass (measured: no gain -- the GEMM
-    # workgroups fill a CU's registers and LDS, so nothing co-resides with them)
-    trainer = HipTrainer(model, hp, overlap_adam=bool(os.environ.get("B2S_ADAM_OVERLAP")))
+    # gradient wire of the data-parallel exchange: the bf16 performance lines send bf16 (167 instead of 334 MB per step over the
+    # point-to-point xGMI links; HipTrainer's own default is the reference's fp32 mean) -- stated in config.grad_payload
+    payload = os.environ.get("B2S_GRAD_PAYLOAD") or ("bf16" if args.dtype == "bf16" else "fp32")
+    trainer = HipTrainer(model, hp, grad_payload=payload)
     cfg = hp                                           # (synthetic_batch reads vocab_size / num_mels / max_num_* only)
     B, S, T = args.batch, args.S, args.T
-    batch = make_batch(cfg, B, S, T, seed=rank, device=device)     # same shape on every rank, different data
+    batch = make_batch(cfg, B, S, T, seed=rank, device=device, n_spk=n_spk, n_lang=n_lang)     # same shape on every rank, different data
     batches = [batch]
     if finetune:        # 30-utterance adaptation pool; every step trains on B of them (same padded shape, lengths vary)
-        pool = make_batch(cfg, 30, S, T, seed=1000 + rank, device=device)
+        pool = make_batch(cfg, 30, S, T, seed=1000 + rank, device=device, n_spk=n_spk, n_lang=n_lang)
         rng = np.random.default_rng(rank)
         batches = []
         for _ in range(8):
@@ -209,7 +222,7 @@ def main():
     # the two extremes of the reference's packer (dataloader.py:401-410: <= 8000 frames and B (S^2 + T^2) <= 7e6 per batch) next to the
     # typical batch: same model, same step, a few steps each
     extremes = {}
-    if world == 1 and args.mode == "train" and (B, S, T) == (14, 114, 582) and not args.no_extras:
+    if world == 1 and args.mode == "train" and args.workload == "lj" and (B, S, T) == (14, 114, 582) and not args.no_extras:
         for (b_, s_, t_) in ((32, 50, 250), (9, 158, 808)):
             _, el, _, _ = timed([make_batch(cfg, b_, s_, t_, seed=7, device=device)], max(5, args.steps // 2), 2)
             n_ = max(5, args.steps // 2)
@@ -231,10 +244,13 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic", "final_loss": round(loss, 5),
-               "config": {"workload": "LJSpeech-shaped packed batch per GPU: B=%d S=%d T=%d, default hparams (83.5M params), "
-                                      "dropout on, single speaker/language%s" % (B, S, T, ", frozen encoder, guided-attention weight 1.0, "
-                                                                                 "batches drawn from a 30-utterance pool" if finetune else ""),
-                          "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world},
+               "config": {"workload": "%s packed batch per GPU: B=%d S=%d T=%d, default hparams (83.5M params), "
+                                      "dropout on, %s%s" % ("LJSpeech-shaped (BASELINE configs[1])" if args.workload == "lj" else
+                                                            "38-language byte2speech (BASELINE configs[2])", B, S, T,
+                                                            "single speaker/language" if args.workload == "lj" else "572 speakers / 38 languages, different seed per rank",
+                                                            ", frozen encoder, guided-attention weight 1.0, batches drawn from a 30-utterance pool" if finetune else ""),
+                          "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
+                          "grad_payload": (payload if (world > 1 or force_dp) else None)},
                "device_ms_per_step": round(dev_ms / args.steps, 3), "host_launch_ms_per_step": round(host_s / args.steps * 1e3, 3)}
         valid = float(np.mean([int(b["target_lengths"].sum()) for b in batches]))
         out["valid_frames_per_s"] = round(world * valid * args.steps / elapsed, 1)     # sum(target_lengths): the batch is ~10 % padding
@@ -282,7 +298,7 @@ def main():
         traffic = mfma_util = traffic_source = None
         from bench_decode import load_pmc
         pmc, pmc_commit, pmc_rows = load_pmc("train_bf16_pmc_hbm_traffic_mfma.json")
-        if pmc and args.dtype == "bf16" and args.mode == "train" and (B, S, T) == (14, 114, 582):
+        if pmc and args.dtype == "bf16" and args.mode == "train" and args.workload == "lj" and (B, S, T) == (14, 114, 582):
             pre = dom["kernel"].split(", NB, MW>")[0].replace(", G", ", ")
             rows = [r for r in pmc_rows if r["kernel"].startswith(pre)]
             traffic_source = "profiles/%s @ commit %s (committed rocprofv3 --pmc run, not measured in this process)" % (pmc, pmc_commit)
@@ -345,7 +361,7 @@ def main():
         out_n = torch.distributed.get_world_size()
         if rank == 0:
             out["rccl_ranks"] = out_n                  # what the RCCL group itself reports (== n_gpus)
-    if rank == 0 and world == 1 and args.mode == "train" and args.dtype == "bf16" and not args.no_extras:
+    if rank == 0 and world == 1 and args.mode == "train" and args.dtype == "bf16" and args.workload == "lj" and not args.no_extras:
         # the other BASELINE.json configs on the same JSON line (each in its own process: the hparams object is global):
         #   decode     configs[3]  64 utterances x 1000 frames, hipGraph-captured KV-cached loop
         #   finetune   configs[4]  frozen encoder + guided-attention loss, batches from a 30-utterance pool
@@ -362,10 +378,12 @@ def main():
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             dp_port = sk.getsockname()[1]
-        dp = _sub_bench(["--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-roofline-pass", "--no-extras"],
-                        env={"B2S_FORCE_DP": "1", "B2S_GRAD_PAYLOAD": "bf16", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(dp_port), "RANK": "0",
-                             "WORLD_SIZE": "1"})
+        dp_env = {"B2S_FORCE_DP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(dp_port), "RANK": "0", "WORLD_SIZE": "1"}
+        dp = _sub_bench(["--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-roofline-pass", "--no-extras"], env=dp_env)
         out["dp_path_ms_per_step"] = dp.get("ms_per_step", dp.get("error"))
+        # BASELINE configs[2] on one GPU: the per-rank workload of the N-GPU run (what `--gpus N` times on every rank), exchange path on
+        out["c3"] = _sub_bench(["--workload", "c3", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-roofline-pass",
+                                "--no-extras"], env=dp_env)
     if world > 1 or force_dp:
         torch.distributed.destroy_process_group()
     if rank == 0:

@@ -38,7 +38,7 @@ class GradBucketer(object):
         everything inside a rank (accumulation, Adam moments, masters) stays fp32.  pack(src_f32, dst_bf16) / unpack(src_bf16,
         dst_f32): conversion ops (the trainer passes the HIP kernels b2s_pack_bf16 / b2s_unpack_bf16; default: torch copies, for
         CPU tests).  stream: torch.cuda.Stream the collectives (and the pack kernels) are launched on -- the engine orders THAT
-        stream behind the stage's gradient work (b2s_model_set_stage_hook_stream), the backward's own stream is not held up."""
+        stream behind the stage's gradient work (b2s_model_set_stage_hook), the backward's own stream is not held up."""
         self.flat, self.stage_ranges, self.n_stages = flat, stage_ranges, n_stages
         self.bucket_elems = int(bucket_elems)
         self.dist = dist if dist is not None else torch.distributed
@@ -118,6 +118,18 @@ class GradBucketer(object):
                 rest.append((w, lo, hi))
         self._works = rest
         return True
+
+    def covers_all(self, expect_all=True):
+        """Non-raising, non-waiting form of finish()'s coverage check: do the ranges launched so far plus the pending one tile the whole flat
+        buffer in order?  (expect_all=False: always True -- a frozen encoder's stages never report.)"""
+        if not expect_all:
+            return True
+        pos = 0
+        for lo, hi in self.launched + ([self._pending] if self._pending is not None else []):
+            if lo != pos:
+                return False
+            pos = hi
+        return pos == self.flat.numel()
 
     def finish(self, expect_all=True):
         """Launch what is still pending, wait for every all-reduce and (expect_all) check that the launched ranges tile the

@@ -140,7 +140,7 @@ class HipEngine(object):
             # the gradient exchange -- off the 16-byte grid that the vector paths of the optimizer, the weight-gradient epilogues
             # and the collectives want
             order = sorted((i for i, k in enumerate(self.kinds) if k == 1), key=lambda i: (self.stage_of(self.names[i]), i))
-            al = max(1, int(os.environ.get("B2S_GRAD_ALIGN", "64")))          # (elements; 1 = the packed layout, A/B switch)
+            al = 64                                                           # elements (256 bytes); the packed layout measured +0.21 ms per step
             slot = lambda n: (n + al - 1) // al * al
             total = sum(slot(ts[i].numel()) for i in order)
             if self._gflat is None or self._gflat.device != dev:
@@ -173,7 +173,7 @@ class HipEngine(object):
         # data-parallel trainer rewrites them before every step (broadcast_buffers), which must not trigger a re-cast of every weight
         vers = tuple(t._version for t, k in zip(ts, self.kinds) if k == 1)
         if vers != self._versions:
-            L.check(self.lib.b2s_model_sync_weights(self.handle, L.stream()))
+            L.check(self.lib.b2s_model_sync_weights(self.handle, L.stream(), 0))
             self._versions = vers
         return dev
 
@@ -217,7 +217,7 @@ class HipEngine(object):
 
     def begin_backward(self):
         if self._needs_zero:
-            L.check(self.lib.b2s_zero_grads(self.handle, L.stream()))
+            L.check(self.lib.b2s_zero_grads(self.handle, L.stream(), 0))
             self._needs_zero = False
             self._bwd_seen = set()
 
@@ -258,7 +258,7 @@ class HipEngine(object):
 
     def decoder_forward(self, memory, in32, targets, tgt32, train, seed, keep_ctx, memory_ready=None, padded_unobserved=False):
         """memory_ready: torch.cuda.Event recorded behind the encoder forward on ANOTHER stream; this stream waits for it only when the
-        decoder first reads `memory` (b2s_decoder_forward_ev).
+        decoder first reads `memory` (b2s_decoder_forward: memory_ready).
         padded_unobserved: the caller will not ask for alignments of query rows >= target length (B2S_DEC_PADDED_UNOBSERVED): the
         attention kernels skip tiles of padded query rows."""
         dev = self.ensure_bound()
@@ -271,7 +271,7 @@ class HipEngine(object):
         mels = torch.empty(B, T, NM, dtype=torch.float32, device=dev)
         stop = torch.empty(B, T, dtype=torch.float32, device=dev)
         h = L.P()
-        L.check(self.lib.b2s_decoder_forward_ev(self.handle, L.ptr(memory), L.ptr(in32), L.ptr(targets), L.ptr(tgt32), B, S, T,
+        L.check(self.lib.b2s_decoder_forward(self.handle, L.ptr(memory), L.ptr(in32), L.ptr(targets), L.ptr(tgt32), B, S, T,
                                                 int(bool(train)) | (2 if padded_unobserved else 0), seed, L.ptr(ws), nbytes, L.ptr(mels), L.ptr(stop),
                                                 memory_ready.cuda_event if memory_ready is not None else None, L.stream(), C.byref(h)))
         self._needs_zero = True
@@ -285,7 +285,7 @@ class HipEngine(object):
         self.begin_backward()
         dmem = torch.empty(mem_shape, dtype=torch.float32, device=dmels.device) if want_dmem else None
         flags = (0 if want_dmem else 1) | ((4 if dmem_done is not None else 2) if defer_join else 0)
-        L.check(self.lib.b2s_decoder_backward_ev(self.handle, ctx.handle, L.ptr(dmels.contiguous()),
+        L.check(self.lib.b2s_decoder_backward(self.handle, ctx.handle, L.ptr(dmels.contiguous()),
                                                  L.ptr(dstop.contiguous()) if dstop is not None else None,
                                                  L.ptr(d_guided.contiguous()) if d_guided is not None else None,
                                                  flags, L.ptr(dmem), dmem_done.cuda_event if dmem_done is not None else None, L.stream()))
@@ -324,13 +324,13 @@ class HipEngine(object):
         second stream has been joined (end of the decoder / encoder backward)."""
         self.begin_backward()
         din = torch.empty_like(dout)
-        L.check(self.lib.b2s_postnet_backward_ex(self.handle, ctx.handle, L.ptr(dout.contiguous()), L.ptr(din), 1 if defer_join else 0,
+        L.check(self.lib.b2s_postnet_backward(self.handle, ctx.handle, L.ptr(dout.contiguous()), L.ptr(din), 1 if defer_join else 0,
                                                  L.stream()))
         return din
 
     def add(self, a, b):
         out = torch.empty_like(a)
-        L.check(self.lib.b2s_add(L.ptr(a.contiguous()), L.ptr(b.contiguous()), L.ptr(out), a.numel(), L.stream()))
+        L.check(self.lib.b2s_add3(L.ptr(a.contiguous()), L.ptr(b.contiguous()), None, L.ptr(out), a.numel(), L.stream()))
         return out
 
     def add3(self, a, b, c):

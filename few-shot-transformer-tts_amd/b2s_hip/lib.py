@@ -11,12 +11,10 @@ import os
 # (+10 % step time).  Effective only if the HIP runtime has not initialised yet -- importing this package before the first
 # torch.cuda call is enough; launchers can also export it.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# Data-parallel runs (a launcher exported WORLD_SIZE > 1): every RCCL channel is a workgroup that holds a CU while the collective runs, and
-# the step loses 4-5 % with 8-32 CUs held, 10.6 % with 64 (profiles/r03_cu_loss.txt) -- while the exchange moves 167 MB per ~7.5 ms step
-# (22 GB/s per GPU), a fraction of what a handful of channels carry.  Cap the channel count unless the launcher chose one itself.
-# Effective only before the process group is created.
-if int(os.environ.get("WORLD_SIZE", "1") or "1") > 1:
-    os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
+# (RCCL's channel count is the LAUNCHER's setting, not this package's: every channel is a workgroup that holds a CU while a collective
+# runs -- the step loses 4-5 % with 8-32 CUs held, 10.6 % with 64 (profiles/r03_cu_loss.txt) -- so bench.py exports NCCL_MAX_NCHANNELS=16
+# before it creates its process group, and INTEGRATION.md section 5 recommends the same for train.py; importing this package no longer
+# touches NCCL_* -- it would throttle every collective of the process, the caller's own included.)
 
 import torch  # noqa: E402
 
@@ -60,31 +58,25 @@ _PROTOS = {
     "b2s_model_num_tensors": (C.c_int, [P]),
     "b2s_model_tensor_info": (C.c_int, [P, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "b2s_model_bind": (C.c_int, [P, C.POINTER(P), C.POINTER(P), C.c_int]),
-    "b2s_model_sync_weights": (C.c_int, [P, P]),
-    "b2s_model_sync_weights_ex": (C.c_int, [P, P, C.c_int]),
+    "b2s_model_sync_weights": (C.c_int, [P, P, C.c_int]),
     "b2s_encoder_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int]),
     "b2s_encoder_forward": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, C.POINTER(P)]),
     "b2s_encoder_backward": (C.c_int, [P, P, P, P]),
     "b2s_decoder_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int, C.c_int]),
-    "b2s_decoder_forward": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, P, C.POINTER(P)]),
-    "b2s_decoder_forward_ev": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, P, P, C.POINTER(P)]),
-    "b2s_decoder_backward_ev": (C.c_int, [P, P, P, P, P, C.c_int, P, P, P]),
-    "b2s_decoder_backward": (C.c_int, [P, P, P, P, P, P]),
-    "b2s_decoder_backward_ex": (C.c_int, [P, P, P, P, P, C.c_int, P, P]),
+    "b2s_decoder_forward": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, P, P, C.POINTER(P)]),
+    "b2s_decoder_backward": (C.c_int, [P, P, P, P, P, C.c_int, P, P, P]),
     "b2s_decoder_guided_loss": (C.c_int, [P, P, P, P, P]),
     "b2s_decoder_alignment": (C.c_int, [P, P, C.c_int, C.c_int, P, P]),
     "b2s_postnet_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int]),
     "b2s_postnet_forward": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_uint64, P, C.c_size_t, P, P, C.POINTER(P)]),
-    "b2s_postnet_backward": (C.c_int, [P, P, P, P, P]),
-    "b2s_postnet_backward_ex": (C.c_int, [P, P, P, P, C.c_int, P]),
+    "b2s_postnet_backward": (C.c_int, [P, P, P, P, C.c_int, P]),
     "b2s_ctx_free": (None, [P]),
     "b2s_loss_forward": (C.c_int, [P, P, P, P, P, P, C.c_int, C.c_int, P, P, P, P]),
     "b2s_loss_backward": (C.c_int, [P, P, P, P, P, P, C.c_int, C.c_int, P, P, P, P, P]),
     "b2s_l2_backward": (C.c_int, [P, P, P]),
     "b2s_adam_bind": (C.c_int, [P, C.POINTER(P), C.POINTER(P), C.c_int]),
     "b2s_adam_step": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, P]),
-    "b2s_zero_grads": (C.c_int, [P, P]),
-    "b2s_zero_grads_ex": (C.c_int, [P, P, C.c_int]),
+    "b2s_zero_grads": (C.c_int, [P, P, C.c_int]),
     "b2s_model_set_grad_slot_padding": (C.c_int, [P, C.c_int]),
     "b2s_gemm": (C.c_int, [C.POINTER(GemmDesc), P, P, P, P, P, P, P, P]),
     "b2s_gemm_splitk": (C.c_int, [C.POINTER(GemmDesc), C.c_int, P, P, P, P, C.c_size_t, P]),
@@ -103,7 +95,6 @@ _PROTOS = {
     "b2s_flash_attention_align": (C.c_int, [C.c_int, P, C.c_int, P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P,
                                             P]),
     "b2s_align_from_probs": (C.c_int, [C.c_int, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P]),
-    "b2s_add": (C.c_int, [P, P, P, C.c_int64, P]),
     "b2s_add3": (C.c_int, [P, P, P, P, C.c_int64, P]),
     "b2s_pack_bf16": (C.c_int, [P, P, C.c_int64, P]),
     "b2s_unpack_bf16": (C.c_int, [P, P, C.c_int64, P]),
@@ -116,15 +107,12 @@ _PROTOS = {
     "b2s_decode_fetch": (C.c_int, [P, P, C.c_int, P, P, P]),
     "b2s_decode_alignment": (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "b2s_decode_end": (None, [P]),
-    "b2s_model_set_stage_hook_stream": (C.c_int, [P, P]),
     "b2s_model_second_stream": (C.c_void_p, [P]),
     "b2s_gemm_set_tile_policy": (C.c_int, [C.c_int]),
     "b2s_model_backward_abort": (C.c_int, [P, P]),
     "b2s_model_mark_grads_ready": (C.c_int, [P]),
-    "b2s_model_set_stage_hook": (C.c_int, [P, P, P]),
+    "b2s_model_set_stage_hook": (C.c_int, [P, P, P, P]),
     "b2s_prof_enable": (None, [C.c_int]),
-    "b2s_adam_step_ex": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, P]),
-    "b2s_adam_wait": (C.c_int, [P, P]),
     "b2s_adam_set_grad_wire": (C.c_int, [P, P, P]),
     "b2s_adam_step_groups": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, P]),
     "b2s_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.c_int]),

@@ -42,28 +42,20 @@ class _SchedView(object):
 
 
 class HipTrainer(object):
-    def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0, overlap_adam=False, grad_payload=None, dist=None):
+    def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0, grad_payload=None, dist=None, tail_adam=True, overlap_encoder=True):
         from transformer.tacotron import learning_rate_schedule
         self.model, self.hp = model, hp
-        # overlap_adam: the optimizer step runs on the engine's second stream while the next step's forward pass starts
-        # (every engine entry point waits for the parameter groups it reads).  Code that reads parameters or optimizer state
-        # with plain torch ops between steps must call sync() first; state_dict() / load_state_dict() / utils.checkpoint do.
-        self.overlap_adam = bool(overlap_adam)
-        # split_adam: decoder / postnet parameters are updated on the second stream while the encoder backward still runs
-        # (b2s_adam_step_groups).  Measured on MI355X (profiles/README.md, round 2): no gain -- a wide Adam launch puts waves
-        # on every CU and the backward's GEMM workgroups (a whole CU each) starve; a narrow launch (64 workgroups) leaves
-        # them CUs but its HBM stream raises memory latency and the latency-bound encoder kernels run 1.6x slower while it
-        # lasts; a CU-masked stream serialised the two queues.  Off by default, kept as an option (B2S_SPLIT_ADAM=1).
-        self.split_adam = os.environ.get("B2S_SPLIT_ADAM", "0") == "1"
         # tail_adam: with the encoder backward on its own stream, this stream is idle from the end of the decoder backward until the
         # encoder's last weight gradients are done (~0.9 ms); the decoder / postnet update (HBM-bound) runs there, behind the second
-        # stream's last decoder weight-gradient group, and only the encoder group's update follows the encoder backward
-        self.tail_adam = os.environ.get("B2S_TAIL_ADAM", "1") != "0"
-        # overlap_encoder: the encoder is 5 % of the step's FLOPs in ~55 launches per pass of 78..208 workgroups -- a fifth of the step on
+        # stream's last decoder weight-gradient group, and only the encoder group's update follows the encoder backward.  False: one
+        # optimizer launch after the whole backward pass.  (Schedules measured and dropped, profiles/NOTES_r02.md / r04.md: the update
+        # on the second stream under the encoder backward, the update overlapped with the next forward pass.)
+        self.tail_adam = bool(tail_adam)
+        # overlap_encoder: the encoder is 5 % of the step's FLOPs in ~30 launches per pass of ~112 workgroups -- a fifth of the step on
         # a quarter of the chip.  Its forward runs on a stream of its own beside the decoder's prenet and first self-attention (which
         # do not read the encoder output), its backward starts as soon as d(memory) is complete, beside the first decoder layer's
-        # self-attention backward, the prenet backward and their weight gradients.  B2S_ENC_OVERLAP=0 restores the single chain.
-        self.overlap_encoder = os.environ.get("B2S_ENC_OVERLAP", "1") != "0"
+        # self-attention backward, the prenet backward and their weight gradients.  False: the single chain.
+        self.overlap_encoder = bool(overlap_encoder)
         self._enc_stream = None
         self.eng = model.engine()
         self.eng.ensure_bound()
@@ -104,8 +96,10 @@ class HipTrainer(object):
             # whose point-to-point links (7 x ~153 GB/s per GPU) bound the ring all-reduce -- converted by HIP
             # kernels on the exchange stream around each bucket's all-reduce; everything inside a rank (accumulation, Adam moments,
             # masters) stays fp32.  "fp32": the exact mean of the rank gradients (the reference's DDP arithmetic).
-            # B2S_GRAD_PAYLOAD overrides the default, the constructor argument overrides both.
-            payload = grad_payload or os.environ.get("B2S_GRAD_PAYLOAD", "bf16" if self.world > 1 else "fp32")
+            # Default "fp32" (the reference's arithmetic: a drop-in must not change what DDP computes); B2S_GRAD_PAYLOAD overrides the
+            # default, the constructor argument overrides both (bench.py selects "bf16" for its bf16 performance lines and says so;
+            # tests/test_gpu_dp_race.py::test_bf16_wire_tracks_fp32_wire_over_200_steps is the convergence-level evidence for it).
+            payload = grad_payload or os.environ.get("B2S_GRAD_PAYLOAD", "fp32")
             # the exchange's channel kernels hold CUs while the backward (and the next forward) runs: GEMM tiles that do not need all 256
             # CUs for a whole round (b2s_gemm_set_tile_policy; measured with tools/cu_loss.py, profiles/NOTES_r03.md)
             if self.world > 1:
@@ -121,18 +115,18 @@ class HipTrainer(object):
             # the backward pass itself never waits for the second stream on their account
             # -- the engine's own second stream: a stage's gradients are complete exactly there (its weight-gradient group is the stage's last
             # work), so the pack kernel and the collective's launch need no extra ordering, and the process stays at four active streams
-            # (main, second, encoder, RCCL's).  A fifth one (B2S_HOOK_STREAM=own: the round-3 layout) oversubscribes the hardware queues:
-            # 12.6 ms per step instead of 7.9 with the encoder on its own stream (profiles/NOTES_r04.md)
+            # (main, second, encoder, RCCL's).  A fifth one (a dedicated exchange stream: the round-3 layout)
+            # oversubscribes the hardware queues: 12.6 ms per step instead of 7.9 with the encoder on its own stream (profiles/NOTES_r04.md)
             self._hook_stream = None
             if on_gpu:
                 aux = self.lib.b2s_model_second_stream(self.eng.handle)
-                if aux and os.environ.get("B2S_HOOK_STREAM", "second") != "own":
+                if aux:
                     self._hook_stream = torch.cuda.ExternalStream(aux, device=self.eng._gflat.device)
                 else:
                     self._hook_stream = torch.cuda.Stream(device=self.eng._gflat.device)
             # bf16 payload: the fused Adam reads the all-reduced gradients straight from the wire buffer (no unpack kernel, no fp32 re-read of
-            # 334 MB: ~0.15 ms per step at N > 1); B2S_ADAM_FROM_WIRE=0 restores unpack + fp32 read
-            consume = payload == "bf16" and on_gpu and os.environ.get("B2S_ADAM_FROM_WIRE", "1") != "0" and not self.split_adam
+            # 334 MB: ~0.15 ms per step at N > 1)
+            consume = payload == "bf16" and on_gpu
             self.bucketer = GradBucketer(self.eng._gflat, self.eng.stage_ranges, self.eng.n_stages(),
                                          bucket_mb * 1024 * 1024 / 4, dist=self.dist, payload=payload,
                                          pack=pack if on_gpu else None, unpack=unpack if on_gpu else None, stream=self._hook_stream,
@@ -147,9 +141,8 @@ class HipTrainer(object):
                 print("[b2s] data-parallel gradient payload: %s%s (HipTrainer(grad_payload=...) / B2S_GRAD_PAYLOAD; fp32 = the reference's exact "
                       "mean of the rank gradients, train.py:125)" % (payload, ", consumed by the optimizer from the wire buffer" if consume else ""),
                       file=sys.stderr)
-            L.check(self.lib.b2s_model_set_stage_hook(self.eng.handle, C.cast(self._hook, L.P), None))
-            if self._hook_stream is not None:
-                L.check(self.lib.b2s_model_set_stage_hook_stream(self.eng.handle, self._hook_stream.cuda_stream))
+            L.check(self.lib.b2s_model_set_stage_hook(self.eng.handle, C.cast(self._hook, L.P), None,
+                                                      self._hook_stream.cuda_stream if self._hook_stream is not None else None))
             # broadcast parameters and BN buffers from rank 0 once (DDP constructor semantics, train.py:125)
             with torch.no_grad():
                 for t in self.eng._tensors():
@@ -167,8 +160,8 @@ class HipTrainer(object):
         return [n for n, _ in self.model.named_parameters()]           # = torch.optim.Adam(m.parameters()) index order
 
     def sync(self):
-        """Make the current torch stream wait for an overlapped optimizer step (no-op otherwise)."""
-        L.check(self.lib.b2s_adam_wait(self.eng.handle, L.stream()))
+        """Kept for callers written against the overlapped-optimizer schedules: every update now runs on the stream train_step was
+        called on, so plain stream order already covers it (no-op)."""
 
     def close(self):
         """Undo the process-wide settings this trainer made (the data-parallel GEMM tile policy); the trainer stays usable."""
@@ -238,6 +231,18 @@ class HipTrainer(object):
         except BaseException as e:          # noqa: B902 (must not propagate into ctypes)
             self._hook_error = e
 
+    def _consume_partial_step(self, step_no, cause):
+        """A failure AFTER the decoder / postnet update of step `step_no` was issued (a collective of the encoder buckets, the final
+        update): those groups are at step_no, the encoder group is not.  The step cannot be retried under the same number (Adam's bias
+        correction of the updated groups has advanced; b2s_adam_step_groups refuses a second update of a group in one step), so it is
+        marked consumed -- the next train_step runs as step_no + 1 on every group -- and the error says so."""
+        self.global_step = step_no
+        self.last_step_tail_update = True
+        raise RuntimeError("training step %d failed after its decoder / postnet optimizer update had been issued: a PARTIAL update was "
+                           "applied (encoder parameters keep their step-%d values).  The step counter has advanced to %d so that "
+                           "training can continue; restore a checkpoint if the replicas must stay bit-identical." %
+                           (step_no, step_no - 1, step_no)) from cause
+
     # ------------------------------------------------------------------ one step
     def train_step(self, batch):
         """batch: the dataloader dict (dataloader.py:498-508) on the device.  Returns the 7 loss values (device)."""
@@ -251,13 +256,12 @@ class HipTrainer(object):
             from .dp import broadcast_buffers
             broadcast_buffers(self._bn_buffers, self.dist, 0)
         # the fused Adam kernel rewrote the fp32 masters AND their bf16 shadows; only conv re-layouts remain
-        L.check(lib.b2s_model_sync_weights_ex(eng.handle, L.stream(), int(self.global_step > 0)))
+        L.check(lib.b2s_model_sync_weights(eng.handle, L.stream(), int(self.global_step > 0)))
         in32, tgt32 = _i32(batch["input_lengths"]), _i32(batch["target_lengths"])
         cur = torch.cuda.current_stream()
-        ovl = self.overlap_encoder and not self.split_adam
+        ovl = self.overlap_encoder
         if ovl and self._enc_stream is None:
-            self._lab_skipped = [torch.cuda.Stream(device=eng._gflat.device) for _ in range(int(os.environ.get('B2S_LAB_SKIP_STREAMS', '0')))]
-            self._enc_stream = torch.cuda.Stream(device=eng._gflat.device, priority=int(os.environ.get("B2S_ENC_PRIO", "0")))
+            self._enc_stream = torch.cuda.Stream(device=eng._gflat.device)
         enc_s = self._enc_stream if ovl else None
         if enc_s is not None:
             enc_s.wait_stream(cur)                         # (weights synced above; the previous step's optimizer update)
@@ -277,40 +281,32 @@ class HipTrainer(object):
         if guided:
             self.last_ga_loss = eng.guided_loss(c_dec, add_to=vals)       # vals[0] (total loss) += weight * guided loss
         # (1 = B2S_ZERO_GRADS_OVERWRITE_DW: this step runs every backward segment exactly once)
-        L.check(lib.b2s_zero_grads_ex(eng.handle, L.stream(), 1))
+        L.check(lib.b2s_zero_grads(eng.handle, L.stream(), 1))
         eng._needs_zero = False
         if self.bucketer is not None:
             self.bucketer.begin_step()
         self._hook_error = None
+        partial = False                                      # the decoder / postnet part of this step's optimizer update has been issued
+        step_no = self.global_step + 1
         try:
             dbef, daft, dstop = eng.loss_backward(mels, aft, stop, batch["mel_targets"], tgt32, None)
             din = eng.postnet_backward(c_post, daft, defer_join=True)           # (the decoder backward below takes over the second stream's join)
             dmel = eng.add3(din, daft, dbef)                  # (same order of additions as two b2s_add calls)
-            # split: the decoder / postnet gradients (78 % of the parameters) get their optimizer update (HBM-bound, no LDS) on the
-            # engine's second stream under the encoder backward, whose GEMMs are 78..208 workgroups on 256 CUs; the encoder group
-            # follows on this stream.  Data parallel: those gradients' all-reduce must be complete first, so the split is used only
-            # without a process group (the exchange itself overlaps the encoder backward there).
-            split = self.split_adam and self.bucketer is None and not self.freeze_encoder and not self.overlap_adam
-            # With a deferred join the last stages' weight-gradient groups, bias column sums and LayerNorm reductions of the decoder
-            # backward are still queued when it returns (the encoder backward launches them): the split update must not run on
-            # incomplete decoder gradients, so it takes the join here.
             enc_bwd_s = enc_s if (enc_s is not None and not self.freeze_encoder) else None
             dmem_done = None
             if enc_bwd_s is not None:
                 dmem_done = torch.cuda.Event()
                 dmem_done.record(cur)                          # (torch creates the HIP event at its first record: the library re-records this handle)
             dmem = eng.decoder_backward(c_dec, dmel, dstop, mem.shape, self._one if guided else None, not self.freeze_encoder,
-                                        defer_join=not self.freeze_encoder and not split, dmem_done=dmem_done)    # (encoder_backward below joins the second stream)
+                                        defer_join=not self.freeze_encoder, dmem_done=dmem_done)    # (encoder_backward below joins the second stream)
             lr = self.hp.max_lr * self.lr_lambda(self.global_step)
             step_no = self.global_step + 1
             adam = (lr, step_no, self.beta1, self.beta2, self.hp.adam_eps, self.hp.reg_weight, 1.0 / self.world)
             # (data parallel: the same schedule once the decoder / postnet buckets' all-reduces are complete -- GradBucketer.split keeps a
             # bucket from straddling the group boundary, wait_prefix orders this stream behind exactly those collectives)
-            tail = (self.tail_adam and enc_bwd_s is not None and not self.overlap_adam and not split and
+            tail = (self.tail_adam and enc_bwd_s is not None and
                     (self.bucketer is None or getattr(self.bucketer, "split", None) is not None))
-            if split:
-                L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 1, L.stream()))
-            elif tail:
+            if tail:
                 L.check(lib.b2s_model_mark_grads_ready(eng.handle))     # decoder / postnet gradients are final behind this point of the second stream
             if not self.freeze_encoder:
                 if enc_bwd_s is not None:
@@ -318,19 +314,23 @@ class HipTrainer(object):
                     with torch.cuda.stream(enc_bwd_s):
                         eng.encoder_backward(c_enc, dmem)
                     if tail and self.bucketer is not None:
-                        # every decoder / postnet stage has reported by now (their hooks fire at the encoder backward's first hand-over);
-                        # a hook that failed, or a stage that has not reported, falls back to the single update after the whole exchange
-                        tail = self._hook_error is None and self.bucketer.wait_prefix(self.bucketer.split)
+                        # Every stage has reported by now (the encoder backward's drain fired the last hooks).  Everything that can be
+                        # checked WITHOUT waiting is checked before any part of the update is issued: a hook that failed, a stage that did
+                        # not report, ranges that do not tile the buffer -- each falls back to the single update after the whole exchange
+                        # (which then refuses the step as a whole).  What remains after the partial update is the collectives themselves.
+                        tail = (self._hook_error is None and self.bucketer.covers_all(expect_all=not self.freeze_encoder) and
+                                self.bucketer.wait_prefix(self.bucketer.split))
                     if tail:
                         # issued only now (a failure in the encoder backward call above leaves the step unapplied), but ordered behind the
                         # mark only: on the device it runs beside the encoder backward
-                        L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 2, L.stream()))
+                        L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 2 | 4, 1, L.stream()))
+                        partial = True
                     cur.wait_stream(enc_bwd_s)                 # (its last stage joined the engine's second stream)
                 else:
                     eng.encoder_backward(c_enc, dmem)
             elif enc_s is not None:
                 cur.wait_stream(enc_s)
-        except BaseException:
+        except BaseException as e:
             # the backward entry points hand work to each other (deferred joins): whatever is still queued points into contexts that are
             # freed below -- drop it and rejoin the second stream before anything else touches the engine (b2s_model_backward_abort)
             try:
@@ -344,28 +344,33 @@ class HipTrainer(object):
                     if c is not None:
                         c.free()
                 eng._needs_zero = True
+            if partial:
+                self._consume_partial_step(step_no, e)
             raise
         for c in (c_post, c_dec, c_enc):
             if c is not None:
                 c.free()
-        if self._hook_error is not None:
-            err, self._hook_error = self._hook_error, None
+        try:
+            if self._hook_error is not None:
+                err, self._hook_error = self._hook_error, None
+                raise RuntimeError("gradient exchange failed in the backward stage hook; the optimizer step was NOT applied") from err
+            if self.bucketer is not None:
+                self.bucketer.finish(expect_all=not self.freeze_encoder)
+            if self.grad_probe is not None:
+                self.grad_probe(eng._gflat, self.bucketer.wire if (self.bucketer is not None and self.bucketer.consume_wire) else None)
+            if partial:
+                L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 1, 0, L.stream()))
+            else:
+                L.check(lib.b2s_adam_step(eng.handle, *adam, L.stream()))
+        except BaseException as e:
             if self.bucketer is not None:
                 self.bucketer.abort()
-            raise RuntimeError("gradient exchange failed in the backward stage hook; the optimizer step was NOT applied") from err
-        if self.bucketer is not None:
-            self.bucketer.finish(expect_all=not self.freeze_encoder)
-        if self.grad_probe is not None:
-            self.grad_probe(eng._gflat, self.bucketer.wire if (self.bucketer is not None and self.bucketer.consume_wire) else None)
+            eng._needs_zero = True
+            if partial:
+                self._consume_partial_step(step_no, e)
+            raise
         self.global_step = step_no
-        self.last_step_tail_update = bool(tail)            # (tests: which optimizer schedule the step took)
-        if split or tail:
-            L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 1, 0, L.stream()))
-            # order this stream behind the second-stream update (done long before the encoder backward ends): plain torch
-            # code that reads parameters right after train_step needs no explicit sync()
-            L.check(lib.b2s_adam_wait(eng.handle, L.stream()))
-        else:
-            L.check(lib.b2s_adam_step_ex(eng.handle, *adam, int(self.overlap_adam), L.stream()))
+        self.last_step_tail_update = bool(partial)         # (tests: which optimizer schedule the step took)
         eng._needs_zero = True
         self.last_aft_losses = per
         return vals

@@ -11,6 +11,8 @@
 //
 // Operand layouts: q [B, Lq, H*dh] with leading dimension ldq (heads interleaved, exactly as the fused QKV / KV
 // projection GEMMs write them), k, v likewise; ctx [B, Lq, H*dh].
+#include <cstdlib>
+#include <mutex>
 #include "b2s_common.h"
 #include "attention.h"
 
@@ -540,6 +542,224 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
 }
 
+// ================================================================================================ resident keys (Lk <= 128, no causal mask)
+// Encoder-decoder attention reads a SHORT key sequence (the utterance's <= 128 text bytes) against ~600 query frames.  In the generic
+// kernels above a workgroup's whole life is then prologue + two key tiles + epilogue, and the 44 KB of K / V of a (batch, head) are staged
+// through LDS once per 64-query tile -- ten times.  Here K and V of the (batch, head) stay in LDS (2 x 128 rows), a workgroup walks
+// `tpw` consecutive query tiles, and with every key on chip the softmax is single-pass: no running maximum, no rescale, and NO barrier
+// after the prologue -- a wave's 16 query rows depend on nothing another wave does, so the four waves drift apart and hide each other's
+// latencies.  Forward and dQ; dK / dV keeps the generic kernel (it loops over queries, its keys were always resident).
+// Same arithmetic as the generic kernels up to the summation order of the row sum (results agree to fp32 rounding; the saved
+// log-sum-exp is the same quantity), same dropout / guided-attention / padded-tile semantics.
+constexpr int RES_KEYS = 128;
+
+// K, V rows [0, 128) of one (batch, head) -> LDS images [128][LD] (zero beyond Lk), then one barrier
+template <typename T, int DH>
+__device__ inline void res_load_kv(T* sK, T* sV, const T* K, const T* V, const AttnArgs& a, int nkt, int tid) {
+    constexpr int LD = DH + AT<T>::PAD;
+    TileRegs<T, DH> rk, rv;
+    for (int kt = 0; kt < nkt; ++kt) {
+        tile_fetch<T, DH>(rk, K, a.ldk, kt * 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, kt * 64, a.Lk, tid);
+        tile_store<T, DH>(sK + kt * 64 * LD, rk, tid); tile_store<T, DH>(sV + kt * 64 * LD, rv, tid);
+    }
+    __syncthreads();
+}
+
+template <typename T, int DH>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_res_kernel(AttnArgs a, int tpw) {
+    constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
+    extern __shared__ __attribute__((aligned(16))) unsigned char res_smem[];
+    T* sK = reinterpret_cast<T*>(res_smem);
+    T* sV = sK + RES_KEYS * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    int chunk, z;
+    xcd_block(chunk, z);
+    const int b = z / a.H, h = z - b * a.H;
+    const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
+    const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
+    int kend = a.Lk;
+    if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
+    const int nkt = (kend + 63) / 64;                              // 0, 1 or 2 key tiles carry valid keys
+    const int ntiles = (a.Lq + 63) / 64;
+    const int t_begin = chunk * tpw, t_end = min(t_begin + tpw, ntiles);
+    // tiles of padded query rows need no keys: a chunk that holds nothing else skips the K / V load as well
+    const int q_live = a.qskip ? min(a.qskip[b], a.Lq) : a.Lq;
+    if (t_begin * 64 < q_live) res_load_kv<T, DH>(sK, sV, K, V, a, nkt, tid);
+    const bool ga = a.ga_rows != nullptr;
+    float ga_iq = 0.f, ga_ik = 0.f;
+    if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
+    const float sl2 = a.scale * B2S_LOG2E;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int qb0 = tile * 64, q = qb0 + wave * 16 + li, qc = min(q, a.Lq - 1);
+        f32x4_t o[DH / 16];
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (qb0 >= q_live && a.qskip) {                            // a tile of padded query rows (workgroup-uniform)
+            if (q < a.Lq) {
+                store_rows<T, DH>(reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q) * a.ldo + h * DH, o, 1.f, lg);
+                if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = 0.f;
+                if (lg == 0 && ga) a.ga_rows[(long)z * a.Lq + q] = 0.f;
+            }
+            continue;
+        }
+        typename AT<T>::frag qf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = frag_global<T>(Q, a.ldq, qc, ks, lg);
+        f32x4_t s[2][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt >= nkt) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) s[kt][t] = (f32x4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                continue;
+            }
+            first_product<T, DH, LD>(s[kt], sK + kt * 64 * LD, qf, li, lg);
+            if (kt * 64 + 64 > kend) {                             // the boundary tile: keys >= kend are masked
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[kt][t][r] = (kt * 64 + t * 16 + lg * 4 + r) < kend ? s[kt][t][r] : -INFINITY;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[kt][t][0], s[kt][t][1])), fmaxf(s[kt][t][2], s[kt][t][3]));
+        }
+        mx = group_max(mx) * sl2;
+        const float mref = mx == -INFINITY ? 0.f : mx;
+        float l = 0.f, g = 0.f;
+        const uint32_t drow = (uint32_t)(((long)z * a.Lq + qc) * a.Lk);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt >= nkt) continue;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fast_exp2(fmaf(s[kt][t][r], sl2, -mref));      // masked: 2^-inf = 0
+                    l += p;
+                    s[kt][t][r] = p;
+                }
+            if (ga) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g += s[kt][t][r] * ga_w(q, kt * 64 + t * 16 + lg * 4 + r, ga_iq, ga_ik, a.ga_inv2s2);
+            }
+            if (a.drop.thresh) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        s[kt][t][r] = b2s_keep(a.drop, drow + (uint32_t)(kt * 64 + t * 16 + lg * 4 + r)) ? s[kt][t][r] * a.drop.scale : 0.f;
+            }
+            SP<T, DH, LD>::run(o, sV + kt * 64 * LD, s[kt], li, lg);
+        }
+        l = group_sum(l);
+        if (ga) g = group_sum(g);
+        if (q < a.Lq) {
+            const float inv = 1.f / l;
+            store_rows<T, DH>(reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q) * a.ldo + h * DH, o, inv, lg);
+            if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = (mref + __log2f(l)) * B2S_LN2;
+            if (lg == 0 && ga) a.ga_rows[(long)z * a.Lq + q] = q < a.qlen[b] ? g * inv : 0.f;
+        }
+    }
+}
+
+template <typename T, int DH>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_res_kernel(AttnArgs a, int tpw) {
+    constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
+    extern __shared__ __attribute__((aligned(16))) unsigned char res_smem[];
+    T* sK = reinterpret_cast<T*>(res_smem);
+    T* sV = sK + RES_KEYS * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    int chunk, z;
+    xcd_block(chunk, z);
+    const int b = z / a.H, h = z - b * a.H;
+    const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
+    const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
+    const T* dO = reinterpret_cast<const T*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
+    const T* O = reinterpret_cast<const T*>(a.oref) + (long)b * a.Lq * a.ldo + h * DH;
+    int kend = a.Lk;
+    if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
+    const int nkt = (kend + 63) / 64;
+    const int ntiles = (a.Lq + 63) / 64;
+    const int t_begin = chunk * tpw, t_end = min(t_begin + tpw, ntiles);
+    const int q_live = a.qskip ? min(a.qskip[b], a.Lq) : a.Lq;
+    if (t_begin * 64 < q_live) res_load_kv<T, DH>(sK, sV, K, V, a, nkt, tid);
+    float gc0 = 0.f, ga_iq = 0.f, ga_ik = 0.f;
+    int ga_ql = 0;
+    if (a.ga_rows) {
+        ga_ql = min(a.qlen[b], a.Lq);
+        gc0 = *a.ga_scale;
+        ga_iq = 1.f / (float)max(ga_ql, 1); ga_ik = 1.f / (float)max(kend, 1);
+    }
+    const float sl2 = a.scale * B2S_LOG2E;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int qb0 = tile * 64, q = qb0 + wave * 16 + li, qc = min(q, a.Lq - 1);
+        f32x4_t dq[DH / 16];
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (qb0 >= q_live && a.qskip) {                            // padded query rows: d context is zero there, so is dQ
+            if (q < a.Lq) {
+                store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)b * a.Lq + q) * a.lddq + h * DH, dq, 1.f, lg);
+                if (lg == 0) a.dsum[(long)z * a.Lq + q] = 0.f;
+            }
+            continue;
+        }
+        typename AT<T>::frag qf[NKS], dof[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) { qf[ks] = frag_global<T>(Q, a.ldq, qc, ks, lg); dof[ks] = frag_global<T>(dO, a.ldo, qc, ks, lg); }
+        const float lse2 = a.lse[(long)z * a.Lq + qc] * B2S_LOG2E;
+        float Dq = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) Dq += frag_dot(frag_global<T>(O, a.ldo, qc, ks, lg), dof[ks]);
+        Dq = group_sum(Dq);
+        float gc = 0.f;
+        if (a.ga_rows) {
+            if (q < ga_ql) gc = gc0;
+            Dq += gc * a.ga_rows[(long)z * a.Lq + qc];
+        }
+        if (lg == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;              // the dK/dV kernel reads it
+        const uint32_t drow = (uint32_t)(((long)z * a.Lq + qc) * a.Lk);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt >= nkt) continue;
+            f32x4_t s[4], dp[4];
+            first_product<T, DH, LD>(s, sK + kt * 64 * LD, qf, li, lg);
+            first_product<T, DH, LD>(dp, sV + kt * 64 * LD, dof, li, lg);
+            const bool interior = kt * 64 + 64 <= kend;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = interior || (kt * 64 + t * 16 + lg * 4 + r) < kend;
+                    s[t][r] = ok ? fast_exp2(fmaf(s[t][r], sl2, -lse2)) : 0.f;
+                }
+            if (a.drop.thresh) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dp[t][r] = b2s_keep(a.drop, drow + (uint32_t)(kt * 64 + t * 16 + lg * 4 + r)) ? dp[t][r] * a.drop.scale : 0.f;
+            }
+            if (__any(gc != 0.f)) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[t][r] += gc * ga_w(q, kt * 64 + t * 16 + lg * 4 + r, ga_iq, ga_ik, a.ga_inv2s2);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - Dq) * a.scale;
+            SP<T, DH, LD>::run(dq, sK + kt * 64 * LD, s, li, lg);
+        }
+        if (q < a.Lq) store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)b * a.Lq + q) * a.lddq + h * DH, dq, 1.f, lg);
+    }
+}
+
 // alignment rows on demand: align[z][k][q] = softmax weight, recomputed from q, k and the saved log-sum-exp
 template <typename T>
 __global__ __launch_bounds__(256) void attn_align_kernel(AttnArgs a, float* align, int dh) {
@@ -580,8 +800,34 @@ __global__ __launch_bounds__(256) void attn_align_kernel(AttnArgs a, float* alig
     }
 }
 
+// resident-key kernels: short key sequences without the causal mask (the encoder-decoder attention, and a short encoder's self-attention)
+inline bool res_ok(const AttnArgs& a) { return !(a.mask_mode & 2) && a.Lk <= RES_KEYS && a.Lq > 64; }
+// query tiles per workgroup: 2 -> B*H*ceil(tiles/2) workgroups (560 at B = 14, T = 582): one resident round at 2 workgroups per CU
+#ifdef B2S_LAB
+static const int g_res_tpw = getenv("B2S_LAB_ATTN_TPW") ? atoi(getenv("B2S_LAB_ATTN_TPW")) : 2;       // (0: generic kernels)
+#else
+constexpr int g_res_tpw = 2;
+#endif
+template <typename T, int DH>
+int launch_res(const AttnArgs& a, int which, hipStream_t st) {
+    constexpr size_t smem = (size_t)2 * RES_KEYS * (DH + AT<T>::PAD) * sizeof(T);
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_res_kernel<T, DH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_res_kernel<T, DH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    B2S_HIP(err);
+    dim3 grid(cdiv(cdiv(a.Lq, 64), g_res_tpw), a.B * a.H);
+    if (which == 0) hipLaunchKernelGGL((attn_fwd_res_kernel<T, DH>), grid, dim3(256), smem, st, a, g_res_tpw);
+    else hipLaunchKernelGGL((attn_bwd_dq_res_kernel<T, DH>), grid, dim3(256), smem, st, a, g_res_tpw);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
 template <typename T, int DH>
 int launch_dh(const AttnArgs& a, int which, hipStream_t st) {
+    if (which < 2 && g_res_tpw > 0 && res_ok(a)) return launch_res<T, DH>(a, which, st);
     if (which == 0) {
         dim3 grid(cdiv(a.Lq, 64), a.B * a.H);
         hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(256), 0, st, a);

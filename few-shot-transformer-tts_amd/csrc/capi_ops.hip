@@ -137,13 +137,9 @@ extern "C" int b2s_unpack_bf16(const void* src_bf16, float* dst, int64_t n, void
     B2S_CHECK(src_bf16 && dst && n >= 0, "bad argument");
     return n ? ro_cast_back(1, src_bf16, dst, n, S_(stream)) : 0;
 }
-extern "C" int b2s_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
-    B2S_CHECK(a && b && out, "null argument");
-    return ro_add(a, b, out, n, S_(stream));
-}
 extern "C" int b2s_add3(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream) {
-    B2S_CHECK(a && b && c && out, "null argument");
-    return ro_add3(a, b, c, out, n, S_(stream));
+    B2S_CHECK(a && b && out, "null argument");
+    return c ? ro_add3(a, b, c, out, n, S_(stream)) : ro_add(a, b, out, n, S_(stream));
 }
 extern "C" int b2s_cast(int dtype, const float* in, void* out, int64_t n, void* stream) {
     B2S_CHECK(in && out, "null argument");

@@ -282,7 +282,7 @@ void plan_decode(const b2s_model* m, b2s_decode_state& s, Arena& a) {
     s.a3 = a.f32((long)B * D); s.x = a.f32((long)B * D); s.mean = a.f32(B); s.rstd = a.f32(B);
     s.h = a.T((long)B * D, esz); s.qkv = a.T((long)B * 3 * D, esz); s.ctx = a.T((long)B * D, esz); s.f = a.T((long)B * 4 * D, esz);
     s.outT = a.T((long)B * D, esz); s.mel_step = a.f32((long)B * cf.num_mels); s.stop_step = a.f32(B);
-    static const bool no_fused = getenv("B2S_DECODE_UNFUSED") != nullptr;          // A/B switch: one kernel per op (round-1 path)
+    constexpr bool no_fused = false;          // A/B switch: one kernel per op (round-1 path)
     s.ns_ffn = b2s_df_ffn_slices(m->dtype, D, H, 4 * D);
     s.fused = !no_fused && b2s_df_supported(m->dtype, D, H, 4 * D, cf.num_mels, cf.prenet_hidden, std::max(T, S));
     if (s.fused) {
@@ -464,7 +464,6 @@ extern "C" int b2s_decode_begin(b2s_model* m, const float* memory, const int32_t
     B2S_CHECK(m && m->bound, "model parameters are not bound");
     B2S_CHECK(memory && input_lengths && ws && out && B > 0 && S > 0 && max_frames > 0, "bad argument");
     hipStream_t st = S_(stream);
-    B2S_TRY(b2s_adam_wait(m, stream));                         // an overlapped optimizer step may still be writing the weights
     b2s_decode_state* s = new b2s_decode_state();
     s->B = B; s->S = S; s->maxT = max_frames; s->train = train; s->seed = seed; s->in_len = input_lengths;
     s->keep_self = keep_self_alignments != 0;

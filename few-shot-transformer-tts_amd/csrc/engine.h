@@ -152,12 +152,7 @@ struct b2s_model {
     // launches that only feed parameter gradients (bias / stop-net column sums, the speaker / language nets' backward): queued and
     // issued on the second stream with the next weight-gradient hand-over
     mutable std::vector<std::function<int(hipStream_t)>> aux_jobs;
-    // Optimizer step overlapped with the next forward pass (b2s_adam_step_ex, overlap = 1): the fused Adam runs on the aux
-    // stream in three groups -- postnet, encoder, decoder parameters (the order the next step first needs them) -- and
-    // every entry point waits on its caller's stream for the groups it reads before it touches a weight.
-    int adam_grp[4] = {0, 0, 0, 0};                            // chunk ranges [grp[g], grp[g+1]) of encoder / decoder / postnet
-    mutable hipEvent_t adam_ev[3] = {nullptr, nullptr, nullptr};
-    mutable bool adam_pending[3] = {false, false, false};
+    int adam_grp[4] = {0, 0, 0, 0};                            // chunk ranges [grp[g], grp[g+1]) of encoder / decoder / postnet (b2s_adam_step_groups)
     const void* adam_wire = nullptr;                           // b2s_adam_set_grad_wire: bf16 gradients (the exchange's wire buffer) laid out like the
     const float* adam_gbase = nullptr;                         // fp32 gradient buffer that starts at adam_gbase
     int adam_step_no = 0, adam_step_mask = 0;                  // b2s_adam_step_groups: groups already updated in step adam_step_no
@@ -188,7 +183,7 @@ struct b2s_model {
     void (*stage_hook)(int, void*) = nullptr;       // called on the host after each backward stage is enqueued
     void* stage_user = nullptr;
     void stage_done(int s) const { if (stage_hook) stage_hook(s, stage_user); }   // callers order the hook's stream first (hook_after_*)
-    hipStream_t hook_stream = nullptr;              // stream the hook launches its collective on (b2s_model_set_stage_hook_stream); null: the backward's
+    hipStream_t hook_stream = nullptr;              // stream the hook launches its collective on (b2s_model_set_stage_hook); null: the backward's
 
     int id(const std::string& n) const;
     float* P(const std::string& n) const { return (float*)data[id(n)]; }

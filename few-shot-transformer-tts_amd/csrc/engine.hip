@@ -215,7 +215,7 @@ int pick_splitk(int Mo, int No, int K, int dtype) {
     const int bk = dtype ? 64 : 16;
     const int nk = cdiv(K, bk);
     if (dtype) {
-        static const int target = getenv("B2S_DW_BLOCKS") ? atoi(getenv("B2S_DW_BLOCKS")) : 256;
+        constexpr int target = 256;
         const long tiles = (long)cdiv(Mo, 256) * cdiv(No, 128);
         int s = (int)std::min<long>(std::max<long>(1, target / tiles), std::max(1, nk / 4));
         return std::max(1, std::min(s, 32));
@@ -254,7 +254,7 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
     if (m->dw_pending.empty()) return flush_colsums(m, st);
     std::vector<GemmArgs>& q = m->dw_pending;
     std::stable_sort(q.begin(), q.end(), [](const GemmArgs& a, const GemmArgs& b) { return a.K > b.K; });    // long tiles first
-    static const bool serial = getenv("B2S_DW_GROUP_SERIAL") != nullptr;       // experiment: groups on the main stream
+    constexpr bool serial = false;       // experiment: groups on the main stream
     if (serial) {
         for (size_t i = 0; i < q.size(); i += B2S_MAX_GROUP)
             B2S_TRY(b2s_gemm_grouped_launch(q.data() + i, (int)std::min<size_t>(B2S_MAX_GROUP, q.size() - i), st));
@@ -292,7 +292,7 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
         // step's last groups, 7.34 -> 7.24 ms).  Beside the main stream's GEMMs the same packing LOSES (7.43 -> 7.55 ms per step): a
         // 252-tile launch takes every CU for a whole round and the main stream's one-round GEMMs stall behind it, while the CU time
         // (tiles x time per tile) is the same either way -- there the launches stay contiguous runs of up to B2S_MAX_GROUP problems.
-        static const int round_env = getenv("B2S_DW_ROUND_TILES") ? atoi(getenv("B2S_DW_ROUND_TILES")) : 256;       // (0: never)
+        constexpr int round_env = 256;       // (0: never)
         const int round_tiles = m->dw_flush_exposed ? round_env : 0;
         const bool capped = m->dw_flush_capped && m->dw_tail_cap > 0;
         const long cap = capped ? m->dw_tail_cap : (round_tiles > 0 ? round_tiles : (1L << 30));
@@ -341,8 +341,13 @@ int flush_ln_jobs(const b2s_model* m, hipStream_t st);
 // Ordering for the stage hook.  The hook launches a collective on gradients that the second stream completes: the stream the hook
 // works on must wait for that.  With a dedicated hook stream the backward's own stream never waits for the second stream here (it
 // used to, at every stage -- 0.45 ms per step in data-parallel runs).
-// (B2S_LAB_NO_HOOK_ORDER: drops these waits -- only to show that tests/test_gpu_dp_race.py fails without them)
+// Lab builds only (csrc/build.sh --lab, -DB2S_LAB -> tools/bin/libb2s_hip_lab.so): B2S_LAB_NO_HOOK_ORDER drops these waits -- to show that
+// tests/test_gpu_dp_race.py fails without them.  The product library does not contain the switch (tests/test_host_logic.py greps for it).
+#ifdef B2S_LAB
 static const bool g_lab_no_hook_order = getenv("B2S_LAB_NO_HOOK_ORDER") != nullptr;
+#else
+constexpr bool g_lab_no_hook_order = false;
+#endif
 int hook_after_event(const b2s_model* m, hipStream_t st, hipEvent_t ev) {      // ev: second-stream event after the stage's last gradient work
     if (g_lab_no_hook_order) return 0;
     if (ev) B2S_HIP(hipStreamWaitEvent(m->hook_stream ? m->hook_stream : st, ev, 0));
@@ -363,7 +368,7 @@ void fire_stages(const b2s_model* m, std::vector<int>& v) {
     v.clear();
 }
 int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain, bool force_flush = false) {
-    static const bool serial = getenv("B2S_DW_GROUP_SERIAL") != nullptr;
+    constexpr bool serial = false;
     if (!m->dw_group) {
         B2S_TRY(flush_ln_jobs(m, st));                     // the stage's LayerNorm parameter gradients
         B2S_TRY(join_aux(m, st));
@@ -378,7 +383,7 @@ int end_stage(const b2s_model* m, hipStream_t st, int stage, bool drain, bool fo
     // stage without weight-gradient GEMMs (an output LayerNorm) has nothing to hand over by itself.  The hooks of the stages a
     // hand-over covers fire together at the next one, once the hook's stream has been ordered behind the second stream's event
     // (two decoder-layer stages are one 32 MB bucket of the gradient exchange anyway).
-    static const int per_flush = getenv("B2S_DW_STAGES") ? atoi(getenv("B2S_DW_STAGES")) : 2;
+    constexpr int per_flush = 2;
     const bool held = m->dw_hold_from >= 0 && stage >= m->dw_hold_from;          // (tail policy, engine.h)
     if (!serial && !drain && !force_flush && (held || m->dw_pending.empty() || ++m->dw_stages_pending < per_flush)) {
         m->unflushed_stages.push_back(stage);
@@ -413,7 +418,7 @@ struct AttnScratch { float* S; float* dP; void* dS; };
 struct GuidedArgs { float* rows = nullptr; const int* qlen = nullptr; const float* scale = nullptr; float inv2s2 = 0.f; };
 // fused attention (attention.hip) unless B2S_ATTN_V1 is set (A/B switch: materialised logits through the GEMM)
 bool use_flash(int dh) {
-    static const bool v1 = getenv("B2S_ATTN_V1") != nullptr;
+    constexpr bool v1 = false;
     return !v1 && b2s_flash_supported(dh);
 }
 AttnArgs flash_args(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int H, int Lq, int Lk, int dh,
@@ -435,7 +440,7 @@ int attn_core_fwd(int dtype, hipStream_t st, const void* q, int ldq, const void*
         if (ga) { a.ga_rows = ga->rows; a.qlen = ga->qlen; a.ga_inv2s2 = ga->inv2s2; }
         return b2s_flash_fwd(dtype, a, dh, st);
     }
-    B2S_CHECK(!ga, "the guided-attention term needs the fused attention kernels (head size 32/64/96, B2S_ATTN_V1 unset)");
+    B2S_CHECK(!ga, "the guided-attention term needs the fused attention kernels (head size 32 / 64 / 96)");
     const int ldp = rup8(Lk);
     GemmArgs g;
     g.A.p = q; g.A.ld = ldq; g.A.R = Lq; g.A.C = dh; g.A.bs_o = (long)Lq * ldq; g.A.bs_i = dh;
@@ -708,13 +713,13 @@ extern "C" int b2s_model_create(const b2s_config* cfg, b2s_model** out) {
         // partial sublayer outputs in bf16 (default): the 8 slabs of a sublayer are written and re-read once each -- 26 MB instead of 52 MB per
         // sublayer and direction; the sum and the residual stream stay fp32 (same rounding point as every other bf16 operand of the step).
         // B2S_ENC_SLAB_BF16=0: fp32 slabs.  Measured (profiles/NOTES_r04.md): 7.76 -> 7.70 ms per step
-        static const int slab_bf16 = getenv("B2S_ENC_SLAB_BF16") ? atoi(getenv("B2S_ENC_SLAB_BF16")) : 1;
+        constexpr int slab_bf16 = 1;
         m->enc_fused = m->dtype == 1 && !no_fused && c.n_encoder_layer > 0 && c.n_encoder_layer * 4 <= 24 &&
                        b2s_encf_supported(c.encoder_hidden, c.n_attention_head, 4 * c.encoder_hidden, 1);
         m->enc_slab_bf16 = slab_bf16;
         static const bool no_dx16 = getenv("B2S_DX_BF16") && atoi(getenv("B2S_DX_BF16")) == 0;
         auto fast_ln = [](int d) { return d == 512 || d == 768; };
-        m->dx_bf16 = m->dtype == 1 && !no_dx16 && !getenv("B2S_LN_GENERIC") && fast_ln(c.encoder_hidden) && fast_ln(c.decoder_hidden);
+        m->dx_bf16 = m->dtype == 1 && !no_dx16 && true && fast_ln(c.encoder_hidden) && fast_ln(c.decoder_hidden);
     }
     build_layout(m);
     const size_t n = m->tinfo.size();
@@ -729,7 +734,6 @@ extern "C" void b2s_model_destroy(b2s_model* m) {
     (void)hipDeviceSynchronize();                 // nothing of this model is in flight any more
     if (m->aux) (void)hipStreamDestroy(m->aux);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
-    for (int g = 0; g < 3; ++g) if (m->adam_ev[g]) (void)hipEventDestroy(m->adam_ev[g]);
     if (m->enc_wT_ev) (void)hipEventDestroy(m->enc_wT_ev);
     for (void* p : m->owned) (void)hipFree(p);
     delete m;
@@ -809,7 +813,7 @@ int build_zero_table(b2s_model* m) {
     const size_t n = m->tinfo.size();
     m->dw_ow.assign(n, 0);
     m->dw_ow_ptrs.clear();
-    static const bool off = (getenv("B2S_DW_OVERWRITE") && atoi(getenv("B2S_DW_OVERWRITE")) == 0) || (getenv("B2S_DW_SPLIT") && atoi(getenv("B2S_DW_SPLIT")) > 1);
+    constexpr bool off = false;
     if (m->dtype == 1 && m->dw_group && !off) {
         auto tiles = [&](const TensorInfo& t) { return (long)cdiv(t.shape[0], 256) * cdiv(t.shape[1], 128); };
         auto layer_key = [](const std::string& nme, std::string& key) {          // "encoder.encoder.<list>.<i>.<leaf>" -> stack + layer index
@@ -882,15 +886,6 @@ int relayout_convs(b2s_model* m, hipStream_t st) {
     }
     return 0;
 }
-// the caller's stream waits for the overlapped optimizer groups in `mask` (bit 0 encoder, 1 decoder, 2 postnet)
-int wait_adam(const b2s_model* m, hipStream_t st, int mask) {
-    for (int g = 0; g < 3; ++g)
-        if ((mask >> g & 1) && m->adam_pending[g]) {
-            B2S_HIP(hipStreamWaitEvent(st, m->adam_ev[g], 0));
-            m->adam_pending[g] = false;
-        }
-    return 0;
-}
 }  // namespace
 
 extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const* grad_host, int n) {
@@ -902,7 +897,7 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
         m->grad[i] = grad_host ? grad_host[i] : nullptr;
     }
     // compute-dtype shadows
-    if (m->dtype == 1 && !m->kv_cat && m->cfg.n_decoder_layer > 0 && !getenv("B2S_NO_KVCAT")) {
+    if (m->dtype == 1 && !m->kv_cat && m->cfg.n_decoder_layer > 0 && true) {
         const int L = m->cfg.n_decoder_layer, D = m->cfg.decoder_hidden;
         B2S_HIP(hipMalloc(&m->kv_cat, (size_t)L * 2 * D * D * 2));
         m->owned.push_back(m->kv_cat);
@@ -950,11 +945,10 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
             if (hipMalloc(&m->sk_ws[i], m->sk_ws_floats * sizeof(float)) == hipSuccess) m->owned.push_back(m->sk_ws[i]);
             else { m->sk_ws[i] = nullptr; (void)hipGetLastError(); }      // (no slab: that stream's split-K launches use atomics)
     }
-    if (!m->aux && !getenv("B2S_NO_AUX")) {
+    if (!m->aux && true) {
         // (a lowest-priority second stream was measured: no change -- a weight-gradient workgroup holds its CU for ~110 us once it
         // has started, whatever the queue priorities say)
-        if (getenv("B2S_AUX_PRIO")) B2S_HIP(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, atoi(getenv("B2S_AUX_PRIO"))));
-        else B2S_HIP(hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking));
+        B2S_HIP(hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking));
         m->ev_pool.resize(256);
         for (auto& ev : m->ev_pool) B2S_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
@@ -975,11 +969,9 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
     return 0;
 }
 
-extern "C" int b2s_model_sync_weights(b2s_model* m, void* stream) { return b2s_model_sync_weights_ex(m, stream, 0); }
-extern "C" int b2s_model_sync_weights_ex(b2s_model* m, void* stream, int shadows_fresh) {
+extern "C" int b2s_model_sync_weights(b2s_model* m, void* stream, int shadows_fresh) {
     B2S_TRY(check_bound(m));
     hipStream_t st = S_(stream);
-    B2S_TRY(wait_adam(m, st, shadows_fresh ? 4 : 7));
     if (!shadows_fresh) m->l2_fresh = false;
     if (m->dtype && !shadows_fresh)
         for (size_t i = 0; i < m->tinfo.size(); ++i)
@@ -1007,14 +999,9 @@ extern "C" int b2s_dropout_site(const char* site, int layer, int decode, uint32_
     return b2s_fail(__FILE__, __LINE__, "unknown dropout site %s", site);
 }
 extern "C" void* b2s_model_second_stream(b2s_model* m) { return (m && m->bound) ? (void*)m->aux : nullptr; }
-extern "C" int b2s_model_set_stage_hook_stream(b2s_model* m, void* stream) {
+extern "C" int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int, void*), void* user, void* stream) {
     B2S_CHECK(m, "null model");
-    m->hook_stream = (hipStream_t)stream;
-    return 0;
-}
-extern "C" int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int, void*), void* user) {
-    B2S_CHECK(m, "null model");
-    m->stage_hook = hook; m->stage_user = user;
+    m->stage_hook = hook; m->stage_user = user; m->hook_stream = hook ? (hipStream_t)stream : nullptr;
     return 0;
 }
 
@@ -1034,7 +1021,6 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
                                    uint64_t seed, void* ws, size_t ws_bytes, float* memory_out, void* stream,
                                    b2s_ctx** ctx_out) {
     B2S_TRY(check_bound(m));
-    B2S_TRY(wait_adam(m, S_(stream), 1));
     const b2s_config& cf = m->cfg;
     B2S_CHECK(inputs && input_lengths && memory_out && ws, "null argument");
     B2S_CHECK(B > 0 && S > 0, "bad shape B=%d S=%d", B, S);
@@ -1110,7 +1096,11 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
             const std::string ln0 = p + "attn_layer_norms.0";
             B2S_TRY(ro_layernorm_fwd(dt, xs[0], m->P(ln0 + ".weight"), m->P(ln0 + ".bias"), c->self_attn[0].h, D, nullptr, 0, c->self_attn[0].mean,
                                      c->self_attn[0].rstd, (int)M, D, 1e-6f, nullptr, 1, st));
-            static const int lab_skip = getenv("B2S_LAB_ENC_SKIP") ? atoi(getenv("B2S_LAB_ENC_SKIP")) : 0;     // measurement aid: what would a free encoder buy?
+#ifdef B2S_LAB
+            static const int lab_skip = getenv("B2S_LAB_ENC_SKIP") ? atoi(getenv("B2S_LAB_ENC_SKIP")) : 0;     // measurement aid (lab builds only): what would a free encoder buy?
+#else
+            constexpr int lab_skip = 0;
+#endif
             for (int l = 0; l < L && !lab_skip; ++l) {
                 AttnSave& s = c->self_attn[l];
                 FfnSave& f = c->ffn[l];
@@ -1277,7 +1267,6 @@ int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, 
 
 extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_memory, void* stream) {
     B2S_TRY(check_bound(m));
-    B2S_TRY(wait_adam(m, S_(stream), 1));       // reads encoder weights only (b2s_adam_step_groups may be updating the other groups)
     B2S_CHECK(c && c->kind == 1 && d_memory, "bad encoder context");
     const b2s_config& cf = m->cfg;
     hipStream_t st = S_(stream);
@@ -1345,7 +1334,11 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
             sc.dy_ready = dy2 != nullptr;
             return 0;
         };
+#ifdef B2S_LAB
         static const int lab_skip = getenv("B2S_LAB_ENC_SKIP") ? atoi(getenv("B2S_LAB_ENC_SKIP")) : 0;
+#else
+        constexpr int lab_skip = 0;
+#endif
         for (int l = cf.n_encoder_layer - 1; l >= 0; --l) {
             const AttnSave& s = c->self_attn[l];
             const FfnSave& f = c->ffn[l];
@@ -1417,21 +1410,14 @@ extern "C" size_t b2s_decoder_ws_bytes(const b2s_model* m, int B, int S, int T) 
     return a.off + 4096;
 }
 
-extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
-                                   const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
-                                   size_t ws_bytes, float* mels_out, float* stop_out, void* stream, b2s_ctx** ctx_out) {
-    return b2s_decoder_forward_ev(m, memory, input_lengths, targets, target_lengths, B, S, T, train, seed, ws, ws_bytes, mels_out, stop_out, nullptr,
-                                  stream, ctx_out);
-}
 // memory_ready (hipEvent_t or NULL): `memory` is produced on ANOTHER stream (the encoder forward); this call's stream waits for the event
 // right before the first kernel that reads it -- the prenet and the first decoder layer's self-attention do not, and run beside the encoder.
-extern "C" int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
-                                      const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
-                                      size_t ws_bytes, float* mels_out, float* stop_out, void* memory_ready, void* stream, b2s_ctx** ctx_out) {
+extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
+                                   const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
+                                   size_t ws_bytes, float* mels_out, float* stop_out, void* memory_ready, void* stream, b2s_ctx** ctx_out) {
     const bool padded_unobserved = (train & B2S_DEC_PADDED_UNOBSERVED) != 0;
     train &= 1;
     B2S_TRY(check_bound(m));
-    B2S_TRY(wait_adam(m, S_(stream), 7));
     const b2s_config& cf = m->cfg;
     B2S_CHECK(memory && input_lengths && targets && target_lengths && mels_out && stop_out && ws, "null argument");
     B2S_CHECK(B > 0 && S > 0 && T > 0, "bad shape B=%d S=%d T=%d", B, S, T);
@@ -1477,7 +1463,7 @@ extern "C" int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const i
         // per-row sub-layers never let a valid row read them -- the attention kernels skip whole 64-row tiles of them (attention.h: qskip)
         // -- only for callers that declare those rows unobserved (B2S_DEC_PADDED_UNOBSERVED): the alignments the reference returns for
         // padded query rows of later layers depend on what earlier layers computed there
-        static const bool no_qskip = getenv("B2S_ATTN_QSKIP") && atoi(getenv("B2S_ATTN_QSKIP")) == 0;
+        constexpr bool no_qskip = false;
         const int* qskip = (no_qskip || !padded_unobserved) ? nullptr : target_lengths;
         if (guided)
             hipLaunchKernelGGL(k_ga_scale, dim3(1), dim3(64), 0, st, input_lengths, target_lengths, B, S, T,
@@ -1553,10 +1539,6 @@ __global__ void k_rowmask_copy(const float* in, float* out, const int* lens, int
 }
 }  // namespace
 
-extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mels, const float* d_stop, float* d_memory_out,
-                                    void* stream) {
-    return b2s_decoder_backward_ex(m, c, d_mels, d_stop, nullptr, 0, d_memory_out, stream);
-}
 extern "C" int b2s_decoder_guided_loss(b2s_model* m, b2s_ctx* c, float* out, float* add_to, void* stream) {
     B2S_CHECK(m && c && c->kind == 2 && out, "bad decoder context");
     B2S_CHECK(c->ga_small, "guided_attention_weight is 0: this forward has no guided-attention term");
@@ -1564,18 +1546,13 @@ extern "C" int b2s_decoder_guided_loss(b2s_model* m, b2s_ctx* c, float* out, flo
     B2S_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_mels, const float* d_stop, const float* d_guided,
-                                       int flags, float* d_memory_out, void* stream) {
-    return b2s_decoder_backward_ev(m, c, d_mels, d_stop, d_guided, flags, d_memory_out, nullptr, stream);
-}
 // dmem_done (hipEvent_t or NULL): recorded on `stream` as soon as d_memory_out is complete -- right after the first decoder layer's
 // encoder-decoder attention backward, before that layer's self-attention, the input / prenet backward and their weight gradients.  A caller
 // that runs the encoder backward on another stream makes that stream wait for the event only (B2S_DEC_BWD_FLUSH_TAIL must then be set:
 // this call hands its last stages' weight-gradient work to the second stream itself instead of leaving it to the next entry point).
-extern "C" int b2s_decoder_backward_ev(b2s_model* m, b2s_ctx* c, const float* d_mels, const float* d_stop, const float* d_guided,
-                                       int flags, float* d_memory_out, void* dmem_done, void* stream) {
+extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mels, const float* d_stop, const float* d_guided,
+                                    int flags, float* d_memory_out, void* dmem_done, void* stream) {
     B2S_TRY(check_bound(m));
-    B2S_TRY(wait_adam(m, S_(stream), 7));
     const bool want_dmem = !(flags & B2S_DEC_BWD_NO_DMEMORY);
     B2S_CHECK(c && c->kind == 2 && d_mels && (d_memory_out || !want_dmem), "bad decoder context");
     const b2s_config& cf = m->cfg;
@@ -1609,8 +1586,8 @@ extern "C" int b2s_decoder_backward_ev(b2s_model* m, b2s_ctx* c, const float* d_
     // tail policy (engine.h: dw_hold_from): B2S_DW_TAIL_LAYERS decoder layers' (and the prenet's) weight-gradient groups wait for the end
     // of this call and are launched capped at B2S_DW_TAIL_CAP workgroups, beside the encoder backward on the caller's other stream
     // (measured, profiles/NOTES_r03.md: 2 layers / 200 tiles: 8.04 -> 7.88 ms; 1 layer 7.95; 4 layers 7.98; caps <= 176 lose what the holding wins)
-    static const int tail_layers = getenv("B2S_DW_TAIL_LAYERS") ? atoi(getenv("B2S_DW_TAIL_LAYERS")) : 2;
-    static const int tail_cap = getenv("B2S_DW_TAIL_CAP") ? atoi(getenv("B2S_DW_TAIL_CAP")) : 200;
+    constexpr int tail_layers = 2;
+    constexpr int tail_cap = 200;
     m->dw_hold_from = -1; m->dw_tail_cap = 0;
     // (whatever way this call is left -- a failing B2S_TRY included -- the tail policy does not outlive it: a following stand-alone
     // b2s_encoder_backward must not find its stages held)
@@ -1746,7 +1723,6 @@ extern "C" int b2s_postnet_forward(b2s_model* m, const float* inputs, const int3
                                    int train, uint64_t seed, void* ws, size_t ws_bytes, float* out, void* stream,
                                    b2s_ctx** ctx_out) {
     B2S_TRY(check_bound(m));
-    B2S_TRY(wait_adam(m, S_(stream), 7));
     const b2s_config& cf = m->cfg;
     B2S_CHECK(inputs && lengths && out && ws && B > 0 && T > 0, "bad argument");
     hipStream_t st = S_(stream);
@@ -1763,7 +1739,7 @@ extern "C" int b2s_postnet_forward(b2s_model* m, const float* inputs, const int3
     // Training: the batch statistics are column sums taken by the conv GEMM's epilogue (GemmEpilogue::colstat) and turned into mean /
     // rstd / running statistics by the normalisation kernel itself: conv + one row kernel per layer (was conv + memset + two reduction
     // passes + finalize + apply).  B2S_BN_SEPARATE=1 keeps the separate two-pass statistics (A/B switch).
-    static const bool bn_separate = getenv("B2S_BN_SEPARATE") != nullptr;
+    constexpr bool bn_separate = false;
     const bool fused_stats = train && !bn_separate && M > 1;
     auto run = [&]() -> int {
         B2S_TRY(ro_cast(dt, inputs, c->u[0], M * cf.num_mels, st));
@@ -1806,12 +1782,8 @@ extern "C" int b2s_postnet_forward(b2s_model* m, const float* inputs, const int3
     return 0;
 }
 
-extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out, float* d_inputs_out, void* stream) {
-    return b2s_postnet_backward_ex(m, c, d_out, d_inputs_out, 0, stream);
-}
-extern "C" int b2s_postnet_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_out, float* d_inputs_out, int flags, void* stream) {
+extern "C" int b2s_postnet_backward(b2s_model* m, b2s_ctx* c, const float* d_out, float* d_inputs_out, int flags, void* stream) {
     B2S_TRY(check_bound(m));
-    B2S_TRY(wait_adam(m, S_(stream), 7));
     B2S_CHECK(c && c->kind == 3 && d_out && d_inputs_out, "bad postnet context");
     B2S_CHECK(c->train, "postnet backward requires a train-mode forward (batch statistics)");
     const b2s_config& cf = m->cfg;
@@ -1860,7 +1832,7 @@ extern "C" int b2s_postnet_backward_ex(b2s_model* m, b2s_ctx* c, const float* d_
         hipEvent_t ready = m->next_event();
         B2S_HIP(hipEventRecord(ready, st));
         B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
-        static const bool in_kernel_gather = getenv("B2S_CONV_DW_GATHER") != nullptr;          // A/B switch: the previous form
+        constexpr bool in_kernel_gather = false;          // A/B switch: the previous form
         for (GemmArgs& g : dws) {
             if (ps.col && !in_kernel_gather && g.B.g_cin % 8 == 0) {
                 B2S_TRY(ro_im2col5(dt, g.B.p, g.B.g_len, g.B.g_T, g.B.g_cin, ps.col, (long)g.B.R, m->aux));
@@ -1893,7 +1865,6 @@ extern "C" int b2s_loss_forward(b2s_model* m, const float* mel_bef, const float*
                                 const float* mel_targets, const int32_t* target_lengths, int B, int T, float* losses_out,
                                 float* aft_losses_out, float* scratch, void* stream) {
     B2S_TRY(check_bound(m));
-    B2S_TRY(wait_adam(m, S_(stream), 7));
     B2S_CHECK(mel_bef && mel_aft && stop_logits && mel_targets && target_lengths && losses_out && aft_losses_out && scratch, "null argument");
     hipStream_t st = S_(stream);
     float* l2 = scratch;                      // scratch[0] = l2, scratch[1..] partial sums
@@ -1916,7 +1887,6 @@ extern "C" int b2s_loss_backward(b2s_model* m, const float* mel_bef, const float
 }
 extern "C" int b2s_l2_backward(b2s_model* m, const float* grad_scale, void* stream) {
     B2S_TRY(check_bound(m));
-    B2S_TRY(wait_adam(m, S_(stream), 7));
     for (size_t i = 0; i < m->tinfo.size(); ++i)
         B2S_CHECK(!m->tinfo[i].l2 || m->grad[i], "gradient of %s is not bound", m->tinfo[i].name.c_str());
     return ro_mt_axpy(m->l2_chunks, m->n_l2_chunks, m->cfg.reg_weight, grad_scale, S_(stream));
@@ -1930,51 +1900,28 @@ extern "C" int b2s_adam_bind(b2s_model* m, void* const* exp_avg_host, void* cons
     }
     return rebuild_adam_chunks(m);
 }
-extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
-                             void* stream) {
-    return b2s_adam_step_ex(m, lr, step, beta1, beta2, eps, l2, grad_scale, 0, stream);
-}
 extern "C" int b2s_adam_set_grad_wire(b2s_model* m, const void* wire_bf16, const float* grad_base) {
     B2S_CHECK(m && (!wire_bf16 || grad_base), "null argument");
     B2S_CHECK(!wire_bf16 || (((size_t)wire_bf16 & 15) == 0 && ((size_t)grad_base & 15) == 0), "wire / gradient buffers must be 16-byte aligned");
     m->adam_wire = wire_bf16; m->adam_gbase = wire_bf16 ? grad_base : nullptr;
     return 0;
 }
-extern "C" int b2s_adam_wait(b2s_model* m, void* stream) {
-    B2S_CHECK(m, "null model");
-    return wait_adam(m, S_(stream), 7);
+namespace {
+// bias corrections of `step`, uploaded into a rotating slot (earlier steps may still be in flight)
+int adam_hyper(b2s_model* m, float lr, int step, float beta1, float beta2, hipStream_t st, float** dhp) {
+    float hp[3] = {lr, (float)(1.0 - std::pow((double)beta1, step)), (float)std::sqrt(1.0 - std::pow((double)beta2, step))};
+    *dhp = m->small + 16 + (step % 8) * 4;
+    B2S_HIP(hipMemcpyAsync(*dhp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
+    return 0;
 }
-extern "C" int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
-                                int overlap, void* stream) {
+}  // namespace
+extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
+                             void* stream) {
     B2S_TRY(check_bound(m));
     B2S_CHECK(m->adam_chunks && step >= 1, "Adam state not bound or bad step");
     hipStream_t st = S_(stream);
-    B2S_TRY(wait_adam(m, st, 7));
-    if (overlap && m->aux) {
-        float hp[3] = {lr, (float)(1.0 - std::pow((double)beta1, step)), (float)std::sqrt(1.0 - std::pow((double)beta2, step))};
-        float* dhp = m->small + 16 + (step % 8) * 4;
-        B2S_HIP(hipMemcpyAsync(dhp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
-        const bool cover = !m->cfg.freeze_encoder;
-        B2S_TRY(join_aux(m, st));                              // (normally a no-op: the backward entry points drain the aux stream)
-        hipEvent_t ready = m->next_event();
-        B2S_HIP(hipEventRecord(ready, st));                    // gradients (and their all-reduce) are complete here
-        B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
-        static const int order[3] = {2, 0, 1};                 // postnet (conv re-layout at the top of the step), encoder, decoder
-        for (int k = 0; k < 3; ++k) {
-            const int g = order[k], lo = m->adam_grp[g], n = m->adam_grp[g + 1] - lo;
-            if (n <= 0) continue;
-            B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, m->aux, m->adam_wire, m->adam_gbase));
-            if (g == 2 && m->dtype == 0) B2S_TRY(relayout_convs(m, m->aux));     // fp32: the conv GEMM images follow the masters
-            if (!m->adam_ev[g]) B2S_HIP(hipEventCreateWithFlags(&m->adam_ev[g], hipEventDisableTiming));
-            B2S_HIP(hipEventRecord(m->adam_ev[g], m->aux));
-            m->adam_pending[g] = true;
-        }
-        m->l2_fresh = cover;
-        return 0;
-    }
-    float hp[3] = {lr, (float)(1.0 - std::pow((double)beta1, step)), (float)std::sqrt(1.0 - std::pow((double)beta2, step))};
-    float* dhp = m->small + 16 + (step % 8) * 4;         // rotate slots: earlier steps may still be in flight
-    B2S_HIP(hipMemcpyAsync(dhp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
+    float* dhp;
+    B2S_TRY(adam_hyper(m, lr, step, beta1, beta2, st, &dhp));
     // l2 is applied to the L2 member set only (chunk flag), i.e. g = grad*grad_scale + l2*p for members
     // the partial sums cover the L2 regulariser only if every member is in the chunk table (not with a frozen encoder)
     const bool cover = !m->cfg.freeze_encoder;
@@ -1982,67 +1929,51 @@ extern "C" int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, f
     // fp32 (parity) mode: the Adam kernel does not write the conv GEMM images (in bf16 mode it does); refresh them here so that
     // an eval / synthesis forward between two training steps sees the weights the step just produced
     if (m->dtype == 0) B2S_TRY(relayout_convs(m, st));
+    m->adam_step_no = step; m->adam_step_mask = 7;
     m->l2_fresh = cover;
     return 0;
 }
 extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
-                                    int groups, int on_aux, void* stream) {
+                                    int groups, int behind_mark, void* stream) {
     B2S_TRY(check_bound(m));
-    B2S_CHECK(m->adam_chunks && step >= 1 && groups > 0 && groups < 8 && on_aux >= 0 && on_aux <= 2, "Adam state not bound, bad step, group mask or placement");
-    B2S_CHECK(!(m->adam_wire && on_aux == 1), "the narrow optimizer launch on the second stream does not read a bf16 gradient wire buffer");
+    B2S_CHECK(m->adam_chunks && step >= 1 && groups > 0 && groups < 8 && (behind_mark == 0 || behind_mark == 1), "Adam state not bound, bad step, group mask or placement");
     if (step != m->adam_step_no) { m->adam_step_no = step; m->adam_step_mask = 0; }
     B2S_CHECK((m->adam_step_mask & groups) == 0, "parameter group mask %d was already updated in step %d", groups & m->adam_step_mask, step);
     hipStream_t st = S_(stream);
-    B2S_TRY(wait_adam(m, st, groups));
-    float hp[3] = {lr, (float)(1.0 - std::pow((double)beta1, step)), (float)std::sqrt(1.0 - std::pow((double)beta2, step))};
-    float* dhp = m->small + 16 + (step % 8) * 4;               // (every piece of one step uploads the same three values)
-    B2S_HIP(hipMemcpyAsync(dhp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
     const bool cover = !m->cfg.freeze_encoder;
-    hipStream_t run = st;
     // A backward entry point called with a deferred join leaves the last stages' weight-gradient groups, column sums and LayerNorm
     // reductions queued for the next entry point: an update issued now would consume incomplete gradients (and those parameters would
     // never train -- the late gradients are zeroed at the next step).  Refuse instead of guessing.
     B2S_CHECK(m->dw_pending.empty() && m->aux_jobs.empty() && m->ln_jobs.n == 0 && m->dw_stages_pending == 0 && m->unflushed_stages.empty(),
               "b2s_adam_step_groups: gradient work of the last backward stages is still queued (the preceding backward call deferred its "
               "join): call it without B2S_DEC_BWD_DEFER_JOIN / B2S_POST_BWD_DEFER_JOIN before a partial optimizer step");
-    if (on_aux == 1 && m->aux) {
-        hipEvent_t ready = m->next_event();
-        B2S_HIP(hipEventRecord(ready, st));                    // gradients of `groups` (and their all-reduce) are complete here
-        B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
-        run = m->aux;
-    } else if (on_aux == 2) {
-        // on the caller's stream, behind the mark only (b2s_model_mark_grads_ready): whatever the second stream was given after the
-        // mark -- the encoder's weight-gradient groups -- belongs to groups that are not in `groups`
-        B2S_CHECK(m->grads_marked, "b2s_adam_step_groups(on_aux = 2) needs b2s_model_mark_grads_ready after the last backward call of these groups");
-        B2S_CHECK(!(groups & B2S_ADAM_ENCODER), "on_aux = 2 is for the groups whose gradients were complete at the mark");
+    if (behind_mark) {
+        // behind the mark only (b2s_model_mark_grads_ready): whatever the second stream was given after the mark -- the encoder's
+        // weight-gradient groups -- belongs to groups that are not in `groups`
+        B2S_CHECK(m->grads_marked, "b2s_adam_step_groups(behind_mark = 1) needs b2s_model_mark_grads_ready after the last backward call of these groups");
+        B2S_CHECK(!(groups & B2S_ADAM_ENCODER), "behind_mark = 1 is for the groups whose gradients were complete at the mark");
+    }
+    float* dhp;
+    B2S_TRY(adam_hyper(m, lr, step, beta1, beta2, st, &dhp));
+    if (behind_mark) {
         B2S_HIP(hipStreamWaitEvent(st, m->grads_mark_ev, 0));
         m->grads_marked = false;
     } else {
-        // on the caller's stream: the weight-gradient groups a backward entry point handed to the second stream without joining it
-        // (B2S_DEC_BWD_FLUSH_TAIL) must have landed first
+        // the weight-gradient groups a backward entry point handed to the second stream without joining it (B2S_DEC_BWD_FLUSH_TAIL)
+        // must have landed first
         B2S_TRY(join_aux(m, st));
     }
-    // beside the backward pass: a narrow launch (see k_mt_adam_narrow); B2S_ADAM_CUS = number of its workgroups, 0 = wide launch
-    // (measured, MI355X: a CU-masked stream made the two queues run one after the other instead of side by side)
-    static const int narrow = getenv("B2S_ADAM_CUS") ? atoi(getenv("B2S_ADAM_CUS")) : 64;
     static const int order[3] = {1, 2, 0};                     // decoder, postnet, encoder
-    // on_aux = 2 runs beside the encoder backward (on its own stream) and the last weight-gradient groups: a capped grid -- the full one
-    // saturates HBM and the latency-bound encoder kernels take 3-4x as long while it runs (measured, profiles/NOTES_r04.md)
-    static const int tail_wg = getenv("B2S_TAIL_ADAM_WG") ? atoi(getenv("B2S_TAIL_ADAM_WG")) : 512;
+    // behind the mark the update runs beside the encoder backward (on its own stream) and the last weight-gradient groups: a grid capped
+    // at 512 workgroups -- the full one saturates HBM and the latency-bound encoder kernels take 3-4x as long while it runs (measured,
+    // profiles/NOTES_r04.md: caps 64 / 128 / 256 / 384 / 512 / 768 / 1024: 7.98 / 7.54 / 7.46 / 7.44 / 7.39 / 7.39 / 7.46 ms per step)
+    constexpr int kTailWorkgroups = 512;
     for (int k = 0; k < 3; ++k) {
         const int g = order[k], lo = m->adam_grp[g], n = m->adam_grp[g + 1] - lo;
         if (!(groups >> g & 1) || n <= 0) continue;
-        if (run != st && narrow > 0)
-            B2S_TRY(ro_mt_adam_narrow(m->adam_chunks + lo, n, narrow, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, run));
-        else
-            B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, run, m->adam_wire, m->adam_gbase,
-                               on_aux == 2 ? tail_wg : 0));
-        if (g == 2 && m->dtype == 0) B2S_TRY(relayout_convs(m, run));
-        if (run != st) {
-            if (!m->adam_ev[g]) B2S_HIP(hipEventCreateWithFlags(&m->adam_ev[g], hipEventDisableTiming));
-            B2S_HIP(hipEventRecord(m->adam_ev[g], run));
-            m->adam_pending[g] = true;
-        }
+        B2S_TRY(ro_mt_adam(m->adam_chunks + lo, n, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part + lo : nullptr, st, m->adam_wire, m->adam_gbase,
+                           behind_mark ? kTailWorkgroups : 0));
+        if (g == 2 && m->dtype == 0) B2S_TRY(relayout_convs(m, st));
     }
     m->adam_step_mask |= groups;
     // the per-chunk sums of squares cover the regulariser once every group has been stepped (groups whose chunk range is
@@ -2085,10 +2016,8 @@ extern "C" int b2s_model_set_grad_slot_padding(b2s_model* m, int bytes) {
     m->grad_pad_bytes = (size_t)bytes;
     return 0;
 }
-extern "C" int b2s_zero_grads(b2s_model* m, void* stream) { return b2s_zero_grads_ex(m, stream, 0); }
-extern "C" int b2s_zero_grads_ex(b2s_model* m, void* stream, int flags) {
+extern "C" int b2s_zero_grads(b2s_model* m, void* stream, int flags) {
     B2S_TRY(check_bound(m));
-    B2S_TRY(wait_adam(m, S_(stream), 7));
     // a new backward pass starts here: nothing of an earlier one may still be queued (it would run on freed contexts)
     if (!m->dw_pending.empty() || !m->aux_jobs.empty() || m->ln_jobs.n > 0 || !m->pending_stages.empty() || !m->unflushed_stages.empty())
         B2S_TRY(b2s_model_backward_abort(m, stream));

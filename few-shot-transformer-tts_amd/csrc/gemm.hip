@@ -277,17 +277,14 @@ extern "C" void b2s_prof_enable(int on) { g_prof_on = on != 0; }
 // v = 16: grouped bf16 weight-gradient launches
 extern "C" int b2s_prof_collect(double* out, int n_variants) {
     for (int i = 0; i < n_variants * 3; ++i) out[i] = 0.0;
-    FILE* dump = getenv("B2S_PROF_DUMP") ? fopen(getenv("B2S_PROF_DUMP"), "w") : nullptr;
     std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& r : g_prof) {
         B2S_HIP(hipEventSynchronize(r.b));
         float ms = 0.f;
         B2S_HIP(hipEventElapsedTime(&ms, r.a, r.b));
         if (r.variant < n_variants) { out[r.variant * 3] += r.flops; out[r.variant * 3 + 1] += ms; out[r.variant * 3 + 2] += 1.0; }
-        if (dump) fprintf(dump, "%d %d %d %d %d %d %.3f %.1f\n", r.variant, r.M, r.N, r.K, r.batch, r.splitk, ms * 1e3, r.flops / (ms * 1e-3) / 1e12);
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
-    if (dump) fclose(dump);
     g_prof.clear();
     return 0;
 }
@@ -335,7 +332,7 @@ static int gemm_launch_inner(const GemmArgs& g, int dtype, bool ta, bool tb, hip
                                                    !g.epi.relu_aux && !g.epi.drop.thresh)),
               "gemm: split-K needs a linear fp32 accumulate epilogue");
     B2S_CHECK(!g.epi.kv_k, "gemm: the cache-append fusion exists in the decode-step kernel only (M <= 64, K %% 32 == 0)");
-    static const bool use_v1 = getenv("B2S_GEMM_V1") != nullptr;         // A/B switch: register-staged bf16 main loop
+    constexpr bool use_v1 = false;         // A/B switch: register-staged bf16 main loop
     if (dtype && !use_v1) return b2s_gemm_glds_launch(g, ta, tb, stream);
     return dtype ? launch_d<bf16_t>(g, ta, tb, stream) : launch_d<float>(g, ta, tb, stream);
 }

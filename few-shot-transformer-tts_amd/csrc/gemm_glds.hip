@@ -263,7 +263,7 @@ int launch_t(const GemmArgs& g_in, hipStream_t stream) {
 }  // namespace
 
 int b2s_splitk_reduce_launch(const float* ws, float* dst, int M, int N, int ldc, int splitk, int conv_dw_cin, hipStream_t stream) {
-    static const bool conv_v1 = getenv("B2S_CONV_REDUCE_V1") != nullptr;        // A/B switch
+    constexpr bool conv_v1 = false;        // A/B switch
     if (conv_dw_cin > 0 && N == 5 * conv_dw_cin && !conv_v1) {
         const long pairs = (long)M * conv_dw_cin;
         hipLaunchKernelGGL(splitk_reduce_conv_kernel, dim3((int)std::min<long>((pairs + 255) / 256, 2048)), dim3(256), 0, stream, ws, dst, M, N, ldc, splitk,

@@ -483,7 +483,7 @@ template <bool TA, bool TB, int GATHER>
 int launch256_t(const GemmArgs& g, const bf16_t* zero, hipStream_t stream) {
     if (!TA && GATHER == 0) {
         // 128-row tiles when 256-row tiles would occupy at most half of the CUs
-        static const int small_tiles = getenv("B2S_GEMM128_MAX_TILES") ? atoi(getenv("B2S_GEMM128_MAX_TILES")) : 128;
+        constexpr int small_tiles = 128;
         const int nb = pick_nb(g);
         const long t256n = (long)cdiv(g.M, BM) * cdiv(g.N, nb * 32) * g.batch * std::max(1, g.splitk);
         if (t256n <= small_tiles && g.M > 128) {
@@ -502,7 +502,7 @@ int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* 
     B2S_CHECK(n >= 1 && n <= B2S_MAX_GROUP, "grouped GEMM: %d problems (max %d)", n, B2S_MAX_GROUP);
     b2s_gemm_group grp;
     grp.n = n;
-    static const int xcd_order = getenv("B2S_DW_XCD_ORDER") ? atoi(getenv("B2S_DW_XCD_ORDER")) : 1;
+    constexpr int xcd_order = 1;
     grp.order = xcd_order;
     // Launch order = dispatch order.  Tiles cost ~K; with one workgroup per CU the makespan of "deepest first" against
     // "shallowest first" is decided by list scheduling on the CU count (288 tiles of a decoder layer: 252 deep + 36 shallow --
@@ -529,7 +529,7 @@ int b2s_gemm_glds256_grouped_launch(const GemmArgs* probs, int n, const bf16_t* 
     const long deep = makespan(true), shallow = makespan(false);
     if (deep <= shallow) makespan(true);               // (leaves `order` as chosen)
     int tiles = 0;
-    static const int split = getenv("B2S_DW_SPLIT") ? std::max(1, std::min(atoi(getenv("B2S_DW_SPLIT")), 4)) : 1;
+    constexpr int split = 1;
     for (int k = 0; k < n; ++k) {
         const GemmArgs& g = probs[order[k]];
         B2S_CHECK(g.batch == 1 && g.c_fp32 && g.A.g_cin == 0 && g.B.g_cin == 0, "grouped GEMM: problem %d is not a plain fp32 dW", order[k]);
@@ -574,7 +574,7 @@ int b2s_gemm_glds256_launch(const GemmArgs& g, bool ta, bool tb, const bf16_t* z
             // forward / backward-data convolution over >= 64-aligned channel counts: aligned gather on the producer waves
             const bool aligned = g.A.g_cin > 0 && g.B.g_cin == 0 && g.A.g_cin % t256::BK == 0 && g.K % t256::BK == 0 && g.splitk == 1 &&
                                  (long)g.A.R * g.A.ld < (1L << 29) && (long)g.B.R * g.B.ld < (1L << 30) && g.A.g_T > 0;
-            static const bool no_fast = getenv("B2S_CONV_GENERIC") != nullptr;      // A/B switch
+            constexpr bool no_fast = false;      // A/B switch
             if (aligned && !no_fast) return t256::launch256_t<false, false, 2>(g, zero, stream);
             return t256::launch256_t<false, false, 1>(g, zero, stream);
         }

@@ -116,7 +116,7 @@ int b2s_gemm_skinny_launch(const GemmArgs& g, int dtype, hipStream_t stream) {
     // K split over workgroups for the few-column, deep-K problems of the bf16 decode step (fp32 keeps one deterministic
     // summation order): the epilogue must be linear in the accumulator and the output must already hold the residual
     int ksplit = 1;
-    static const bool no_split = getenv("B2S_SKINNY_NOSPLIT") != nullptr;
+    constexpr bool no_split = false;
     if (dtype && !no_split && g.K >= 2048 && g.N <= 1024 && g.c_fp32 && g.epi.residual == g.C && g.epi.ldr == g.ldc && !g.epi.relu &&
         !g.epi.accumulate && !g.epi.row_len && !g.epi.kv_k)
         ksplit = 4;

@@ -116,8 +116,6 @@ int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gsc
 int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1, float beta2, float eps, float l2,
                float grad_scale, float* sumsq_part, hipStream_t st, const void* wire = nullptr, const float* gbase = nullptr,
                int max_wg = 0);                                                             // max_wg > 0: at most that many workgroups walk the chunk list
-int ro_mt_adam_narrow(const MtChunk* chunks, int nchunks, int nwg, const float* hp, float beta1, float beta2, float eps, float l2,
-                      float grad_scale, float* sumsq_part, hipStream_t st);
 // out[m][j*cin + ci] = x[m + j - 2][ci] if 0 <= t + j - 2 < min(lens[b], T) (m = b*T + t) else 0: the conv1d k=5 p=2 input of every token
 // with its five taps side by side (bf16 only; cin % 8 == 0)
 int ro_im2col5(int dtype, const void* x, const int* lens, int T, int cin, void* out, long M, hipStream_t st);

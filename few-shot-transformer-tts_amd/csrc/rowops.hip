@@ -1138,46 +1138,6 @@ __global__ __launch_bounds__(256) void k_mt_adam2(const MtChunk* __restrict__ ch
         }
     }
 }
-// The same update from a NARROW grid: gridDim.x workgroups of 1024 threads walk the chunk list.  For the optimizer update that
-// runs beside the encoder backward: a few dozen 16-wave workgroups settle on as many CUs and stay there, the other CUs remain
-// completely free for the backward's GEMM workgroups (which need a whole CU's LDS and registers and cannot start on a CU
-// that holds any other wave -- the one-workgroup-per-chunk launch above puts waves on every CU and starved them).
-__global__ __launch_bounds__(1024) void k_mt_adam_narrow(const MtChunk* ch, int nchunks, const float* hp, float b1, float b2, float eps,
-                                                         float l2, float gs, float* sumsq_part) {
-    __shared__ float sh[16];
-    const float lr = hp[0], bc1 = hp[1], sbc2 = hp[2];
-    for (int ci_ = blockIdx.x; ci_ < nchunks; ci_ += gridDim.x) {
-        const MtChunk c = ch[ci_];
-        float ss = 0.f;
-        for (int i = threadIdx.x; i < c.n; i += 1024) {
-            float p = c.a[i], g = c.b[i] * gs + (c.pad ? l2 : 0.f) * p, m = c.c[i], v = c.d[i];
-            m = b1 * m + (1.f - b1) * g;
-            v = b2 * v + (1.f - b2) * g * g;
-            c.c[i] = m; c.d[i] = v;
-            p -= (lr / bc1) * m / (sqrtf(v) / sbc2 + eps);
-            c.a[i] = p;
-            if (c.cin) {
-                const long gi = c.off + i, r = gi / 5;
-                const int j = (int)(gi - r * 5), co = (int)(r / c.cin), ci = (int)(r - (long)co * c.cin);
-                const bf16_t pb = f2bf(p);
-                c.s[(long)co * 5 * c.cin + (long)j * c.cin + ci] = pb;
-                c.s2[(long)ci * 5 * c.cout + (long)(4 - j) * c.cout + co] = pb;
-            } else if (c.s) c.s[i] = f2bf(p);
-            ss += p * p;
-        }
-        if (sumsq_part) {
-            ss = wave_sum(ss);
-            __syncthreads();                                   // (sh is reused by the next chunk)
-            if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
-            __syncthreads();
-            if (threadIdx.x < 64) {
-                float t = threadIdx.x < 16 ? sh[threadIdx.x] : 0.f;
-                t = wave_sum(t);
-                if (threadIdx.x == 0) sumsq_part[ci_] = c.pad ? t : 0.f;
-            }
-        }
-    }
-}
 // out[0] = scale * sum(part[0..n))
 // (+ clears nzero floats at zero: the loss kernels' accumulators -- a hipMemsetAsync of an odd-sized, 4-byte-aligned range is up to three
 // 5 us fill kernels on the critical path)
@@ -1231,7 +1191,7 @@ int ro_layernorm_fwd(int dtype, const float* x, const float* gamma, const float*
                      int ldy32, float* mean, float* rstd, int M, int D, float eps, const int* row_len,
                      int rows_per_batch, hipStream_t st) {
     B2S_CHECK(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
-    static const bool no_fast = getenv("B2S_LN_GENERIC") != nullptr;             // A/B switch
+    constexpr bool no_fast = false;             // A/B switch
     if (!no_fast && (D == 768 || D == 512) && M > 0) {
         if (D == 768) RO_DISPATCH(dtype, hipLaunchKernelGGL((k_ln_fwd_fast<TY, 3>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, (TY*)y, ldy,
                                                             y32, ldy32, mean, rstd, M, eps, row_len, rows_per_batch));
@@ -1248,13 +1208,13 @@ int ro_layernorm_bwd(int dtype, const void* dy, int dy_fp32, int lddy, const flo
                      int M, int D, const int* row_len, int rows_per_batch, hipStream_t st, float* ws, void* dy2, DropCfg drop2,
                      int* defer_nblk, int dx_bf16) {
     B2S_CHECK(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
-    B2S_CHECK(!dx_bf16 || ((D == 768 || D == 512) && (lddy & 3) == 0 && !getenv("B2S_LN_GENERIC")), "layernorm backward: a bf16 residual gradient needs the D = 512 / 768 kernels");
+    B2S_CHECK(!dx_bf16 || ((D == 768 || D == 512) && (lddy & 3) == 0 && true), "layernorm backward: a bf16 residual gradient needs the D = 512 / 768 kernels");
     int grid = cdiv(M, 4); if (grid > (ws ? RO_LN_WS_ROWS : 512)) grid = ws ? RO_LN_WS_ROWS : 512;
-    static const bool no_fast = getenv("B2S_LN_GENERIC") != nullptr;             // A/B switch
+    constexpr bool no_fast = false;             // A/B switch
     const bool f32 = dy_fp32 || !dtype;
     if (!no_fast && (D == 768 || D == 512) && M > 0 && (lddy & 3) == 0) {
         // ~3 rows per wave (the next row's loads fly under the current row's reductions); at most RO_LN_WS_ROWS partial rows
-        static const int rows_per_wg = getenv("B2S_LN_BWD_ROWS") ? atoi(getenv("B2S_LN_BWD_ROWS")) : 12;
+        constexpr int rows_per_wg = 12;
         grid = std::max(1, std::min(cdiv(M, rows_per_wg), ws ? RO_LN_WS_ROWS : 512));
 #define B2S_LN_FAST(TD, NCH, ACC, DY2) do { if (dx_bf16) hipLaunchKernelGGL((k_ln_bwd_fast<TD, NCH, ACC, DY2, bf16_t>), dim3(grid), dim3(256), 0, st, (const TD*)dy, lddy, x, \
             gamma, mean, rstd, (bf16_t*)dx, M, row_len, rows_per_batch, ws, dgamma, dbeta, (bf16_t*)dy2, drop2); \
@@ -1436,7 +1396,7 @@ int ro_bn_apply(int dtype, const float* y, const float* mean, const float* rstd,
                 const float* beta, int use_tanh, void* outT, float* out32, const float* add32, int M, int C,
                 DropCfg drop, hipStream_t st) {
     B2S_CHECK(C % 4 == 0, "bn_apply: C=%d must be a multiple of 4", C);
-    static const bool scalar = getenv("B2S_BN_SCALAR") != nullptr;               // A/B switch: the round-2 kernels
+    constexpr bool scalar = false;               // A/B switch: the round-2 kernels
     if (!scalar) {
         BnStat bs = {nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), nullptr, nullptr, nullptr, 0.f, 0.f};
         dim3 grid(cdiv(C / 4, 64), cdiv(M, 4 * BN_RU));
@@ -1450,7 +1410,7 @@ int ro_bn_apply(int dtype, const float* y, const float* mean, const float* rstd,
 int ro_bn_bwd(int dtype, const void* dout, int dout_fp32, const float* y, const float* mean, const float* rstd,
               const float* gamma, const float* beta, int use_tanh, float* dgamma, float* dbeta, void* dyT, int M,
               int C, DropCfg drop, hipStream_t st) {
-    static const bool scalar = getenv("B2S_BN_SCALAR") != nullptr;               // A/B switch: the round-2 kernels
+    constexpr bool scalar = false;               // A/B switch: the round-2 kernels
     if (!scalar && C % 4 == 0) {
         dim3 gv(cdiv(C / 4, 64), cdiv(M, 4 * BN_RU));
 #define B2S_BN_BWD(TD, T) do { \
@@ -1509,7 +1469,7 @@ int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gsc
 }
 int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1, float beta2, float eps, float l2,
                float grad_scale, float* sumsq_part, hipStream_t st, const void* wire, const float* gbase, int max_wg) {
-    static const bool v1 = getenv("B2S_ADAM_V1") != nullptr;
+    constexpr bool v1 = false;
     const int grid = max_wg > 0 ? std::min(max_wg, nchunks) : nchunks;
     if (nchunks > 0 && wire)
         hipLaunchKernelGGL(k_mt_adam2<true>, dim3(grid), dim3(256), 0, st, chunks, nchunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part, (const bf16_t*)wire, gbase);
@@ -1518,13 +1478,6 @@ int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1,
     else if (nchunks > 0)
         hipLaunchKernelGGL(k_mt_adam2<false>, dim3(grid), dim3(256), 0, st, chunks, nchunks, hp, beta1, beta2, eps, l2, grad_scale, sumsq_part, (const bf16_t*)nullptr,
                            (const float*)nullptr);
-    B2S_LAUNCH_CHECK(); return 0;
-}
-int ro_mt_adam_narrow(const MtChunk* chunks, int nchunks, int nwg, const float* hp, float beta1, float beta2, float eps, float l2,
-                      float grad_scale, float* sumsq_part, hipStream_t st) {
-    if (nchunks > 0)
-        hipLaunchKernelGGL(k_mt_adam_narrow, dim3(std::min(nwg, nchunks)), dim3(1024), 0, st, chunks, nchunks, hp, beta1, beta2, eps, l2,
-                           grad_scale, sumsq_part);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_sum_scaled(const float* part, int n, float scale, float* out, hipStream_t st, float* zero, int nzero) {

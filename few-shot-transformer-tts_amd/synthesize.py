@@ -76,8 +76,6 @@ def eval_batch(model_eval, data, use_bar=True, bar_interval=10, use_graph=True, 
         train = bool(model_eval.decoder.training)          # the reference synthesises with decoder.train() (eval.py:116-117)
         if lanes is None:
             lanes = int(os.environ.get("B2S_DECODE_LANES", "1"))
-        if os.environ.get("B2S_DECODE_EAGER"):              # development switch: plain launches instead of graph replay
-            use_graph = False
         H, NL, NM = eng.cfg.n_attention_head, eng.cfg.n_decoder_layer, hp.num_mels
 
         class Lane(object):

@@ -60,11 +60,10 @@ int b2s_model_tensor_info(const b2s_model* m, int i, char* name, int name_cap, i
 /* Bind device pointers of every state_dict entry (data) and of the gradient of every parameter
  * (grad[i] may be NULL for buffers).  Arrays are host arrays of device pointers. */
 int b2s_model_bind(b2s_model* m, void* const* data_host, void* const* grad_host, int n);
-/* Refresh the compute-dtype weight shadows (bf16 copies, conv re-layouts) after parameters changed. */
-int b2s_model_sync_weights(b2s_model* m, void* stream);
-/* shadows_fresh != 0: b2s_adam_step already refreshed the bf16 shadows (it writes them in the same pass); only the conv
+/* Refresh the compute-dtype weight shadows (bf16 copies, conv re-layouts) after parameters changed.
+ * shadows_fresh != 0: b2s_adam_step already refreshed the bf16 shadows (it writes them in the same pass); only the conv
  * weight re-layouts are redone. */
-int b2s_model_sync_weights_ex(b2s_model* m, void* stream, int shadows_fresh);
+int b2s_model_sync_weights(b2s_model* m, void* stream, int shadows_fresh);
 
 /* ---- Encoder.forward (tacotron.py:33-44; modules.py:49-69) ---------------------------------------
  * memory_out: [B, S, encoder_hidden (+spk) (+lang)].  train != 0 enables dropout (seeded by `seed`).
@@ -78,10 +77,7 @@ int b2s_encoder_backward(b2s_model* m, b2s_ctx* ctx, const float* d_memory, void
 /* ---- Decoder.forward (tacotron.py:107-116; modules.py:108-145) -----------------------------------
  * memory [B,S,Dm], targets [B,T,num_mels] -> mels [B,T,num_mels], stop_logits [B,T]. */
 size_t b2s_decoder_ws_bytes(const b2s_model* m, int B, int S, int T);
-int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
-                        const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
-                        size_t ws_bytes, float* mels_out, float* stop_out, void* stream, b2s_ctx** ctx_out);
-/* The same with the encoder output arriving from another stream: memory_ready (hipEvent_t as void*, or NULL) is waited for on `stream`
+/* memory_ready (hipEvent_t as void*, or NULL): the encoder output arrives from another stream -- the event is waited for on `stream`
  * right before the first kernel that reads `memory` (the memory K / V projection ahead of the first encoder-decoder attention); the prenet
  * and the first layer's self-attention are enqueued before the wait and overlap the encoder forward running on the other stream. */
 /* train: bit 0 = training mode (dropout live).  Bit 1 (B2S_DEC_PADDED_UNOBSERVED): the caller reads nothing of this forward at query rows
@@ -89,14 +85,11 @@ int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_
  * 64-row tiles of padded queries (forward and backward).  Losses, outputs and every gradient are unchanged: the heads mask those rows and
  * the backward zeroes their gradient whatever d_mels / d_stop hold there. */
 #define B2S_DEC_PADDED_UNOBSERVED 2
-int b2s_decoder_forward_ev(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
-                           const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
-                           size_t ws_bytes, float* mels_out, float* stop_out, void* memory_ready, void* stream, b2s_ctx** ctx_out);
-/* d_memory_out [B,S,Dm] is overwritten. */
-int b2s_decoder_backward(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, float* d_memory_out,
-                         void* stream);
-/* Extended backward.  d_guided: device scalar = d loss / d guided_loss (NULL: the guided-attention term gets no
- * gradient).  flags bit 0: do not compute d_memory (frozen encoder; d_memory_out may be NULL).  bit 1: the caller's next call
+int b2s_decoder_forward(b2s_model* m, const float* memory, const int32_t* input_lengths, const float* targets,
+                        const int32_t* target_lengths, int B, int S, int T, int train, uint64_t seed, void* ws,
+                        size_t ws_bytes, float* mels_out, float* stop_out, void* memory_ready, void* stream, b2s_ctx** ctx_out);
+/* Backward.  d_memory_out [B,S,Dm] is overwritten.  d_guided: device scalar = d loss / d guided_loss (NULL: the guided-attention term gets no
+ * gradient).  flags = 0 and dmem_done = NULL: the plain call.  flags bit 0: do not compute d_memory (frozen encoder; d_memory_out may be NULL).  bit 1: the caller's next call
  * on this model and stream is b2s_encoder_backward -- the second stream (weight-gradient GEMMs) is then joined at the end of
  * that call instead of this one; ctx (its workspace) must stay alive until that call has returned, and the last decoder
  * stage's hook fires from inside it. */
@@ -105,13 +98,11 @@ int b2s_decoder_backward(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const 
 /* bit 2: like DEFER_JOIN the second stream is not joined here, but everything still queued (the last stages' weight-gradient groups) is
  * handed to it by this call, ordered behind this call's stream -- required when the next entry point runs on a DIFFERENT stream */
 #define B2S_DEC_BWD_FLUSH_TAIL 4
-int b2s_decoder_backward_ex(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, const float* d_guided,
-                            int flags, float* d_memory_out, void* stream);
 /* dmem_done (hipEvent_t as void*, or NULL) is recorded on `stream` as soon as d_memory_out is complete -- after the FIRST decoder layer's
  * encoder-decoder attention backward, ahead of that layer's self-attention, the prenet backward and their weight gradients -- so that an
  * encoder backward on another stream can start then (train.py has no counterpart: autograd runs one stream). */
-int b2s_decoder_backward_ev(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, const float* d_guided,
-                            int flags, float* d_memory_out, void* dmem_done, void* stream);
+int b2s_decoder_backward(b2s_model* m, b2s_ctx* ctx, const float* d_mels, const float* d_stop, const float* d_guided,
+                         int flags, float* d_memory_out, void* dmem_done, void* stream);
 /* Guided-attention loss of the forward held in ctx (already multiplied by guided_attention_weight):
  *   weight * mean over layers, heads and valid (b, t < T_b, n < N_b) of  A[b,h,t,n] * (1 - exp(-(n/N_b - t/T_b)^2 / (2 sigma^2)))
  * written to out[0]; if add_to != NULL it is also added to add_to[0] (the total loss).  Error if the weight is 0. */
@@ -126,13 +117,12 @@ size_t b2s_postnet_ws_bytes(const b2s_model* m, int B, int T);
 int b2s_postnet_forward(b2s_model* m, const float* inputs, const int32_t* lengths, const float* add, int B, int T,
                         int train, uint64_t seed, void* ws, size_t ws_bytes, float* out, void* stream,
                         b2s_ctx** ctx_out);
-/* d_inputs_out [B,T,num_mels] = gradient through the conv stack only (caller adds the skip path). */
-int b2s_postnet_backward(b2s_model* m, b2s_ctx* ctx, const float* d_out, float* d_inputs_out, void* stream);
-/* flags bit 0: the caller's next call on this model and stream is b2s_decoder_backward(_ex) -- the second stream (the conv
+/* d_inputs_out [B,T,num_mels] = gradient through the conv stack only (caller adds the skip path).  flags = 0: the plain call.
+ * flags bit 0: the caller's next call on this model and stream is b2s_decoder_backward -- the second stream (the conv
  * weight-gradient GEMMs run there) is joined by that call (or, with B2S_DEC_BWD_DEFER_JOIN, by the encoder backward after it);
  * ctx must stay alive until the joining call has returned. */
 #define B2S_POST_BWD_DEFER_JOIN 1
-int b2s_postnet_backward_ex(b2s_model* m, b2s_ctx* ctx, const float* d_out, float* d_inputs_out, int flags, void* stream);
+int b2s_postnet_backward(b2s_model* m, b2s_ctx* ctx, const float* d_out, float* d_inputs_out, int flags, void* stream);
 
 void b2s_ctx_free(b2s_ctx* ctx);
 
@@ -141,15 +131,14 @@ void b2s_ctx_free(b2s_ctx* ctx);
  * caller can launch that stage's gradient all-reduce (RCCL) while later stages still compute.  Stages in
  * execution order: 0 postnet; 1 decoder heads + output LayerNorm; 2..1+Ld decoder layers Ld-1..0; 2+Ld prenet
  * + decoder pe_scale; 3+Ld speaker/language nets + encoder output LayerNorm; 4+Ld..3+Ld+Le encoder layers
- * Le-1..0; 4+Ld+Le byte embedding + encoder pe_scale. */
-int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int stage, void* user), void* user);
-/* The stream the hook launches its collective on.  NULL (default): the stream of the backward call -- the library then makes
- * that stream wait for the second stream's weight-gradient work of the stage before the hook fires.  A dedicated stream: only
+ * Le-1..0; 4+Ld+Le byte embedding + encoder pe_scale.
+ * stream: the stream the hook launches its collective on.  NULL: the stream of the backward call -- the library then makes
+ * that stream wait for the second stream's weight-gradient work of the stage before the hook fires.  Another stream: only
  * that stream waits, the backward pass is not held up (the hook must launch its work on it; the final optimizer step has to
- * wait for the collectives as before). */
-int b2s_model_set_stage_hook_stream(b2s_model* m, void* stream);
+ * wait for the collectives as before).  hook = NULL removes the hook. */
+int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int stage, void* user), void* user, void* stream);
 /* The engine's second stream (hipStream_t; NULL before b2s_model_bind or when the model runs single-stream): the stream its weight-gradient
- * work runs on.  A data-parallel caller passes it to b2s_model_set_stage_hook_stream, so that the gradient exchange is launched from the
+ * work runs on.  A data-parallel caller passes it to b2s_model_set_stage_hook, so that the gradient exchange is launched from the
  * stream that completes the gradients instead of a fifth stream: more than four concurrently ACTIVE HIP streams (main, second, encoder,
  * exchange, RCCL's own) were measured at 12.6 ms per step against 7.9 with four (MI355X, profiles/NOTES_r04.md). */
 void* b2s_model_second_stream(b2s_model* m);
@@ -203,44 +192,33 @@ void b2s_decode_end(b2s_decode_state* s);
 int b2s_adam_bind(b2s_model* m, void* const* exp_avg_host, void* const* exp_avg_sq_host, int n);
 int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
                   void* stream);
-/* overlap = 1: the update runs on the model's second stream in three groups (postnet, encoder, decoder parameters) and
- * the call returns with `stream` free to go on; every entry point that reads weights makes ITS stream wait for the groups
- * it needs (b2s_encoder_forward: encoder only), so the next step's forward overlaps the tail of the update.  Anything that
- * reads the bound parameter / Adam-state tensors outside this library must call b2s_adam_wait on its stream first. */
-int b2s_adam_step_ex(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
-                     int overlap, void* stream);
-int b2s_adam_wait(b2s_model* m, void* stream);
 /* Data-parallel runs with a bf16 gradient payload: `wire_bf16` is the exchange's wire buffer -- bf16, element i = gradient element i of the
  * flat fp32 gradient buffer that starts at `grad_base` (the bound gradient tensors are slices of it).  From now on every b2s_adam_step*
  * reads its gradients from the wire buffer, i.e. consumes the all-reduced sum where the collective left it: no unpack pass, no fp32
  * re-read (train.py:125,130-131: DDP's averaged gradient feeding optim.step()).  NULL restores the fp32 gradient buffers. */
 int b2s_adam_set_grad_wire(b2s_model* m, const void* wire_bf16, const float* grad_base);
 /* One optimizer step applied in pieces: `groups` is a mask of parameter groups (B2S_ADAM_ENCODER | _DECODER | _POSTNET)
- * whose gradients are final.  on_aux = 1: those groups are updated on the model's second stream, ordered after everything
- * already enqueued on `stream`, and the call returns with `stream` free to go on -- the fused trainer updates the decoder
- * and postnet parameters this way while the encoder backward (small kernels that leave most CUs idle) still runs, then the
- * encoder group on `stream` itself.  Every group must be stepped exactly once per `step`; entry points wait for the groups
- * they read (as with b2s_adam_step_ex).
- * on_aux = 2: the groups are updated on `stream` itself by a capped grid, behind the mark b2s_model_mark_grads_ready left on the second
- * stream (and nothing later): the trainer marks after the decoder backward, enqueues the encoder backward on its own stream, and only
- * then issues the decoder / postnet update -- which runs beside the encoder backward on the device, while a host-side failure in the
+ * whose gradients are final.  Every group must be stepped exactly once per `step`.
+ * behind_mark = 0: the groups are updated on `stream` after the second stream has been joined.
+ * behind_mark = 1: the groups are updated on `stream` by a grid capped at 512 workgroups, behind the mark b2s_model_mark_grads_ready left on
+ * the second stream (and nothing later): the trainer marks after the decoder backward, enqueues the encoder backward on its own stream, and
+ * only then issues the decoder / postnet update -- which runs beside the encoder backward on the device, while a host-side failure in the
  * encoder backward still finds no part of the step applied. */
 #define B2S_ADAM_ENCODER 1
 #define B2S_ADAM_DECODER 2
 #define B2S_ADAM_POSTNET 4
 int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
-                         int groups, int on_aux, void* stream);
+                         int groups, int behind_mark, void* stream);
 int b2s_model_mark_grads_ready(b2s_model* m);
-/* Zero every bound parameter gradient.  Every *_backward entry point ACCUMULATES into the bound gradient
- * buffers (several use atomics), so the host calls this once at the start of each backward pass. */
-int b2s_zero_grads(b2s_model* m, void* stream);
-/* flags = B2S_ZERO_GRADS_OVERWRITE_DW: the caller is about to run ONE complete backward pass (postnet, decoder, encoder -- every segment
+/* Zero every bound parameter gradient (flags = 0).  Every *_backward entry point ACCUMULATES into the bound gradient
+ * buffers (several use atomics), so the host calls this once at the start of each backward pass.
+ * flags = B2S_ZERO_GRADS_OVERWRITE_DW: the caller is about to run ONE complete backward pass (postnet, decoder, encoder -- every segment
  * exactly once, as b2s_hip.trainer.HipTrainer does).  bf16 mode: the weight gradients of the encoder / decoder layers are then STORED by
  * their grouped weight-gradient launch instead of accumulated, and only the remaining gradients (biases, LayerNorm / BatchNorm, embeddings,
  * convolutions, prenet, heads) are cleared -- one small kernel instead of a 334 MB memset, and no read-modify-write in the weight-gradient
- * epilogues.  Without the flag (or in fp32 mode) this is b2s_zero_grads. */
+ * epilogues.  In fp32 mode the flag is ignored. */
 #define B2S_ZERO_GRADS_OVERWRITE_DW 1
-int b2s_zero_grads_ex(b2s_model* m, void* stream, int flags);
+int b2s_zero_grads(b2s_model* m, void* stream, int flags);
 /* Gradient tensors bound as slots of ONE flat buffer with up to `bytes` of alignment padding between them (the Python engine: 256):
  * b2s_zero_grads then clears the padding along with the slots (one memset).  Default 0: separately bound gradient tensors are cleared
  * range by range and nothing between them is touched. */
@@ -299,9 +277,7 @@ int b2s_flash_attention_backward(int dtype, const void* dctx, const void* ctx, i
 int b2s_flash_attention_align(int dtype, const void* q, int ldq, const void* k, int ldk, const float* lse, int B, int H,
                               int Lq, int Lk, int dh, int mask_mode, const int32_t* klen, float* align_out, void* stream);
 int b2s_align_from_probs(int dtype, const void* P, float* align, int B, int H, int Lq, int Lk, void* stream);
-/* out = a + b (fp32, n elements) */
-int b2s_add(const float* a, const float* b, float* out, int64_t n, void* stream);
-/* out = (a + b) + c: the three contributions to d(mel_before) -- postnet input gradient, d(mel_after) routed around it and the direct loss
+/* out = (a + b) + c (fp32, n elements; c = NULL: out = a + b): the three contributions to d(mel_before) -- postnet input gradient, d(mel_after) routed around it and the direct loss
  * term (tacotron.py:126-133 + autograd) -- in one launch */
 int b2s_add3(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream);
 /* Gradient payload conversion for the data-parallel exchange (b2s_hip/dp.py): fp32 gradients -> bf16 wire buffer and back (half

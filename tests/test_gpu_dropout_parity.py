@@ -96,8 +96,8 @@ def check_fp32(tag, outs, ls, grads, ref_out, ref_l, ref_g, mel_tol):
 
 @pytest.mark.parametrize("tag,over", [("tiny", TINY), ("tiny96", TINY96)])
 def test_dropout_on_forward_loss_grads_fp32_tiny(tag, over):
-    """The two tiny golden configurations (head sizes 32 / 64 and 16 / 24: the fused attention kernels and the materialised GEMM + softmax
-    path), reference rates 0.1 / 0.5, the golden batch: outputs, alignments (pre-dropout: attention.py:88), losses, every gradient."""
+    """The two tiny golden configurations (head sizes 32 / 64 and 64 / 96: every attention goes through the fused kernels),
+    reference rates 0.1 / 0.5, the golden batch: outputs, alignments (pre-dropout: attention.py:88), losses, every gradient."""
     over = with_dropout(over)
     cfg0 = make_config(over)
     st = synth.synthetic_state(cfg0, 1234)

@@ -150,25 +150,25 @@ def test_adam_training_steps_match_oracle():
                 assert abs(float(v.double().norm()) - rn) <= 2e-3 * rn + 1e-4, (step, n)
 
 
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("back_to_back", [False, True])
 @pytest.mark.parametrize("tag,over", [("tiny", TINY), ("tiny96", TINY96)])
-def test_fused_trainer_matches_oracle(tag, over, overlap):
+def test_fused_trainer_matches_oracle(tag, over, back_to_back):
     """The benchmarked path (HipTrainer: engine fwd/bwd without autograd + fused multi-tensor Adam with the L2 term and
     the LambdaLR schedule folded in) reproduces three reference training steps: losses, every parameter, BN buffers.
-    overlap: the optimizer step runs on the second stream under the next step's forward pass (what bench.py times)."""
+    back_to_back: no host synchronisation between the steps (what bench.py times: ordered by stream order and the engine's events alone)."""
     from b2s_hip.trainer import HipTrainer
     m, cfg, st, hp = build(over)
     m.train()
     nb = synth.synthetic_batch(cfg, B=3, S=11, T=23, seed=7, in_lens=[11, 7, 4], tgt_lens=[23, 15, 9])
     b = dev_batch(nb)
-    tr = HipTrainer(m, hp, overlap_adam=overlap)
+    tr = HipTrainer(m, hp)
     P = O.to_torch_state(st, requires_grad=True)
     ob = O.to_torch_batch(nb)
     opt = {}
     for step in range(3):
         vals = tr.train_step(b)
         _, losses, _ = O.train_step(P, cfg, ob, opt, step, train=True)
-        if not overlap:                     # (with the overlap the steps run back to back, ordered by the engine's events alone)
+        if not back_to_back:
             torch.cuda.synchronize()
         v = vals.cpu().numpy()
         for i, k in enumerate(("loss", "bef_loss", "aft_loss", "mse_loss", "l2", "stop_loss")):

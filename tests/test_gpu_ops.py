@@ -180,7 +180,10 @@ def _attn_ref(q, k, v, H, mask_mode, klen):
 
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("dh,mask_mode,Lq,Lk", [(32, 1, 21, 13), (64, 2, 40, 40), (96, 1, 150, 33), (96, 2, 130, 130), (64, 1, 70, 200)])
+@pytest.mark.parametrize("dh,mask_mode,Lq,Lk", [(32, 1, 21, 13), (64, 2, 40, 40), (96, 1, 150, 33), (96, 2, 130, 130), (64, 1, 70, 200),
+                                                   # resident-key kernels (no causal mask, Lk <= 128, more than one query tile): the benchmark's
+                                                   # encoder-decoder shape, a full 128-key image, 65 keys (one valid key in the second tile), no mask at all
+                                                   (96, 1, 582, 114), (64, 1, 200, 128), (32, 1, 130, 65), (96, 0, 321, 100)])
 def test_attention_core_fwd_bwd(fused, dtype, dh, mask_mode, Lq, Lk):
     ops, lib = _ops()
     g = torch.Generator().manual_seed(dh + Lq)
@@ -220,7 +223,7 @@ def test_attention_dense_bias_matches_mask():
     assert torch.equal(a, b) and torch.equal(pa, pb)
 
 
-@pytest.mark.parametrize("Lk", [140, 131])
+@pytest.mark.parametrize("Lk", [140, 131, 114, 70])          # (114, 70: the resident-key kernels)
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_fused_attention_matches_materialised_with_dropout(dtype, Lk):
     """Same seed -> the fused kernels and the GEMM+softmax path draw the same dropout mask: outputs and gradients agree.

@@ -104,10 +104,11 @@ def test_stage_hook_exception_is_raised_before_the_optimizer_step(with_split):
         def finish(self, expect_all=True): raise AssertionError("finish must not run after a failed hook")
         def abort(self): self.aborted = True
         def wait_prefix(self, limit): raise AssertionError("the tail update must not be attempted after a failed hook")
+        def covers_all(self, expect_all=True): raise AssertionError("the tail update must not be attempted after a failed hook")
     if with_split:
         Boom.split = 1
     tr.bucketer = Boom()
-    L.check(tr.lib.b2s_model_set_stage_hook(tr.eng.handle, C.cast(tr._hook, L.P), None))
+    L.check(tr.lib.b2s_model_set_stage_hook(tr.eng.handle, C.cast(tr._hook, L.P), None, None))
     before = {n: p.detach().clone() for n, p in m.named_parameters()}
     with pytest.raises(RuntimeError, match="optimizer step was NOT applied") as ei:
         tr.train_step(b)
@@ -144,48 +145,26 @@ def test_autograd_path_refuses_two_forwards_in_one_backward():
 
 
 @pytest.mark.parametrize("extra", ["", ",n_decoder_layer=3"])
-def test_split_optimizer_step_matches_single_launch(monkeypatch, extra):
-    """b2s_adam_step_groups (decoder + postnet parameters updated on the second stream under the encoder backward, encoder
-    group afterwards) is the same arithmetic as the single-launch step: identical parameters after three steps.  An odd number of
-    decoder stages leaves the prenet stage's weight-gradient group un-handed-over when the decoder backward returns with a deferred
-    join: the split step must take the join itself (decoder.prenet.* would otherwise never train -- checked explicitly)."""
-    from b2s_hip.trainer import HipTrainer
-    res = []
-    for split in ("0", "1"):
-        monkeypatch.setenv("B2S_SPLIT_ADAM", split)
-        m, cfg, _, hp = build(TINY96 + extra, compute_dtype="bf16")
-        w0 = m.decoder.prenet.dense0.weight.detach().clone()
-        _, b = _batch(cfg)
-        m.train()
-        tr = HipTrainer(m, hp)
-        assert tr.split_adam == (split == "1")
-        for _ in range(3):
-            v = tr.train_step(b)
-        res.append(({k: t.detach().clone() for k, t in m.state_dict().items()}, v.cpu().numpy()))
-        assert float((m.decoder.prenet.dense0.weight.detach() - w0).abs().max()) > 1e-4      # the prenet did train
-    for k, t in res[0][0].items():
-        d = float((t.double() - res[1][0][k].double()).abs().max())
-        assert d <= 2e-2 * (1.0 + float(t.double().abs().max())), (k, d)           # bf16 + atomics: runs are not bit-reproducible
-    assert abs(res[0][1][0] - res[1][1][0]) < 2e-2 * abs(res[0][1][0])
-
-
-def test_tail_optimizer_step_matches_single_launch(monkeypatch):
-    """Default schedule (B2S_TAIL_ADAM): the decoder / postnet update runs on the trainer's stream behind b2s_model_mark_grads_ready,
+def test_tail_optimizer_step_matches_single_launch(extra):
+    """Default schedule (HipTrainer(tail_adam=True)): the decoder / postnet update runs on the trainer's stream behind b2s_model_mark_grads_ready,
     beside the encoder backward on its own stream, the encoder group after it.  Same arithmetic as the single launch after the whole
     backward pass: fp32 mode (no atomics in the compared path beyond the column sums), identical losses and parameters after 3 steps."""
     from b2s_hip.trainer import HipTrainer
     res = []
-    for tail in ("0", "1"):
-        monkeypatch.setenv("B2S_TAIL_ADAM", tail)
-        m, cfg, _, hp = build(TINY96, compute_dtype="bf16")
+    for tail in (False, True):
+        m, cfg, _, hp = build(TINY96 + extra, compute_dtype="bf16")
+        w0 = m.decoder.prenet.dense0.weight.detach().clone()
         _, b = _batch(cfg)
         m.train()
-        tr = HipTrainer(m, hp)
-        assert tr.tail_adam == (tail == "1") and tr.overlap_encoder
+        tr = HipTrainer(m, hp, tail_adam=tail)
+        assert tr.tail_adam == tail and tr.overlap_encoder
         for _ in range(3):
             v = tr.train_step(b)
         torch.cuda.synchronize()
+        assert tr.last_step_tail_update == tail
         res.append(({k: t.detach().clone() for k, t in m.state_dict().items()}, v.cpu().numpy()))
+        # (an odd number of decoder stages leaves the prenet stage's weight-gradient group to the drain: the prenet must still train)
+        assert float((m.decoder.prenet.dense0.weight.detach() - w0).abs().max()) > 1e-4
     for k, t in res[0][0].items():
         d = float((t.double() - res[1][0][k].double()).abs().max())
         assert d <= 2e-2 * (1.0 + float(t.double().abs().max())), (k, d)           # bf16 + atomics: runs are not bit-reproducible
@@ -193,8 +172,8 @@ def test_tail_optimizer_step_matches_single_launch(monkeypatch):
 
 
 def test_tail_update_protocol_is_checked():
-    """b2s_adam_step_groups(on_aux = 2) is only valid behind b2s_model_mark_grads_ready, never for the encoder group, and a group is
-    stepped once per step: each misuse is an error code with a message, not a silent partial update.  b2s_add3 == two b2s_add calls."""
+    """b2s_adam_step_groups(behind_mark = 1) is only valid behind b2s_model_mark_grads_ready, never for the encoder group, and a group is
+    stepped once per step: each misuse is an error code with a message, not a silent partial update.  b2s_add3(c) == two b2s_add3(NULL) calls."""
     from b2s_hip.trainer import HipTrainer
     from b2s_hip import lib as L
     m, cfg, _, hp = build(TINY96, compute_dtype="bf16")
@@ -206,10 +185,10 @@ def test_tail_update_protocol_is_checked():
     lib, h = tr.lib, tr.eng.handle
     adam = (1e-3, 2, 0.9, 0.999, 1e-6, 0.0, 1.0)
     with pytest.raises(L.B2SError, match="mark_grads_ready"):
-        L.check(lib.b2s_adam_step_groups(h, *adam, 2 | 4, 2, L.stream()))           # no mark
+        L.check(lib.b2s_adam_step_groups(h, *adam, 2 | 4, 1, L.stream()))           # no mark
     L.check(lib.b2s_model_mark_grads_ready(h))
     with pytest.raises(L.B2SError, match="complete at the mark"):
-        L.check(lib.b2s_adam_step_groups(h, *adam, 1 | 2, 2, L.stream()))           # encoder group behind a decoder mark
+        L.check(lib.b2s_adam_step_groups(h, *adam, 1 | 2, 1, L.stream()))           # encoder group behind a decoder mark
     with pytest.raises(L.B2SError, match="placement"):
         L.check(lib.b2s_adam_step_groups(h, *adam, 2, 3, L.stream()))
     before = {k: v.detach().clone() for k, v in m.state_dict().items() if v.is_floating_point()}
@@ -219,12 +198,67 @@ def test_tail_update_protocol_is_checked():
             assert torch.equal(v, before[k]), k                                         # nothing was applied by the refused calls
     lib.b2s_model_backward_abort(h, L.stream())                                         # (drops the mark)
     with pytest.raises(L.B2SError, match="mark_grads_ready"):
-        L.check(lib.b2s_adam_step_groups(h, *adam, 2 | 4, 2, L.stream()))
+        L.check(lib.b2s_adam_step_groups(h, *adam, 2 | 4, 1, L.stream()))
     x, y, z = (torch.randn(1000, 80, device=DEV) for _ in range(3))
-    assert torch.equal(tr.eng.add3(x, y, z), tr.eng.add(tr.eng.add(x, y), z))
+    assert torch.equal(tr.eng.add3(x, y, z), tr.eng.add(tr.eng.add(x, y), z))          # (eng.add = b2s_add3 with c = NULL)
     tr.train_step(b)                                                                    # the trainer is still usable
     torch.cuda.synchronize()
     assert tr.global_step == 2
+
+
+def test_failure_after_the_partial_update_consumes_the_step():
+    """Data-parallel tail schedule: the decoder / postnet update is issued before the remaining collectives are waited for.  If one of THOSE
+    fails (finish() raises), the step is half applied -- the trainer must say so, advance its step counter (a retry under the same number
+    would be refused by b2s_adam_step_groups: the trainer used to be wedged) and keep working.  What can be checked without waiting (a
+    hook error, a stage that did not report) is checked BEFORE the partial update: such a step is refused as a whole, nothing applied."""
+    from b2s_hip.trainer import HipTrainer
+    from test_gpu_dp_race import FakeDist
+    m, cfg, _, hp = build(TINY96, compute_dtype="bf16")
+    _, b = _batch(cfg)
+    m.train()
+    tr = HipTrainer(m, hp, dist=FakeDist(spin_cycles=0), grad_payload="bf16")
+    tr.close()                                                                           # (world 2 selected the data-parallel GEMM tile policy process-wide)
+    assert tr.bucketer is not None and tr.bucketer.split is not None
+    tr.train_step(b)
+    torch.cuda.synchronize()
+    assert tr.global_step == 1 and tr.last_step_tail_update
+    enc0 = m.encoder.encoder.ffn_layers[0].input_layer.weight.detach().clone()
+    dec0 = m.decoder.decoder.ffn_layers[0].input_layer.weight.detach().clone()
+    real_finish = tr.bucketer.finish
+
+    def failing_finish(expect_all=True):
+        real_finish(expect_all)
+        raise RuntimeError("collective failed")
+    tr.bucketer.finish = failing_finish
+    with pytest.raises(RuntimeError, match="PARTIAL update") as ei:
+        tr.train_step(b)
+    assert "collective failed" in str(ei.value.__cause__)
+    torch.cuda.synchronize()
+    assert tr.global_step == 2                                                           # consumed
+    assert not torch.equal(m.decoder.decoder.ffn_layers[0].input_layer.weight.detach(), dec0)      # decoder group was updated ...
+    assert torch.equal(m.encoder.encoder.ffn_layers[0].input_layer.weight.detach(), enc0)          # ... the encoder group was not
+    tr.bucketer.finish = real_finish
+    tr.train_step(b)                                                                     # not wedged: the next step is step 3 on every group
+    torch.cuda.synchronize()
+    assert tr.global_step == 3 and tr.last_step_tail_update
+    assert not torch.equal(m.encoder.encoder.ffn_layers[0].input_layer.weight.detach(), enc0)
+    # a stage that never reports: noticed before any update is issued -> the single-update path refuses the whole step
+    snap = {k: v.detach().clone() for k, v in m.state_dict().items() if v.is_floating_point()}
+    real_stage_done = tr.bucketer.stage_done
+    last = tr.eng.n_stages() - 1
+    tr.bucketer.stage_done = lambda st: None if st == last - 1 else real_stage_done(st)
+    with pytest.raises((RuntimeError, AssertionError)) as ei2:
+        tr.train_step(b)
+    assert "PARTIAL" not in str(ei2.value)
+    torch.cuda.synchronize()
+    assert tr.global_step == 3
+    for k, v in m.state_dict().items():
+        if k in snap and "running" not in k:
+            assert torch.equal(v, snap[k]), k
+    tr.bucketer.stage_done = real_stage_done
+    tr.train_step(b)
+    torch.cuda.synchronize()
+    assert tr.global_step == 4
 
 
 @pytest.mark.parametrize("where", ["decoder_backward", "encoder_backward"])

@@ -134,7 +134,37 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(l, name), "libb2s_hip.so does not export %s" % name
     assert declared == set(lib.EXPORTS), (declared ^ set(lib.EXPORTS))
+    assert len(declared) <= 68, "C-ABI sprawl: %d entry points (scheduling variants belong in flags of ONE entry point)" % len(declared)
     assert l.b2s_version() >= 100
+    # the dropout-site table is readable without a GPU, and unknown sites / decode-less sites are errors with a message
+    op, kind, salt = C.c_uint32(), C.c_int(), C.c_int()
+    lib.check(l.b2s_dropout_site(b"decoder.cross_attn", 3, 0, C.byref(op), C.byref(kind), C.byref(salt)))
+    assert (op.value, kind.value, salt.value) == (2 * 4096 + 3 * 32 + 6, 1, 0)
+    lib.check(l.b2s_dropout_site(b"decoder.ffn_res", 2, 1, C.byref(op), C.byref(kind), C.byref(salt)))
+    assert (kind.value, salt.value) == (0, 1) and op.value != 2 * 4096 + 2 * 32 + 9
+    assert l.b2s_dropout_site(b"postnet.conv", 0, 1, C.byref(op), None, None) != 0 and b"decode loop" in l.b2s_last_error()
+    assert l.b2s_dropout_site(b"decoder.nothing", 0, 0, C.byref(op), None, None) != 0 and b"unknown dropout site" in l.b2s_last_error()
+
+
+def test_product_library_has_no_lab_switches():
+    """Measurement switches that change RESULTS (skip the encoder, drop the exchange ordering) exist only in -DB2S_LAB builds
+    (csrc/build.sh --lab): the shipped library does not contain their names, so no environment variable can make it compute something
+    else; and the number of environment switches the product reads at all stays small and documented."""
+    from b2s_hip import lib
+    blob = open(lib.LIB_PATH, "rb").read()
+    assert b"B2S_LAB" not in blob
+    names = set(re.findall(rb"B2S_[A-Z0-9_]{3,}", blob))
+    header = open(os.path.join(ROOT, "include", "b2s_hip.h")).read()
+    names -= {m.encode() for m in re.findall(r"#define\s+(B2S_[A-Z0-9_]+)", header)}      # flag names quoted in error messages
+    allowed = {b"B2S_DW_GROUP", b"B2S_DX_BF16", b"B2S_ENC_FUSED", b"B2S_GEMM256_MIN_M", b"B2S_GEMM256_NB"}
+    assert names <= allowed, sorted(names - allowed)
+    src = os.path.join(ROOT, "few-shot-transformer-tts_amd")
+    py = set()
+    for d, _, fs in os.walk(src):
+        for f in fs:
+            if f.endswith(".py"):
+                py |= set(re.findall(r"environ[^\n]*?[\"'](B2S_[A-Z0-9_]+)[\"']", open(os.path.join(d, f)).read()))
+    assert py <= {"B2S_LIB_PATH", "B2S_FORCE_DP", "B2S_GRAD_PAYLOAD", "B2S_BN_BROADCAST", "B2S_DECODE_LANES"}, sorted(py)
 
 
 def test_c_abi_layout_queries_and_errors():
@@ -157,7 +187,7 @@ def test_c_abi_layout_queries_and_errors():
     assert l.b2s_model_tensor_info(h, 999, buf, 256, shape, C.byref(nd), C.byref(kind)) != 0
     assert b"out of range" in l.b2s_last_error()
     # forward before binding -> error code, not a crash
-    assert l.b2s_model_sync_weights(h, None) != 0 and b"not bound" in l.b2s_last_error()
+    assert l.b2s_model_sync_weights(h, None, 0) != 0 and b"not bound" in l.b2s_last_error()
     l.b2s_model_destroy(h)
     bad = config_from_hparams(fresh_hp("decoder_hidden=512"))       # the reference crashes on this config too
     assert l.b2s_model_create(C.byref(bad), C.byref(h)) != 0 and b"decoder_hidden" in l.b2s_last_error()

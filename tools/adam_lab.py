@@ -1,4 +1,4 @@
-"""Optimizer update alone (default hparams, bf16): microseconds per b2s_adam_step_ex call.  A/B through B2S_ADAM_V1 (separate processes)."""
+"""Optimizer update alone (default hparams, bf16): microseconds per b2s_adam_step call."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ eng = tr.eng
 eng._gflat.normal_(0, 1e-3)
 args = (1e-3, 1, 0.9, 0.999, hp.adam_eps, hp.reg_weight, 1.0)
 def step(i):
-    L.check(tr.lib.b2s_adam_step_ex(eng.handle, args[0], i + 1, *args[2:], 0, L.stream()))
+    L.check(tr.lib.b2s_adam_step(eng.handle, args[0], i + 1, *args[2:], L.stream()))
 for i in range(5): step(i)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
