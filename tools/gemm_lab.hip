@@ -136,6 +136,7 @@ int main(int argc, char** argv) {
         if (si < 17 || getenv("LAB_SHAPES")) { tot_us += us; tot_fl += fl; }
     }
     printf("step-shape mix: %.1f us total, %.1f TF/s\n", tot_us, tot_fl / tot_us / 1e6);
+#ifndef LAB_NO256
     if (getenv("LAB_GROUPED")) {
         // the weight gradients of one decoder layer as the engine launches them: one grouped launch, 7 problems, full-depth K
         struct P { int M, N, K; };
@@ -198,5 +199,6 @@ int main(int argc, char** argv) {
             printf("  problem %d alone, sk=1 (%d tiles): %.1f us\n", i, (g.M / 256) * ((g.N + 127) / 128), ms * 1e3 / iters);
         }
     }
+#endif
     return 0;
 }
