@@ -138,11 +138,12 @@ def test_shifted_op_id_at_one_site_is_noticed():
         assert d > 5e-3 and e > 1e-2, (site, d, e)
 
 
-def _lj(seed_state=11, seed_batch=2):
+def _fullsize(shape, seed_state=11, seed_batch=2):
     over = DROP
     cfg = make_config(over)
     st = synth.synthetic_state(cfg, seed_state)
-    nb = synth.synthetic_batch(cfg, 14, 114, 582, seed=seed_batch, n_spk=1, n_lang=1)
+    B, S, T, n_spk, n_lang = shape
+    nb = synth.synthetic_batch(cfg, B, S, T, seed=seed_batch, n_spk=n_spk, n_lang=n_lang)
     return over, cfg, st, nb
 
 
@@ -160,28 +161,30 @@ def _trainer_step(over, st, batch, compute_dtype):
     return ls, grads, seeds
 
 
-def test_dropout_on_lj_shape_vs_oracle():
-    """BASELINE configs[1] exactly as bench.py times it -- B = 14, S = 114, T = 582, default hparams, dropout 0.1 / 0.5 -- against the fp32
-    oracle under the engine's masks.  fp32 mode through the module surface (outputs + losses + gradients at the fp32 bars) and through
-    the fused trainer (padded query tiles skipped); bf16 mode (fused encoder sublayers, bf16 residual gradient) through the fused
-    trainer at the recorded-drift gates."""
-    over, cfg, st, nb = _lj()
+@pytest.mark.parametrize("tag,shape", [("lj", (14, 114, 582, 1, 1)), ("c3", (4, 256, 300, 572, 38))])
+def test_dropout_on_fullsize_vs_oracle(tag, shape):
+    """Default hparams, dropout 0.1 / 0.5, against the fp32 oracle under the engine's masks.  lj: BASELINE configs[1] exactly as bench.py times
+    it (B = 14, S = 114, T = 582: resident-key encoder-decoder attention, fused encoder sublayers in bf16); c3: the configs[2] row shape
+    (S = 256 text bytes, 572 speakers / 38 languages, at B = 4, T = 300 to keep the CPU oracle affordable: generic attention kernels,
+    the kernel-by-kernel encoder).  fp32 mode through the module surface (outputs + losses + gradients at the fp32 bars) and through
+    the fused trainer (padded query tiles skipped); bf16 mode through the fused trainer at the recorded-drift gates."""
+    over, cfg, st, nb = _fullsize(shape)
     _, outs, ls, grads, seeds = hip_autograd_step(over, st, nb)
     ref_out, ref_l, ref_g, _ = oracle_step(cfg, st, nb, seeds)
-    check_fp32("LJ shape (module surface)", outs, ls, grads, ref_out, ref_l, ref_g, 1e-3)
+    check_fp32("%s shape (module surface)" % tag, outs, ls, grads, ref_out, ref_l, ref_g, 1e-3)
     batch = dev_batch(nb)
     for mode in ("fp32", "bf16"):
         ls, grads, seeds = _trainer_step(over, st, batch, mode)
         _, ref_l, ref_g, _ = oracle_step(cfg, st, nb, seeds)
         lworst = max(abs(ls[k] - ref_l[k]) / (abs(ref_l[k]) + 1e-9) for k in ("loss", "bef_loss", "aft_loss", "stop_loss", "l2"))
         e, n = worst_direction({k: v for k, v in grads.items() if v.numel() > 1}, {k: v for k, v in ref_g.items() if v.numel() > 1})
-        print("LJ shape dropout on, fused trainer %s: worst loss-term error %.3e, worst per-tensor relative L2 gradient error %.3e (%s)" % (mode, lworst, e, n))
+        print("%s shape dropout on, fused trainer %s: worst loss-term error %.3e, worst per-tensor relative L2 gradient error %.3e (%s)" % (tag, mode, lworst, e, n))
         if mode == "fp32":
             assert lworst < 2e-4 and e < 1e-3, (lworst, e, n)
         else:
-            record_drift("lj_dropout/loss_terms_rel", lworst)
-            record_drift("lj_dropout/worst_grad_dir_rel", e)
-            assert lworst < drift_gate("lj_dropout/loss_terms_rel", 0.01, floor=1e-3) and e < drift_gate("lj_dropout/worst_grad_dir_rel", 0.15, floor=0.05), (lworst, e, n)
+            record_drift(tag + "_dropout/loss_terms_rel", lworst)
+            record_drift(tag + "_dropout/worst_grad_dir_rel", e)
+            assert lworst < drift_gate(tag + "_dropout/loss_terms_rel", 0.01, floor=1e-3) and e < drift_gate(tag + "_dropout/worst_grad_dir_rel", 0.15, floor=0.05), (lworst, e, n)
 
 
 def test_dropout_on_decode_replayed_against_recompute_loop():

@@ -1,5 +1,7 @@
 """Op-level parity of the fused encoder sublayer kernels (csrc/enc_fused.hip, through the C ABI) against plain torch float64 math on the same
-bf16-rounded operands.  Reference semantics: transformer/modules.py:49-69, transformer/attention.py:53-122, transformer/modules.py:8-20.
+bf16-rounded operands.  The kernels exist in bf16 arithmetic only (v_mfma_f32_16x16x32_bf16, ds_read_b64_tr_b16), so there is no fp32-mode run
+of them to hold to 1e-3; instead every stage is ALSO checked teacher-forced -- against exact arithmetic on the kernel's own inputs to that
+stage: bf16 outputs within one bf16 ulp element by element, fp32 slabs within 2e-4 (summation order only).  Reference semantics: transformer/modules.py:49-69, transformer/attention.py:53-122, transformer/modules.py:8-20.
 
 Row counts cover S = 114 (the LJ-typical batch), 128 (a full tile), 50 / 17 (less than one 64-row granule; not a multiple of 16) and ragged
 key lengths; dropout masks are replayed from the counter RNG (b2s_dropout_mask) with the index convention of the unfused kernels.
@@ -29,6 +31,18 @@ def _bf(x):
 def _rel(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+TIGHT = 2e-4          # fp32 outputs of a product whose operands are the kernel's OWN bf16 tensors: only the fp32 summation order differs
+
+
+def _within_one_bf16_ulp(got, ref, slack=1e-5):
+    """A bf16 tensor the kernel rounded from an fp32 accumulator against the float64 value of the same sum: they may differ by the rounding
+    itself (half an ulp) plus one flip caused by the summation order -- element by element, |got - ref| <= 2^-7 |ref| (+ slack near zero).
+    This is the '<= 1e-3 class' check of kernels that exist in bf16 arithmetic only: nothing but the documented roundings separates them
+    from exact arithmetic."""
+    g, r = got.double(), ref.double()
+    return bool(((g - r).abs() <= r.abs() * 2.0 ** -7 + slack * max(1.0, float(r.abs().max()))).all())
 
 
 def _mask(lib, L, p, seed, op, n):
@@ -101,6 +115,13 @@ def test_fused_attention_forward_backward(B, S, kl, p, slab_bf16):
     assert torch.isfinite(got).all()
     assert _rel(got, r_slabs) < TOL, report("slabs", got.cpu(), r_slabs.cpu())
     assert _rel(got.sum(0), r_slabs.sum(0)) < TOL
+    # teacher-forced: every stage against exact arithmetic on the kernel's own inputs to that stage
+    assert _within_one_bf16_ulp(qkv, h.double() @ Wqkv.double().t()), "q / k / v projection is more than one bf16 ulp away from the exact product"
+    own = torch.stack([ctx.double()[:, hh * DH:(hh + 1) * DH] @ Wo.double()[:, hh * DH:(hh + 1) * DH].t() for hh in range(H)])
+    if not slab_bf16:
+        assert _rel(got, own) < TIGHT, report("slabs vs the kernel's own ctx", got.cpu(), own.cpu())
+    else:
+        assert _within_one_bf16_ulp(got, own, slack=1e-4)
 
     # ---- backward on the kernel's own saved tensors
     dY = _bf(torch.randn(M, D, generator=g, device=DEV))
@@ -129,6 +150,10 @@ def test_fused_attention_forward_backward(B, S, kl, p, slab_bf16):
     assert torch.isfinite(gotb).all()
     assert _rel(gotb.sum(0), r_b.sum(0)) < 2 * TOL, report("dh", gotb.sum(0).cpu(), r_b.sum(0).cpu())
     assert _rel(gotb, r_b) < 3 * TOL, report("dh slabs", gotb.cpu(), r_b.cpu())
+    own_b = torch.stack([sum(dqkv.double()[:, i * D + hh * DH:i * D + (hh + 1) * DH] @ Wqkv.double()[i * D + hh * DH:i * D + (hh + 1) * DH, :]
+                             for i in range(3)) for hh in range(H)])
+    if not slab_bf16:
+        assert _rel(gotb, own_b) < TIGHT, report("dh slabs vs the kernel's own dqkv", gotb.cpu(), own_b.cpu())
 
 
 @pytest.mark.parametrize("slab_bf16", [0, 1])
@@ -158,6 +183,9 @@ def test_fused_ffn_forward_backward(B, S, p, slab_bf16):
     assert torch.isfinite(got).all()
     assert _rel(got, r_slabs) < TOL, report("slabs", got.cpu(), r_slabs.cpu())
     assert _rel(got.sum(0), r_slabs.sum(0)) < TOL
+    assert _within_one_bf16_ulp(f, r_f), "hidden activations are more than one bf16 ulp away from exact relu(h W1^T) * mask"
+    if not slab_bf16:                        # (r_slabs is computed from the kernel's own f: summation order only)
+        assert _rel(got, r_slabs) < TIGHT, report("slabs (fp32)", got.cpu(), r_slabs.cpu())
 
     dY = _bf(torch.randn(M, D, generator=g, device=DEV))
     W2T, W1T = W2.t().contiguous(), W1.t().contiguous()
@@ -173,6 +201,9 @@ def test_fused_ffn_forward_backward(B, S, p, slab_bf16):
     gotb = _slab_view(bslabs, NS, M, slab_bf16)
     assert torch.isfinite(gotb).all()
     assert _rel(gotb, r_b) < TOL, report("dh slabs", gotb.cpu(), r_b.cpu())
+    assert _within_one_bf16_ulp(dz, r_dz), "d hidden is more than one bf16 ulp away from the exact (dY W2) * relu' * scale"
+    if not slab_bf16:
+        assert _rel(gotb, r_b) < TIGHT, report("dh slabs (fp32)", gotb.cpu(), r_b.cpu())
 
 
 @pytest.mark.parametrize("slab_bf16", [0, 1])
