@@ -78,7 +78,8 @@ struct b2s_ctx {
     float *mean_f = nullptr, *rstd_f = nullptr;
     float *spk_e = nullptr, *spk_h = nullptr, *lang_e = nullptr, *lang_h = nullptr, *spk_dh = nullptr, *lang_dh = nullptr;
     // decoder
-    bool enc_fused = false, enc_wT_done = false;     // encoder: forward ran the fused sublayer kernels / left the transposed weight copies behind enc_wT_ev
+    int enc_fused = 0;               // encoder: 0 = the forward ran kernel by kernel, 1 = fused sublayer kernels, 2 = fused FFN sublayers only (S > 128)
+    bool enc_wT_done = false;        // the forward left the transposed weight copies behind enc_wT_ev
     void* memT = nullptr;
     void *tgtT = nullptr, *a1 = nullptr, *a2 = nullptr;
     void* outT = nullptr;               // imputed decoder output (T)

@@ -535,6 +535,18 @@ struct Scratch {
 bool enc_use_fused(const b2s_model* m, int S) {
     return m->enc_fused && b2s_encf_supported(m->cfg.encoder_hidden, m->cfg.n_attention_head, 4 * m->cfg.encoder_hidden, S);
 }
+// Utterances longer than the fused kernels' 128-row tile (multi-byte scripts: BASELINE configs[2] has S = 256): the attention sublayer needs every
+// key of its utterance and runs kernel by kernel, but the FFN sublayer and the slab-sum / LayerNorm kernels are ROW-wise -- any cut of the M = B * S
+// token rows into B' chunks of S' <= 128 rows is a valid "batch" for them.  S' = the largest divisor of M in [64, 128] (0: none -> unfused FFN too).
+int enc_ffn_cut(const b2s_model* m, int B, int S) {
+    if (!m->enc_fused || S <= encf::MAXS) return 0;
+    const long M = (long)B * S;
+    for (int sp = encf::MAXS; sp >= 64; --sp)
+        if (M % sp == 0) return sp;
+    return 0;
+}
+// 0: kernel by kernel; 1: both sublayers fused; 2: FFN sublayers fused (rows re-cut), attention sublayers kernel by kernel
+int enc_mode(const b2s_model* m, int B, int S) { return enc_use_fused(m, S) ? 1 : (enc_ffn_cut(m, B, S) ? 2 : 0); }
 void plan_attn(Arena& a, AttnSave& s, int esz, long M, int D, int B, int H, int Lq, int Lk, bool cross, long Mk,
                bool dropout) {
     s.Lq = Lq; s.Lk = Lk; s.ldp = rup8(Lk);
@@ -593,7 +605,7 @@ void plan_encoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     sc.dctx = a.T(M * D, esz); sc.dh = a.T(M * D, esz); sc.dx = a.f32(M * D);
     sc.lnws = a.f32((long)RO_LN_WS_ROWS * 2 * D);
     for (int i = 0; i < (m->dw_group ? 2 * cf.n_encoder_layer + 2 : RO_LN_BATCH); ++i) sc.r_lnws.push_back(a.f32((long)RO_LN_WS_ROWS * 2 * D));
-    if (enc_use_fused(m, S)) sc.slabs = a.take((size_t)encf::NSF * M * D * (m->enc_slab_bf16 ? 2 : 4));
+    if (enc_mode(m, B, S)) sc.slabs = a.take((size_t)encf::NSF * M * D * (m->enc_slab_bf16 ? 2 : 4));
 }
 
 void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::vector<float*>& xs) {
@@ -1059,7 +1071,9 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
         return 0;
     };
     hipEvent_t side_done = nullptr;
-    const bool fused = enc_use_fused(m, S) && cf.n_encoder_layer > 0;
+    const int emode = cf.n_encoder_layer > 0 ? enc_mode(m, B, S) : 0;
+    const bool fused = emode != 0;
+    const int fB = emode == 2 ? (int)(M / enc_ffn_cut(m, B, S)) : B, fS = emode == 2 ? enc_ffn_cut(m, B, S) : S;      // the FFN kernels' row cut
     // the fused backward streams transposed copies of this step's encoder weights: written now, beside the forward pass (second stream)
     const bool want_wT = fused && ctx_out && !cf.freeze_encoder;
     auto transposes = [&](hipStream_t s2) -> int {
@@ -1106,18 +1120,31 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
                 FfnSave& f = c->ffn[l];
                 s.op_attn = drop_op(DS_ENC_ATTN, l); s.op_res = drop_op(DS_ENC_ATTN_RES, l); s.mask_mode = 1;
                 f.op_hid = drop_op(DS_ENC_FFN_HID, l); f.op_res = drop_op(DS_ENC_FFN_RES, l);
-                EncfAttnFwd fa;
-                fa.hN = (const bf16_t*)s.h; fa.Wqkv = (const bf16_t*)m->W(nm(p, "self_attentions", l, "qkv_transform.weight"));
-                fa.Wo = (const bf16_t*)m->W(nm(p, "self_attentions", l, "output_transform.weight")); fa.klen = input_lengths; fa.B = B; fa.S = S;
-                fa.datt = make_drop(pt, seed, s.op_attn); fa.qkv = (bf16_t*)s.qkv; fa.ctx = (bf16_t*)s.ctx; fa.lse = s.lse; fa.slabs = sc.slabs;
-                B2S_TRY(b2s_encf_attn_fwd(fa, sb, st));
                 const std::string lnf = p + "ffn_layer_norms." + std::to_string(l);
-                B2S_TRY(b2s_encf_reduce_ln_fwd(xs[2 * l], sc.slabs, encf::NH, sb, make_drop(pt, seed, s.op_res), m->P(lnf + ".weight"), m->P(lnf + ".bias"),
-                                               xs[2 * l + 1], (bf16_t*)f.h, D, nullptr, 0, f.mean, f.rstd, (int)M, st));
+                if (emode == 1) {
+                    EncfAttnFwd fa;
+                    fa.hN = (const bf16_t*)s.h; fa.Wqkv = (const bf16_t*)m->W(nm(p, "self_attentions", l, "qkv_transform.weight"));
+                    fa.Wo = (const bf16_t*)m->W(nm(p, "self_attentions", l, "output_transform.weight")); fa.klen = input_lengths; fa.B = B; fa.S = S;
+                    fa.datt = make_drop(pt, seed, s.op_attn); fa.qkv = (bf16_t*)s.qkv; fa.ctx = (bf16_t*)s.ctx; fa.lse = s.lse; fa.slabs = sc.slabs;
+                    B2S_TRY(b2s_encf_attn_fwd(fa, sb, st));
+                    B2S_TRY(b2s_encf_reduce_ln_fwd(xs[2 * l], sc.slabs, encf::NH, sb, make_drop(pt, seed, s.op_res), m->P(lnf + ".weight"), m->P(lnf + ".bias"),
+                                                   xs[2 * l + 1], (bf16_t*)f.h, D, nullptr, 0, f.mean, f.rstd, (int)M, st));
+                } else {
+                    // attention sublayer kernel by kernel (more than 128 keys per utterance): projection, fused attention, output projection
+                    // with the residual in its epilogue, the FFN's LayerNorm
+                    B2S_TRY(linear(m, st, s.h, D, m->W(nm(p, "self_attentions", l, "qkv_transform.weight")), (int)M, 3 * D, D, s.qkv, 0, 3 * D, GemmEpilogue()));
+                    const char* q = (const char*)s.qkv;
+                    B2S_TRY(attn_core_fwd(dt, st, q, 3 * D, q + (size_t)D * m->esz, 3 * D, q + (size_t)2 * D * m->esz, 3 * D, s.ctx, D,
+                                          B, H, S, S, dh, 1, input_lengths, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd, s.lse));
+                    GemmEpilogue e; e.drop = make_drop(pt, seed, s.op_res); e.residual = xs[2 * l]; e.ldr = D;
+                    B2S_TRY(linear(m, st, s.ctx, D, m->W(nm(p, "self_attentions", l, "output_transform.weight")), (int)M, D, D, xs[2 * l + 1], 1, D, e));
+                    B2S_TRY(ro_layernorm_fwd(dt, xs[2 * l + 1], m->P(lnf + ".weight"), m->P(lnf + ".bias"), f.h, D, nullptr, 0, f.mean, f.rstd, (int)M, D, 1e-6f,
+                                             nullptr, 1, st));
+                }
                 EncfFfn ff;
                 ff.X = (const bf16_t*)f.h; ff.Wa = (const bf16_t*)m->W(nm(p, "ffn_layers", l, "input_layer.weight"));
                 ff.Wb = (const bf16_t*)m->W(nm(p, "ffn_layers", l, "output_layer.weight")); ff.F = (bf16_t*)f.f; ff.dz = nullptr; ff.slabs = sc.slabs;
-                ff.B = B; ff.S = S; ff.dhid = make_drop(pt, seed, f.op_hid); ff.aux_scale = 1.f;
+                ff.B = fB; ff.S = fS; ff.dhid = make_drop(pt, seed, f.op_hid); ff.aux_scale = 1.f;
                 B2S_TRY(b2s_encf_ffn(ff, false, sb, st));
                 const bool last = l + 1 == L;
                 const std::string lnn = last ? p + "output_layer_norm" : p + "attn_layer_norms." + std::to_string(l + 1);
@@ -1158,7 +1185,7 @@ extern "C" int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const in
         if (side_done) B2S_HIP(hipStreamWaitEvent(st, side_done, 0));       // the speaker / language columns (second stream, see above)
         else B2S_TRY(embed_nets(st));
         if (want_wT && !c->enc_wT_done) { B2S_TRY(transposes(st)); B2S_HIP(hipEventRecord(m->enc_wT_ev, st)); c->enc_wT_done = true; }
-        c->enc_fused = fused;
+        c->enc_fused = emode;
         return 0;
     };
     rc = run();
@@ -1364,13 +1391,20 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
             sc.dz = Scratch::rot(sc.r_dz, sc.i_dz);
             B2S_TRY(guard_write(m, sc.dz, st));
             EncfFfn fb;
-            fb.X = (const bf16_t*)dy; fb.Wa = wT[3]; fb.Wb = wT[2]; fb.F = (bf16_t*)f.f; fb.dz = (bf16_t*)sc.dz; fb.slabs = sc.slabs; fb.B = B; fb.S = S;
+            fb.X = (const bf16_t*)dy; fb.Wa = wT[3]; fb.Wb = wT[2]; fb.F = (bf16_t*)f.f; fb.dz = (bf16_t*)sc.dz; fb.slabs = sc.slabs;
+            fb.B = c->enc_fused == 2 ? (int)(M / enc_ffn_cut(m, B, S)) : B; fb.S = c->enc_fused == 2 ? enc_ffn_cut(m, B, S) : S;
             fb.dhid = DropCfg{0, 0, 1.f}; fb.aux_scale = make_drop(pt, c->seed, f.op_hid).scale;
             B2S_TRY(b2s_encf_ffn(fb, true, sb, st));
             B2S_TRY(linear_dw(m, st, sc.dz, 4 * D, f.h, D, (int)M, 4 * D, D, m->G(w1)));
             nd = make_drop(pt, c->seed, s.op_res);
             B2S_TRY(rl_exit(encf::NSF, f.x_in, lnf, f.mean, f.rstd, &nd));
             // ---- attention sublayer
+            if (c->enc_fused == 2) {           // kernel by kernel (the forward's choice for more than 128 keys per utterance)
+                if (l > 0) nd = make_drop(pt, c->seed, c->ffn[l - 1].op_res);
+                B2S_TRY(self_attn_bwd(m, st, s, sc, M, D, B, H, S, pt, c->seed, wq, wo, lna, c->in_len, l > 0 ? &nd : nullptr));
+                B2S_TRY(end_stage(m, st, 4 + cf.n_decoder_layer + (cf.n_encoder_layer - 1 - l), false));
+                continue;
+            }
             B2S_TRY(take_dy(m, st, sc, M, D, nd, &dy));
             B2S_TRY(linear_dw(m, st, dy, D, s.ctx, D, (int)M, D, D, m->G(wo)));
             sc.dqkv = Scratch::rot(sc.r_dqkv, sc.i_dqkv);
