@@ -32,7 +32,7 @@ class GradBucketer(object):
     must tile the flat buffer in that order (HipEngine lays gradients out that way)."""
 
     def __init__(self, flat, stage_ranges, n_stages, bucket_elems, group=None, dist=None, payload="fp32", pack=None, unpack=None,
-                 stream=None, consume_wire=False):
+                 stream=None, consume_wire=False, mode="allreduce"):
         """payload "bf16": every bucket is converted to a bf16 wire buffer before its all-reduce and back afterwards -- half the
         bytes over xGMI (167 MB instead of 334 MB per step at the default sizes); the sum over ranks is then taken in bf16,
         everything inside a rank (accumulation, Adam moments, masters) stays fp32.  pack(src_f32, dst_bf16) / unpack(src_bf16,
@@ -59,6 +59,48 @@ class GradBucketer(object):
         # split (element index, or None): a bucket never straddles it -- the trainer updates the parameters below it (decoder + postnet)
         # as soon as THEIR all-reduces are complete (wait_prefix), beside the encoder backward
         self.split = None
+        # mode "rs_ag" (sharded optimizer): every bucket is reduce-SCATTERED in place -- rank r keeps the r-th 1/world slice of each bucket
+        # (owned_ranges), runs the optimizer on those slices only, and the updated parameters come back through all_gather_params
+        if mode not in ("allreduce", "rs_ag"):
+            raise ValueError("mode must be 'allreduce' or 'rs_ag'")
+        self.mode = mode
+        self.world = self.dist.get_world_size(group) if mode == "rs_ag" else 1
+        self.rank = self.dist.get_rank(group) if mode == "rs_ag" else 0
+
+    def plan(self):
+        """The buckets a complete backward pass will launch, in order: [(lo, hi)] -- a pure function of the stage ranges, the bucket size
+        and `split` (the same merging rule stage_done applies)."""
+        out, pending = [], None
+        for stage in range(self.n_stages):
+            rng = self.stage_ranges.get(stage)
+            if rng is not None and rng[1] > rng[0]:
+                pending = rng if pending is None else (pending[0], rng[1])
+            if pending is not None and (pending[1] - pending[0] >= self.bucket_elems or stage == self.n_stages - 1 or pending[1] == self.split):
+                out.append(pending)
+                pending = None
+        return out
+
+    def shard_of(self, lo, hi, rank=None):
+        """Slice of bucket [lo, hi) that `rank` owns after the reduce-scatter (equal slices; bucket lengths are multiples of 8 x world elements:
+        the flat layout's slots are multiples of 64)."""
+        n = hi - lo
+        if n % (8 * self.world):
+            raise ValueError("bucket [%d, %d) is not a multiple of 8 x world (%d) elements" % (lo, hi, self.world))
+        sh = n // self.world
+        r = self.rank if rank is None else rank
+        return lo + r * sh, lo + (r + 1) * sh
+
+    def owned_ranges(self, rank=None):
+        return [self.shard_of(lo, hi, rank) for lo, hi in self.plan()]
+
+    def all_gather_params(self, wire):
+        """wire: the flat fp32 parameter wire (b2s_param_wire) with this rank's owned slices filled in; in-place all-gather, bucket by bucket."""
+        works = []
+        for lo, hi in self.plan():
+            a, b = self.shard_of(lo, hi)
+            works.append(self.dist.all_gather_into_tensor(wire[lo:hi], wire[a:b], group=self.group, async_op=True))
+        for w in works:
+            w.wait()
 
     def begin_step(self):
         self._pending, self._works, self.launched = None, [], []
@@ -83,6 +125,9 @@ class GradBucketer(object):
         if self.wire is not None:
             buf = self.wire[lo:hi]
             self.pack(self.flat[lo:hi], buf)
+        if self.mode == "rs_ag":
+            a, b = self.shard_of(lo, hi)
+            return self.dist.reduce_scatter_tensor(buf[a - lo:b - lo], buf, group=self.group, async_op=True)      # in place: the own slice holds the sum
         return self.dist.all_reduce(buf, group=self.group, async_op=True)
 
     def stage_done(self, stage):
@@ -142,6 +187,8 @@ class GradBucketer(object):
             if self.wire is not None and not self.consume_wire:
                 self.unpack(self.wire[lo:hi], self.flat[lo:hi])
         self._works = []
+        if self.mode == "rs_ag" and expect_all and self.launched != self.plan():
+            raise RuntimeError("reduce-scatter mode: the step launched buckets %s, the optimizer's shard was bound to %s" % (self.launched[:4], self.plan()[:4]))
         if expect_all:
             pos = 0
             for lo, hi in self.launched:

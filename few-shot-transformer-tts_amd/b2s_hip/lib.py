@@ -96,8 +96,6 @@ _PROTOS = {
                                             P]),
     "b2s_align_from_probs": (C.c_int, [C.c_int, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P]),
     "b2s_add3": (C.c_int, [P, P, P, P, C.c_int64, P]),
-    "b2s_pack_bf16": (C.c_int, [P, P, C.c_int64, P]),
-    "b2s_unpack_bf16": (C.c_int, [P, P, C.c_int64, P]),
     "b2s_cast": (C.c_int, [C.c_int, P, P, C.c_int64, P]),
     "b2s_cast_back": (C.c_int, [C.c_int, P, P, C.c_int64, P]),
     "b2s_decode_ws_bytes": (C.c_size_t, [P, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -111,6 +109,8 @@ _PROTOS = {
     "b2s_gemm_set_tile_policy": (C.c_int, [C.c_int]),
     "b2s_model_backward_abort": (C.c_int, [P, P]),
     "b2s_model_mark_grads_ready": (C.c_int, [P]),
+    "b2s_adam_shard": (C.c_int, [P, P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
+    "b2s_param_wire": (C.c_int, [P, P, C.c_int, P]),
     "b2s_model_set_stage_hook": (C.c_int, [P, P, P, P]),
     "b2s_prof_enable": (None, [C.c_int]),
     "b2s_adam_set_grad_wire": (C.c_int, [P, P, P]),

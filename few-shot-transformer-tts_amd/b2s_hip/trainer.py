@@ -42,7 +42,8 @@ class _SchedView(object):
 
 
 class HipTrainer(object):
-    def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0, grad_payload=None, dist=None, tail_adam=True, overlap_encoder=True):
+    def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0, grad_payload=None, dist=None, tail_adam=True, overlap_encoder=True,
+                 dp_mode=None):
         from transformer.tacotron import learning_rate_schedule
         self.model, self.hp = model, hp
         # tail_adam: with the encoder backward on its own stream, this stream is idle from the end of the decoder backward until the
@@ -90,6 +91,7 @@ class HipTrainer(object):
             self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.bucketer = None
+        self.dp_mode = "allreduce"
         self._hook = _HOOK_T(self._on_stage)      # keep a reference: ctypes callbacks must outlive their use
         if self.world > 1 or (self.dist and os.environ.get("B2S_FORCE_DP")):    # B2S_FORCE_DP: 1-rank group, test aid
             # grad_payload "bf16" (default for world > 1): gradients travel as bf16 -- 167 MB instead of 334 MB per step over xGMI,
@@ -107,9 +109,16 @@ class HipTrainer(object):
                 self._set_tile_policy = True               # (process-wide switch: close() restores the per-shape choice)
             lib = self.lib
             def pack(src, dst):
-                L.check(lib.b2s_pack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()))
+                L.check(lib.b2s_cast(1, src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()))
             def unpack(src, dst):
-                L.check(lib.b2s_unpack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()))
+                L.check(lib.b2s_cast_back(1, src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()))
+            # dp_mode "rs_ag" (B2S_DP_MODE=rs_ag): reduce-scatter of the gradient buckets, Adam on this rank's 1/world slice of every bucket, all-gather
+            # of the updated parameters through a flat fp32 wire (masters stay replicated).  Default "allreduce" (DESIGN.md (e) prices both).
+            self.dp_mode = dp_mode or os.environ.get("B2S_DP_MODE", "allreduce")
+            if self.dp_mode not in ("allreduce", "rs_ag"):
+                raise ValueError("dp_mode must be 'allreduce' or 'rs_ag'")
+            if self.dp_mode == "rs_ag" and self.freeze_encoder:
+                raise L.B2SError("dp_mode='rs_ag' with a frozen encoder is not supported (its stages never report: the bucket plan is not static)")
             on_gpu = self.eng._gflat.is_cuda
             # the collectives are launched from a stream of their own: the engine orders it behind each stage's gradient work,
             # the backward pass itself never waits for the second stream on their account
@@ -130,10 +139,16 @@ class HipTrainer(object):
             self.bucketer = GradBucketer(self.eng._gflat, self.eng.stage_ranges, self.eng.n_stages(),
                                          bucket_mb * 1024 * 1024 / 4, dist=self.dist, payload=payload,
                                          pack=pack if on_gpu else None, unpack=unpack if on_gpu else None, stream=self._hook_stream,
-                                         consume_wire=consume)
+                                         consume_wire=consume, mode=self.dp_mode)
             enc0 = self.eng.stage_ranges.get(3 + self.eng.cfg.n_decoder_layer)            # first encoder stage: the flat buffer's decoder | encoder boundary
-            if self.tail_adam and not self.freeze_encoder and enc0 is not None and enc0[0] > 0:
+            if self.tail_adam and not self.freeze_encoder and enc0 is not None and enc0[0] > 0 and self.dp_mode == "allreduce":
                 self.bucketer.split = enc0[0]
+            if self.dp_mode == "rs_ag":
+                own = self.bucketer.owned_ranges()
+                lo = (C.c_int64 * len(own))(*[a for a, _ in own])
+                hi = (C.c_int64 * len(own))(*[b for _, b in own])
+                L.check(self.lib.b2s_adam_shard(self.eng.handle, self.eng._gflat.data_ptr(), lo, hi, len(own)))
+                self.param_wire = torch.empty_like(self.eng._gflat)
             if consume:
                 L.check(self.lib.b2s_adam_set_grad_wire(self.eng.handle, self.bucketer.wire.data_ptr(), self.eng._gflat.data_ptr()))
             if self.world > 1 and self.dist.get_rank() == 0:
@@ -302,6 +317,7 @@ class HipTrainer(object):
             lr = self.hp.max_lr * self.lr_lambda(self.global_step)
             step_no = self.global_step + 1
             adam = (lr, step_no, self.beta1, self.beta2, self.hp.adam_eps, self.hp.reg_weight, 1.0 / self.world)
+            self._last_adam = adam                          # (tests: the stand-in process group of test_gpu_rs_ag.py replays the peer's shard update)
             # (data parallel: the same schedule once the decoder / postnet buckets' all-reduces are complete -- GradBucketer.split keeps a
             # bucket from straddling the group boundary, wait_prefix orders this stream behind exactly those collectives)
             tail = (self.tail_adam and enc_bwd_s is not None and
@@ -362,6 +378,11 @@ class HipTrainer(object):
                 L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 1, 0, L.stream()))
             else:
                 L.check(lib.b2s_adam_step(eng.handle, *adam, L.stream()))
+            if self.bucketer is not None and self.bucketer.mode == "rs_ag":
+                # sharded update: this rank's slices -> parameter wire -> all-gather -> the other ranks' slices into masters / shadows
+                L.check(lib.b2s_param_wire(eng.handle, self.param_wire.data_ptr(), 0, L.stream()))
+                self.bucketer.all_gather_params(self.param_wire)
+                L.check(lib.b2s_param_wire(eng.handle, self.param_wire.data_ptr(), 1, L.stream()))
         except BaseException as e:
             if self.bucketer is not None:
                 self.bucketer.abort()

@@ -129,14 +129,6 @@ extern "C" int b2s_align_from_probs(int dtype, const void* P, float* align, int 
     B2S_CHECK(P && align, "null argument");
     return ro_align_transpose(dtype, P, align, B * H, Lq, Lk, rup8(Lk), S_(stream));
 }
-extern "C" int b2s_pack_bf16(const float* src, void* dst_bf16, int64_t n, void* stream) {
-    B2S_CHECK(src && dst_bf16 && n >= 0, "bad argument");
-    return n ? ro_cast(1, src, dst_bf16, n, S_(stream)) : 0;
-}
-extern "C" int b2s_unpack_bf16(const void* src_bf16, float* dst, int64_t n, void* stream) {
-    B2S_CHECK(src_bf16 && dst && n >= 0, "bad argument");
-    return n ? ro_cast_back(1, src_bf16, dst, n, S_(stream)) : 0;
-}
 extern "C" int b2s_add3(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream) {
     B2S_CHECK(a && b && out, "null argument");
     return c ? ro_add3(a, b, c, out, n, S_(stream)) : ro_add(a, b, out, n, S_(stream));

@@ -156,6 +156,13 @@ struct b2s_model {
     int adam_grp[4] = {0, 0, 0, 0};                            // chunk ranges [grp[g], grp[g+1]) of encoder / decoder / postnet (b2s_adam_step_groups)
     const void* adam_wire = nullptr;                           // b2s_adam_set_grad_wire: bf16 gradients (the exchange's wire buffer) laid out like the
     const float* adam_gbase = nullptr;                         // fp32 gradient buffer that starts at adam_gbase
+    // Sharded optimizer (b2s_adam_shard: reduce-scatter / all-gather data parallelism): chunk tables of the flat-gradient element ranges this rank
+    // owns (updated by b2s_adam_step, packed into the parameter wire) and of the rest (scattered back from the wire after the all-gather)
+    MtChunk *shard_chunks = nullptr, *other_chunks = nullptr;
+    int n_shard_chunks = 0, n_other_chunks = 0;
+    std::vector<std::pair<long, long>> shard_ranges;           // owned [lo, hi) in elements of the flat gradient buffer that starts at shard_gbase
+    const float* shard_gbase = nullptr;
+    float adam_hp_host[8][4] = {};                             // host staging of {lr, bias corrections} per step slot (source of the async upload)
     int adam_step_no = 0, adam_step_mask = 0;                  // b2s_adam_step_groups: groups already updated in step adam_step_no
     mutable bool dw_flush_exposed = false;                     // end_stage -> flush_dw: this hand-over is the entry point's drain (nothing overlaps it)
     mutable hipEvent_t grads_mark_ev = nullptr;                // b2s_model_mark_grads_ready: second-stream event behind the gradient work queued so far

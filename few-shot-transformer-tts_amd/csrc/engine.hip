@@ -875,6 +875,65 @@ int build_zero_table(b2s_model* m) {
     }
     return 0;
 }
+// one Adam / scatter chunk of tensor i: elements [o, o + cnt) of the tensor (the fields b2s_adam_bind's table carries)
+MtChunk state_chunk(const b2s_model* m, size_t i, long o, long cnt) {
+    const TensorInfo& t = m->tinfo[i];
+    MtChunk c;
+    c.a = (float*)m->data[i] + o; c.b = (float*)m->grad[i] + o; c.c = (float*)m->exp_avg[i] + o; c.d = (float*)m->exp_avg_sq[i] + o;
+    c.n = (int)cnt; c.pad = t.l2 ? 1 : 0;
+    c.s = (m->dtype == 1 && t.gemm_weight && m->shadow[i] && m->shadow[i] != m->data[i]) ? (bf16_t*)m->shadow[i] + o : nullptr;
+    c.s2 = nullptr; c.cin = 0; c.cout = 0; c.off = o;
+    if (m->dtype == 1 && t.name.compare(0, 20, "postnet.conv_layers.") == 0 && t.shape.size() == 3) {
+        const int l = atoi(t.name.c_str() + 20);
+        if (l >= 0 && l < m->cfg.n_postnet_layer && m->conv_wf[l] && m->conv_wb[l]) {
+            c.s = (bf16_t*)m->conv_wf[l]; c.s2 = (bf16_t*)m->conv_wb[l]; c.cout = (int)t.shape[0]; c.cin = (int)t.shape[1];
+        }
+    }
+    return c;
+}
+void free_table(b2s_model* m, MtChunk*& p) {
+    if (!p) return;
+    auto it = std::find(m->owned.begin(), m->owned.end(), (void*)p);
+    if (it != m->owned.end()) m->owned.erase(it);
+    (void)hipFree(p);
+    p = nullptr;
+}
+// chunk tables of the owned / not-owned parts of every updated parameter (m->shard_ranges: sorted, disjoint element ranges of the flat gradient buffer)
+int build_shard_tables(b2s_model* m) {
+    free_table(m, m->shard_chunks); free_table(m, m->other_chunks);
+    m->n_shard_chunks = m->n_other_chunks = 0;
+    if (m->shard_ranges.empty()) return 0;
+    const int CH = 16384;
+    std::vector<MtChunk> own, oth;
+    auto emit = [&](std::vector<MtChunk>& v, size_t i, long o, long e) { for (long x = o; x < e; x += CH) v.push_back(state_chunk(m, i, x, std::min<long>(CH, e - x))); };
+    for (size_t i = 0; i < m->tinfo.size(); ++i) {
+        const TensorInfo& t = m->tinfo[i];
+        if (t.kind != 1 || !m->grad[i]) continue;
+        if (m->cfg.freeze_encoder && t.name.compare(0, 8, "encoder.") == 0) continue;
+        B2S_CHECK(m->exp_avg[i] && m->exp_avg_sq[i], "b2s_adam_shard: Adam state of %s is not bound", t.name.c_str());
+        const long g0 = (const float*)m->grad[i] - m->shard_gbase, g1 = g0 + t.numel;       // the tensor's range in the flat buffer
+        long pos = g0;
+        for (const auto& r : m->shard_ranges) {
+            const long lo = std::max(r.first, g0), hi = std::min(r.second, g1);
+            if (lo >= hi) continue;
+            if (lo > pos) emit(oth, i, pos - g0, lo - g0);
+            emit(own, i, lo - g0, hi - g0);
+            pos = hi;
+        }
+        if (pos < g1) emit(oth, i, pos - g0, g1 - g0);
+    }
+    auto upload = [&](const std::vector<MtChunk>& h, MtChunk** d, int* n) -> int {
+        *n = (int)h.size();
+        if (h.empty()) return 0;
+        B2S_HIP(hipMalloc(d, h.size() * sizeof(MtChunk)));
+        B2S_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(MtChunk), hipMemcpyHostToDevice));
+        m->owned.push_back(*d);
+        return 0;
+    };
+    B2S_TRY(upload(own, &m->shard_chunks, &m->n_shard_chunks));
+    B2S_TRY(upload(oth, &m->other_chunks, &m->n_other_chunks));
+    return 0;
+}
 int rebuild_adam_chunks(b2s_model* m) {
     const int before = m->n_adam_chunks;
     B2S_TRY(build_chunks(m, false, true, &m->adam_chunks, &m->n_adam_chunks));
@@ -888,6 +947,7 @@ int rebuild_adam_chunks(b2s_model* m) {
         }
         if (m->n_adam_chunks) { B2S_HIP(hipMalloc(&m->l2_part, (size_t)m->n_adam_chunks * sizeof(float))); m->owned.push_back(m->l2_part); }
     }
+    if (!m->shard_ranges.empty()) B2S_TRY(build_shard_tables(m));          // (a re-bind replaced parameter pointers: the shard tables follow)
     return 0;
 }
 // postnet conv weights -> the two GEMM images [Cout][5*Cin] / [Cin][5*Cout] (flipped) in the compute dtype
@@ -1943,9 +2003,10 @@ extern "C" int b2s_adam_set_grad_wire(b2s_model* m, const void* wire_bf16, const
 namespace {
 // bias corrections of `step`, uploaded into a rotating slot (earlier steps may still be in flight)
 int adam_hyper(b2s_model* m, float lr, int step, float beta1, float beta2, hipStream_t st, float** dhp) {
-    float hp[3] = {lr, (float)(1.0 - std::pow((double)beta1, step)), (float)std::sqrt(1.0 - std::pow((double)beta2, step))};
+    float* hp = m->adam_hp_host[step % 8];                    // (lives in the model: an asynchronous copy must not read a dead stack frame)
+    hp[0] = lr; hp[1] = (float)(1.0 - std::pow((double)beta1, step)); hp[2] = (float)std::sqrt(1.0 - std::pow((double)beta2, step));
     *dhp = m->small + 16 + (step % 8) * 4;
-    B2S_HIP(hipMemcpyAsync(*dhp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
+    B2S_HIP(hipMemcpyAsync(*dhp, hp, 3 * sizeof(float), hipMemcpyHostToDevice, st));
     return 0;
 }
 }  // namespace
@@ -1959,6 +2020,15 @@ extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, floa
     // l2 is applied to the L2 member set only (chunk flag), i.e. g = grad*grad_scale + l2*p for members
     // the partial sums cover the L2 regulariser only if every member is in the chunk table (not with a frozen encoder)
     const bool cover = !m->cfg.freeze_encoder;
+    if (!m->shard_ranges.empty()) {
+        // sharded (b2s_adam_shard): this rank updates the element ranges it owns; the caller then packs them into the parameter wire, all-gathers
+        // it and scatters the other ranks' updates back (b2s_param_wire).  The regulariser's sum of squares is recomputed from the complete
+        // parameters by the next loss call (l2_fresh = false): this rank's Adam pass sees only its shard.
+        B2S_TRY(ro_mt_adam(m->shard_chunks, m->n_shard_chunks, dhp, beta1, beta2, eps, l2, grad_scale, nullptr, st, m->adam_wire, m->adam_gbase));
+        m->adam_step_no = step; m->adam_step_mask = 7;
+        m->l2_fresh = false;
+        return 0;
+    }
     B2S_TRY(ro_mt_adam(m->adam_chunks, m->n_adam_chunks, dhp, beta1, beta2, eps, l2, grad_scale, cover ? m->l2_part : nullptr, st, m->adam_wire, m->adam_gbase));
     // fp32 (parity) mode: the Adam kernel does not write the conv GEMM images (in bf16 mode it does); refresh them here so that
     // an eval / synthesis forward between two training steps sees the weights the step just produced
@@ -1971,6 +2041,7 @@ extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta
                                     int groups, int behind_mark, void* stream) {
     B2S_TRY(check_bound(m));
     B2S_CHECK(m->adam_chunks && step >= 1 && groups > 0 && groups < 8 && (behind_mark == 0 || behind_mark == 1), "Adam state not bound, bad step, group mask or placement");
+    B2S_CHECK(m->shard_ranges.empty(), "b2s_adam_step_groups: the optimizer is sharded (b2s_adam_shard): one b2s_adam_step per step");
     if (step != m->adam_step_no) { m->adam_step_no = step; m->adam_step_mask = 0; }
     B2S_CHECK((m->adam_step_mask & groups) == 0, "parameter group mask %d was already updated in step %d", groups & m->adam_step_mask, step);
     hipStream_t st = S_(stream);
@@ -2013,6 +2084,38 @@ extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta
     // the per-chunk sums of squares cover the regulariser once every group has been stepped (groups whose chunk range is
     // empty -- a frozen encoder -- never are: `cover` is false then)
     m->l2_fresh = cover && m->adam_step_mask == 7;
+    return 0;
+}
+// Sharded optimizer (reduce-scatter + all-gather data parallelism; train.py:125,130-131,188-189 semantics: the mean gradient feeds Adam, every rank ends the step
+// with the same parameters).  lo / hi: the n sorted, disjoint element ranges of the flat gradient buffer starting at grad_base that THIS rank owns (the slices the
+// reduce-scatter leaves it); b2s_adam_step then updates exactly those.  n = 0 un-shards.
+extern "C" int b2s_adam_shard(b2s_model* m, const float* grad_base, const int64_t* lo, const int64_t* hi, int n) {
+    B2S_TRY(check_bound(m));
+    B2S_CHECK(m->adam_chunks, "b2s_adam_shard: bind the Adam state first (b2s_adam_bind)");
+    B2S_CHECK(n == 0 || (grad_base && lo && hi && n > 0), "null argument");
+    std::vector<std::pair<long, long>> r;
+    for (int i = 0; i < n; ++i) {
+        B2S_CHECK(lo[i] >= 0 && hi[i] > lo[i] && (i == 0 || lo[i] >= hi[i - 1]), "b2s_adam_shard: ranges must be sorted, disjoint and non-empty (range %d)", i);
+        r.push_back({(long)lo[i], (long)hi[i]});
+    }
+    m->shard_ranges = r;
+    m->shard_gbase = n ? grad_base : nullptr;
+    m->l2_fresh = false;
+    return build_shard_tables(m);
+}
+// The parameter wire of the sharded optimizer: `wire` is a flat fp32 buffer laid out like the flat gradient buffer (element i <-> gradient element i).
+// direction 0: pack -- the parameters this rank's b2s_adam_step just updated are copied into their wire positions (ahead of the all-gather of the wire);
+// direction 1: scatter -- every parameter element this rank does NOT own is overwritten from the wire (after the all-gather), together with its compute-dtype
+// shadow and the conv GEMM images, exactly as the Adam kernel would have written them: all ranks end the step with identical masters and shadows.
+extern "C" int b2s_param_wire(b2s_model* m, float* wire, int direction, void* stream) {
+    B2S_TRY(check_bound(m));
+    B2S_CHECK(wire && (direction == 0 || direction == 1), "bad argument");
+    B2S_CHECK(!m->shard_ranges.empty(), "b2s_param_wire: the optimizer is not sharded (b2s_adam_shard)");
+    B2S_CHECK(((size_t)wire & 15) == 0, "the parameter wire must be 16-byte aligned");
+    hipStream_t st = S_(stream);
+    if (direction == 0) return ro_mt_param_wire(m->shard_chunks, m->n_shard_chunks, wire, m->shard_gbase, false, st);
+    B2S_TRY(ro_mt_param_wire(m->other_chunks, m->n_other_chunks, wire, m->shard_gbase, true, st));
+    if (m->dtype == 0) B2S_TRY(relayout_convs(m, st));                // fp32 mode: the conv GEMM images follow the (now complete) masters
     return 0;
 }
 // Marks the point of the second stream behind all gradient work handed to it so far (a decoder backward called with

@@ -981,6 +981,10 @@ __global__ __launch_bounds__(256) void k_mt_axpy(const MtChunk* ch, float alpha,
 }
 __device__ __forceinline__ float adam_elem(float& p, float g_raw, float& m, float& v, float gs, float l2p, float b1, float b2, float step, float sbc2,
                                            float eps) {
+    // no fused multiply-add contraction: the update of an element must not depend on which loop of which chunking reaches it (the unrolled
+    // body, the tail loop, a clipped chunk of the sharded optimizer) -- the two virtual ranks of tests/test_gpu_rs_ag.py reproduce the unsharded
+    // step bit for bit.  The kernel is HBM-bound; the few extra instructions are free.
+#pragma clang fp contract(off)
     const float g = g_raw * gs + l2p * p;
     m = b1 * m + (1.f - b1) * g;
     v = b2 * v + (1.f - b2) * g * g;
@@ -1527,6 +1531,46 @@ __global__ __launch_bounds__(256) void k_mt_zero(const MtChunk* __restrict__ ch)
         i0 = (c.n >> 2) << 2;
     }
     for (int i = i0 + threadIdx.x; i < c.n; i += 256) c.a[i] = 0.f;
+}
+// Parameter wire of the sharded optimizer (engine.hip: b2s_param_wire): a flat fp32 buffer laid out like the flat gradient buffer that starts at gbase.
+//   PACK     wire[c.b - gbase + i] = c.a[i]                (the parameters this rank just updated, ahead of the all-gather)
+//   SCATTER  c.a[i] = wire[...] + the compute-dtype shadow / the two conv images, exactly as the Adam kernel writes them
+//            (the parameters the OTHER ranks updated, after the all-gather)
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_mt_param_wire(const MtChunk* __restrict__ ch, float* __restrict__ wire, const float* gbase) {
+    const MtChunk c = ch[blockIdx.x];
+    float* w = wire + (c.b - gbase);
+    int i0 = 0;
+    const bool vec = ((((size_t)c.a | (size_t)w) & 15) == 0) && (c.cin || ((size_t)c.s & 7) == 0);
+    if (vec) {
+        f4v* P = reinterpret_cast<f4v*>(c.a); f4v* W = reinterpret_cast<f4v*>(w);
+        for (int i = threadIdx.x; i < (c.n >> 2); i += 256) {
+            if (!SCATTER) { W[i] = P[i]; continue; }
+            const f4v p = W[i];
+            P[i] = p;
+            if (c.cin) adam_store_shadow<2>(c, i, p); else if (c.s) adam_store_shadow<1>(c, i, p);
+        }
+        i0 = (c.n >> 2) << 2;
+    }
+    for (int i = i0 + threadIdx.x; i < c.n; i += 256) {
+        if (!SCATTER) { w[i] = c.a[i]; continue; }
+        const float p = w[i];
+        c.a[i] = p;
+        if (c.cin) {
+            const long gi = c.off + i, r = gi / 5;
+            const int j = (int)(gi - r * 5), co = (int)(r / c.cin), ci = (int)(r - (long)co * c.cin);
+            const bf16_t pb = f2bf(p);
+            c.s[(long)co * 5 * c.cin + (long)j * c.cin + ci] = pb;
+            c.s2[(long)ci * 5 * c.cout + (long)(4 - j) * c.cout + co] = pb;
+        } else if (c.s) c.s[i] = f2bf(p);
+    }
+}
+int ro_mt_param_wire(const MtChunk* chunks, int nchunks, float* wire, const float* gbase, bool scatter, hipStream_t st) {
+    if (nchunks > 0) {
+        if (scatter) hipLaunchKernelGGL(k_mt_param_wire<true>, dim3(nchunks), dim3(256), 0, st, chunks, wire, gbase);
+        else hipLaunchKernelGGL(k_mt_param_wire<false>, dim3(nchunks), dim3(256), 0, st, chunks, wire, gbase);
+    }
+    B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_mt_zero(const MtChunk* chunks, int nchunks, hipStream_t st) {
     if (nchunks > 0) hipLaunchKernelGGL(k_mt_zero, dim3(nchunks), dim3(256), 0, st, chunks);

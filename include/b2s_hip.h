@@ -210,6 +210,16 @@ int b2s_adam_set_grad_wire(b2s_model* m, const void* wire_bf16, const float* gra
 int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
                          int groups, int behind_mark, void* stream);
 int b2s_model_mark_grads_ready(b2s_model* m);
+/* Sharded optimizer for reduce-scatter / all-gather data parallelism (train.py:125,130-131,188-189 semantics -- the mean gradient feeds Adam and every
+ * rank ends the step with the same parameters -- with the optimizer's 30 bytes per parameter paid on 1/N of the parameters per rank).
+ * b2s_adam_shard: lo / hi = the n sorted, disjoint element ranges of the flat gradient buffer starting at grad_base that THIS rank owns (the slices a
+ * reduce-scatter of the gradient buckets leaves it); b2s_adam_step then updates exactly those (b2s_adam_step_groups is refused).  n = 0 un-shards.
+ * b2s_param_wire: `wire` = a flat fp32 buffer laid out like the gradient buffer.  direction 0 (after b2s_adam_step): the owned parameters are copied
+ * into their wire positions; the caller all-gathers the wire; direction 1: every parameter element this rank does not own is overwritten from the
+ * wire, together with its compute-dtype shadow / conv GEMM images -- fp32 masters stay REPLICATED (checkpoints, the fp32-read parameters and the
+ * parity mode are untouched).  HipTrainer(dp_mode="rs_ag") drives it; the default remains bucketed all-reduce. */
+int b2s_adam_shard(b2s_model* m, const float* grad_base, const int64_t* lo, const int64_t* hi, int n);
+int b2s_param_wire(b2s_model* m, float* wire, int direction, void* stream);
 /* Zero every bound parameter gradient (flags = 0).  Every *_backward entry point ACCUMULATES into the bound gradient
  * buffers (several use atomics), so the host calls this once at the start of each backward pass.
  * flags = B2S_ZERO_GRADS_OVERWRITE_DW: the caller is about to run ONE complete backward pass (postnet, decoder, encoder -- every segment
@@ -280,10 +290,9 @@ int b2s_align_from_probs(int dtype, const void* P, float* align, int B, int H, i
 /* out = (a + b) + c (fp32, n elements; c = NULL: out = a + b): the three contributions to d(mel_before) -- postnet input gradient, d(mel_after) routed around it and the direct loss
  * term (tacotron.py:126-133 + autograd) -- in one launch */
 int b2s_add3(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream);
-/* Gradient payload conversion for the data-parallel exchange (b2s_hip/dp.py): fp32 gradients -> bf16 wire buffer and back (half
- * the bytes per all-reduce over xGMI; parameters, Adam moments and the accumulation inside a rank stay fp32). */
-int b2s_pack_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
-int b2s_unpack_bf16(const void* src_bf16, float* dst, int64_t n, void* stream);
+/* fp32 <-> compute dtype.  With dtype = B2S_DTYPE_BF16 these are also the gradient payload conversions of the data-parallel exchange (b2s_hip/dp.py):
+ * fp32 gradients -> bf16 wire buffer and back (half the bytes per all-reduce over xGMI; parameters, Adam moments and the accumulation inside a
+ * rank stay fp32). */
 int b2s_cast(int dtype, const float* in, void* out, int64_t n, void* stream);      /* fp32 -> compute dtype */
 int b2s_cast_back(int dtype, const void* in, float* out, int64_t n, void* stream); /* compute dtype -> fp32 */
 /* keep-mask of the dropout RNG for element indices [0,n): out[i] = 1 or 0 (statistical tests) */

@@ -129,3 +129,65 @@ def test_buffer_broadcast_every_step_semantics():
     """DDP(broadcast_buffers=True), train.py:125: every rank's BatchNorm buffers become rank 0's (one flat float message + one int64
     message; shapes, dtypes and 0-dim counters preserved)."""
     mp.spawn(_bn_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _worker_rs_ag(rank, world, port, payload):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from b2s_hip.dp import GradBucketer
+    torch.set_num_threads(2)
+    # a flat layout as HipEngine makes it: every stage a run of 64-element slots
+    g = torch.Generator().manual_seed(5)
+    n_stages, off, ranges = 9, 0, {}
+    for st in range(n_stages):
+        n = 64 * int(torch.randint(1, 40, (1,), generator=g))
+        ranges[st] = (off, off + n)
+        off += n
+    total = off
+    local = torch.randn(total, generator=torch.Generator().manual_seed(100 + rank))
+    flat = local.clone()
+    b = GradBucketer(flat, ranges, n_stages, bucket_elems=3000, dist=dist, payload=payload, mode="rs_ag")
+    plan = b.plan()
+    assert plan[0][0] == 0 and plan[-1][1] == total and all(a[1] == c[0] for a, c in zip(plan, plan[1:])) and 1 < len(plan) < n_stages
+    b.begin_step()
+    for st in range(n_stages):
+        b.stage_done(st)
+    b.finish()
+    assert b.launched == plan, "the buckets a step launches are the planned ones (the optimizer's shard was bound to the plan)"
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    ref = sum(gathered)
+    own = b.owned_ranges()
+    # every element is owned by exactly one rank ...
+    cover = torch.zeros(total)
+    for r in range(world):
+        for lo, hi in b.owned_ranges(r):
+            cover[lo:hi] += 1
+    assert bool((cover == 1).all())
+    # ... and the owner holds the sum over ranks there (fp32 wire: exactly; bf16 wire: each contribution and the sum rounded to bf16)
+    for lo, hi in own:
+        if payload == "fp32":
+            assert torch.allclose(flat[lo:hi], ref[lo:hi], atol=1e-6)
+        else:
+            rb = sum(x.to(torch.bfloat16).float() for x in gathered)
+            assert torch.allclose(flat[lo:hi], rb[lo:hi], atol=2e-2, rtol=2e-2)
+    # parameter all-gather: every rank writes its owned slices of the wire, afterwards every rank holds every owner's values
+    wire = torch.full((total,), -1.0)
+    for lo, hi in own:
+        wire[lo:hi] = float(rank + 1)
+    b.all_gather_params(wire)
+    want = torch.zeros(total)
+    for r in range(world):
+        for lo, hi in b.owned_ranges(r):
+            want[lo:hi] = float(r + 1)
+    assert torch.equal(wire, want)
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_all_gather_mode_two_ranks():
+    """dp_mode = "rs_ag" on 2 gloo ranks: the planned buckets are the launched ones, every element of the flat buffer is owned by exactly one
+    rank, the owner's slice holds the sum over ranks after the in-place reduce-scatter (fp32 and bf16 wire), and the in-place parameter
+    all-gather leaves every rank with every owner's values (train.py:125,188-189: all replicas step to the same parameters)."""
+    for payload in ("fp32", "bf16"):
+        mp.spawn(_worker_rs_ag, args=(2, _free_port(), payload), nprocs=2, join=True)

@@ -1,0 +1,226 @@
+"""Sharded optimizer for reduce-scatter / all-gather data parallelism (HipTrainer(dp_mode="rs_ag"), b2s_adam_shard / b2s_param_wire): the
+reference's semantics are DDP's -- the mean gradient feeds Adam and every replica steps to the same parameters (train.py:125,130-131,188-189).
+A 1-GPU box cannot run two ranks, so the sharding arithmetic is checked with two VIRTUAL ranks on one model:
+
+  * every parameter element is updated by exactly one rank, and the two ranks' shard updates together are bit-identical to the unsharded
+    b2s_adam_step (masters, both moments);
+  * pack -> (emulated) all-gather -> scatter leaves the non-owned elements bit-identical to the owner's update, and the compute-dtype shadows /
+    conv images the scatter kernel writes are the ones a fresh weight sync would produce (forward outputs bit-identical);
+  * the whole trainer path in rs_ag mode against the plain trainer, with a stand-in process group of two identical ranks whose all-gather runs
+    the peer's shard update locally.
+(The collective side on real ranks: tests/test_dp_gloo.py::test_reduce_scatter_all_gather_mode_two_ranks.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV  # noqa: E402
+from oracle import synth, TINY96  # noqa: E402
+from test_gpu_model import build, dev_batch  # noqa: E402
+from test_gpu_dp_race import FakeDist, _Work  # noqa: E402
+
+
+class _World2(object):
+    """just enough of torch.distributed for GradBucketer.plan / owned_ranges"""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def get_world_size(self, group=None):
+        return 2
+
+    def get_rank(self, group=None):
+        return self.rank
+
+
+def _owned(tr, rank, bucket_elems=20000):
+    from b2s_hip.dp import GradBucketer
+    b = GradBucketer(tr.eng._gflat, tr.eng.stage_ranges, tr.eng.n_stages(), bucket_elems, dist=_World2(rank), mode="rs_ag")
+    return b.owned_ranges()
+
+
+def _shard(tr, ranges):
+    from b2s_hip import lib as L
+    lo = (C.c_int64 * len(ranges))(*[a for a, _ in ranges])
+    hi = (C.c_int64 * len(ranges))(*[b for _, b in ranges])
+    L.check(tr.lib.b2s_adam_shard(tr.eng.handle, tr.eng._gflat.data_ptr(), lo, hi, len(ranges)))
+
+
+def _snap(m, tr):
+    return ({n: p.detach().clone() for n, p in m.named_parameters()}, tr.exp_avg.clone(), tr.exp_avg_sq.clone())
+
+
+def _restore(m, tr, snap):
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.data.copy_(snap[0][n])
+        tr.exp_avg.copy_(snap[1]); tr.exp_avg_sq.copy_(snap[2])
+
+
+@pytest.mark.parametrize("compute_dtype", ["bf16", "fp32"])
+def test_two_virtual_ranks_equal_the_unsharded_update(compute_dtype):
+    from b2s_hip.trainer import HipTrainer
+    from b2s_hip import lib as L
+    m, cfg, _, hp = build(TINY96, compute_dtype=compute_dtype)
+    b = dev_batch(synth.synthetic_batch(cfg, B=3, S=11, T=23, seed=7, in_lens=[11, 7, 4], tgt_lens=[23, 15, 9]))
+    m.train()
+    tr = HipTrainer(m, hp)
+    tr.train_step(b)                                        # real gradients in the flat buffer, non-zero moments
+    torch.cuda.synchronize()
+    lib, h = tr.lib, tr.eng.handle
+    adam = (1e-3, 2, 0.9, 0.999, 1e-6, 5e-9, 1.0)
+    s0 = _snap(m, tr)
+    L.check(lib.b2s_adam_step(h, *adam, L.stream()))
+    torch.cuda.synchronize()
+    full = _snap(m, tr)
+    assert any(not torch.equal(full[0][n], s0[0][n]) for n in full[0])
+    # every element owned exactly once
+    own = [_owned(tr, r) for r in (0, 1)]
+    cover = torch.zeros(tr.eng._gflat.numel(), dtype=torch.int32)
+    for r in (0, 1):
+        for lo, hi in own[r]:
+            cover[lo:hi] += 1
+    assert bool((cover == 1).all()) and len(own[0]) > 1
+    # rank 0's shard, then rank 1's, from the same starting point
+    _restore(m, tr, s0)
+    for r in (0, 1):
+        _shard(tr, own[r])
+        with pytest.raises(L.B2SError, match="sharded"):
+            L.check(lib.b2s_adam_step_groups(h, *adam, 2, 0, L.stream()))
+        L.check(lib.b2s_adam_step(h, *adam, L.stream()))
+        torch.cuda.synchronize()
+        if r == 0:                                          # only rank 0's elements moved so far
+            moved = 0
+            for n, p in m.named_parameters():
+                off, cnt = tr.eng.param_offsets[n]
+                ch = (p.detach().reshape(-1) != s0[0][n].reshape(-1)).cpu()
+                mine = torch.zeros(cnt, dtype=torch.bool)
+                for lo, hi in own[0]:
+                    a, e = max(lo, off), min(hi, off + cnt)
+                    if a < e:
+                        mine[a - off:e - off] = True
+                assert not bool((ch & ~mine).any()), n      # nothing outside the shard was touched
+                moved += int(ch.sum())
+            assert moved > 0
+    both = _snap(m, tr)
+    for n in full[0]:
+        assert torch.equal(both[0][n], full[0][n]), n
+    assert torch.equal(both[1], full[1]) and torch.equal(both[2], full[2])
+    _shard(tr, [])                                          # un-shard: the plain step works again
+    L.check(lib.b2s_adam_step_groups(h, 1e-3, 3, 0.9, 0.999, 1e-6, 5e-9, 1.0, 7, 0, L.stream()))
+    torch.cuda.synchronize()
+
+
+def test_parameter_wire_pack_gather_scatter():
+    from b2s_hip.trainer import HipTrainer
+    from b2s_hip import lib as L
+    m, cfg, _, hp = build(TINY96, compute_dtype="bf16")
+    nb = synth.synthetic_batch(cfg, B=3, S=11, T=23, seed=7, in_lens=[11, 7, 4], tgt_lens=[23, 15, 9])
+    b = dev_batch(nb)
+    m.train()
+    tr = HipTrainer(m, hp)
+    tr.train_step(b)
+    torch.cuda.synchronize()
+    lib, h = tr.lib, tr.eng.handle
+    adam = (1e-3, 2, 0.9, 0.999, 1e-6, 5e-9, 1.0)
+    s0 = _snap(m, tr)
+    L.check(lib.b2s_adam_step(h, *adam, L.stream()))
+    torch.cuda.synchronize()
+    full = _snap(m, tr)
+    truth = torch.zeros_like(tr.eng._gflat)                 # the unsharded result in the flat layout
+    for n, p in full[0].items():
+        off, cnt = tr.eng.param_offsets[n]
+        truth[off:off + cnt] = p.reshape(-1)
+    own0, own1 = _owned(tr, 0), _owned(tr, 1)
+    _restore(m, tr, s0)
+    _shard(tr, own0)
+    L.check(lib.b2s_adam_step(h, *adam, L.stream()))
+    wire = torch.full_like(tr.eng._gflat, float("nan"))
+    L.check(lib.b2s_param_wire(h, wire.data_ptr(), 0, L.stream()))
+    torch.cuda.synchronize()
+    for lo, hi in own0:                                      # packed: exactly the owned elements, with the values the owner computed
+        w = wire[lo:hi]
+        real = ~torch.isnan(w)
+        assert torch.equal(w[real], truth[lo:hi][real])
+    for lo, hi in own1:
+        assert bool(torch.isnan(wire[lo:hi]).all())
+        wire[lo:hi] = truth[lo:hi]                          # the all-gather: the peer's slices arrive
+    L.check(lib.b2s_param_wire(h, wire.data_ptr(), 1, L.stream()))
+    torch.cuda.synchronize()
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), full[0][n]), n        # masters: identical to the unsharded update everywhere
+    # shadows / conv images written by the Adam and scatter kernels == what a fresh weight sync derives from the masters
+    m.eval()
+    with torch.no_grad():
+        o1 = m(**b)["mel_aft"].clone()
+        tr.eng._versions = None                             # force the re-cast of every shadow from the masters
+        o2 = m(**b)["mel_aft"].clone()
+    assert torch.equal(o1, o2) and bool(torch.isfinite(o1).all())
+    _shard(tr, [])
+
+
+class _PeerDist(FakeDist):
+    """Two identical ranks (this process is rank 1).  reduce_scatter: the own slice doubles; all_gather: the PEER's slices of the parameter wire
+    are produced by running the peer's shard update here (same gradients, same step) -- what rank 0 would have sent."""
+
+    def __init__(self):
+        FakeDist.__init__(self, 0)
+        self.trainer = None
+        self.peer_done = False
+
+    def reduce_scatter_tensor(self, out, inp, group=None, async_op=False):
+        self.calls += 1
+        self.peer_done = False
+        self.comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm):
+            inp.mul_(2)                                     # (both halves: the peer's half is what its reduce-scatter would hold)
+            ev = torch.cuda.Event(); ev.record(self.comm)
+        return _Work(ev)
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        from b2s_hip import lib as L
+        tr = self.trainer
+        if not self.peer_done:
+            self.peer_done = True
+            lib, h = tr.lib, tr.eng.handle
+            _shard(tr, tr.bucketer.owned_ranges(0))
+            L.check(lib.b2s_adam_step(h, *tr._last_adam, L.stream()))
+            L.check(lib.b2s_param_wire(h, tr.param_wire.data_ptr(), 0, L.stream()))
+            _shard(tr, tr.bucketer.owned_ranges(1))
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+        return _Work(ev)
+
+
+def test_trainer_in_rs_ag_mode_matches_plain_trainer():
+    """fp32 compute, fp32 wire, two identical ranks: the rs_ag trainer's parameters after 3 steps equal the plain trainer's (same seeds)."""
+    from b2s_hip.trainer import HipTrainer
+    res = []
+    for mode in ("plain", "rs_ag"):
+        torch.manual_seed(11)
+        m, cfg, _, hp = build(TINY96, compute_dtype="fp32")
+        b = dev_batch(synth.synthetic_batch(cfg, B=3, S=11, T=23, seed=7, in_lens=[11, 7, 4], tgt_lens=[23, 15, 9]))
+        m.train()
+        if mode == "plain":
+            tr = HipTrainer(m, hp)
+        else:
+            fd = _PeerDist()
+            tr = HipTrainer(m, hp, dist=fd, grad_payload="fp32", dp_mode="rs_ag", bucket_mb=0.08)
+            fd.trainer = tr
+            assert tr.bucketer.mode == "rs_ag" and len(tr.bucketer.plan()) > 2
+        try:
+            for _ in range(3):
+                v = tr.train_step(b)
+            torch.cuda.synchronize()
+            if mode == "rs_ag":
+                assert not tr.last_step_tail_update and fd.calls >= 3 * len(tr.bucketer.plan())
+        finally:
+            tr.close()
+        res.append(({k: t.detach().clone() for k, t in m.state_dict().items()}, v.cpu().numpy()))
+    for k, t in res[0][0].items():
+        if t.is_floating_point():
+            d = float((t.double() - res[1][0][k].double()).abs().max())
+            assert d <= 1e-5 * (1.0 + float(t.double().abs().max())), (k, d)
+    assert abs(res[0][1][0] - res[1][1][0]) < 1e-4 * abs(res[0][1][0])
