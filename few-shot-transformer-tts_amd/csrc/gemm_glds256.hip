@@ -441,6 +441,283 @@ __global__ __launch_bounds__(nthreads_of(false), 1) void gemm_glds256_grouped_ke
     gemm256_body<true, true, 0, NB>(grp.p[p], zero, nullptr, bx, by, bz);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Persistent variant for launches of MORE than one round of tiles (the step's N >= 2304 forms at M = 8148: 768 tiles of 256 x 96 / 128):
+// 256 workgroups, workgroup p walks tiles p, p + 256, p + 512 (the same XCD-aware tile list, so an XCD's 32 resident workgroups share the
+// operand panels they share in the plain launch).  The operand ring keeps rolling across the tile boundary -- the producer waves number
+// the K steps of all of the workgroup's tiles consecutively, so the next tile's first three stages are in flight while the MFMA waves
+// store the finished one -- and the epilogue is OFF the ring: a wave stages 16 rows x (NB * 16) columns of compute-dtype results at a
+// time through a private 2 KB slice of the 16 KB the ring leaves free (the plain kernel's epilogue takes 128 of the ring's 144 KB, which
+// is why it cannot overlap anything).  What a tile boundary costs is then the epilogue itself, not workgroup launch + address set-up +
+// a three-stage prologue.  Restricted to what the multi-round launches of the step are: plain K-contiguous A, K a multiple of 64, N a
+// multiple of the tile width, compute-dtype output, epilogue MODE 0 / 1 / 2 of gemm_epi.h (same arithmetic, same dropout indices).
+template <int NB, int MODE>
+__device__ __forceinline__ void epi_small(const EpiFast& e, const DropCfg dcfg, f32x4_t (&acc)[4][NB], unsigned stg, int mb, int nb, int lane) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int CH = NB * 2, TASKS = 16 * CH, TPL = (TASKS + 63) / 64;
+    const int li = lane & 15, lg = lane >> 4;
+    int trow[TPL], tch[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) { const int id = k * 64 + lane; trow[k] = id / CH; tch[k] = id - trow[k] * CH; }
+    u32x4 qa[MODE == 2 ? 4 : 1][MODE == 2 ? TPL : 1];
+    if (MODE == 2) {
+        const bf16_t* aux = reinterpret_cast<const bf16_t*>(e.relu_aux);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int k = 0; k < TPL; ++k) {
+                const int m = min(mb + a * 16 + trow[k], e.M - 1);              // (rows past M: clamped load, never stored)
+                qa[a][k] = *reinterpret_cast<const u32x4*>(aux + (long)m * e.ld_aux + nb + tch[k] * 8);
+            }
+    }
+    bf16_t* Ct = reinterpret_cast<bf16_t*>(e.C);
+    // staging address of this lane's element (row lg*4 + r, column b*16 + li): 16-byte chunk (2b + li/8) ^ 2 lg = 2 (b ^ lg) + li/8 -- one register per
+    // b, the row offset r * 128 is an immediate of the write (sixteen precomputed addresses cost the 128-column kernel its register budget: the compiler
+    // kept them in scratch and reloaded one before every write)
+    unsigned wa[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) wa[b] = stg + (unsigned)(lg * 512 + ((((b ^ lg) * 2 + (li >> 3)) << 4) | ((li & 7) << 1)));
+    // dropout: hash input of element (m, n) = (m N + n) C + key (b2s_keep) = x00 + (a*16 + r) (N C) [wave-uniform] + b*16 C [literal]
+    constexpr uint32_t HC = 0x9E3779B1u;
+    const uint32_t x00 = ((uint32_t)(mb + lg * 4) * (uint32_t)e.N + (uint32_t)(nb + li)) * HC + dcfg.key;
+    const uint32_t nc = (uint32_t)e.N * HC;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t xr = x00 + (uint32_t)(a * 16 + r) * nc;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float v = acc[a][b][r];
+                if (MODE == 1 || MODE == 3) v = fmaxf(v, 0.f);
+                if (MODE == 3) v = b2s_hash32(xr + (uint32_t)(b * 16) * HC) >= dcfg.thresh ? v * dcfg.scale : 0.f;      // ReLU + dropout
+                if (MODE == 2) v *= e.aux_scale;
+                const uint32_t h = f2bf2(v, 0.f);
+                asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(wa[b]), "v"(h), "n"(r * 128) : "memory");
+            }
+        }
+        // (same-wave LDS hand-off: DS operations of one wave complete in order)
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+            if (TASKS % 64 != 0 && k == TPL - 1 && k * 64 + lane >= TASKS) continue;
+            u32x4 o;
+            const unsigned off = (unsigned)(trow[k] * 128 + ((tch[k] ^ (((trow[k] >> 2) & 3) << 1)) << 4));
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(stg + off) : "memory");
+            if (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t w = qa[a][k][j];
+                    const uint32_t lo = (w & 0xffffu) != 0 && !(w & 0x8000u) ? 0xffffu : 0u;
+                    const uint32_t hi = (w >> 16) != 0 && !(w & 0x80000000u) ? 0xffff0000u : 0u;
+                    o[j] &= (lo | hi);
+                }
+            }
+            const int m = mb + a * 16 + trow[k];
+            if (m < e.M) *reinterpret_cast<u32x4*>(Ct + (long)m * e.ldc + nb + tch[k] * 8) = o;
+        }
+    }
+}
+
+template <bool TB, int NB>
+__global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_kernel(GemmArgs g, int tiles_m, int tiles_n, int mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NP = nprod_of(0, 4), NC = 8, STG = STAGE_BYTES, A_B = A_BYTES, BN = NB * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * (NB * 16);
+    const char* Ab = reinterpret_cast<const char*>(g.A.p);
+    const char* Bb = reinterpret_cast<const char*>(g.B.p);
+    const int total = tiles_m * tiles_n, G = gridDim.x;
+    const int ntile = (total - (int)blockIdx.x + G - 1) / G;
+    const int nk = g.K / BK;
+    const long S = (long)ntile * nk;                                  // K steps of this workgroup, over all of its tiles
+    auto tile_of = [&](int t, int& m0, int& n0) {
+        const int id = xcd_tile_id((int)blockIdx.x + t * G, total);  // (G is a multiple of 8: every tile of a workgroup is on its XCD's list)
+        int by, bx;
+        if (GROUP_M > 0 && tiles_n >= 16) {
+            const int gsz = GROUP_M * tiles_n, grp = id / gsz, in = id - grp * gsz;
+            const int rows = min(GROUP_M, tiles_m - grp * GROUP_M);
+            bx = in / rows; by = grp * GROUP_M + (in - bx * rows);
+        } else { by = id / tiles_n; bx = id - by * tiles_n; }
+        m0 = by * BM; n0 = bx * BN;
+    };
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem_raw;
+
+    if (wave >= NC) {
+        // ---- producer waves: one flat sequence of K steps over all tiles
+        constexpr int NBI = (NB == 4 || TB) ? 16 : 12, NIA = (BM / 8) / NP, NIB = NBI / NP, IPW = NIA + NIB;
+        const int iw = wave - NC, ia0 = iw * NIA, ib0 = iw * NIB;
+        const long stepA = 2L * BK, stepB = TB ? 2L * BK * g.B.ld : 2L * BK;        // bytes per K step
+        unsigned goffA[NIA], goffB[NIB];
+        auto set_tile = [&](int t) {
+            int m0, n0; tile_of(t, m0, n0);
+#pragma unroll
+            for (int i = 0; i < NIA; ++i) {
+                const LaneSrc s = lane_src<false, true>(ia0 + i, lane);
+                goffA[i] = 2u * (unsigned)((long)min(m0 + s.r, g.A.R - 1) * g.A.ld + s.c);
+            }
+#pragma unroll
+            for (int i = 0; i < NIB; ++i) {
+                const LaneSrc s = lane_src<TB, false>(ib0 + i, lane);
+                if (TB) goffB[i] = 2u * (unsigned)((long)s.r * g.B.ld + min(n0 + s.c, max(g.B.C - 8, 0)));
+                else    goffB[i] = 2u * (unsigned)((long)min(n0 + s.r, g.B.R - 1) * g.B.ld + s.c);
+            }
+        };
+        int pt = 0, pk = 0;
+        set_tile(0);
+        auto issue_next = [&](int slot) {
+            unsigned char* sbase = smem_raw + slot * STG;
+            const char* sa = Ab + pk * stepA;
+            const char* sb = Bb + pk * stepB;
+#pragma unroll
+            for (int i = 0; i < NIA; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(sa + goffA[i]), (lptr_t)(sbase + (ia0 + i) * 1024), 16, 0, B2S_DMA_AUX);
+#pragma unroll
+            for (int i = 0; i < NIB; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(sb + goffB[i]), (lptr_t)(sbase + A_B + (ib0 + i) * 1024), 16, 0, B2S_DMA_AUX);
+            if (++pk == nk) { pk = 0; if (++pt < ntile) set_tile(pt); }
+        };
+#pragma unroll
+        for (int p = 0; p < NSTAGE; ++p)
+            if (p < S) issue_next(p);
+        if (S >= 3) wait_vm<2 * IPW>(); else if (S == 2) wait_vm<IPW>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        int slot = 0;
+        for (long s = 0; s < S; ++s) {
+            if (s + 2 < S) wait_vm<IPW>(); else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (s + NSTAGE < S) issue_next(slot);
+            slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+        }
+        return;
+    }
+
+    // ---- MFMA waves
+    unsigned offA[2][4], offB[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = wrow + t * 16 + li;
+        offA[0][t] = (unsigned)(r * 128 + ((lg ^ swz_n(r)) << 4)); offA[1][t] = offA[0][t] ^ 64u;
+        if (TB) {
+            const int k = lg * 8 + (li >> 2), col = wcol + t * 16 + (li & 3) * 4, sw = ((li >> 2) | ((lg & 1) << 2)) << 1;
+            const unsigned o = (unsigned)A_B + 2u * (k * 128 + (((col >> 3) ^ sw) << 3) + (col & 7));
+            offB[0][t] = o; offB[1][t] = o + UNIT;
+        } else {
+            const int rb = wcol + t * 16 + li;
+            offB[0][t] = (unsigned)(A_B + rb * 128 + ((lg ^ swz_n(rb)) << 4)); offB[1][t] = offB[0][t] ^ 64u;
+        }
+    }
+    auto frag_issue = [&](bf16x8_t& dst, bool trans, unsigned addr) {
+        if (!trans) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+        } else {
+            bf16x4_t lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"
+                         : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
+            dst[0] = lo[0]; dst[1] = lo[1]; dst[2] = lo[2]; dst[3] = lo[3];
+            dst[4] = hi[0]; dst[5] = hi[1]; dst[6] = hi[2]; dst[7] = hi[3];
+        }
+    };
+#define B2S_MMA16(CA, CB)                                                                                         \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < NB; ++b)                  \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CA[a], CB[b], acc[a][b], 0, 0, 0);
+#define B2S_READ8(FA, FB, SLOT, H)                                                                                \
+    {                                                                                                              \
+        const unsigned sb_ = lds_base + (unsigned)((SLOT) * STG);                                                  \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                            \
+            frag_issue(FA[t], false, sb_ + offA[H][t]);                                                            \
+            if (t < NB) frag_issue(FB[t], TB, sb_ + offB[H][t]);                                                   \
+        }                                                                                                          \
+    }
+    const EpiFast ef = {g.C, g.ldc, g.M, g.N, nullptr, 0, g.epi.relu_aux, g.epi.ld_aux, g.epi.aux_scale, g.epi.drop, g.epi.drop_salt};
+    DropCfg dcfg = g.epi.drop;
+    if (dcfg.thresh && g.epi.drop_salt) dcfg.key ^= b2s_hash32((uint32_t)(*g.epi.drop_salt) * 2246822519u + 3266489917u);
+    const unsigned stg = lds_base + (unsigned)(NSTAGE * STG + wave * 2048);
+    f32x4_t acc[4][NB];
+    bf16x8_t fa0[4], fb0[4], fa1[4], fb1[4];
+    __builtin_amdgcn_s_barrier();                                      // stage 0 of the first tile has landed
+    int slot = 0;
+    for (int t = 0; t < ntile; ++t) {
+        int m0, n0; tile_of(t, m0, n0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        B2S_READ8(fa0, fb0, slot, 0)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+            B2S_READ8(fa1, fb1, slot, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            B2S_MMA16(fa0, fb0)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // (the last step of a tile reads the first half of the NEXT tile's stage 0 here and drops it: the loop body stays the tuned one,
+            // the epilogue below gets the registers)
+            B2S_READ8(fa0, fb0, nslot, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            B2S_MMA16(fa1, fb1)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            slot = nslot;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (mode == 0) epi_small<NB, 0>(ef, dcfg, acc, stg, m0 + wrow, n0 + wcol, lane);
+        else if (mode == 1 && !dcfg.thresh) epi_small<NB, 1>(ef, dcfg, acc, stg, m0 + wrow, n0 + wcol, lane);
+        else if (mode == 1) epi_small<NB, 3>(ef, dcfg, acc, stg, m0 + wrow, n0 + wcol, lane);
+        else epi_small<NB, 2>(ef, dcfg, acc, stg, m0 + wrow, n0 + wcol, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef B2S_READ8
+#undef B2S_MMA16
+}
+
+// which epilogue MODE of gemm_epi.h a launch takes when every wave is on the fast path (-1: none of 0 / 1 / 2)
+inline int persist_mode(const GemmArgs& g) {
+    const GemmEpilogue& e = g.epi;
+    if (g.c_fp32 || e.residual || e.bias || e.row_len || e.alpha != 1.f || e.kv_k || e.accumulate || e.conv_dw_cin || e.colstat) return -1;
+    if ((g.ldc & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.cs_o || g.cs_i) return -1;
+    if (!e.relu && !e.relu_aux && !e.drop.thresh) return 0;
+    if (e.relu && !e.relu_aux) return 1;
+    if (e.relu_aux && !e.relu && !e.drop.thresh && (e.ld_aux & 7) == 0 && (reinterpret_cast<uintptr_t>(e.relu_aux) & 15) == 0) return 2;
+    return -1;
+}
+#ifdef B2S_LAB
+static const int g_persist = getenv("B2S_LAB_GEMM_PERSIST") ? atoi(getenv("B2S_LAB_GEMM_PERSIST")) : 1;
+#else
+constexpr int g_persist = 1;
+#endif
+template <bool TB, int NB>
+int launch256_persist(const GemmArgs& g, int mode, hipStream_t stream) {
+    constexpr size_t smem = (size_t)NSTAGE * STAGE_BYTES + 8 * 2048;             // 144 KB ring + 16 KB of per-wave staging = the CU's 160 KB
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds256_persist_kernel<TB, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    B2S_HIP(attr_err);
+    const int tiles_m = cdiv(g.M, BM), tiles_n = g.N / (NB * 32);
+    hipLaunchKernelGGL((gemm_glds256_persist_kernel<TB, NB>), dim3(256), dim3(nthreads_of(0, 4)), smem, stream, g, tiles_m, tiles_n, mode);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
+// >= 0: launched (or failed) through the persistent kernel; -1: not eligible
+template <bool TA, bool TB, int GATHER, int NB>
+int try_persist(const GemmArgs& g, hipStream_t stream) {
+    if (TA || GATHER != 0 || !g_persist) return -1;
+    const long tiles = (long)cdiv(g.M, BM) * cdiv(g.N, NB * 32);
+    if (tiles <= 256 || g.batch != 1 || g.splitk != 1 || g.K < BK || g.K % BK != 0 || g.N % (NB * 32) != 0) return -1;
+    if ((long)g.A.R * g.A.ld >= (1L << 30) || (long)g.B.R * g.B.ld >= (1L << 30) || g.A.g_cin || g.B.g_cin) return -1;
+    if (TB && !(g.B.C >= 8 && (g.B.C & 7) == 0)) return -1;
+    const int mode = persist_mode(g);
+    if (mode < 0) return -1;
+    return launch256_persist<TB, NB>(g, mode, stream);
+}
+
 template <bool TA, bool TB, int GATHER, int NB, int MW = 4>
 int launch256_nb(const GemmArgs& g_in, const bf16_t* zero, hipStream_t stream) {
     GemmArgs g = g_in;
@@ -492,8 +769,11 @@ int launch256_t(const GemmArgs& g, const bf16_t* zero, hipStream_t stream) {
                            : launch256_nb<ta, TB, 0, 4, 2>(g, zero, stream);
         }
     }
-    return pick_nb(g) == 3 ? launch256_nb<TA, TB, GATHER, 3>(g, zero, stream)
-                           : launch256_nb<TA, TB, GATHER, 4>(g, zero, stream);
+    const int nb = pick_nb(g);
+    const int rc = nb == 3 ? try_persist<TA, TB, GATHER, 3>(g, stream) : try_persist<TA, TB, GATHER, 4>(g, stream);
+    if (rc >= 0) return rc;
+    return nb == 3 ? launch256_nb<TA, TB, GATHER, 3>(g, zero, stream)
+                   : launch256_nb<TA, TB, GATHER, 4>(g, zero, stream);
 }
 
 }  // namespace t256

@@ -317,6 +317,44 @@ def test_gemm_256_tile_kernel_all_forms(nb):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize("policy", [0, 4])
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("M,N,K", [(3000, 3072, 192), (2900, 2304, 64), (3333, 4608, 832)])
+def test_gemm_persistent_multi_round_kernel(policy, tb, M, N, K):
+    """Launches of more than one round of tiles (> 256 tiles of 256 x 96 / 128) take the persistent kernel (gemm_glds256.hip: one workgroup walks
+    several tiles, the operand ring rolls across the tile boundary, the epilogue is staged outside the ring).  Its compute-dtype results -- plain,
+    ReLU, ReLU + dropout -- must be BIT-identical to the plain kernel's arithmetic: the fp32 products of the same GEMM computed in row slices of one
+    round each (plain kernel, fp32 output), then ReLU / exported dropout mask / one rounding to bf16 on the host side."""
+    ops, lib = _ops()
+    l = lib.load()
+    torch.manual_seed(M + N + K + int(tb))
+    A = ops.to_compute(torch.randn(M, K, device=DEV), 1)
+    Bm = ops.to_compute(torch.randn(K, N, device=DEV) if tb else torch.randn(N, K, device=DEV), 1)
+    lib.check(l.b2s_gemm_set_tile_policy(policy))
+    try:
+        acc = torch.empty(M, N, device=DEV)
+        step = 512                                     # 2 row panels x <= 48 column panels: one round, plain kernel
+        for r0 in range(0, M, step):
+            r1 = min(M, r0 + step)
+            acc[r0:r1] = ops.gemm(1, A[r0:r1].contiguous(), Bm, r1 - r0, N, K, trans_b=tb, c_fp32=True)
+        p, seed = 0.2, 4242
+        mask = torch.empty(M * N, dtype=torch.uint8, device=DEV)
+        lib.check(l.b2s_dropout_mask(p, seed, 7, lib.ptr(mask), M * N, lib.stream()))
+        keep = mask.reshape(M, N).bool()
+        cases = {"plain": (dict(), acc),
+                 "relu": (dict(relu=True), acc.clamp_min(0)),
+                 "relu+dropout": (dict(relu=True, drop_p=p, seed=seed),
+                                  torch.where(keep, acc.clamp_min(0) * float(np.float32(1) / (np.float32(1) - np.float32(p))), torch.zeros_like(acc)))}
+        for what, (kw, want) in cases.items():
+            got = ops.gemm(1, A, Bm, M, N, K, trans_b=tb, c_fp32=False, **kw)
+            torch.cuda.synchronize()
+            want16 = want.to(torch.bfloat16).view(torch.int16)
+            bad = int((got != want16).sum())
+            assert bad == 0, (what, policy, tb, M, N, K, bad)
+    finally:
+        lib.check(l.b2s_gemm_set_tile_policy(0))
+
+
 @pytest.mark.parametrize("slabs", [True, False])
 def test_splitk_weight_gradient_gemms_on_two_streams(slabs):
     """Split-K slab workspaces belong to the caller, one per stream (GemmArgs::ws; the library owns none): two different
