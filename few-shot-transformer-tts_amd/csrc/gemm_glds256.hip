@@ -443,83 +443,98 @@ __global__ __launch_bounds__(nthreads_of(false), 1) void gemm_glds256_grouped_ke
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Persistent variant for launches of MORE than one round of tiles (the step's N >= 2304 forms at M = 8148: 768 tiles of 256 x 96 / 128):
-// 256 workgroups, workgroup p walks tiles p, p + 256, p + 512 (the same XCD-aware tile list, so an XCD's 32 resident workgroups share the
-// operand panels they share in the plain launch).  The operand ring keeps rolling across the tile boundary -- the producer waves number
+// 256 workgroups walk the (XCD-aware) tile list.  The operand ring keeps rolling across the tile boundary -- the producer waves number
 // the K steps of all of the workgroup's tiles consecutively, so the next tile's first three stages are in flight while the MFMA waves
-// store the finished one -- and the epilogue is OFF the ring: a wave stages 16 rows x (NB * 16) columns of compute-dtype results at a
-// time through a private 2 KB slice of the 16 KB the ring leaves free (the plain kernel's epilogue takes 128 of the ring's 144 KB, which
-// is why it cannot overlap anything).  What a tile boundary costs is then the epilogue itself, not workgroup launch + address set-up +
-// a three-stage prologue.  Restricted to what the multi-round launches of the step are: plain K-contiguous A, K a multiple of 64, N a
-// multiple of the tile width, compute-dtype output, epilogue MODE 0 / 1 / 2 of gemm_epi.h (same arithmetic, same dropout indices).
-template <int NB, int MODE>
+// store the finished one -- and the epilogue is OFF the ring: a wave stages 8 rows x (NB * 16) columns of compute-dtype results at a
+// time through a private 1 KB slice behind the ring (the plain kernel's epilogue takes 128 of the ring's 144 KB, which is why it cannot
+// overlap anything).  What a tile boundary costs is then the epilogue itself, not workgroup launch + address set-up + a three-stage
+// prologue (8148 x 2304 x 768: 43.6 -> 32.6 us).
+// Which tiles a workgroup walks: its first two are static (workgroup p -> list positions p and p + 256, as in the plain launch), every further
+// one is a TICKET drawn from a per-XCD counter (XCD x hands out positions x + 8 j of the list, j = 64, 65, ...), so workgroups that could not
+// be placed right away -- a CU held by a weight-gradient tile of the second stream or by a collective's channel -- leave their share to
+// the ones that are running instead of starting a three-tile walk late.  Producer wave 0 draws the tickets (one atomic, two tiles ahead,
+// its result consumed two K steps later, behind the counted waits) and hands them to the other waves through a 4-entry LDS queue.
+// Restricted to what the multi-round launches of the step are: plain K-contiguous A, K a multiple of 64 and >= 384, N a multiple of the
+// tile width, compute-dtype output, epilogue MODE 0 / 1 / 2 of gemm_epi.h (same arithmetic, same dropout indices: bit-identical results).
+constexpr int PST_STG = NSTAGE * STAGE_BYTES, PST_TQ = PST_STG + 8 * 1024, PST_LDS = PST_TQ + 64;
+constexpr int PST_END = 0x7fffffff;
+
+// The persistent kernel feeds the MFMA with its operands swapped (B fragment first): the products and their summation order are the same, but a
+// lane then holds FOUR CONSECUTIVE COLUMNS of one row -- acc[a][b][j] = C[a*16 + li][b*16 + lg*4 + j] -- so the staging writes are 8 bytes wide
+// (32 per tile and wave instead of 64 two-byte ones) and the dropout index of an element is one add away from its neighbour's.
+template <int NB, int MODE>   // MODE: 0 plain, 1 ReLU, 2 ReLU mask of relu_aux, 3 ReLU + dropout
 __device__ __forceinline__ void epi_small(const EpiFast& e, const DropCfg dcfg, f32x4_t (&acc)[4][NB], unsigned stg, int mb, int nb, int lane) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int CH = NB * 2, TASKS = 16 * CH, TPL = (TASKS + 63) / 64;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int CH = NB * 2, TASKS = 8 * CH;                        // one pass = 8 rows: 64 (48) tasks of one 16-byte chunk, <= 1 per lane
     const int li = lane & 15, lg = lane >> 4;
-    int trow[TPL], tch[TPL];
-#pragma unroll
-    for (int k = 0; k < TPL; ++k) { const int id = k * 64 + lane; trow[k] = id / CH; tch[k] = id - trow[k] * CH; }
-    u32x4 qa[MODE == 2 ? 4 : 1][MODE == 2 ? TPL : 1];
+    const int trow = lane / CH, tch = lane - trow * CH;
+    const bool tvalid = lane < TASKS;
+    u32x4 qa[MODE == 2 ? 8 : 1];
     if (MODE == 2) {
         const bf16_t* aux = reinterpret_cast<const bf16_t*>(e.relu_aux);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int k = 0; k < TPL; ++k) {
-                const int m = min(mb + a * 16 + trow[k], e.M - 1);              // (rows past M: clamped load, never stored)
-                qa[a][k] = *reinterpret_cast<const u32x4*>(aux + (long)m * e.ld_aux + nb + tch[k] * 8);
-            }
+        for (int ps = 0; ps < 8; ++ps) {
+            const int m = min(mb + ps * 8 + min(trow, 7), e.M - 1);              // (rows past M: clamped load, never stored)
+            qa[ps] = *reinterpret_cast<const u32x4*>(aux + (long)m * e.ld_aux + nb + min(tch, CH - 1) * 8);
+        }
     }
     bf16_t* Ct = reinterpret_cast<bf16_t*>(e.C);
-    // staging address of this lane's element (row lg*4 + r, column b*16 + li): 16-byte chunk (2b + li/8) ^ 2 lg = 2 (b ^ lg) + li/8 -- one register per
-    // b, the row offset r * 128 is an immediate of the write (sixteen precomputed addresses cost the 128-column kernel its register budget: the compiler
-    // kept them in scratch and reloaded one before every write)
-    unsigned wa[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) wa[b] = stg + (unsigned)(lg * 512 + ((((b ^ lg) * 2 + (li >> 3)) << 4) | ((li & 7) << 1)));
-    // dropout: hash input of element (m, n) = (m N + n) C + key (b2s_keep) = x00 + (a*16 + r) (N C) [wave-uniform] + b*16 C [literal]
+    // staging slice: 8 rows x 128 bytes, 16-byte chunk c of row r at chunk c ^ r (32 active lanes x 8 bytes = every bank once).  This lane's
+    // four columns b*16 + lg*4 .. + 3 of pass row li & 7 are the (lg & 1) half of chunk 2b + lg/2: one address register, b*32 is XORed in -- the
+    // XOR of a multiple of 32 commutes with the row swizzle, so it is (address ^ b*32), a compile-time constant per b
+    const unsigned wa0 = stg + (unsigned)((li & 7) * 128 + ((((lg >> 1) ^ (li & 7)) << 4) | ((lg & 1) << 3)));
+    const unsigned ra = stg + (unsigned)(trow * 128 + ((tch ^ (trow & 7)) << 4));
+    // dropout: hash input of element (m, n) = (m N + n) C + key (b2s_keep) = x00 + a*16 (N C) [wave-uniform] + (b*16 + j) C [literal]
     constexpr uint32_t HC = 0x9E3779B1u;
-    const uint32_t x00 = ((uint32_t)(mb + lg * 4) * (uint32_t)e.N + (uint32_t)(nb + li)) * HC + dcfg.key;
+    const uint32_t x00 = ((uint32_t)(mb + li) * (uint32_t)e.N + (uint32_t)(nb + lg * 4)) * HC + dcfg.key;
     const uint32_t nc = (uint32_t)e.N * HC;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
+        u32x2 pk[NB];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t xr = x00 + (uint32_t)(a * 16 + r) * nc;
+        for (int b = 0; b < NB; ++b) {
+            float v[4];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                float v = acc[a][b][r];
-                if (MODE == 1 || MODE == 3) v = fmaxf(v, 0.f);
-                if (MODE == 3) v = b2s_hash32(xr + (uint32_t)(b * 16) * HC) >= dcfg.thresh ? v * dcfg.scale : 0.f;      // ReLU + dropout
-                if (MODE == 2) v *= e.aux_scale;
-                const uint32_t h = f2bf2(v, 0.f);
-                asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(wa[b]), "v"(h), "n"(r * 128) : "memory");
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[a][b][j];
+                if (MODE == 1 || MODE == 3) v[j] = fmaxf(v[j], 0.f);
+                if (MODE == 3) v[j] = b2s_hash32(x00 + (uint32_t)(a * 16) * nc + (uint32_t)(b * 16 + j) * HC) >= dcfg.thresh ? v[j] * dcfg.scale : 0.f;
+                if (MODE == 2) v[j] *= e.aux_scale;
             }
+            pk[b][0] = f2bf2(v[0], v[1]); pk[b][1] = f2bf2(v[2], v[3]);
         }
-        // (same-wave LDS hand-off: DS operations of one wave complete in order)
 #pragma unroll
-        for (int k = 0; k < TPL; ++k) {
-            if (TASKS % 64 != 0 && k == TPL - 1 && k * 64 + lane >= TASKS) continue;
-            u32x4 o;
-            const unsigned off = (unsigned)(trow[k] * 128 + ((tch[k] ^ (((trow[k] >> 2) & 3) << 1)) << 4));
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(stg + off) : "memory");
-            if (MODE == 2) {
+        for (int h = 0; h < 2; ++h) {
+            if ((li >> 3) == h) {                                     // rows a*16 + h*8 .. + 7 belong to the lanes with li / 8 == h
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t w = qa[a][k][j];
-                    const uint32_t lo = (w & 0xffffu) != 0 && !(w & 0x8000u) ? 0xffffu : 0u;
-                    const uint32_t hi = (w >> 16) != 0 && !(w & 0x80000000u) ? 0xffff0000u : 0u;
-                    o[j] &= (lo | hi);
+                for (int b = 0; b < NB; ++b) {
+                    const unsigned wa = wa0 ^ (unsigned)(b * 32);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(wa), "v"(pk[b]) : "memory");
                 }
             }
-            const int m = mb + a * 16 + trow[k];
-            if (m < e.M) *reinterpret_cast<u32x4*>(Ct + (long)m * e.ldc + nb + tch[k] * 8) = o;
+            // (same-wave LDS hand-off: DS operations of one wave complete in order)
+            if (tvalid) {
+                u32x4 o;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(ra) : "memory");
+                if (MODE == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t w = qa[a * 2 + h][j];
+                        const uint32_t lo = (w & 0xffffu) != 0 && !(w & 0x8000u) ? 0xffffu : 0u;
+                        const uint32_t hi = (w >> 16) != 0 && !(w & 0x80000000u) ? 0xffff0000u : 0u;
+                        o[j] &= (lo | hi);
+                    }
+                }
+                const int m = mb + a * 16 + h * 8 + trow;
+                if (m < e.M) *reinterpret_cast<u32x4*>(Ct + (long)m * e.ldc + nb + tch * 8) = o;
+            }
         }
     }
 }
 
 template <bool TB, int NB>
-__global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_kernel(GemmArgs g, int tiles_m, int tiles_n, int mode) {
+__global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_kernel(GemmArgs g, int tiles_m, int tiles_n, int mode, int* tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NP = nprod_of(0, 4), NC = 8, STG = STAGE_BYTES, A_B = A_BYTES, BN = NB * 32;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -528,12 +543,11 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
     const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * (NB * 16);
     const char* Ab = reinterpret_cast<const char*>(g.A.p);
     const char* Bb = reinterpret_cast<const char*>(g.B.p);
-    const int total = tiles_m * tiles_n, G = gridDim.x;
-    const int ntile = (total - (int)blockIdx.x + G - 1) / G;
+    const int total = tiles_m * tiles_n, G = gridDim.x, xcd = (int)blockIdx.x & 7;
     const int nk = g.K / BK;
-    const long S = (long)ntile * nk;                                  // K steps of this workgroup, over all of its tiles
-    auto tile_of = [&](int t, int& m0, int& n0) {
-        const int id = xcd_tile_id((int)blockIdx.x + t * G, total);  // (G is a multiple of 8: every tile of a workgroup is on its XCD's list)
+    // position v of the XCD-aware list -> tile origin
+    auto tile_at = [&](int v, int& m0, int& n0) {
+        const int id = xcd_tile_id(v, total);
         int by, bx;
         if (GROUP_M > 0 && tiles_n >= 16) {
             const int gsz = GROUP_M * tiles_n, grp = id / gsz, in = id - grp * gsz;
@@ -543,15 +557,29 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
         m0 = by * BM; n0 = bx * BN;
     };
     const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem_raw;
+    // T[t]: list position of this workgroup's t-th tile (PST_END: none).  T[0] = blockIdx.x; without a ticket buffer T[t] = blockIdx.x + t G.
+    // The queue entry of T[t], t >= 1, is written by producer wave 0 at least two workgroup barriers before anybody reads it.
+    // (explicit DS instructions: through a generic pointer the compiler emits FLAT accesses, which count on vmcnt and drain the producers' DMA queue)
+    const unsigned tq = lds_base + (unsigned)PST_TQ;
+    auto tq_put = [&](int t, int val) {       // one lane
+        asm volatile("ds_write_b32 %0, %1" ::"v"(tq + (unsigned)((t & 3) * 4)), "v"(val) : "memory");
+    };
+    auto queued = [&](int t) -> int {
+        if (!tickets || t < 2) { const int v = (int)blockIdx.x + t * G; return v < total ? v : PST_END; }
+        int val;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(val) : "v"(tq + (unsigned)((t & 3) * 4)) : "memory");
+        return __builtin_amdgcn_readfirstlane(val);
+    };
 
     if (wave >= NC) {
         // ---- producer waves: one flat sequence of K steps over all tiles
         constexpr int NBI = (NB == 4 || TB) ? 16 : 12, NIA = (BM / 8) / NP, NIB = NBI / NP, IPW = NIA + NIB;
         const int iw = wave - NC, ia0 = iw * NIA, ib0 = iw * NIB;
+        const bool drawer = tickets && iw == 0;
         const long stepA = 2L * BK, stepB = TB ? 2L * BK * g.B.ld : 2L * BK;        // bytes per K step
         unsigned goffA[NIA], goffB[NIB];
-        auto set_tile = [&](int t) {
-            int m0, n0; tile_of(t, m0, n0);
+        auto set_tile = [&](int v) {
+            int m0, n0; tile_at(v, m0, n0);
 #pragma unroll
             for (int i = 0; i < NIA; ++i) {
                 const LaneSrc s = lane_src<false, true>(ia0 + i, lane);
@@ -564,8 +592,33 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
                 else    goffB[i] = 2u * (unsigned)((long)min(n0 + s.r, g.B.R - 1) * g.B.ld + s.c);
             }
         };
+        // ticket draw (drawer wave, lane 0): an atomic whose result register is read two K steps later -- the counted waits of the steps in
+        // between (loads return in order, the atomic is older than the loads they leave in flight) have retired it by then
+        int tk_raw = 0;                   // j of the draw in flight
+        int tk_for = -1;                  // ... and the tile index t it is for (-1: none)
+        int tk_age = 0;
+        bool drew_end = false;
+        auto draw = [&](int t) {
+            if (!drawer || drew_end) return;
+            if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(tk_raw) : "v"(tickets + xcd), "v"(1) : "memory");
+            tk_for = t; tk_age = 0;
+        };
+        auto land = [&]() {               // called once per K step
+            if (!drawer || tk_for < 0) return;
+            if (++tk_age < 2) return;
+            const int j = __builtin_amdgcn_readfirstlane(tk_raw);
+            const int v = xcd + 8 * (2 * (G / 8) + j);
+            const int val = v < total ? v : PST_END;
+            if (val == PST_END) drew_end = true;
+            if (lane == 0) tq_put(tk_for, val);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tk_for = -1;
+        };
         int pt = 0, pk = 0;
-        set_tile(0);
+        bool more = true;                 // a stage is left to issue
+        set_tile((int)blockIdx.x);
+        if (drawer && (int)blockIdx.x + G < total) draw(2);      // (T[0], T[1] are static; no third tile without a second one)
+        int issued = 0;
         auto issue_next = [&](int slot) {
             unsigned char* sbase = smem_raw + slot * STG;
             const char* sa = Ab + pk * stepA;
@@ -576,19 +629,35 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
 #pragma unroll
             for (int i = 0; i < NIB; ++i)
                 __builtin_amdgcn_global_load_lds((gptr_t)(sb + goffB[i]), (lptr_t)(sbase + A_B + (ib0 + i) * 1024), 16, 0, B2S_DMA_AUX);
-            if (++pk == nk) { pk = 0; if (++pt < ntile) set_tile(pt); }
+            ++issued;
+            if (++pk == nk) {
+                pk = 0; ++pt;
+                const int v = queued(pt);
+                if (v == PST_END) more = false;
+                else { set_tile(v); if (pt >= 1) draw(pt + 2); }
+            }
         };
+        // (nk >= 6: the three prologue stages are all of tile 0, and T[1] is in the queue long before the first wrap)
 #pragma unroll
-        for (int p = 0; p < NSTAGE; ++p)
-            if (p < S) issue_next(p);
-        if (S >= 3) wait_vm<2 * IPW>(); else if (S == 2) wait_vm<IPW>(); else wait_vm<0>();
+        for (int p = 0; p < NSTAGE; ++p) issue_next(p);
+        wait_vm<2 * IPW>();
         __builtin_amdgcn_s_barrier();
         int slot = 0;
-        for (long s = 0; s < S; ++s) {
-            if (s + 2 < S) wait_vm<IPW>(); else wait_vm<0>();
+        for (int s = 0; s < issued; ++s) {
+            if (issued - s >= 3) wait_vm<IPW>(); else wait_vm<0>();          // stage s + 1 landed (stage s + 2 may still fly)
+            land();
             __builtin_amdgcn_s_barrier();
-            if (s + NSTAGE < S) issue_next(slot);
+            if (more) issue_next(slot);
             slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+        }
+        if (drawer && lane == 0) {
+            // the last workgroup to get here (every drawer has seen the end of its XCD's list by now) re-arms the counters for the launch
+            // that uses this set next (csrc: a pool of sets handed out round-robin)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (atomicAdd(tickets + 8, 1) == G - 1) {
+#pragma unroll
+                for (int x = 0; x < 9; ++x) tickets[x] = 0;
+            }
         }
         return;
     }
@@ -621,7 +690,7 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
     };
 #define B2S_MMA16(CA, CB)                                                                                         \
     _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < NB; ++b)                  \
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CA[a], CB[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CB[b], CA[a], acc[a][b], 0, 0, 0);     /* operands swapped: epi_small */
 #define B2S_READ8(FA, FB, SLOT, H)                                                                                \
     {                                                                                                              \
         const unsigned sb_ = lds_base + (unsigned)((SLOT) * STG);                                                  \
@@ -633,13 +702,14 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
     const EpiFast ef = {g.C, g.ldc, g.M, g.N, nullptr, 0, g.epi.relu_aux, g.epi.ld_aux, g.epi.aux_scale, g.epi.drop, g.epi.drop_salt};
     DropCfg dcfg = g.epi.drop;
     if (dcfg.thresh && g.epi.drop_salt) dcfg.key ^= b2s_hash32((uint32_t)(*g.epi.drop_salt) * 2246822519u + 3266489917u);
-    const unsigned stg = lds_base + (unsigned)(NSTAGE * STG + wave * 2048);
+    const unsigned stg = lds_base + (unsigned)(PST_STG + wave * 1024);
     f32x4_t acc[4][NB];
     bf16x8_t fa0[4], fb0[4], fa1[4], fb1[4];
     __builtin_amdgcn_s_barrier();                                      // stage 0 of the first tile has landed
     int slot = 0;
-    for (int t = 0; t < ntile; ++t) {
-        int m0, n0; tile_of(t, m0, n0);
+    int v = (int)blockIdx.x;
+    for (int t = 0; v != PST_END; ++t) {
+        int m0, n0; tile_at(v, m0, n0);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -666,6 +736,7 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
             slot = nslot;
         }
         __builtin_amdgcn_sched_barrier(0);
+        v = queued(t + 1);                                             // (written two or more barriers ago)
         if (mode == 0) epi_small<NB, 0>(ef, dcfg, acc, stg, m0 + wrow, n0 + wcol, lane);
         else if (mode == 1 && !dcfg.thresh) epi_small<NB, 1>(ef, dcfg, acc, stg, m0 + wrow, n0 + wcol, lane);
         else if (mode == 1) epi_small<NB, 3>(ef, dcfg, acc, stg, m0 + wrow, n0 + wcol, lane);
@@ -691,9 +762,23 @@ static const int g_persist = getenv("B2S_LAB_GEMM_PERSIST") ? atoi(getenv("B2S_L
 #else
 constexpr int g_persist = 1;
 #endif
+// Ticket counters of the persistent launches: a pool of 64 sets (8 per-XCD counters + 1 arrival counter each, 64 bytes apart), zeroed once and
+// re-armed by the last workgroup of every launch that used a set; sets go round-robin, so a set is next used 64 persistent launches later --
+// far more than can be in flight on the streams of a process.  Device memory of the process, like the zero page.
+int* persist_ticket_set() {
+    static int* pool = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* p = nullptr;
+        if (hipMalloc(&p, 64 * 64) == hipSuccess && hipMemset(p, 0, 64 * 64) == hipSuccess) pool = (int*)p;
+        else (void)hipGetLastError();               // (no pool: static tile assignment)
+    });
+    static std::atomic<unsigned> next{0};
+    return pool ? pool + (next.fetch_add(1, std::memory_order_relaxed) & 63u) * 16 : nullptr;
+}
 template <bool TB, int NB>
 int launch256_persist(const GemmArgs& g, int mode, hipStream_t stream) {
-    constexpr size_t smem = (size_t)NSTAGE * STAGE_BYTES + 8 * 2048;             // 144 KB ring + 16 KB of per-wave staging = the CU's 160 KB
+    constexpr size_t smem = PST_LDS;               // 144 KB ring + 8 KB of per-wave staging + the ticket queue
     static std::once_flag attr_once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(attr_once, [] {
@@ -701,7 +786,8 @@ int launch256_persist(const GemmArgs& g, int mode, hipStream_t stream) {
     });
     B2S_HIP(attr_err);
     const int tiles_m = cdiv(g.M, BM), tiles_n = g.N / (NB * 32);
-    hipLaunchKernelGGL((gemm_glds256_persist_kernel<TB, NB>), dim3(256), dim3(nthreads_of(0, 4)), smem, stream, g, tiles_m, tiles_n, mode);
+    int* tickets = g_persist == 2 ? nullptr : persist_ticket_set();
+    hipLaunchKernelGGL((gemm_glds256_persist_kernel<TB, NB>), dim3(256), dim3(nthreads_of(0, 4)), smem, stream, g, tiles_m, tiles_n, mode, tickets);
     B2S_LAUNCH_CHECK();
     return 0;
 }
@@ -710,7 +796,7 @@ template <bool TA, bool TB, int GATHER, int NB>
 int try_persist(const GemmArgs& g, hipStream_t stream) {
     if (TA || GATHER != 0 || !g_persist) return -1;
     const long tiles = (long)cdiv(g.M, BM) * cdiv(g.N, NB * 32);
-    if (tiles <= 256 || g.batch != 1 || g.splitk != 1 || g.K < BK || g.K % BK != 0 || g.N % (NB * 32) != 0) return -1;
+    if (tiles <= 256 || tiles >= (1 << 24) || g.batch != 1 || g.splitk != 1 || g.K < 6 * BK || g.K % BK != 0 || g.N % (NB * 32) != 0) return -1;
     if ((long)g.A.R * g.A.ld >= (1L << 30) || (long)g.B.R * g.B.ld >= (1L << 30) || g.A.g_cin || g.B.g_cin) return -1;
     if (TB && !(g.B.C >= 8 && (g.B.C & 7) == 0)) return -1;
     const int mode = persist_mode(g);

@@ -319,7 +319,7 @@ def test_gemm_256_tile_kernel_all_forms(nb):
 
 @pytest.mark.parametrize("policy", [0, 4])
 @pytest.mark.parametrize("tb", [False, True])
-@pytest.mark.parametrize("M,N,K", [(3000, 3072, 192), (2900, 2304, 64), (3333, 4608, 832)])
+@pytest.mark.parametrize("M,N,K", [(3000, 3072, 384), (2900, 2304, 64), (3333, 4608, 832)])
 def test_gemm_persistent_multi_round_kernel(policy, tb, M, N, K):
     """Launches of more than one round of tiles (> 256 tiles of 256 x 96 / 128) take the persistent kernel (gemm_glds256.hip: one workgroup walks
     several tiles, the operand ring rolls across the tile boundary, the epilogue is staged outside the ring).  Its compute-dtype results -- plain,
