@@ -759,8 +759,12 @@ inline int persist_mode(const GemmArgs& g) {
 }
 #ifdef B2S_LAB
 static const int g_persist = getenv("B2S_LAB_GEMM_PERSIST") ? atoi(getenv("B2S_LAB_GEMM_PERSIST")) : 1;
+static const int g_persist_min = getenv("B2S_LAB_GEMM_PERSIST_MIN") ? atoi(getenv("B2S_LAB_GEMM_PERSIST_MIN")) : 1;      // fewest tiles of a persistent launch
 #else
 constexpr int g_persist = 1;
+// one-round launches take the kernel too (one tile per workgroup: its epilogue has no workgroup barrier and half the staging instructions;
+// step 7.34 -> 7.29 ms, three interleaved rounds)
+constexpr int g_persist_min = 1;
 #endif
 // Ticket counters of the persistent launches: a pool of 64 sets (8 per-XCD counters + 1 arrival counter each, 64 bytes apart), zeroed once and
 // re-armed by the last workgroup of every launch that used a set; sets go round-robin, so a set is next used 64 persistent launches later --
@@ -787,7 +791,8 @@ int launch256_persist(const GemmArgs& g, int mode, hipStream_t stream) {
     B2S_HIP(attr_err);
     const int tiles_m = cdiv(g.M, BM), tiles_n = g.N / (NB * 32);
     int* tickets = g_persist == 2 ? nullptr : persist_ticket_set();
-    hipLaunchKernelGGL((gemm_glds256_persist_kernel<TB, NB>), dim3(256), dim3(nthreads_of(0, 4)), smem, stream, g, tiles_m, tiles_n, mode, tickets);
+    const int grid = std::min(256, tiles_m * tiles_n);             // (a multiple of 8: try_persist)
+    hipLaunchKernelGGL((gemm_glds256_persist_kernel<TB, NB>), dim3(grid), dim3(nthreads_of(0, 4)), smem, stream, g, tiles_m, tiles_n, mode, tickets);
     B2S_LAUNCH_CHECK();
     return 0;
 }
@@ -796,7 +801,7 @@ template <bool TA, bool TB, int GATHER, int NB>
 int try_persist(const GemmArgs& g, hipStream_t stream) {
     if (TA || GATHER != 0 || !g_persist) return -1;
     const long tiles = (long)cdiv(g.M, BM) * cdiv(g.N, NB * 32);
-    if (tiles <= 256 || tiles >= (1 << 24) || g.batch != 1 || g.splitk != 1 || g.K < 6 * BK || g.K % BK != 0 || g.N % (NB * 32) != 0) return -1;
+    if (tiles < g_persist_min || (tiles < 256 && (tiles & 7)) || tiles >= (1 << 24) || g.batch != 1 || g.splitk != 1 || g.K < 6 * BK || g.K % BK != 0 || g.N % (NB * 32) != 0) return -1;
     if ((long)g.A.R * g.A.ld >= (1L << 30) || (long)g.B.R * g.B.ld >= (1L << 30) || g.A.g_cin || g.B.g_cin) return -1;
     if (TB && !(g.B.C >= 8 && (g.B.C & 7) == 0)) return -1;
     const int mode = persist_mode(g);

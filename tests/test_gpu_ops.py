@@ -319,9 +319,9 @@ def test_gemm_256_tile_kernel_all_forms(nb):
 
 @pytest.mark.parametrize("policy", [0, 4])
 @pytest.mark.parametrize("tb", [False, True])
-@pytest.mark.parametrize("M,N,K", [(3000, 3072, 384), (2900, 2304, 64), (3333, 4608, 832)])
+@pytest.mark.parametrize("M,N,K", [(3000, 3072, 384), (2900, 2304, 64), (3333, 4608, 832), (1000, 768, 512), (2040, 1536, 448)])
 def test_gemm_persistent_multi_round_kernel(policy, tb, M, N, K):
-    """Launches of more than one round of tiles (> 256 tiles of 256 x 96 / 128) take the persistent kernel (gemm_glds256.hip: one workgroup walks
+    """Launches with a compute-dtype output and K >= 384 -- several rounds of tiles (> 256 tiles of 256 x 96 / 128) or a single one -- take the persistent kernel (gemm_glds256.hip: one workgroup walks
     several tiles, the operand ring rolls across the tile boundary, the epilogue is staged outside the ring).  Its compute-dtype results -- plain,
     ReLU, ReLU + dropout -- must be BIT-identical to the plain kernel's arithmetic: the fp32 products of the same GEMM computed in row slices of one
     round each (plain kernel, fp32 output), then ReLU / exported dropout mask / one rounding to bf16 on the host side."""

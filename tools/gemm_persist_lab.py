@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 l = L.load()
 M = 8148
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for what, N, K, tb in (("qkv", 2304, 768, False), ("ffn-in", 3072, 768, False), ("dX ffn-out", 3072, 768, True)):
+for what, N, K, tb in (("q / out", 768, 768, False), ("dX q / out", 768, 768, True), ("dX qkv", 768, 2304, True), ("qkv", 2304, 768, False), ("ffn-in", 3072, 768, False), ("dX ffn-out", 3072, 768, True)):
     A = ops.to_compute(torch.randn(M, K, device=dev), 1)
     B = ops.to_compute(torch.randn(K, N, device=dev) if tb else torch.randn(N, K, device=dev), 1)
     out = torch.empty(M, N, dtype=torch.int16, device=dev)

@@ -5,7 +5,7 @@ tag=$1; shift
 repo=$PWD; out=$repo/gpurun_out; mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o t -- python $repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass --no-extras > $out/${tag}_prof.log 2>&1
+env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o t -- python $repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass --no-extras $KS_ARGS > $out/${tag}_prof.log 2>&1
 cd $repo
 f=$(find $out/${tag}_prof -name "*kernel_stats.csv" | head -1)
 cp $f $out/${tag}_kernel_stats.csv
