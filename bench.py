@@ -277,7 +277,9 @@ def main():
             tf = lambda x: "true" if x else "false"
             if dt:                  # 256-row tile kernel, 128- or 96-column variant chosen per shape (NB = 4 | 3)
                 # NB = 3 | 4 (96- / 128-column tiles), MW = 4 | 2 (256- / 128-row tiles), G = 1 | 2 (conv gather)
-                return "t256::gemm_glds256_kernel<%s, %s, %s, NB, MW>" % (tf(ta), tf(tb), "G" if ga else "0")
+                # (plain K-contiguous A with a compute-dtype output: the persistent kernel of the same form, gemm_glds256.hip)
+                base = "t256::gemm_glds256_kernel<%s, %s, %s, NB, MW>" % (tf(ta), tf(tb), "G" if ga else "0")
+                return base if (ta or ga) else base + " + t256::gemm_glds256_persist_kernel<%s, NB>" % tf(tb)
             return "gemm_kernel<float, %s, %s>%s" % (tf(ta), tf(tb), " (conv gather)" if ga else "")
         names = {v: kname(v) for v in range(16)}
         names[16] = "t256::gemm_glds256_grouped_kernel<4>"     # one launch = the weight gradients of one backward stage
@@ -299,8 +301,8 @@ def main():
         from bench_decode import load_pmc
         pmc, pmc_commit, pmc_rows = load_pmc("train_bf16_pmc_hbm_traffic_mfma.json")
         if pmc and args.dtype == "bf16" and args.mode == "train" and args.workload == "lj" and (B, S, T) == (14, 114, 582):
-            pre = dom["kernel"].split(", NB, MW>")[0].replace(", G", ", ")
-            rows = [r for r in pmc_rows if r["kernel"].startswith(pre)]
+            pres = [k.split(", NB")[0].replace(", G", ", ") for k in dom["kernel"].split(" + ")]
+            rows = [r for r in pmc_rows if any(r["kernel"].startswith(pre) for pre in pres)]
             traffic_source = "profiles/%s @ commit %s (committed rocprofv3 --pmc run, not measured in this process)" % (pmc, pmc_commit)
             n = sum(r["launches"] for r in rows)
             if n:

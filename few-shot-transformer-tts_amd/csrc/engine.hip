@@ -1680,8 +1680,13 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
     // tail policy (engine.h: dw_hold_from): B2S_DW_TAIL_LAYERS decoder layers' (and the prenet's) weight-gradient groups wait for the end
     // of this call and are launched capped at B2S_DW_TAIL_CAP workgroups, beside the encoder backward on the caller's other stream
     // (measured, profiles/NOTES_r03.md: 2 layers / 200 tiles: 8.04 -> 7.88 ms; 1 layer 7.95; 4 layers 7.98; caps <= 176 lose what the holding wins)
-    constexpr int tail_layers = 2;
+#ifdef B2S_LAB
+    static const int tail_layers = getenv("B2S_LAB_DW_TAIL_LAYERS") ? atoi(getenv("B2S_LAB_DW_TAIL_LAYERS")) : 1;
+    static const int tail_cap = getenv("B2S_LAB_DW_TAIL_CAP") ? atoi(getenv("B2S_LAB_DW_TAIL_CAP")) : 200;
+#else
+    constexpr int tail_layers = 1;      // (re-measured with the persistent GEMM kernel, round 5: 2 layers 7.30, 1 layer 7.25, none 7.35-7.38 ms on the slower box pair)
     constexpr int tail_cap = 200;
+#endif
     m->dw_hold_from = -1; m->dw_tail_cap = 0;
     // (whatever way this call is left -- a failing B2S_TRY included -- the tail policy does not outlive it: a following stand-alone
     // b2s_encoder_backward must not find its stages held)
@@ -2072,7 +2077,11 @@ extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta
     // behind the mark the update runs beside the encoder backward (on its own stream) and the last weight-gradient groups: a grid capped
     // at 512 workgroups -- the full one saturates HBM and the latency-bound encoder kernels take 3-4x as long while it runs (measured,
     // profiles/NOTES_r04.md: caps 64 / 128 / 256 / 384 / 512 / 768 / 1024: 7.98 / 7.54 / 7.46 / 7.44 / 7.39 / 7.39 / 7.46 ms per step)
+#ifdef B2S_LAB
+    static const int kTailWorkgroups = getenv("B2S_LAB_TAIL_ADAM_WG") ? atoi(getenv("B2S_LAB_TAIL_ADAM_WG")) : 512;
+#else
     constexpr int kTailWorkgroups = 512;
+#endif
     for (int k = 0; k < 3; ++k) {
         const int g = order[k], lo = m->adam_grp[g], n = m->adam_grp[g + 1] - lo;
         if (!(groups >> g & 1) || n <= 0) continue;

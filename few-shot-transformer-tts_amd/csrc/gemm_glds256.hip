@@ -449,10 +449,10 @@ __global__ __launch_bounds__(nthreads_of(false), 1) void gemm_glds256_grouped_ke
 // time through a private 1 KB slice behind the ring (the plain kernel's epilogue takes 128 of the ring's 144 KB, which is why it cannot
 // overlap anything).  What a tile boundary costs is then the epilogue itself, not workgroup launch + address set-up + a three-stage
 // prologue (8148 x 2304 x 768: 43.6 -> 32.6 us).
-// Which tiles a workgroup walks: its first two are static (workgroup p -> list positions p and p + 256, as in the plain launch), every further
-// one is a TICKET drawn from a per-XCD counter (XCD x hands out positions x + 8 j of the list, j = 64, 65, ...), so workgroups that could not
+// Which tiles a workgroup walks: its first one is static (workgroup p -> list position p, as in the plain launch), every further one is
+// a TICKET drawn from a per-XCD counter (XCD x hands out positions x + 8 j of the list, j = 32, 33, ...), so workgroups that could not
 // be placed right away -- a CU held by a weight-gradient tile of the second stream or by a collective's channel -- leave their share to
-// the ones that are running instead of starting a three-tile walk late.  Producer wave 0 draws the tickets (one atomic, two tiles ahead,
+// the ones that are running instead of starting a three-tile walk late.  Producer wave 0 draws the tickets (one atomic, one tile ahead,
 // its result consumed two K steps later, behind the counted waits) and hands them to the other waves through a 4-entry LDS queue.
 // Restricted to what the multi-round launches of the step are: plain K-contiguous A, K a multiple of 64 and >= 384, N a multiple of the
 // tile width, compute-dtype output, epilogue MODE 0 / 1 / 2 of gemm_epi.h (same arithmetic, same dropout indices: bit-identical results).
@@ -561,11 +561,12 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
     // The queue entry of T[t], t >= 1, is written by producer wave 0 at least two workgroup barriers before anybody reads it.
     // (explicit DS instructions: through a generic pointer the compiler emits FLAT accesses, which count on vmcnt and drain the producers' DMA queue)
     const unsigned tq = lds_base + (unsigned)PST_TQ;
+    const bool dyn = tickets != nullptr && total > G;          // (a one-round launch draws nothing: T[1] is the end for everybody)
     auto tq_put = [&](int t, int val) {       // one lane
         asm volatile("ds_write_b32 %0, %1" ::"v"(tq + (unsigned)((t & 3) * 4)), "v"(val) : "memory");
     };
     auto queued = [&](int t) -> int {
-        if (!tickets || t < 2) { const int v = (int)blockIdx.x + t * G; return v < total ? v : PST_END; }
+        if (!dyn || t < 1) { const int v = (int)blockIdx.x + t * G; return v < total ? v : PST_END; }
         int val;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(val) : "v"(tq + (unsigned)((t & 3) * 4)) : "memory");
         return __builtin_amdgcn_readfirstlane(val);
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
         // ---- producer waves: one flat sequence of K steps over all tiles
         constexpr int NBI = (NB == 4 || TB) ? 16 : 12, NIA = (BM / 8) / NP, NIB = NBI / NP, IPW = NIA + NIB;
         const int iw = wave - NC, ia0 = iw * NIA, ib0 = iw * NIB;
-        const bool drawer = tickets && iw == 0;
+        const bool drawer = dyn && iw == 0;
         const long stepA = 2L * BK, stepB = TB ? 2L * BK * g.B.ld : 2L * BK;        // bytes per K step
         unsigned goffA[NIA], goffB[NIB];
         auto set_tile = [&](int v) {
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
             if (!drawer || tk_for < 0) return;
             if (++tk_age < 2) return;
             const int j = __builtin_amdgcn_readfirstlane(tk_raw);
-            const int v = xcd + 8 * (2 * (G / 8) + j);
+            const int v = xcd + 8 * (G / 8 + j);
             const int val = v < total ? v : PST_END;
             if (val == PST_END) drew_end = true;
             if (lane == 0) tq_put(tk_for, val);
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
         int pt = 0, pk = 0;
         bool more = true;                 // a stage is left to issue
         set_tile((int)blockIdx.x);
-        if (drawer && (int)blockIdx.x + G < total) draw(2);      // (T[0], T[1] are static; no third tile without a second one)
+        draw(1);                                                  // (T[0] is static)
         int issued = 0;
         auto issue_next = [&](int slot) {
             unsigned char* sbase = smem_raw + slot * STG;
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(nthreads_of(0, 4), 1) void gemm_glds256_persist_ker
                 pk = 0; ++pt;
                 const int v = queued(pt);
                 if (v == PST_END) more = false;
-                else { set_tile(v); if (pt >= 1) draw(pt + 2); }
+                else { set_tile(v); draw(pt + 1); }
             }
         };
         // (nk >= 6: the three prologue stages are all of tile 0, and T[1] is in the queue long before the first wrap)

@@ -345,6 +345,10 @@ def test_gemm_persistent_multi_round_kernel(policy, tb, M, N, K):
                  "relu": (dict(relu=True), acc.clamp_min(0)),
                  "relu+dropout": (dict(relu=True, drop_p=p, seed=seed),
                                   torch.where(keep, acc.clamp_min(0) * float(np.float32(1) / (np.float32(1) - np.float32(p))), torch.zeros_like(acc)))}
+        # (a three-round launch first: it leaves real list positions in the workgroups' LDS ticket queues -- a one-round launch that read its
+        # queue instead of stopping after its only tile would walk those)
+        big = ops.to_compute(torch.zeros(2048, 384, device=DEV), 1)
+        ops.gemm(1, big, ops.to_compute(torch.zeros(9216, 384, device=DEV), 1), 2048, 9216, 384, trans_b=False, c_fp32=False)
         for what, (kw, want) in cases.items():
             got = ops.gemm(1, A, Bm, M, N, K, trans_b=tb, c_fp32=False, **kw)
             torch.cuda.synchronize()
