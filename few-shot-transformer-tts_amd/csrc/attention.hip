@@ -318,9 +318,18 @@ __global__ void attn_bwd_prep_kernel(const T* dO, const T* O, int ldo, float* D,
     if (lane == 0) D[((long)b * H + h) * Lq + q] = acc;
 }
 
+// workgroups per CU the backward kernels are compiled for (2: up to 256 registers per lane; 3: 168).  dQ fits 166 registers without spilling and is
+// latency-bound like the forward kernel: 48.0 -> 43.1 us per launch at 3 (same box, rocprofv3), step 7.11 -> 7.08 ms; dK / dV spills 145 registers
+// at 168 (45 -> 118 us) and stays at 2
+#ifndef B2S_ATTN_DQ_WPC
+#define B2S_ATTN_DQ_WPC 3
+#endif
+#ifndef B2S_ATTN_DKV_WPC
+#define B2S_ATTN_DKV_WPC 2
+#endif
 // dQ: per workgroup 64 query rows; loops over key tiles
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DQ_WPC : 1) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
     __shared__ __attribute__((aligned(16))) T sK[64 * LD];
     __shared__ __attribute__((aligned(16))) T sV[64 * LD];
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // dK, dV: per workgroup 64 keys; loops over query tiles
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DKV_WPC : 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int LD = DH + AT<T>::PAD, NKS = DH / (sizeof(T) == 2 ? 32 : 4);
     __shared__ __attribute__((aligned(16))) T sQ[64 * LD];
     __shared__ __attribute__((aligned(16))) T sO[64 * LD];
