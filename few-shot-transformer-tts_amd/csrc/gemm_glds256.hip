@@ -852,7 +852,11 @@ template <bool TA, bool TB, int GATHER>
 int launch256_t(const GemmArgs& g, const bf16_t* zero, hipStream_t stream) {
     if (!TA && GATHER == 0) {
         // 128-row tiles when 256-row tiles would occupy at most half of the CUs
+#ifdef B2S_LAB
+        static const int small_tiles = getenv("B2S_LAB_SMALL_TILES") ? atoi(getenv("B2S_LAB_SMALL_TILES")) : 128;
+#else
         constexpr int small_tiles = 128;
+#endif
         const int nb = pick_nb(g);
         const long t256n = (long)cdiv(g.M, BM) * cdiv(g.N, nb * 32) * g.batch * std::max(1, g.splitk);
         if (t256n <= small_tiles && g.M > 128) {

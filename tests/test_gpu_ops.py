@@ -223,7 +223,7 @@ def test_attention_dense_bias_matches_mask():
     assert torch.equal(a, b) and torch.equal(pa, pb)
 
 
-@pytest.mark.parametrize("Lk", [140, 131, 114, 70])          # (114, 70: the resident-key kernels)
+@pytest.mark.parametrize("Lk", [300, 256, 200, 140, 131, 114, 70])          # (<= 128: the resident-key kernels)
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_fused_attention_matches_materialised_with_dropout(dtype, Lk):
     """Same seed -> the fused kernels and the GEMM+softmax path draw the same dropout mask: outputs and gradients agree.
