@@ -767,19 +767,19 @@ constexpr int g_persist = 1;
 // step 7.34 -> 7.29 ms, three interleaved rounds)
 constexpr int g_persist_min = 1;
 #endif
-// Ticket counters of the persistent launches: a pool of 64 sets (8 per-XCD counters + 1 arrival counter each, 64 bytes apart), zeroed once and
-// re-armed by the last workgroup of every launch that used a set; sets go round-robin, so a set is next used 64 persistent launches later --
+// Ticket counters of the persistent launches: a pool of 1024 sets (8 per-XCD counters + 1 arrival counter each, 64 bytes apart), zeroed once and
+// re-armed by the last workgroup of every launch that used a set; sets go round-robin, so a set is next used 1024 persistent launches (~12 steps) later --
 // far more than can be in flight on the streams of a process.  Device memory of the process, like the zero page.
 int* persist_ticket_set() {
     static int* pool = nullptr;
     static std::once_flag once;
     std::call_once(once, [] {
         void* p = nullptr;
-        if (hipMalloc(&p, 64 * 64) == hipSuccess && hipMemset(p, 0, 64 * 64) == hipSuccess) pool = (int*)p;
+        if (hipMalloc(&p, 1024 * 64) == hipSuccess && hipMemset(p, 0, 1024 * 64) == hipSuccess) pool = (int*)p;
         else (void)hipGetLastError();               // (no pool: static tile assignment)
     });
     static std::atomic<unsigned> next{0};
-    return pool ? pool + (next.fetch_add(1, std::memory_order_relaxed) & 63u) * 16 : nullptr;
+    return pool ? pool + (next.fetch_add(1, std::memory_order_relaxed) & 1023u) * 16 : nullptr;
 }
 template <bool TB, int NB>
 int launch256_persist(const GemmArgs& g, int mode, hipStream_t stream) {
@@ -791,7 +791,7 @@ int launch256_persist(const GemmArgs& g, int mode, hipStream_t stream) {
     });
     B2S_HIP(attr_err);
     const int tiles_m = cdiv(g.M, BM), tiles_n = g.N / (NB * 32);
-    int* tickets = g_persist == 2 ? nullptr : persist_ticket_set();
+    int* tickets = (g_persist == 2 || tiles_m * tiles_n <= 256) ? nullptr : persist_ticket_set();      // (a one-round launch draws nothing)
     const int grid = std::min(256, tiles_m * tiles_n);             // (a multiple of 8: try_persist)
     hipLaunchKernelGGL((gemm_glds256_persist_kernel<TB, NB>), dim3(grid), dim3(nthreads_of(0, 4)), smem, stream, g, tiles_m, tiles_n, mode, tickets);
     B2S_LAUNCH_CHECK();

@@ -25,4 +25,4 @@ if [ -f $repo/tools/bin/libb2s_hip_lab.so ]; then
 fi
 timeout 200 python tools/step_phases.py 2>&1 | grep "us" > $out/${tag}_step_phases.txt
 B2S_GEMM256_NB=4 timeout 300 python tools/cu_loss.py bwd 2>&1 | grep "mode\|held CUs" > $out/${tag}_cu_loss_policy4.txt
-tail -3 $out/${tag}_gemm_persist_ab.txt $out/${tag}_step_phases.txt
+for f in $out/${tag}_gemm_persist_ab.txt $out/${tag}_step_phases.txt; do tail -n 3 $f; done
