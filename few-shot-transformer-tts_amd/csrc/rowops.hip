@@ -1075,6 +1075,18 @@ __device__ __forceinline__ f4v adam_grad4(const f4v* G, const uint2* GW, int i4)
     const uint2 u = GW[i4];
     return (f4v){bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16))};
 }
+// The optimizer streams 2.5 GB that nothing reads again before the next step: non-temporal loads / stores for the masters and both moments keep it from
+// evicting what the kernels running beside it (the encoder backward) live on.  Six interleaved pairs, same box: 7.148 vs 7.179 ms per step, all six faster.
+#ifndef B2S_ADAM_NT
+#define B2S_ADAM_NT 1
+#endif
+#if B2S_ADAM_NT
+#define B2S_NT_LD(p) __builtin_nontemporal_load(p)
+#define B2S_NT_ST(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define B2S_NT_LD(p) (*(p))
+#define B2S_NT_ST(v, p) (*(p) = (v))
+#endif
 template <int KIND, bool W16>
 __device__ __forceinline__ float adam_chunk(const MtChunk& c, const bf16_t* gw, float gs, float l2p, float b1, float b2, float step, float sbc2, float eps) {
     float ss = 0.f;
@@ -1086,20 +1098,20 @@ __device__ __forceinline__ float adam_chunk(const MtChunk& c, const bf16_t* gw, 
     for (; i + 768 < n4; i += 1024) {
         f4v p[4], g[4], m[4], v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { p[u] = P[i + u * 256]; g[u] = adam_grad4<W16>(G, GW, i + u * 256); m[u] = M[i + u * 256]; v[u] = V[i + u * 256]; }
+        for (int u = 0; u < 4; ++u) { p[u] = B2S_NT_LD(P + i + u * 256); g[u] = adam_grad4<W16>(G, GW, i + u * 256); m[u] = B2S_NT_LD(M + i + u * 256); v[u] = B2S_NT_LD(V + i + u * 256); }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { float pe = p[u][e], me = m[u][e], ve = v[u][e]; ss += adam_elem(pe, g[u][e], me, ve, gs, l2p, b1, b2, step, sbc2, eps); p[u][e] = pe; m[u][e] = me; v[u][e] = ve; }
-            M[i + u * 256] = m[u]; V[i + u * 256] = v[u]; P[i + u * 256] = p[u];
+            B2S_NT_ST(m[u], M + i + u * 256); B2S_NT_ST(v[u], V + i + u * 256); B2S_NT_ST(p[u], P + i + u * 256);
             adam_store_shadow<KIND>(c, i + u * 256, p[u]);
         }
     }
     for (; i < n4; i += 256) {
-        f4v p = P[i], g = adam_grad4<W16>(G, GW, i), m = M[i], v = V[i];
+        f4v p = B2S_NT_LD(P + i), g = adam_grad4<W16>(G, GW, i), m = B2S_NT_LD(M + i), v = B2S_NT_LD(V + i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { float pe = p[e], me = m[e], ve = v[e]; ss += adam_elem(pe, g[e], me, ve, gs, l2p, b1, b2, step, sbc2, eps); p[e] = pe; m[e] = me; v[e] = ve; }
-        M[i] = m; V[i] = v; P[i] = p;
+        B2S_NT_ST(m, M + i); B2S_NT_ST(v, V + i); B2S_NT_ST(p, P + i);
         adam_store_shadow<KIND>(c, i, p);
     }
     return ss;
