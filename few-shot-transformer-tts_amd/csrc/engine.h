@@ -162,7 +162,6 @@ struct b2s_model {
     int n_shard_chunks = 0, n_other_chunks = 0;
     std::vector<std::pair<long, long>> shard_ranges;           // owned [lo, hi) in elements of the flat gradient buffer that starts at shard_gbase
     const float* shard_gbase = nullptr;
-    float adam_hp_host[8][4] = {};                             // host staging of {lr, bias corrections} per step slot (source of the async upload)
     int adam_step_no = 0, adam_step_mask = 0;                  // b2s_adam_step_groups: groups already updated in step adam_step_no
     mutable bool dw_flush_exposed = false;                     // end_stage -> flush_dw: this hand-over is the entry point's drain (nothing overlaps it)
     mutable hipEvent_t grads_mark_ev = nullptr;                // b2s_model_mark_grads_ready: second-stream event behind the gradient work queued so far

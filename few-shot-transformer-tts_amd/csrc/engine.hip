@@ -2006,13 +2006,9 @@ extern "C" int b2s_adam_set_grad_wire(b2s_model* m, const void* wire_bf16, const
     return 0;
 }
 namespace {
-// bias corrections of `step`, uploaded into a rotating slot (earlier steps may still be in flight)
-int adam_hyper(b2s_model* m, float lr, int step, float beta1, float beta2, hipStream_t st, float** dhp) {
-    float* hp = m->adam_hp_host[step % 8];                    // (lives in the model: an asynchronous copy must not read a dead stack frame)
-    hp[0] = lr; hp[1] = (float)(1.0 - std::pow((double)beta1, step)); hp[2] = (float)std::sqrt(1.0 - std::pow((double)beta2, step));
-    *dhp = m->small + 16 + (step % 8) * 4;
-    B2S_HIP(hipMemcpyAsync(*dhp, hp, 3 * sizeof(float), hipMemcpyHostToDevice, st));
-    return 0;
+// bias corrections of `step` (kernel arguments: rowops.h)
+AdamHyper adam_hyper(float lr, int step, float beta1, float beta2) {
+    return AdamHyper{lr, (float)(1.0 - std::pow((double)beta1, step)), (float)std::sqrt(1.0 - std::pow((double)beta2, step))};
 }
 }  // namespace
 extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, float beta2, float eps, float l2, float grad_scale,
@@ -2020,8 +2016,7 @@ extern "C" int b2s_adam_step(b2s_model* m, float lr, int step, float beta1, floa
     B2S_TRY(check_bound(m));
     B2S_CHECK(m->adam_chunks && step >= 1, "Adam state not bound or bad step");
     hipStream_t st = S_(stream);
-    float* dhp;
-    B2S_TRY(adam_hyper(m, lr, step, beta1, beta2, st, &dhp));
+    const AdamHyper dhp = adam_hyper(lr, step, beta1, beta2);
     // l2 is applied to the L2 member set only (chunk flag), i.e. g = grad*grad_scale + l2*p for members
     // the partial sums cover the L2 regulariser only if every member is in the chunk table (not with a frozen encoder)
     const bool cover = !m->cfg.freeze_encoder;
@@ -2063,8 +2058,7 @@ extern "C" int b2s_adam_step_groups(b2s_model* m, float lr, int step, float beta
         B2S_CHECK(m->grads_marked, "b2s_adam_step_groups(behind_mark = 1) needs b2s_model_mark_grads_ready after the last backward call of these groups");
         B2S_CHECK(!(groups & B2S_ADAM_ENCODER), "behind_mark = 1 is for the groups whose gradients were complete at the mark");
     }
-    float* dhp;
-    B2S_TRY(adam_hyper(m, lr, step, beta1, beta2, st, &dhp));
+    const AdamHyper dhp = adam_hyper(lr, step, beta1, beta2);
     if (behind_mark) {
         B2S_HIP(hipStreamWaitEvent(st, m->grads_mark_ev, 0));
         m->grads_marked = false;

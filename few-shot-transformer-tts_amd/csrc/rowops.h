@@ -114,7 +114,10 @@ int ro_mt_zero(const MtChunk* chunks, int nchunks, hipStream_t st);             
 int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gscale, hipStream_t st);  // b += alpha*gscale*a
 // Adam: a=param b=grad c=m d=v ; lr and step read from device (hp[0]=lr, hp[1]=bias_corr1, hp[2]=bias_corr2)
 // wire (optional): bf16 array laid out like the fp32 gradient buffer that starts at gbase -- the gradients are read from there instead
-int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1, float beta2, float eps, float l2,
+// learning rate and the step's bias corrections (bc1 = 1 - beta1^t, sbc2 = sqrt(1 - beta2^t)): kernel arguments -- a device copy cost a 5 us copy kernel in
+// front of every optimizer launch, the encoder group's on the critical path at the end of the step
+struct AdamHyper { float lr, bc1, sbc2; };
+int ro_mt_adam(const MtChunk* chunks, int nchunks, AdamHyper hp, float beta1, float beta2, float eps, float l2,
                float grad_scale, float* sumsq_part, hipStream_t st, const void* wire = nullptr, const float* gbase = nullptr,
                int max_wg = 0);                                                             // max_wg > 0: at most that many workgroups walk the chunk list
 // out[m][j*cin + ci] = x[m + j - 2][ci] if 0 <= t + j - 2 < min(lens[b], T) (m = b*T + t) else 0: the conv1d k=5 p=2 input of every token

@@ -991,11 +991,11 @@ __device__ __forceinline__ float adam_elem(float& p, float g_raw, float& m, floa
     p -= step * m / (sqrtf(v) / sbc2 + eps);
     return p * p;
 }
-__global__ __launch_bounds__(256) void k_mt_adam(const MtChunk* ch, const float* hp, float b1, float b2, float eps,
+__global__ __launch_bounds__(256) void k_mt_adam(const MtChunk* ch, AdamHyper hp, float b1, float b2, float eps,
                                                  float l2, float gs, float* sumsq_part) {
     __shared__ float sh[4];
     const MtChunk c = ch[blockIdx.x];
-    const float lr = hp[0], bc1 = hp[1], sbc2 = hp[2];     // sbc2 = sqrt(1 - beta2^t)
+    const float lr = hp.lr, bc1 = hp.bc1, sbc2 = hp.sbc2;     // sbc2 = sqrt(1 - beta2^t)
     const float step = lr / bc1, l2p = c.pad ? l2 : 0.f;
     float ss = 0.f;
     int i0 = 0;
@@ -1117,10 +1117,10 @@ __device__ __forceinline__ float adam_chunk(const MtChunk& c, const bf16_t* gw, 
     return ss;
 }
 template <bool W16>
-__global__ __launch_bounds__(256) void k_mt_adam2(const MtChunk* __restrict__ ch, int nchunks, const float* __restrict__ hp, float b1, float b2, float eps,
+__global__ __launch_bounds__(256) void k_mt_adam2(const MtChunk* __restrict__ ch, int nchunks, AdamHyper hp, float b1, float b2, float eps,
                                                   float l2, float gs, float* sumsq_part, const bf16_t* __restrict__ wire, const float* gbase) {
     __shared__ float sh[4];
-    const float lr = hp[0], bc1 = hp[1], sbc2 = hp[2];
+    const float lr = hp.lr, bc1 = hp.bc1, sbc2 = hp.sbc2;
     // one chunk per workgroup, or (a capped grid: ro_mt_adam's max_wg) every gridDim.x-th chunk
     for (int cix = blockIdx.x; cix < nchunks; cix += gridDim.x) {
         const MtChunk c = ch[cix];
@@ -1483,7 +1483,7 @@ int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gsc
     if (nchunks > 0) hipLaunchKernelGGL(k_mt_axpy, dim3(nchunks), dim3(256), 0, st, chunks, alpha, gscale);
     B2S_LAUNCH_CHECK(); return 0;
 }
-int ro_mt_adam(const MtChunk* chunks, int nchunks, const float* hp, float beta1, float beta2, float eps, float l2,
+int ro_mt_adam(const MtChunk* chunks, int nchunks, AdamHyper hp, float beta1, float beta2, float eps, float l2,
                float grad_scale, float* sumsq_part, hipStream_t st, const void* wire, const float* gbase, int max_wg) {
     constexpr bool v1 = false;
     const int grid = max_wg > 0 ? std::min(max_wg, nchunks) : nchunks;

@@ -222,5 +222,7 @@ def test_trainer_in_rs_ag_mode_matches_plain_trainer():
     for k, t in res[0][0].items():
         if t.is_floating_point():
             d = float((t.double() - res[1][0][k].double()).abs().max())
-            assert d <= 1e-5 * (1.0 + float(t.double().abs().max())), (k, d)
+            # (the fp32 step has fp32 atomics in its LayerNorm / bias reductions: two runs of ONE trainer differ by up to ~2e-5 after three steps;
+            # a slice updated by nobody or twice is off by the step size, ~1e-3)
+            assert d <= 1e-4 * (1.0 + float(t.double().abs().max())), (k, d)
     assert abs(res[0][1][0] - res[1][1][0]) < 1e-4 * abs(res[0][1][0])
