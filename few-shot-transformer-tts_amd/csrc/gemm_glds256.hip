@@ -132,7 +132,8 @@ __device__ __forceinline__ void gemm256_body(GemmArgs g, const bf16_t* zero, flo
     // DMA issue: wave w owns A instructions w*4 .. w*4+3 and B instructions w*2, w*2+1 of every stage (6 per wave).
     // Plain operands: the source address of a lane is affine in the stage index -> pointer at stage 0 + per-stage step.
     // With producer waves (NP > 0) the 32 A + 16 (12 at BN = 96, K-contiguous B) instructions are dealt to waves 8.. instead.
-    constexpr int NBI = (NB == 4 || TB) ? 16 : 12;
+    constexpr int NBI = (NB == 4 || TB) ? 16 : NB * 4;      // (8 rows of the B image per instruction: 64 / 96 / 128 columns)
+    static_assert(NB >= 3 || (GATHER == 2 && !TB), "64-column tiles: the aligned conv gather only");
     constexpr int NPD = NP ? NP : 1, NIA = NP ? (BMt / 8) / NPD : (BMt / 8) / NC, NIB = NP ? NBI / NPD : 2, IPW = NIA + NIB;
     const int iw = NP ? max(wave - NC, 0) : wave;
     const int ia0 = iw * NIA, ib0 = iw * NIB;
@@ -840,12 +841,18 @@ int launch256_nb(const GemmArgs& g_in, const bf16_t* zero, hipStream_t stream) {
 // BN = 96 when that needs fewer (or cheaper) rounds of one workgroup per CU: N = 768 / 2304 with M = 8148 give exactly
 // 256 / 768 tiles of 256x96, against 192 / 576 tiles of 256x128 (a quarter of the CUs idle)
 std::atomic<int> g_tile_policy{0};          // b2s_gemm_set_tile_policy
-inline int pick_nb(const GemmArgs& g) {
+inline int pick_nb(const GemmArgs& g, bool allow64 = false) {
     static const int env_force = getenv("B2S_GEMM256_NB") ? atoi(getenv("B2S_GEMM256_NB")) : 0;
     const int force = env_force ? env_force : g_tile_policy.load(std::memory_order_relaxed);
     if (force == 3 || force == 4) return force;
     const long per = (long)cdiv(g.M, BM) * g.batch * std::max(1, g.splitk);
     const long r128 = (per * cdiv(g.N, 128) + 255) / 256 * 128, r96 = (per * cdiv(g.N, 96) + 255) / 256 * 101;   // 96 * 1.05
+    // 64-column tiles (aligned conv gather only): the postnet's 512-channel layers are 32 x 8 = exactly 256 tiles of 256 x 64, against 192 tiles of 256 x 96
+    // whose last column panel is one third full
+    if (allow64) {
+        const long r64 = (per * cdiv(g.N, 64) + 255) / 256 * 72;
+        if (r64 < std::min(r96, r128)) return 2;
+    }
     return r96 < r128 ? 3 : 4;
 }
 template <bool TA, bool TB, int GATHER>
@@ -865,7 +872,15 @@ int launch256_t(const GemmArgs& g, const bf16_t* zero, hipStream_t stream) {
                            : launch256_nb<ta, TB, 0, 4, 2>(g, zero, stream);
         }
     }
-    const int nb = pick_nb(g);
+#ifdef B2S_LAB
+    static const bool lab_no64 = getenv("B2S_LAB_NO_NB2") != nullptr;
+#else
+    constexpr bool lab_no64 = false;
+#endif
+    const int nb = pick_nb(g, GATHER == 2 && !TB && !lab_no64);
+    if constexpr (GATHER == 2 && !TB) {
+        if (nb == 2) return launch256_nb<TA, TB, GATHER, 2>(g, zero, stream);
+    }
     const int rc = nb == 3 ? try_persist<TA, TB, GATHER, 3>(g, stream) : try_persist<TA, TB, GATHER, 4>(g, stream);
     if (rc >= 0) return rc;
     return nb == 3 ? launch256_nb<TA, TB, GATHER, 3>(g, zero, stream)
