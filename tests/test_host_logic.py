@@ -370,3 +370,17 @@ def test_dropout_hash_statistics():
         assert 0.9 < keep.sum(1).var() / (Lk * p * (1 - p)) < 1.1 and 0.85 < keep.sum(0).var() / (rows * p * (1 - p)) < 1.15
         other = rng.keep_mask(p, seed, op + 1, rows * Lk).reshape(rows, Lk)
         assert abs((keep.astype(bool) == other).mean() - ((1 - p) ** 2 + p ** 2)) < 3e-3
+
+
+def test_persistent_gemm_ticket_register_is_not_touched_between_draw_and_read():
+    """csrc/gemm_glds256.hip draws its tickets with an asynchronous atomic (inline asm) whose result register is read two K steps later; that holds only
+    while the compiler keeps the value in one register and writes nothing else to it in between.  tools/check_persist_isa.py compiles the file to ISA and
+    checks it for every instantiation (about a minute)."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_persist_isa.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
