@@ -33,6 +33,9 @@ struct AttnArgs {
 };
 
 bool b2s_flash_supported(int dh);
+// bf16 kernels on the 32x32x16 MFMA (attention32.hip); which: 0 forward, 1 dQ (needs oref), 2 dK/dV
+bool b2s_flash32_supported(int dh);
+int b2s_flash32_launch(const AttnArgs& a, int dh, int which, hipStream_t st);
 int b2s_flash_fwd(int dtype, const AttnArgs& a, int dh, hipStream_t st);
 int b2s_flash_bwd(int dtype, const AttnArgs& a, int dh, const void* O, hipStream_t st);
 int b2s_flash_align(int dtype, const AttnArgs& a, int dh, float* align, hipStream_t st);

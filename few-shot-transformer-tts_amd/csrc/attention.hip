@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_fwd_kernel(A
     if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
     const float sl2 = a.scale * B2S_LOG2E;
     const int qw0 = qb0 + wave * 16;                 // first query row of this wave
-    const uint32_t drow = (uint32_t)(((long)z * a.Lq + qc) * a.Lk);
+    const uint32_t drow = (uint32_t)((long)z * a.Lq + qc), dhk = (uint32_t)((a.Lk + 1) >> 1);
     TileRegs<T, DH> rk, rv;
     if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid); }
     for (int kt = 0; kt < ktiles; ++kt) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_fwd_kernel(A
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    s[t][r] = b2s_keep(a.drop, drow + (uint32_t)(k0 + t * 16 + lg * 4 + r)) ? s[t][r] * a.drop.scale : 0.f;
+                    s[t][r] = b2s_keep_w(a.drop, drow, dhk, (uint32_t)(k0 + t * 16 + lg * 4 + r)) ? s[t][r] * a.drop.scale : 0.f;
         }
         SP<T, DH, LD>::run(o, sV, s, li, lg);
     }
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DQ_WPC : 1) void att
     f32x4_t dq[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const uint32_t drow = (uint32_t)(((long)z * a.Lq + qc) * a.Lk);
+    const uint32_t drow = (uint32_t)((long)z * a.Lq + qc), dhk = (uint32_t)((a.Lk + 1) >> 1);
     const float sl2 = a.scale * B2S_LOG2E, lse2 = lse * B2S_LOG2E;
     const int qw0 = qb0 + wave * 16;
     TileRegs<T, DH> rk, rv;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DQ_WPC : 1) void att
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    dp[t][r] = b2s_keep(a.drop, drow + (uint32_t)(k0 + t * 16 + lg * 4 + r)) ? dp[t][r] * a.drop.scale : 0.f;
+                    dp[t][r] = b2s_keep_w(a.drop, drow, dhk, (uint32_t)(k0 + t * 16 + lg * 4 + r)) ? dp[t][r] * a.drop.scale : 0.f;
         }
         if (__any(gc != 0.f)) {
 #pragma unroll
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DKV_WPC : 1) void at
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool keep = b2s_keep(a.drop, (zq + (uint32_t)(q0 + t * 16 + lg * 4 + r)) * (uint32_t)a.Lk + (uint32_t)kc);
+                    const bool keep = b2s_keep_w(a.drop, zq + (uint32_t)(q0 + t * 16 + lg * 4 + r), (uint32_t)((a.Lk + 1) >> 1), (uint32_t)kc);
                     dp[t][r] = keep ? dp[t][r] * a.drop.scale : 0.f;
                     pd[t][r] = keep ? s[t][r] * a.drop.scale : 0.f;
                 }
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_res_kern
         mx = group_max(mx) * sl2;
         const float mref = mx == -INFINITY ? 0.f : mx;
         float l = 0.f, g = 0.f;
-        const uint32_t drow = (uint32_t)(((long)z * a.Lq + qc) * a.Lk);
+        const uint32_t drow = (uint32_t)((long)z * a.Lq + qc), dhk = (uint32_t)((a.Lk + 1) >> 1);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             if (kt >= nkt) continue;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_res_kern
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        s[kt][t][r] = b2s_keep(a.drop, drow + (uint32_t)(kt * 64 + t * 16 + lg * 4 + r)) ? s[kt][t][r] * a.drop.scale : 0.f;
+                        s[kt][t][r] = b2s_keep_w(a.drop, drow, dhk, (uint32_t)(kt * 64 + t * 16 + lg * 4 + r)) ? s[kt][t][r] * a.drop.scale : 0.f;
             }
             SP<T, DH, LD>::run(o, sV + kt * 64 * LD, s[kt], li, lg);
         }
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_res_k
             Dq += gc * a.ga_rows[(long)z * a.Lq + qc];
         }
         if (lg == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;              // the dK/dV kernel reads it
-        const uint32_t drow = (uint32_t)(((long)z * a.Lq + qc) * a.Lk);
+        const uint32_t drow = (uint32_t)((long)z * a.Lq + qc), dhk = (uint32_t)((a.Lk + 1) >> 1);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             if (kt >= nkt) continue;
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_res_k
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        dp[t][r] = b2s_keep(a.drop, drow + (uint32_t)(kt * 64 + t * 16 + lg * 4 + r)) ? dp[t][r] * a.drop.scale : 0.f;
+                        dp[t][r] = b2s_keep_w(a.drop, drow, dhk, (uint32_t)(kt * 64 + t * 16 + lg * 4 + r)) ? dp[t][r] * a.drop.scale : 0.f;
             }
             if (__any(gc != 0.f)) {
 #pragma unroll
@@ -872,9 +872,17 @@ int check(const AttnArgs& a, int dtype, int dh) {
 
 bool b2s_flash_supported(int dh) { return dh == 32 || dh == 64 || dh == 96; }
 
+// bf16: the 32x32x16 kernels of attention32.hip (lab builds: B2S_LAB_ATTN32=0 selects the 16-row kernels of this file)
+#ifdef B2S_LAB
+static const bool g_attn32 = !getenv("B2S_LAB_ATTN32") || atoi(getenv("B2S_LAB_ATTN32")) != 0;
+#else
+constexpr bool g_attn32 = true;
+#endif
+
 int b2s_flash_fwd(int dtype, const AttnArgs& a, int dh, hipStream_t st) {
     B2S_TRY(check(a, dtype, dh));
     B2S_CHECK(a.out, "attention: null output");
+    if (dtype && g_attn32 && b2s_flash32_supported(dh)) return b2s_flash32_launch(a, dh, 0, st);
     return dtype ? launch_t<bf16_t>(a, dh, 0, st) : launch_t<float>(a, dh, 0, st);
 }
 int b2s_flash_bwd(int dtype, const AttnArgs& a_in, int dh, const void* O, hipStream_t st) {
@@ -883,6 +891,10 @@ int b2s_flash_bwd(int dtype, const AttnArgs& a_in, int dh, const void* O, hipStr
     B2S_CHECK(!a_in.ga_rows || a_in.ga_scale, "attention backward: the guided-attention term needs its scale");
     AttnArgs a = a_in;
     a.oref = O;
+    if (dtype && g_attn32 && b2s_flash32_supported(dh)) {
+        B2S_TRY(b2s_flash32_launch(a, dh, 1, st));
+        return b2s_flash32_launch(a, dh, 2, st);
+    }
     B2S_TRY(dtype ? launch_t<bf16_t>(a, dh, 1, st) : launch_t<float>(a, dh, 1, st));
     return dtype ? launch_t<bf16_t>(a, dh, 2, st) : launch_t<float>(a, dh, 2, st);
 }

@@ -71,6 +71,15 @@ struct DropCfg {
 __device__ __host__ inline bool b2s_keep(const DropCfg& d, uint32_t idx) {
     return b2s_hash32(idx * 0x9E3779B1u + d.key) >= d.thresh;
 }
+// attention-weight dropout of the training kernels: ONE hash word per PAIR of adjacent keys of a weight row.  Key k of row r (rows numbered
+// (b H + h) Lq + q, hk = ceil(Lk / 2)) uses the (k & 1)-th 16-bit half of hash32((r hk + (k >> 1)) golden + key) and is dropped when that half
+// is below thresh >> 16 (p = 0.1: 6553 / 65536).  A lane of the 32x32 attention kernels owns adjacent keys of one row: half the hashes.
+__device__ __host__ inline uint32_t b2s_wword(const DropCfg& d, uint32_t row, uint32_t hk, uint32_t kp) {
+    return b2s_hash32((row * hk + kp) * 0x9E3779B1u + d.key);
+}
+__device__ __host__ inline bool b2s_keep_w(const DropCfg& d, uint32_t row, uint32_t hk, uint32_t k) {
+    return ((b2s_wword(d, row, hk, k >> 1) >> ((k & 1u) * 16u)) & 0xffffu) >= (d.thresh >> 16);
+}
 inline DropCfg make_drop(float p, uint64_t seed, uint32_t op_id) {
     DropCfg d;
     if (p <= 0.f) { d.key = 0; d.thresh = 0; d.scale = 1.f; return d; }

@@ -12,7 +12,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 if [ "$1" = "--lab" ]; then OBJ=obj_lab; mkdir -p ../../tools/bin; OUT=../../tools/bin/libb2s_hip_lab.so; FLAGS="$FLAGS -DB2S_LAB"; fi
 if [ "$1" = "--clean" ]; then rm -rf $OBJ; fi
 mkdir -p $OBJ
-SRCS="gemm gemm_glds gemm_glds256 gemm_skinny attention rowops engine capi_ops decode decode_fused enc_fused"
+SRCS="gemm gemm_glds gemm_glds256 gemm_skinny attention attention32 rowops engine capi_ops decode decode_fused enc_fused"
 pids=()
 for f in $SRCS; do
   if [ ! -f $OBJ/$f.o ] || [ $f.hip -nt $OBJ/$f.o ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer $OBJ/$f.o)" ] || [ ../../include/b2s_hip.h -nt $OBJ/$f.o ]; then

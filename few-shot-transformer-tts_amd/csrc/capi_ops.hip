@@ -150,6 +150,19 @@ extern "C" int b2s_dropout_mask(float p, uint64_t seed, uint32_t op_id, uint8_t*
     return 0;
 }
 
+__global__ void k_dropmask_attn(DropCfg d, uint8_t* out, long rows, int Lk) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * Lk) out[i] = b2s_keep_w(d, (uint32_t)(i / Lk), (uint32_t)((Lk + 1) >> 1), (uint32_t)(i % Lk)) ? 1 : 0;
+}
+extern "C" int b2s_dropout_mask_attn(float p, uint64_t seed, uint32_t op_id, uint8_t* out, int64_t rows, int Lk, void* stream) {
+    B2S_CHECK(out && rows >= 0 && Lk > 0, "bad argument");
+    DropCfg d = make_drop(p, seed, op_id);
+    if (p <= 0.f) { B2S_HIP(hipMemsetAsync(out, 1, rows * Lk, S_(stream))); return 0; }
+    hipLaunchKernelGGL(k_dropmask_attn, dim3(cdiv(rows * Lk, 256)), dim3(256), 0, S_(stream), d, out, (long)rows, Lk);
+    B2S_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- fused encoder sublayer kernels (enc_fused.h), op level: what the engine launches per sublayer, for the parity tests
 extern "C" int b2s_encf_attention_forward(const void* hN, const void* Wqkv, const void* Wo, const int32_t* klen, int B, int S, float drop_p,
                                           uint64_t seed, uint32_t op_id, void* qkv, void* ctx, float* lse, void* slabs, int slab_bf16, void* stream) {

@@ -463,6 +463,8 @@ extern "C" int b2s_decode_begin(b2s_model* m, const float* memory, const int32_t
                                 b2s_decode_state** out) {
     B2S_CHECK(m && m->bound, "model parameters are not bound");
     B2S_CHECK(memory && input_lengths && ws && out && B > 0 && S > 0 && max_frames > 0, "bad argument");
+    // dropout op ids of the loop are decode_base + layer with bases 10 apart (drop_sites.h): an 11th layer would share masks with the next site
+    B2S_CHECK(!train || m->cfg.n_decoder_layer <= 10, "decode with dropout supports at most 10 decoder layers (got %d)", m->cfg.n_decoder_layer);
     hipStream_t st = S_(stream);
     b2s_decode_state* s = new b2s_decode_state();
     s->B = B; s->S = S; s->maxT = max_frames; s->train = train; s->seed = seed; s->in_len = input_lengths;

@@ -431,11 +431,15 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_fwd(EncfAttnFwd a) {
             for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], sl2, -mref)); lsum += p; s[t][r] = p; }
         lsum = group_sum(lsum);
         if (a.datt.thresh) {
-            const uint32_t drow_ = (uint32_t)(((long)z * S + mq) * S);
+            const uint32_t drow_ = (uint32_t)((long)z * S + mq), dhk_ = (uint32_t)((S + 1) >> 1);
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[t][r] = b2s_keep(a.datt, drow_ + (uint32_t)(t * 16 + lg * 4 + r)) ? s[t][r] * a.datt.scale : 0.f;
+                for (int r = 0; r < 4; r += 2) {                         // keys (t 16 + lg 4 + r, + 1): one word per pair (b2s_common.h: b2s_wword)
+                    const uint32_t w = b2s_wword(a.datt, drow_, dhk_, (uint32_t)(t * 8 + lg * 2 + (r >> 1)));
+                    s[t][r] = (w & 0xffffu) >= (a.datt.thresh >> 16) ? s[t][r] * a.datt.scale : 0.f;
+                    s[t][r + 1] = (w >> 16) >= (a.datt.thresh >> 16) ? s[t][r + 1] * a.datt.scale : 0.f;
+                }
         }
         f32x4_t o[4];
 #pragma unroll
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_bwd(EncfAttnBwd a) {
                     const int key = (hf * 4 + t) * 16 + lg * 4 + r;
                     const float p = key < kend ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2)) : 0.f;
                     float d = dp[r];
-                    if (a.datt.thresh) d = b2s_keep(a.datt, (uint32_t)(((long)z * S + mq) * S) + (uint32_t)key) ? d * a.datt.scale : 0.f;
+                    if (a.datt.thresh) d = b2s_keep_w(a.datt, (uint32_t)((long)z * S + mq), (uint32_t)((S + 1) >> 1), (uint32_t)key) ? d * a.datt.scale : 0.f;
                     s[r] = p * (d - Dq) * scale;
                 }
                 ds[hf * 4 + t] = s;
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_bwd(EncfAttnBwd a) {
                     const float p = (key_ok && qq < S) ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lq[t][r])) : 0.f;
                     float d = dp[r], pp = p;
                     if (a.datt.thresh) {
-                        const bool keep = b2s_keep(a.datt, (uint32_t)(((long)z * S + qq) * S) + (uint32_t)kk);
+                        const bool keep = b2s_keep_w(a.datt, (uint32_t)((long)z * S + qq), (uint32_t)((S + 1) >> 1), (uint32_t)kk);
                         d = keep ? d * a.datt.scale : 0.f; pp = keep ? p * a.datt.scale : 0.f;
                     }
                     pd[t][r] = pp;

@@ -1060,6 +1060,7 @@ extern "C" void b2s_ctx_free(b2s_ctx* ctx) { delete ctx; }
 extern "C" int b2s_dropout_site(const char* site, int layer, int decode, uint32_t* op_id_out, int* kind_out, int* salt_out) {
     B2S_CHECK(site && op_id_out, "null argument");
     B2S_CHECK(layer >= 0 && layer < 32, "layer %d out of range (op ids hold 32 layers per segment)", layer);
+    B2S_CHECK(!decode || layer < 10, "layer %d out of range (the decode loop's op ids hold 10 layers per site)", layer);
     for (int i = 0; i < DS_COUNT; ++i) {
         if (strcmp(site, g_drop_sites[i].name)) continue;
         B2S_CHECK(!decode || g_drop_sites[i].decode_base > 0, "dropout site %s does not exist in the decode loop", site);

@@ -41,6 +41,22 @@ def keep_mask(p, seed, op_id, n):
     return rand32(idx, drop_key(seed, op_id)) >= np.uint64(drop_thresh(p))
 
 
+def keep_mask_attn(p, seed, op_id, rows, Lk):
+    """bool[rows, Lk]: the TRAINING kernels' attention-weight masks (csrc/b2s_common.h: b2s_wword / b2s_keep_w, csrc/drop_sites.h:
+    B2S_DROP_ATTN): one hash word per pair of adjacent keys of a weight row, word = rand32(row * ceil(Lk / 2) + (k >> 1)); key k uses the
+    (k & 1)-th 16-bit half and is dropped when that half < (p * 2^32) >> 16."""
+    if p <= 0:
+        return np.ones((rows, Lk), dtype=bool)
+    hk = (Lk + 1) // 2
+    assert rows * hk < 2 ** 32, "pair index would wrap"
+    th16 = np.uint64(drop_thresh(p) >> 16)
+    w = rand32(np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(hk) + np.arange(hk, dtype=np.uint64)[None, :], drop_key(seed, op_id))
+    out = np.empty((rows, 2 * hk), dtype=bool)
+    out[:, 0::2] = (w & np.uint64(0xFFFF)) >= th16
+    out[:, 1::2] = (w >> np.uint64(16)) >= th16
+    return out[:, :Lk]
+
+
 def _salt(rule, t):
     """Frame salt of the decode loop (csrc/drop_sites.h: B2S_SALT_*), XORed into the key of frame t."""
     t = np.uint64(int(t))
@@ -59,8 +75,8 @@ class DeviceMasks:
 
     seeds: {"encoder": s, "decoder": s, "postnet": s} -- the `seed` argument of the engine's segment calls (decode loop: the seed
     of b2s_decode_begin under "decoder").  site_info(site, layer, decode) -> (op_id, kind, salt_rule): the library's own table,
-    queried by the test through the C ABI (nothing about op ids is restated here).  The index rules (kind) and the hash are the
-    documented convention of that query.  decode: the autoregressive loop -- row r of a [B, rows, C] tensor (or query row r of
+    queried by the test through the C ABI (nothing about op ids is restated here).  The index rules (kind: 0 = flat element index,
+    1 = attention weights -- key pairs in the training kernels, keep_mask_attn) and the hash are the documented convention of that query.  decode: the autoregressive loop -- row r of a [B, rows, C] tensor (or query row r of
     attention weights) was drawn in frame r + frame_offset with a frame-salted key and the per-frame index rules.
     overrides: {(site, layer): op_id} -- deliberately wrong ids, for the test that shows the comparison notices."""
 
@@ -79,6 +95,8 @@ class DeviceMasks:
         n = int(np.prod(shape))
         if not self.decode:
             assert n < 2 ** 32, "element index would wrap"
+            if kind == 1:                           # weights [B, H, Lq, Lk] of the training kernels: one word per key pair
+                return keep_mask_attn(p, seed, op, int(np.prod(shape[:-1])), shape[-1]).reshape(shape)
             return (rand32(np.arange(n, dtype=np.uint64), key) >= th).reshape(shape)
         out = np.empty(shape, dtype=bool)
         if kind == 0:                               # rows [B, R, C]: frame r + offset, idx = b * C + c

@@ -51,6 +51,13 @@ def _mask(lib, L, p, seed, op, n):
     return m.bool()
 
 
+def _mask_attn(lib, L, p, seed, op, rows, Lk):
+    """attention-weight masks of the training kernels: one hash word per key pair (include/b2s_hip.h: b2s_dropout_mask_attn)"""
+    m = torch.empty(rows * Lk, dtype=torch.uint8, device=DEV)
+    L.check(lib.b2s_dropout_mask_attn(p, seed, op, m.data_ptr(), rows, Lk, None))
+    return m.bool()
+
+
 def _slab_view(slabs, ns, M, bf16):
     return (slabs.view(torch.bfloat16) if bf16 else slabs).view(ns, M, D).double()
 
@@ -105,7 +112,7 @@ def test_fused_attention_forward_backward(B, S, kl, p, slab_bf16):
     L.check(lib.b2s_encf_attention_forward(h.data_ptr(), Wqkv.data_ptr(), Wo.data_ptr(), klen.data_ptr(), B, S, p, seed, op, qkv.data_ptr(),
                                            ctx.data_ptr(), lse.data_ptr(), slabs.data_ptr(), slab_bf16, None))
     torch.cuda.synchronize()
-    keep = _mask(lib, L, p, seed, op, B * H * S * S)
+    keep = _mask_attn(lib, L, p, seed, op, B * H * S, S)
     sd = 1.0 / (1.0 - p)
     r_slabs, r_qkv, r_ctx, r_lse = _attn_ref(h, Wqkv, Wo, klen, B, S, keep, sd)
     assert _rel(qkv, r_qkv) < TOL, report("qkv", qkv.cpu(), r_qkv.cpu())

@@ -300,6 +300,19 @@ def test_dropout_mask_matches_host_restatement():
         assert np.array_equal(m.cpu().numpy().astype(bool), rng.keep_mask(p, seed, op, n)), (p, seed, op)
 
 
+def test_attention_dropout_mask_matches_host_restatement():
+    """The training kernels' attention-weight masks (one hash word per key pair: csrc/b2s_common.h: b2s_keep_w) == oracle/rng.py: keep_mask_attn,
+    bit for bit, for even and odd key counts (an odd Lk leaves the last pair half used)."""
+    from oracle import rng
+    ops, lib = _ops()
+    l = lib.load()
+    for p, seed, op, rows, Lk in ((0.1, 1234, 8324, 997, 582), (0.1, (7 << 40) + 3, 4162, 513, 113), (0.5, 5, 6, 64, 1), (0.9999, 1, 2, 33, 7)):
+        m = torch.empty(rows * Lk, dtype=torch.uint8, device=DEV)
+        lib.check(l.b2s_dropout_mask_attn(p, seed, op, lib.ptr(m), rows, Lk, lib.stream()))
+        torch.cuda.synchronize()
+        assert np.array_equal(m.cpu().numpy().astype(bool).reshape(rows, Lk), rng.keep_mask_attn(p, seed, op, rows, Lk)), (p, seed, op)
+
+
 @pytest.mark.parametrize("nb", ["3", "4"])
 def test_gemm_256_tile_kernel_all_forms(nb):
     """The 256x128 / 256x96 tile kernel (gemm_glds256.hip) is normally chosen for M > 128 with a shape-dependent tile width;

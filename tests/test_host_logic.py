@@ -370,6 +370,25 @@ def test_dropout_hash_statistics():
         assert 0.9 < keep.sum(1).var() / (Lk * p * (1 - p)) < 1.1 and 0.85 < keep.sum(0).var() / (rows * p * (1 - p)) < 1.15
         other = rng.keep_mask(p, seed, op + 1, rows * Lk).reshape(rows, Lk)
         assert abs((keep.astype(bool) == other).mean() - ((1 - p) ** 2 + p ** 2)) < 3e-3
+    # the training kernels' attention-weight masks: two keys per hash word (16-bit halves; keep_mask_attn): the same properties, the drop rate
+    # quantised to 1 / 65536, the two halves of a word independent of each other, odd key counts
+    for p, seed, op, Lk in ((0.1, 1234, 8324, 582), (0.1, 77, 8358, 113), (0.5, 99, 77, 582)):
+        keep = rng.keep_mask_attn(p, seed, op, rows, Lk).astype(np.float64)
+        pq = (rng.drop_thresh(p) >> 16) / 65536.0
+        assert abs(pq - p) < 2e-5
+        assert abs((1 - keep.mean()) - pq) < 4 * (p * (1 - p) / keep.size) ** 0.5
+        k = keep - keep.mean()
+        var = k.var()
+        corr = lambda a, b: abs(float((a * b).mean() / var))
+        ev = Lk & ~1
+        assert corr(k[:, 0:ev:2], k[:, 1:ev:2]) < 4e-3                          # within a word
+        assert corr(k[:, :-1], k[:, 1:]) < 4e-3 and corr(k[:, :-2], k[:, 2:]) < 4e-3
+        assert corr(k[:-1], k[1:]) < 4e-3 and corr(k[:-1, :-1], k[1:, 1:]) < 4e-3
+        assert 0.9 < keep.sum(1).var() / (Lk * p * (1 - p)) < 1.1 and 0.85 < keep.sum(0).var() / (rows * p * (1 - p)) < 1.15
+        other = rng.keep_mask_attn(p, seed, op + 1, rows, Lk)
+        assert abs((keep.astype(bool) == other).mean() - ((1 - p) ** 2 + p ** 2)) < 3e-3
+        flat = rng.keep_mask(p, seed, op, rows * Lk).reshape(rows, Lk)              # and unrelated to the element rule of the same op
+        assert abs((keep.astype(bool) == flat).mean() - ((1 - p) ** 2 + p ** 2)) < 3e-3
 
 
 def test_persistent_gemm_ticket_register_is_not_touched_between_draw_and_read():
