@@ -872,17 +872,23 @@ int check(const AttnArgs& a, int dtype, int dh) {
 
 bool b2s_flash_supported(int dh) { return dh == 32 || dh == 64 || dh == 96; }
 
-// bf16: the 32x32x16 kernels of attention32.hip (lab builds: B2S_LAB_ATTN32=0 selects the 16-row kernels of this file)
+// bf16, causal (the decoder's self-attention: ~10 key tiles per query block): the 32x32x16 kernels of attention32.hip.  The short-key attention
+// without a causal mask (encoder-decoder attention: 2 .. 4 key tiles) stays on the kernels of this file -- same box, us per launch at (14, 8, 582, 114),
+// dropout on: forward 16.7 (resident keys) against 20.3, dQ 25 against 25, dK / dV 25 against 44 (one 128-key block per head leaves 112
+// workgroups); at 256 keys forward 27.3 / 26.5, backward 71 / 79 (profiles/NOTES_r06.md).  Lab builds: B2S_LAB_ATTN32 = 0 never, 2 always.
 #ifdef B2S_LAB
-static const bool g_attn32 = !getenv("B2S_LAB_ATTN32") || atoi(getenv("B2S_LAB_ATTN32")) != 0;
+static const int g_attn32 = getenv("B2S_LAB_ATTN32") ? atoi(getenv("B2S_LAB_ATTN32")) : 1;
 #else
-constexpr bool g_attn32 = true;
+constexpr int g_attn32 = 1;
 #endif
+static inline bool use32(int dtype, const AttnArgs& a, int dh) {
+    return dtype && b2s_flash32_supported(dh) && (g_attn32 == 2 || (g_attn32 == 1 && (a.mask_mode & 2)));
+}
 
 int b2s_flash_fwd(int dtype, const AttnArgs& a, int dh, hipStream_t st) {
     B2S_TRY(check(a, dtype, dh));
     B2S_CHECK(a.out, "attention: null output");
-    if (dtype && g_attn32 && b2s_flash32_supported(dh)) return b2s_flash32_launch(a, dh, 0, st);
+    if (use32(dtype, a, dh)) return b2s_flash32_launch(a, dh, 0, st);
     return dtype ? launch_t<bf16_t>(a, dh, 0, st) : launch_t<float>(a, dh, 0, st);
 }
 int b2s_flash_bwd(int dtype, const AttnArgs& a_in, int dh, const void* O, hipStream_t st) {
@@ -891,7 +897,7 @@ int b2s_flash_bwd(int dtype, const AttnArgs& a_in, int dh, const void* O, hipStr
     B2S_CHECK(!a_in.ga_rows || a_in.ga_scale, "attention backward: the guided-attention term needs its scale");
     AttnArgs a = a_in;
     a.oref = O;
-    if (dtype && g_attn32 && b2s_flash32_supported(dh)) {
+    if (use32(dtype, a, dh)) {
         B2S_TRY(b2s_flash32_launch(a, dh, 1, st));
         return b2s_flash32_launch(a, dh, 2, st);
     }

@@ -2,8 +2,8 @@
 // backward).  Same contract as the kernels of attention.hip (AttnArgs; the fp32 parity mode and head sizes this file does not cover stay there).
 //
 // Structure (forward, dQ, dK/dV alike): a workgroup of NW waves owns NW x 32 rows of one (batch, head) -- query rows in the forward and dQ kernels,
-// key rows in the dK/dV kernel -- and streams 64-row tiles of the other sequence through a two-deep LDS ring (register-staged: the global loads of
-// tile t + 2 are in flight while tile t is consumed; ONE barrier per tile).  Every product is computed "swapped" so that a lane owns ONE row of the
+// key rows in the dK/dV kernel -- and streams 64-row tiles of the other sequence through a two-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4:
+// no staging registers, no ds_write pass; the DMA of the next tile is in flight while the current one is consumed; ONE barrier per tile).  Every product is computed "swapped" so that a lane owns ONE row of the
 // wave's 32 and 16 (of 32) columns of the streamed tile in its accumulator registers (32x32 C layout: col = lane & 31, row = (r & 3) + 8 (r >> 2)
 // + 4 (lane >> 5)):
 //      S^T = K Q^T, dP^T = V dO^T             A = 32 streamed rows x 16 features, one ds_read_b128 per MFMA; B = the wave's own rows, in registers
@@ -23,10 +23,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
 
-#ifndef A32_LAB
-#define A32_LAB 0            // lab builds: bit 0 = no softmax (p = logits), bit 1 = dropout compiled out
-#endif
-
+typedef __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ inline f32x16_t mma32(bf16x8_t a, bf16x8_t b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 // combine a per-lane partial with the one lane ^ 32 holds (the other 16 columns of the same row); identical result in both lanes
 __device__ inline float half_max(float v) {
@@ -46,28 +44,34 @@ constexpr float A32_LAZY = 8.f;                       // running-maximum slack, 
 // chunk swizzle of a tile row: 16 rows of one b128 lane group land on 16 distinct 16-byte slots, 4 consecutive rows x 4 chunks of a transposed read too
 template <int DH> __device__ inline int swz(int row) { return DH == 64 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3); }
 
-// ---- global -> registers -> LDS staging of a [64][DH] tile by NT threads
-template <int DH, int NT> struct Stage { uint4 v[(64 * (DH / 8)) / NT]; };
-template <int DH, int NT>
-__device__ inline void stage_fetch(Stage<DH, NT>& r, const bf16_t* src, long ld, int row0, int nrows, int tid) {
-    constexpr int CPR = DH / 8, NV = 64 * CPR / NT;
-    static_assert(64 * CPR % NT == 0, "tile must split evenly over the workgroup");
+// ---- global -> LDS staging of a [64][DH] tile by LDS-DMA.  One wave-instruction writes 64 consecutive 16-byte chunks (lane-linear), so the
+// swizzle is applied on the SOURCE side: the lane that owns LDS chunk position p = row * CPR + c' fetches the global chunk c' ^ swz(row) of that row.
+// Each wave issues NI = CPR / NW instructions per tile; completion is the wave's vmcnt, publication the workgroup barrier.
+template <int DH, int NW> struct Dma {
+    static constexpr int CPR = DH / 8, NI = CPR / NW;
+    static_assert(CPR % NW == 0, "tile must split evenly over the waves");
+    int row[NI], cb[NI];                                              // tile row and byte offset inside a source row of the chunk this lane fetches
+    const char* base; uint32_t ldb; int last;
+    __device__ inline void init(const bf16_t* b, long ld_, int nrows_, int wave, int lane) {
+        base = reinterpret_cast<const char*>(b); ldb = (uint32_t)ld_ * 2u; last = nrows_ - 1;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * NT, rr = v / CPR, c = v - rr * CPR;
-        r.v[i] = make_uint4(0, 0, 0, 0);
-        if (row0 + rr < nrows) r.v[i] = *reinterpret_cast<const uint4*>(src + (long)(row0 + rr) * ld + c * 8);
+        for (int i = 0; i < NI; ++i) {
+            const int p = (wave * NI + i) * 64 + lane, r = p / CPR, c = (p - r * CPR) ^ swz<DH>(r);
+            row[i] = r; cb[i] = c * 16;
+        }
     }
-}
-template <int DH, int NT>
-__device__ inline void stage_store(bf16_t* lds, const Stage<DH, NT>& r, int tid) {
-    constexpr int CPR = DH / 8, NV = 64 * CPR / NT;
+    // rows beyond the end of the sequence fetch the last row (finite data; every consumer masks those rows)
+    __device__ inline void issue(bf16_t* tile, int row0, int wave) const {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * NT, rr = v / CPR, c = v - rr * CPR;
-        *reinterpret_cast<uint4*>(lds + rr * DH + ((c ^ swz<DH>(rr)) * 8)) = r.v[i];
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t voff = (uint32_t)min(row0 + row[i], last) * ldb + (uint32_t)cb[i];      // uniform base + 32-bit lane offset
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + voff), (lptr_t)(tile + (wave * NI + i) * 512), 16, 0, 0);
+        }
     }
-}
+};
+// compiler-only fence: LDS fragment loads are not hoisted across it (bounds the registers the scheduler spends on loads in flight)
+__device__ inline void cfence() { asm volatile("" ::: "memory"); }
+__device__ inline void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // A operand of a "first" product: tile row `row`, features [16 ks + 8 hi, +8)
 template <int DH> __device__ inline bf16x8_t frag_a(const bf16_t* tile, int row, int ks, int hi) {
     return *reinterpret_cast<const bf16x8_t*>(tile + row * DH + (((ks * 2 + hi) ^ swz<DH>(row)) * 8));
@@ -103,12 +107,19 @@ __device__ inline float frag_dot(bf16x8_t x, bf16x8_t y) {
 // accumulator row index of register r: (r & 3) + 8 (r >> 2) + 4 hi
 __device__ inline int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// XCD-aware (block, head) assignment, as attention.hip: xcd_block
-__device__ inline void a32_block(int& blk, int& z) {
-    const int nx = gridDim.x, nwg = nx * gridDim.y, orig = blockIdx.y * nx + blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    z = wg / nx; blk = wg - z * nx;
+// XCD-aware (block rank, head) assignment.  Workgroups go to the 8 XCDs round-robin by linear id and every XCD has its own L2; with B * H a multiple
+// of 8 every XCD owns B * H / 8 heads (their K / V stay in its L2) and walks them rank-major: every head's block of rank 0 first, then rank 1, ...
+// -- the callers map rank 0 to the block with the most tiles (causal attention), so that the long workgroups start first on every XCD.
+__device__ inline void a32_block(int& rank, int& z) {
+    const int nx = gridDim.x, Z = gridDim.y, orig = blockIdx.y * nx + blockIdx.x;
+    if ((Z & 7) == 0) {
+        const int zc = Z >> 3, x = orig & 7, i = orig >> 3;
+        rank = i / zc; z = x * zc + (i - rank * zc);
+    } else {                                                            // as attention.hip: xcd_block
+        const int nwg = nx * Z, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        z = wg / nx; rank = wg - z * nx;
+    }
 }
 __device__ inline float ga_w(int q, int k, float iq, float ik, float inv2s2) {
     const float d = (float)k * ik - (float)q * iq;
@@ -136,36 +147,72 @@ template <int DH> __device__ inline void zero_own(bf16_t* dst, int hi) {
 __device__ inline uint32_t hash_body(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 constexpr uint32_t GOLD = 0x9E3779B1u;
 
+
+// first products of one 64-row tile against the wave's own rows: s[t] = tile rows [32 t, 32 t + 32) x own
+template <int DH>
+__device__ inline void first2(f32x16_t (&s)[2], const bf16_t* tile, const bf16x8_t (&own)[DH / 16], int l31, int hi) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < DH / 16; ++ks) s[t] = mma32(frag_a<DH>(tile, t * 32 + l31, ks, hi), own[ks], s[t]);
+    }
+}
+template <int DH>
+__device__ inline void first1(f32x16_t& s, const bf16_t* tile, int t, const bf16x8_t (&own)[DH / 16], int l31, int hi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) s = mma32(frag_a<DH>(tile, t * 32 + l31, ks, hi), own[ks], s);
+}
+// second product: acc[dt] += (tile rows [32 t, +32) transposed, features [32 dt, +32)) x packed w
+template <int DH>
+__device__ inline void second1(f32x16_t (&acc)[DH / 32], const bf16_t* tile, int t, const f32x16_t& w, int lane) {
+    const bf16x8_t p0 = pack8<0>(w), p1 = pack8<1>(w);
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt) {
+        acc[dt] = mma32(frag_t<DH>(tile, t * 32, dt * 32, lane), p0, acc[dt]);
+        acc[dt] = mma32(frag_t<DH>(tile, t * 32 + 16, dt * 32, lane), p1, acc[dt]);
+    }
+}
+// dropout words of this lane's 16 key pairs of the 64-key tile at k0 (forward / dQ: the lane owns a weight row; xrow includes the lane's 2 hi pair offset)
+__device__ inline void pair_words(uint32_t (&wd)[16], uint32_t xrow, int k0) {
+    const uint32_t xt = xrow + (uint32_t)(k0 >> 1) * GOLD;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr)      // pair pr of half t: registers 2 pr, 2 pr + 1 = keys k0 + 32 t + 8 (pr >> 1) + 4 hi + 2 (pr & 1) + {0, 1}
+            wd[t * 8 + pr] = hash_body(xt + (uint32_t)(t * 16 + (pr >> 1) * 4 + (pr & 1)) * GOLD);
+}
+
 // ================================================================================================ forward
-template <int DH, int NW>
+// Software pipeline inside a wave: the logits of tile t + 1 (MFMA) are issued before the exponentials / row sums / dropout selects / bf16 packs of
+// tile t (VALU), and the dropout words of tile t + 1 are hashed beside the P V products of tile t -- the K ring therefore runs one tile ahead of the V ring.
+template <int DH, int NW, bool DROP, bool GA>
 __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
-    constexpr int NKS = DH / 16, NDT = DH / 32, TILE = 64 * DH, NT = NW * 64, QB = NW * 32;
+    constexpr int NKS = DH / 16, NDT = DH / 32, TILE = 64 * DH, QB = NW * 32;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2 * TILE];
     __shared__ __attribute__((aligned(16))) bf16_t sV[2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     int blk, z;
     a32_block(blk, z);
-    blk = gridDim.x - 1 - blk;                                      // causal: the blocks with the most key tiles start first
+    blk = gridDim.x - 1 - blk;                                      // rank 0 = the last query block (causal: the most key tiles)
     const int b = z / a.H, h = z - b * a.H;
     const int qb0 = blk * QB, qw0 = qb0 + wave * 32, q = qw0 + l31, qc = min(q, a.Lq - 1);
     // padded query rows (AttnArgs::qskip): 64-row tiles wholly at or beyond qskip[b] are not computed, their rows are written as zeros
     const int qlive = a.qskip ? min(a.qskip[b], a.Lq) : a.Lq;
     const bool wlive = (qw0 & ~63) < qlive && qw0 < a.Lq;           // wave-uniform
     bf16_t* out = reinterpret_cast<bf16_t*>(a.out) + ((long)b * a.Lq + qc) * a.ldo + h * DH;
-    const bool ga = a.ga_rows != nullptr;
     if (!wlive && q < a.Lq) {
         zero_own<DH>(out, hi);
         if (hi == 0 && a.lse) a.lse[(long)z * a.Lq + q] = 0.f;
-        if (hi == 0 && ga) a.ga_rows[(long)z * a.Lq + q] = 0.f;
+        if (hi == 0 && GA) a.ga_rows[(long)z * a.Lq + q] = 0.f;
     }
     if (qb0 >= qlive) return;                                       // nothing live in this workgroup (uniform)
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
-    bf16x8_t qf[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = frag_own(Q, a.ldq, qc, ks, hi);
-
     const bool causal = a.mask_mode & 2;
     int kend = a.Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
@@ -176,6 +223,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
         ktiles = min(ktiles, qlast / 64 + 1);
     }
     const int wkt = !wlive ? 0 : (causal ? min(ktiles, min(qw0 + 31, a.Lq - 1) / 64 + 1) : ktiles);   // key tiles this wave computes
+    Dma<DH, NW> dmk, dmv;
+    dmk.init(K, a.ldk, a.Lk, wave, lane); dmv.init(V, a.ldv, a.Lk, wave, lane);
+    if (ktiles > 0) { dmk.issue(sK, 0, wave); dmv.issue(sV, 0, wave); }
+    if (ktiles > 1) dmk.issue(sK + TILE, 64, wave);
+    bf16x8_t qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = frag_own(Q, a.ldq, qc, ks, hi);
 
     f32x16_t o[NDT];
 #pragma unroll
@@ -184,131 +238,102 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m = -INFINITY, l = 0.f, g = 0.f;
     float ga_iq = 0.f, ga_ik = 0.f;
-    if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
+    if (GA) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
     const float sl2 = a.scale * A32_LOG2E;
-    // dropout word of the key pair kp of this lane's row: hash_body(xrow + kp * GOLD); this lane's pairs of a tile are k0 / 2 + 16 t + 4 g4 + 2 hi + {0, 1}
     const uint32_t hk = (uint32_t)((a.Lk + 1) >> 1);
     const uint32_t xrow = ((uint32_t)((long)z * a.Lq + qc) * hk + (uint32_t)(2 * hi)) * GOLD + a.drop.key;
     const uint32_t t16 = a.drop.thresh & 0xffff0000u;
-
-    Stage<DH, NT> rk, rv;
-    if (ktiles > 0) {
-        stage_fetch<DH, NT>(rk, K, a.ldk, 0, a.Lk, tid); stage_fetch<DH, NT>(rv, V, a.ldv, 0, a.Lk, tid);
-        stage_store<DH, NT>(sK, rk, tid); stage_store<DH, NT>(sV, rv, tid);
-        if (ktiles > 1) { stage_fetch<DH, NT>(rk, K, a.ldk, 64, a.Lk, tid); stage_fetch<DH, NT>(rv, V, a.ldv, 64, a.Lk, tid); }
-    }
+    f32x16_t s0[2], s1[2];
+    uint32_t wd[16];
+    wait_vm0();
     __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
+    if (wkt > 0) {
+        first2<DH>(s0, sK, qf, l31, hi);
+        if (DROP) pair_words(wd, xrow, 0);
+    }
+    __syncthreads();                                                // every wave has read K(0): iteration 0 refills its slot
+    auto iter = [&](const int kt, f32x16_t (&sc)[2], f32x16_t (&sn)[2]) {
         const int k0 = kt * 64, cur = kt & 1;
-        const bf16_t* tK = sK + cur * TILE;
-        const bf16_t* tV = sV + cur * TILE;
-        const bool active = kt < wkt;
-        f32x16_t s[2];
-        if (active) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) s[t] = mma32(frag_a<DH>(tK, t * 32 + l31, ks, hi), qf[ks], s[t]);
-            }
-        }
-        // the next tile goes into the other half of the ring: its last readers finished before the barrier that ended the previous iteration
-        if (kt + 1 < ktiles) {
-            stage_store<DH, NT>(sK + (cur ^ 1) * TILE, rk, tid); stage_store<DH, NT>(sV + (cur ^ 1) * TILE, rv, tid);
-            if (kt + 2 < ktiles) { stage_fetch<DH, NT>(rk, K, a.ldk, k0 + 128, a.Lk, tid); stage_fetch<DH, NT>(rv, V, a.ldv, k0 + 128, a.Lk, tid); }
-        }
-        if (active) {
-            if (!(A32_LAB & 1)) {
-                // every key of the tile visible to every row of this wave?  (wave-uniform; the common case skips the mask arithmetic)
-                const bool interior = k0 + 64 <= kend && (!causal || k0 + 63 <= qw0);
-                float mx = -INFINITY;
-                if (interior) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int key = k0 + t * 32 + crow(r, hi);
-                            const bool ok = key < kend && (!causal || key <= q);
-                            s[t][r] = ok ? s[t][r] : -INFINITY;
-                            mx = fmaxf(mx, s[t][r]);
-                        }
-                }
-                mx = half_max(mx) * sl2;
-                const bool grow = mx > m + A32_LAZY;             // also true for the first finite maximum (m = -inf)
-                if (__any(grow)) {
-                    const float mn = grow ? mx : m;
-                    const float alpha = mn == m ? 1.f : fast_exp2(m - mn);      // m = -inf -> 0
-                    m = mn; l *= alpha; g *= alpha;
-#pragma unroll
-                    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-                }
-                const float mref = m == -INFINITY ? 0.f : m;
+        if (kt + 2 < ktiles) dmk.issue(sK + cur * TILE, k0 + 128, wave);          // K(kt + 2) over K(kt), V(kt + 1) over V(kt - 1)
+        if (kt + 1 < ktiles) dmv.issue(sV + (cur ^ 1) * TILE, k0 + 64, wave);
+        if (kt < wkt) {
+            // every key of the tile visible to every row of this wave?  (wave-uniform; the common case skips the mask arithmetic)
+            const bool interior = k0 + 64 <= kend && (!causal || k0 + 63 <= qw0);
+            if (!interior) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float p = fast_exp2(fmaf(s[t][r], sl2, -mref));   // masked: 2^-inf = 0
-                        l += p;
-                        s[t][r] = p;
-                    }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { s[t][r] *= sl2; l += s[t][r]; }
-                m = 0.f;
-            }
-            if (ga) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) g += s[t][r] * ga_w(q, k0 + t * 32 + crow(r, hi), ga_iq, ga_ik, a.ga_inv2s2);
-            }
-            if (!(A32_LAB & 2) && a.drop.thresh) {
-                const uint32_t xt = xrow + (uint32_t)(k0 >> 1) * GOLD;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int pr = 0; pr < 8; ++pr) {                 // pair pr: registers 2 pr, 2 pr + 1 = keys k0 + 32 t + 8 (pr >> 1) + 4 hi + 2 (pr & 1) + {0, 1}
-                        const uint32_t w = hash_body(xt + (uint32_t)(t * 16 + (pr >> 1) * 4 + (pr & 1)) * GOLD);
-                        s[t][2 * pr] = (w << 16) >= t16 ? s[t][2 * pr] : 0.f;
-                        s[t][2 * pr + 1] = w >= t16 ? s[t][2 * pr + 1] : 0.f;
+                        const int key = k0 + t * 32 + crow(r, hi);
+                        sc[t][r] = (key < kend && (!causal || key <= q)) ? sc[t][r] : -INFINITY;
                     }
             }
+            float mx = fmaxf(sc[0][0], sc[1][0]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const bf16x8_t p0 = pack8<0>(s[t]), p1 = pack8<1>(s[t]);
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sc[0][r], sc[1][r]));
+            mx = half_max(mx) * sl2;
+            const bool grow = mx > m + A32_LAZY;                     // also true for the first finite maximum (m = -inf)
+            if (__any(grow)) {
+                const float mn = grow ? mx : m;
+                const float alpha = mn == m ? 1.f : fast_exp2(m - mn);          // m = -inf -> 0
+                m = mn; l *= alpha; g *= alpha;
 #pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    o[dt] = mma32(frag_t<DH>(tV, t * 32, dt * 32, lane), p0, o[dt]);
-                    o[dt] = mma32(frag_t<DH>(tV, t * 32 + 16, dt * 32, lane), p1, o[dt]);
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
+            const float mref = m == -INFINITY ? 0.f : m;
+            // ---- one block from here: logits of the NEXT tile (results unused after the wave's last tile) beside the softmax arithmetic of this one
+            first2<DH>(sn, sK + (cur ^ 1) * TILE, qf, l31, hi);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = fast_exp2(fmaf(sc[t][r], sl2, -mref));      // masked: 2^-inf = 0
+                    l += p;
+                    sc[t][r] = p;
                 }
+            if (GA) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) g += sc[t][r] * ga_w(q, k0 + t * 32 + crow(r, hi), ga_iq, ga_ik, a.ga_inv2s2);
             }
+            if (DROP) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int pr = 0; pr < 8; ++pr) {
+                        const uint32_t w = wd[t * 8 + pr];
+                        sc[t][2 * pr] = (w << 16) >= t16 ? sc[t][2 * pr] : 0.f;
+                        sc[t][2 * pr + 1] = w >= t16 ? sc[t][2 * pr + 1] : 0.f;
+                    }
+            }
+            second1<DH>(o, sV + cur * TILE, 0, sc[0], lane);
+            second1<DH>(o, sV + cur * TILE, 1, sc[1], lane);
+            if (DROP) pair_words(wd, xrow, k0 + 64);                  // the next tile's words, beside the P V products
         }
+        wait_vm0();
         __syncthreads();
+    };
+    for (int kt = 0; kt < ktiles; kt += 2) {
+        iter(kt, s0, s1);
+        if (kt + 1 < ktiles) iter(kt + 1, s1, s0);
     }
     l = half_sum(l);
-    if (ga) g = half_sum(g);
+    if (GA) g = half_sum(g);
     if (wlive && q < a.Lq) {
         const float inv = 1.f / l;
         store_own<DH>(out, o, inv * a.drop.scale, hi);
         if (hi == 0 && a.lse) a.lse[(long)z * a.Lq + q] = (m + __log2f(l)) * A32_LN2;
-        if (hi == 0 && ga) a.ga_rows[(long)z * a.Lq + q] = q < a.qlen[b] ? g * inv : 0.f;
+        if (hi == 0 && GA) a.ga_rows[(long)z * a.Lq + q] = q < a.qlen[b] ? g * inv : 0.f;
     }
 }
 
 // ================================================================================================ dQ
-template <int DH, int NW>
+template <int DH, int NW, bool DROP, bool GA>
 __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
-    constexpr int NKS = DH / 16, NDT = DH / 32, TILE = 64 * DH, NT = NW * 64, QB = NW * 32;
+    constexpr int NKS = DH / 16, NDT = DH / 32, TILE = 64 * DH, QB = NW * 32;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2 * TILE];
     __shared__ __attribute__((aligned(16))) bf16_t sV[2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -330,6 +355,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
     const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
     const bf16_t* O = reinterpret_cast<const bf16_t*>(a.oref) + (long)b * a.Lq * a.ldo + h * DH;
+    const bool causal = a.mask_mode & 2;
+    int kend = a.Lk;
+    if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
+    int ktiles = (kend + 63) / 64;
+    if (causal) {
+        int qlast = min(qb0 + QB - 1, a.Lq - 1);
+        if (a.qskip) qlast = min(qlast, ((qlive + 63) & ~63) - 1);
+        ktiles = min(ktiles, qlast / 64 + 1);
+    }
+    const int wkt = !wlive ? 0 : (causal ? min(ktiles, min(qw0 + 31, a.Lq - 1) / 64 + 1) : ktiles);
+    Dma<DH, NW> dmk, dmv;
+    dmk.init(K, a.ldk, a.Lk, wave, lane); dmv.init(V, a.ldv, a.Lk, wave, lane);
+    if (ktiles > 0) { dmk.issue(sK, 0, wave); dmv.issue(sV, 0, wave); }
     bf16x8_t qf[NKS], dof[NKS];
     float Dq = 0.f;                                                  // D[q] = sum_d dO[q][d] O[q][d]: this lane holds half of the row's features
 #pragma unroll
@@ -338,24 +376,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
         Dq += frag_dot(frag_own(O, a.ldo, qc, ks, hi), dof[ks]);
     }
     Dq = half_sum(Dq);
-    const bool causal = a.mask_mode & 2;
-    int kend = a.Lk;
-    if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     float gc = 0.f, ga_iq = 0.f, ga_ik = 0.f;
-    if (a.ga_rows) {                                                 // guided attention: dP += c W, D += c rowsum(P W) on valid query rows
+    if (GA) {                                                        // guided attention: dP += c W, D += c rowsum(P W) on valid query rows
         const int ql = min(a.qlen[b], a.Lq);
         if (q < ql) gc = *a.ga_scale;
         ga_iq = 1.f / (float)max(ql, 1); ga_ik = 1.f / (float)max(kend, 1);
         Dq += gc * a.ga_rows[(long)z * a.Lq + qc];
     }
     if (wlive && hi == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;   // the dK/dV kernel reads it
-    int ktiles = (kend + 63) / 64;
-    if (causal) {
-        int qlast = min(qb0 + QB - 1, a.Lq - 1);
-        if (a.qskip) qlast = min(qlast, ((qlive + 63) & ~63) - 1);
-        ktiles = min(ktiles, qlast / 64 + 1);
-    }
-    const int wkt = !wlive ? 0 : (causal ? min(ktiles, min(qw0 + 31, a.Lq - 1) / 64 + 1) : ktiles);
     f32x16_t dq[NDT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
@@ -366,83 +394,65 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
     const uint32_t xrow = ((uint32_t)((long)z * a.Lq + qc) * hk + (uint32_t)(2 * hi)) * GOLD + a.drop.key;
     const uint32_t t16 = a.drop.thresh & 0xffff0000u;
     const float dscale = a.drop.scale;
-
-    Stage<DH, NT> rk, rv;
-    if (ktiles > 0) {
-        stage_fetch<DH, NT>(rk, K, a.ldk, 0, a.Lk, tid); stage_fetch<DH, NT>(rv, V, a.ldv, 0, a.Lk, tid);
-        stage_store<DH, NT>(sK, rk, tid); stage_store<DH, NT>(sV, rv, tid);
-        if (ktiles > 1) { stage_fetch<DH, NT>(rk, K, a.ldk, 64, a.Lk, tid); stage_fetch<DH, NT>(rv, V, a.ldv, 64, a.Lk, tid); }
-    }
+    wait_vm0();
     __syncthreads();
     for (int kt = 0; kt < ktiles; ++kt) {
         const int k0 = kt * 64, cur = kt & 1;
         const bf16_t* tK = sK + cur * TILE;
         const bf16_t* tV = sV + cur * TILE;
-        const bool active = kt < wkt;
-        const bool interior = k0 + 64 <= kend && (!causal || k0 + 63 <= qw0);
-        const uint32_t xt = xrow + (uint32_t)(k0 >> 1) * GOLD;
+        if (kt + 1 < ktiles) { dmk.issue(sK + (cur ^ 1) * TILE, k0 + 64, wave); dmv.issue(sV + (cur ^ 1) * TILE, k0 + 64, wave); }
+        if (kt < wkt) {
+            const bool interior = k0 + 64 <= kend && (!causal || k0 + 63 <= qw0);
+            f32x16_t s[2], dp[2];
+            first2<DH>(s, tK, qf, l31, hi);
+            first2<DH>(dp, tV, dof, l31, hi);
+            if (!interior) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t == 1 && kt + 1 < ktiles) {                         // (between the two halves: the first half's reads of this tile are issued)
-                stage_store<DH, NT>(sK + (cur ^ 1) * TILE, rk, tid); stage_store<DH, NT>(sV + (cur ^ 1) * TILE, rv, tid);
-                if (kt + 2 < ktiles) { stage_fetch<DH, NT>(rk, K, a.ldk, k0 + 128, a.Lk, tid); stage_fetch<DH, NT>(rv, V, a.ldv, k0 + 128, a.Lk, tid); }
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + t * 32 + crow(r, hi);
+                        s[t][r] = (key < kend && (!causal || key <= q)) ? s[t][r] : -INFINITY;
+                    }
             }
-            if (!active) continue;
-            f32x16_t s, dp;
+            const uint32_t xt = xrow + (uint32_t)(k0 >> 1) * GOLD;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                s = mma32(frag_a<DH>(tK, t * 32 + l31, ks, hi), qf[ks], s);
-                dp = mma32(frag_a<DH>(tV, t * 32 + l31, ks, hi), dof[ks], dp);
-            }
-            if (interior) {
+                for (int r = 0; r < 16; ++r) s[t][r] = fast_exp2(fmaf(s[t][r], sl2, -lse2));    // masked: 2^-inf = 0
+                if (DROP) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = fast_exp2(fmaf(s[r], sl2, -lse2));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + t * 32 + crow(r, hi);
-                    const bool ok = key < kend && (!causal || key <= q);
-                    s[r] = ok ? fast_exp2(fmaf(s[r], sl2, -lse2)) : 0.f;
+                    for (int pr = 0; pr < 8; ++pr) {
+                        const uint32_t w = hash_body(xt + (uint32_t)(t * 16 + (pr >> 1) * 4 + (pr & 1)) * GOLD);
+                        dp[t][2 * pr] = (w << 16) >= t16 ? dp[t][2 * pr] * dscale : 0.f;
+                        dp[t][2 * pr + 1] = w >= t16 ? dp[t][2 * pr + 1] * dscale : 0.f;
+                    }
                 }
-            }
-            if (a.drop.thresh) {
+                if (GA) {
 #pragma unroll
-                for (int pr = 0; pr < 8; ++pr) {
-                    const uint32_t w = hash_body(xt + (uint32_t)(t * 16 + (pr >> 1) * 4 + (pr & 1)) * GOLD);
-                    dp[2 * pr] = (w << 16) >= t16 ? dp[2 * pr] * dscale : 0.f;
-                    dp[2 * pr + 1] = w >= t16 ? dp[2 * pr + 1] * dscale : 0.f;
+                    for (int r = 0; r < 16; ++r) dp[t][r] += gc * ga_w(q, k0 + t * 32 + crow(r, hi), ga_iq, ga_ik, a.ga_inv2s2);
                 }
-            }
-            if (__any(gc != 0.f)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dp[r] += gc * ga_w(q, k0 + t * 32 + crow(r, hi), ga_iq, ga_ik, a.ga_inv2s2);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = s[r] * (dp[r] - Dq);           // (x a.scale at the end)
-            const bf16x8_t p0 = pack8<0>(s), p1 = pack8<1>(s);
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                dq[dt] = mma32(frag_t<DH>(tK, t * 32, dt * 32, lane), p0, dq[dt]);
-                dq[dt] = mma32(frag_t<DH>(tK, t * 32 + 16, dt * 32, lane), p1, dq[dt]);
+                for (int r = 0; r < 16; ++r) s[t][r] = s[t][r] * (dp[t][r] - Dq);       // (x a.scale at the end)
+                second1<DH>(dq, tK, t, s[t], lane);
             }
         }
+        wait_vm0();
         __syncthreads();
     }
     if (wlive && q < a.Lq) store_own<DH>(dqo, dq, a.scale, hi);
 }
 
 // ================================================================================================ dK, dV
-template <int DH, int NW>
+template <int DH, int NW, bool DROP, bool GA>
 __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
-    constexpr int NKS = DH / 16, NDT = DH / 32, TILE = 64 * DH, NT = NW * 64, KB = NW * 32;
+    constexpr int NKS = DH / 16, NDT = DH / 32, TILE = 64 * DH, KB = NW * 32;
     __shared__ __attribute__((aligned(16))) bf16_t sQ[2 * TILE];
     __shared__ __attribute__((aligned(16))) bf16_t sO[2 * TILE];
     __shared__ __attribute__((aligned(16))) float sL[2 * 64], sD[2 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     int blk, z;
-    a32_block(blk, z);
+    a32_block(blk, z);                                               // rank 0 = the first key block (causal: the most query tiles)
     const int b = z / a.H, h = z - b * a.H;
     const int kb0 = blk * KB, kw0 = kb0 + wave * 32, key = kw0 + l31, kc = min(key, a.Lk - 1);
     int kend = a.Lk;
@@ -457,13 +467,27 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
     const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
+    int qtiles = (a.Lq + 63) / 64;
+    if (a.qskip) qtiles = min(qtiles, (a.qskip[b] + 63) / 64);       // tiles of padded query rows contribute nothing (d context = 0)
+    const int qt0 = causal ? kb0 / 64 : 0;                           // queries before this key block never see it
+    const int wqt0 = !wlive ? qtiles : (causal ? kw0 / 64 : 0);      // first query tile this wave computes
+    Dma<DH, NW> dmq, dmo;
+    dmq.init(Q, a.ldq, a.Lq, wave, lane); dmo.init(dO, a.ldo, a.Lq, wave, lane);
+    float r_l = 0.f, r_d = 0.f;
+    if (qt0 < qtiles) {
+        dmq.issue(sQ + (qt0 & 1) * TILE, qt0 * 64, wave); dmo.issue(sO + (qt0 & 1) * TILE, qt0 * 64, wave);
+        if (tid < 64) {
+            const int qq = min(qt0 * 64 + tid, a.Lq - 1);
+            sL[(qt0 & 1) * 64 + tid] = a.lse[(long)z * a.Lq + qq] * A32_LOG2E; sD[(qt0 & 1) * 64 + tid] = a.dsum[(long)z * a.Lq + qq];
+        }
+    }
     bf16x8_t kf[NKS], vf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) { kf[ks] = frag_own(K, a.ldk, kc, ks, hi); vf[ks] = frag_own(V, a.ldv, kc, ks, hi); }
     const bool key_ok = key < kend;
     float gc = 0.f, ga_iq = 0.f, ga_ik = 0.f;
     int ga_ql = 0;
-    if (a.ga_rows) {
+    if (GA) {
         ga_ql = min(a.qlen[b], a.Lq);
         gc = *a.ga_scale;
         ga_iq = 1.f / (float)max(ga_ql, 1); ga_ik = 1.f / (float)max(kend, 1);
@@ -473,10 +497,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-    int qtiles = (a.Lq + 63) / 64;
-    if (a.qskip) qtiles = min(qtiles, (a.qskip[b] + 63) / 64);       // tiles of padded query rows contribute nothing (d context = 0)
-    const int qt0 = causal ? kb0 / 64 : 0;                           // queries before this key block never see it
-    const int wqt0 = !wlive ? qtiles : (causal ? kw0 / 64 : 0);      // first query tile this wave computes
     const float sl2 = a.scale * A32_LOG2E, dscale = a.drop.scale;
     // dropout: word(row = z Lq + qq, pair = key >> 1), half (key & 1); x = (row hk + (key >> 1)) GOLD + dropkey, advanced by hk GOLD per query row
     const uint32_t hk = (uint32_t)((a.Lk + 1) >> 1);
@@ -484,19 +504,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
     const uint32_t xkey = ((uint32_t)z * (uint32_t)a.Lq * hk + (uint32_t)(kc >> 1)) * GOLD + a.drop.key + (uint32_t)(4 * hi) * hkg;
     const uint32_t hsh = (kc & 1) ? 0u : 16u;                        // shift that brings this key's half to the top
     const uint32_t t16 = a.drop.thresh & 0xffff0000u;
-
-    Stage<DH, NT> rq, ro;
-    float r_l = 0.f, r_d = 0.f;
-    if (qt0 < qtiles) {
-        stage_fetch<DH, NT>(rq, Q, a.ldq, qt0 * 64, a.Lq, tid); stage_fetch<DH, NT>(ro, dO, a.ldo, qt0 * 64, a.Lq, tid);
-        if (tid < 64) { const int qq = min(qt0 * 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq] * A32_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq]; }
-        stage_store<DH, NT>(sQ + (qt0 & 1) * TILE, rq, tid); stage_store<DH, NT>(sO + (qt0 & 1) * TILE, ro, tid);
-        if (tid < 64) { sL[(qt0 & 1) * 64 + tid] = r_l; sD[(qt0 & 1) * 64 + tid] = r_d; }
-        if (qt0 + 1 < qtiles) {
-            stage_fetch<DH, NT>(rq, Q, a.ldq, qt0 * 64 + 64, a.Lq, tid); stage_fetch<DH, NT>(ro, dO, a.ldo, qt0 * 64 + 64, a.Lq, tid);
-            if (tid < 64) { const int qq = min(qt0 * 64 + 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq] * A32_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq]; }
-        }
-    }
+    wait_vm0();
     __syncthreads();
     for (int qt = qt0; qt < qtiles; ++qt) {
         const int q0 = qt * 64, cur = qt & 1;
@@ -504,110 +512,93 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
         const bf16_t* tO = sO + cur * TILE;
         const float* tL = sL + cur * 64;
         const float* tD = sD + cur * 64;
-        const bool active = qt >= wqt0;
-        // all 32 keys of this wave valid and visible to all 64 queries of the tile?  (wave-uniform)
-        const bool interior = kw0 + 32 <= kend && q0 + 64 <= a.Lq && (!causal || kw0 + 31 <= q0);
+        if (qt + 1 < qtiles) {
+            dmq.issue(sQ + (cur ^ 1) * TILE, q0 + 64, wave); dmo.issue(sO + (cur ^ 1) * TILE, q0 + 64, wave);
+            if (tid < 64) { const int qq = min(q0 + 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq] * A32_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq]; }
+        }
+        if (qt >= wqt0) {
+            // all 32 keys of this wave valid and visible to all 64 queries of the tile?  (wave-uniform)
+            const bool interior = kw0 + 32 <= kend && q0 + 64 <= a.Lq && (!causal || kw0 + 31 <= q0);
+#pragma unroll 1
+            for (int t = 0; t < 2; ++t) {                            // (not unrolled: two halves in flight at once do not fit 256 registers)
+                f32x16_t s, dp;                                      // s[r] = S[q = q0 + 32 t + crow(r, hi)][key = own]
+                first1<DH>(s, tQ, t, kf, l31, hi);
+                cfence();
+                first1<DH>(dp, tO, t, vf, l31, hi);
+                cfence();
+                if (!interior) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t == 1 && qt + 1 < qtiles) {
-                stage_store<DH, NT>(sQ + (cur ^ 1) * TILE, rq, tid); stage_store<DH, NT>(sO + (cur ^ 1) * TILE, ro, tid);
-                if (tid < 64) { sL[(cur ^ 1) * 64 + tid] = r_l; sD[(cur ^ 1) * 64 + tid] = r_d; }
-                if (qt + 2 < qtiles) {
-                    stage_fetch<DH, NT>(rq, Q, a.ldq, q0 + 128, a.Lq, tid); stage_fetch<DH, NT>(ro, dO, a.ldo, q0 + 128, a.Lq, tid);
-                    if (tid < 64) { const int qq = min(q0 + 128 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq] * A32_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq]; }
-                }
-            }
-            if (!active) continue;
-            f32x16_t s, dp;                                          // s[r] = S[q = q0 + 32 t + crow(r, hi)][key = own]
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                s = mma32(frag_a<DH>(tQ, t * 32 + l31, ks, hi), kf[ks], s);
-                dp = mma32(frag_a<DH>(tO, t * 32 + l31, ks, hi), vf[ks], dp);
-            }
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4_t lq = *reinterpret_cast<const f32x4_t*>(tL + t * 32 + g4 * 8 + hi * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = g4 * 4 + j;
-                    if (interior) s[r] = fast_exp2(fmaf(s[r], sl2, -lq[j]));
-                    else {
+                    for (int r = 0; r < 16; ++r) {
                         const int qq = q0 + t * 32 + crow(r, hi);
-                        const bool ok = key_ok && qq < a.Lq && (!causal || key <= qq);
-                        s[r] = ok ? fast_exp2(fmaf(s[r], sl2, -lq[j])) : 0.f;
+                        s[r] = (key_ok && qq < a.Lq && (!causal || key <= qq)) ? s[r] : -INFINITY;
                     }
                 }
-            }
-            f32x16_t pd;
-            if (a.drop.thresh) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4_t lq = *reinterpret_cast<const f32x4_t*>(tL + t * 32 + g4 * 8 + hi * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[g4 * 4 + j] = fast_exp2(fmaf(s[g4 * 4 + j], sl2, -lq[j]));
+                }
+                // in place: dp <- dS = P (dropped dP - D) (x a.scale at the end), s <- dropped P (x dscale at the end)
                 uint32_t x = xkey + (uint32_t)(q0 + t * 32) * hkg;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {                        // query row q0 + 32 t + 8 (r >> 2) + (r & 3) (+ 4 hi, in xkey)
-                    if (r) x += (r & 3) ? hkg : hkg5;
-                    const uint32_t w = hash_body(x);
-                    const bool keep = (w << hsh) >= t16;
-                    dp[r] = keep ? dp[r] * dscale : 0.f;
-                    pd[r] = keep ? s[r] : 0.f;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(tD + t * 32 + g4 * 8 + hi * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = g4 * 4 + j;                     // query row q0 + 32 t + 8 g4 + j (+ 4 hi, in xkey)
+                        bool keep = true;
+                        if (DROP) {
+                            if (r) x += j ? hkg : hkg5;
+                            keep = (hash_body(x) << hsh) >= t16;
+                        }
+                        float d = keep ? dp[r] * dscale : 0.f;
+                        if (GA) { const int qq = q0 + t * 32 + crow(r, hi); d += qq < ga_ql ? gc * ga_w(qq, key, ga_iq, ga_ik, a.ga_inv2s2) : 0.f; }
+                        dp[r] = s[r] * (d - d4[j]);
+                        s[r] = keep ? s[r] : 0.f;
+                    }
                 }
-            } else pd = s;
-            if (gc != 0.f) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int qq = q0 + t * 32 + crow(r, hi);
-                    dp[r] += qq < ga_ql ? gc * ga_w(qq, key, ga_iq, ga_ik, a.ga_inv2s2) : 0.f;
-                }
-            }
-            {
-                const bf16x8_t p0 = pack8<0>(pd), p1 = pack8<1>(pd);    // dV^T[d][key] += sum_q dO[q][d] Pd[q][key]
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    dv[dt] = mma32(frag_t<DH>(tO, t * 32, dt * 32, lane), p0, dv[dt]);
-                    dv[dt] = mma32(frag_t<DH>(tO, t * 32 + 16, dt * 32, lane), p1, dv[dt]);
-                }
-            }
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(tD + t * 32 + g4 * 8 + hi * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s[g4 * 4 + j] = s[g4 * 4 + j] * (dp[g4 * 4 + j] - d4[j]);
-            }
-            {
-                const bf16x8_t p0 = pack8<0>(s), p1 = pack8<1>(s);      // dK^T[d][key] += sum_q Q[q][d] dS[q][key]
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    dk[dt] = mma32(frag_t<DH>(tQ, t * 32, dt * 32, lane), p0, dk[dt]);
-                    dk[dt] = mma32(frag_t<DH>(tQ, t * 32 + 16, dt * 32, lane), p1, dk[dt]);
-                }
+                cfence();
+                second1<DH>(dv, tO, t, s, lane);                     // dV^T[d][key] += sum_q dO[q][d] Pd[q][key]
+                cfence();
+                second1<DH>(dk, tQ, t, dp, lane);                    // dK^T[d][key] += sum_q Q[q][d] dS[q][key]
+                cfence();
             }
         }
+        if (qt + 1 < qtiles && tid < 64) { sL[(cur ^ 1) * 64 + tid] = r_l; sD[(cur ^ 1) * 64 + tid] = r_d; }
+        wait_vm0();
         __syncthreads();
     }
     if (wlive && key < a.Lk) { store_own<DH>(dko, dk, a.scale, hi); store_own<DH>(dvo, dv, dscale, hi); }
 }
 
-template <int DH>
+template <int DH, bool DROP, bool GA>
 int launch32(const AttnArgs& a, int which, hipStream_t st) {
     constexpr int NW = 4;
     if (which == 0) {
-        hipLaunchKernelGGL((attn32_fwd_kernel<DH, NW>), dim3(cdiv(a.Lq, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
+        hipLaunchKernelGGL((attn32_fwd_kernel<DH, NW, DROP, GA>), dim3(cdiv(a.Lq, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
     } else if (which == 1) {
-        hipLaunchKernelGGL((attn32_dq_kernel<DH, NW>), dim3(cdiv(a.Lq, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
+        hipLaunchKernelGGL((attn32_dq_kernel<DH, NW, DROP, GA>), dim3(cdiv(a.Lq, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
     } else {
-        hipLaunchKernelGGL((attn32_dkv_kernel<DH, NW>), dim3(cdiv(a.Lk, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
+        hipLaunchKernelGGL((attn32_dkv_kernel<DH, NW, DROP, GA>), dim3(cdiv(a.Lk, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
     }
     B2S_LAUNCH_CHECK();
     return 0;
+}
+template <int DH>
+int launch32_dh(const AttnArgs& a, int which, hipStream_t st) {
+    const bool drop = a.drop.thresh != 0, ga = a.ga_rows != nullptr;
+    if (ga) return drop ? launch32<DH, true, true>(a, which, st) : launch32<DH, false, true>(a, which, st);
+    return drop ? launch32<DH, true, false>(a, which, st) : launch32<DH, false, false>(a, which, st);
 }
 }  // namespace
 
 bool b2s_flash32_supported(int dh) { return dh == 32 || dh == 64 || dh == 96; }
 int b2s_flash32_launch(const AttnArgs& a, int dh, int which, hipStream_t st) {
     switch (dh) {
-        case 32: return launch32<32>(a, which, st);
-        case 64: return launch32<64>(a, which, st);
-        case 96: return launch32<96>(a, which, st);
+        case 32: return launch32_dh<32>(a, which, st);
+        case 64: return launch32_dh<64>(a, which, st);
+        case 96: return launch32_dh<96>(a, which, st);
     }
     return b2s_fail(__FILE__, __LINE__, "bf16 attention supports head sizes 32/64/96 (got %d)", dh);
 }
