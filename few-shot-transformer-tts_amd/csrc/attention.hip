@@ -169,6 +169,19 @@ __device__ inline float ga_w(int q, int k, float iq, float ik, float inv2s2) {
     return 1.f - __expf(-d * d * inv2s2);
 }
 
+// attention-weight dropout (b2s_common.h: b2s_keep_w) for a lane that owns a weight row (seed = b2s_wseed of the row): registers r = 0 .. 3 of tile t
+// are the quad of keys k0 + t * 16 + lg * 4 + {0 .. 3}; kept elements are multiplied by mul
+__device__ inline void drop_quads(f32x4_t (&w)[4], uint32_t seed, int k0, int lg, int ts, float mul) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t y = b2s_wmix(seed, (uint32_t)((k0 >> 2) + t * 4 + lg)), w0 = y * B2S_WC0, w1 = y * B2S_WC1;
+        w[t][0] = (int)(int16_t)(uint16_t)w0 >= ts ? w[t][0] * mul : 0.f;
+        w[t][1] = (int)(int16_t)(uint16_t)(w0 >> 16) >= ts ? w[t][1] * mul : 0.f;
+        w[t][2] = (int)(int16_t)(uint16_t)w1 >= ts ? w[t][2] * mul : 0.f;
+        w[t][3] = (int)(int16_t)(uint16_t)(w1 >> 16) >= ts ? w[t][3] * mul : 0.f;
+    }
+}
+
 // store a transposed accumulator (col = own row li, rows = feature dt*16 + lg*4 + r) as 4 consecutive features
 template <typename T, int DH>
 __device__ inline void store_rows(T* dst, const f32x4_t (&acc)[DH / 16], float mul, int lg) {
@@ -229,7 +242,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_fwd_kernel(A
     if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
     const float sl2 = a.scale * B2S_LOG2E;
     const int qw0 = qb0 + wave * 16;                 // first query row of this wave
-    const uint32_t drow = (uint32_t)((long)z * a.Lq + qc), dhk = (uint32_t)((a.Lk + 1) >> 1);
+    const uint32_t dseed = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qc));
+    const int dts = b2s_wthresh(a.drop);
     TileRegs<T, DH> rk, rv;
     if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid); }
     for (int kt = 0; kt < ktiles; ++kt) {
@@ -282,13 +296,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_fwd_kernel(A
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g += s[t][r] * ga_w(q, k0 + t * 16 + lg * 4 + r, ga_iq, ga_ik, a.ga_inv2s2);
         }
-        if (a.drop.thresh) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    s[t][r] = b2s_keep_w(a.drop, drow, dhk, (uint32_t)(k0 + t * 16 + lg * 4 + r)) ? s[t][r] * a.drop.scale : 0.f;
-        }
+        if (a.drop.thresh) drop_quads(s, dseed, k0, lg, dts, a.drop.scale);
         SP<T, DH, LD>::run(o, sV, s, li, lg);
     }
     l = group_sum(l);
@@ -381,7 +389,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DQ_WPC : 1) void att
     f32x4_t dq[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const uint32_t drow = (uint32_t)((long)z * a.Lq + qc), dhk = (uint32_t)((a.Lk + 1) >> 1);
+    const uint32_t dseed = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qc));
+    const int dts = b2s_wthresh(a.drop);
     const float sl2 = a.scale * B2S_LOG2E, lse2 = lse * B2S_LOG2E;
     const int qw0 = qb0 + wave * 16;
     TileRegs<T, DH> rk, rv;
@@ -412,13 +421,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DQ_WPC : 1) void att
                     s[t][r] = ok ? fast_exp2(fmaf(s[t][r], sl2, -lse2)) : 0.f;
                 }
         }
-        if (a.drop.thresh) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    dp[t][r] = b2s_keep_w(a.drop, drow, dhk, (uint32_t)(k0 + t * 16 + lg * 4 + r)) ? dp[t][r] * a.drop.scale : 0.f;
-        }
+        if (a.drop.thresh) drop_quads(dp, dseed, k0, lg, dts, a.drop.scale);
         if (__any(gc != 0.f)) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DKV_WPC : 1) void at
     __shared__ __attribute__((aligned(16))) T sQ[64 * LD];
     __shared__ __attribute__((aligned(16))) T sO[64 * LD];
     __shared__ __attribute__((aligned(16))) float sL[64], sD[64];
+    __shared__ __attribute__((aligned(16))) uint32_t sS[64];             // dropout seeds of the tile's query rows (b2s_common.h: b2s_keep_w)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     int tile_, z;
     xcd_block(tile_, z);
@@ -472,23 +476,35 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DKV_WPC : 1) void at
     const int qt0 = (a.mask_mode & 2) ? kb0 / 64 : 0;          // causal: queries before this key tile never see it
     TileRegs<T, DH> rq, ro;
     float r_l = 0.f, r_d = 0.f;
+    uint32_t r_s = 0;
     const float sl2 = a.scale * B2S_LOG2E;
     const int kw0 = kb0 + wave * 16;                 // first key of this wave
     const uint32_t zq = (uint32_t)z * (uint32_t)a.Lq;
+    // this key's part of the dropout rule: quad offset, multiplier, the shift that brings its field to the top 16 bits
+    const uint32_t dxk = (uint32_t)(kc >> 2) * 0x9E3779B1u, dwc = (kc & 2) ? B2S_WC1 : B2S_WC0, dsh = (kc & 1) ? 0u : 16u;
+    const int dts32 = (int)((uint32_t)b2s_wthresh(a.drop) << 16);
     if (qt0 < qtiles) {
         tile_fetch<T, DH>(rq, Q, a.ldq, qt0 * 64, a.Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, qt0 * 64, a.Lq, tid);
-        if (tid < 64) { const int qq = min(qt0 * 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq] * B2S_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq]; }
+        if (tid < 64) {
+            const int qq = min(qt0 * 64 + tid, a.Lq - 1);
+            r_l = a.lse[(long)z * a.Lq + qq] * B2S_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq];
+            if (a.drop.thresh) r_s = b2s_wseed(a.drop, zq + (uint32_t)qq);
+        }
     }
     for (int qt = qt0; qt < qtiles; ++qt) {
         const int q0 = qt * 64;
         __syncthreads();
         tile_store<T, DH>(sQ, rq, tid);
         tile_store<T, DH>(sO, ro, tid);
-        if (tid < 64) { sL[tid] = r_l; sD[tid] = r_d; }
+        if (tid < 64) { sL[tid] = r_l; sD[tid] = r_d; sS[tid] = r_s; }
         __syncthreads();
         if (qt + 1 < qtiles) {
             tile_fetch<T, DH>(rq, Q, a.ldq, q0 + 64, a.Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, q0 + 64, a.Lq, tid);
-            if (tid < 64) { const int qq = min(q0 + 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq] * B2S_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq]; }
+            if (tid < 64) {
+                const int qq = min(q0 + 64 + tid, a.Lq - 1);
+                r_l = a.lse[(long)z * a.Lq + qq] * B2S_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq];
+                if (a.drop.thresh) r_s = b2s_wseed(a.drop, zq + (uint32_t)qq);
+            }
         }
         f32x4_t s[4], dp[4], pd[4];
         first_product<T, DH, LD>(s, sQ, kf, li, lg);          // s[t][r] = S[q = q0 + t*16 + lg*4 + r][key = own]
@@ -516,13 +532,17 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DKV_WPC : 1) void at
         }
         if (a.drop.thresh) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t) {
+                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+                const u32x4_t sd4 = *reinterpret_cast<const u32x4_t*>(sS + t * 16 + lg * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool keep = b2s_keep_w(a.drop, zq + (uint32_t)(q0 + t * 16 + lg * 4 + r), (uint32_t)((a.Lk + 1) >> 1), (uint32_t)kc);
+                    const uint32_t x = sd4[r] + dxk;                                // seed of query row q0 + t 16 + lg 4 + r, + this key's quad
+                    const bool keep = (int)(((x ^ (x >> 16)) * dwc) << dsh) >= dts32;
                     dp[t][r] = keep ? dp[t][r] * a.drop.scale : 0.f;
                     pd[t][r] = keep ? s[t][r] * a.drop.scale : 0.f;
                 }
+            }
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) pd[t] = s[t];
@@ -637,7 +657,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_res_kern
         mx = group_max(mx) * sl2;
         const float mref = mx == -INFINITY ? 0.f : mx;
         float l = 0.f, g = 0.f;
-        const uint32_t drow = (uint32_t)((long)z * a.Lq + qc), dhk = (uint32_t)((a.Lk + 1) >> 1);
+        const uint32_t dseed = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qc));
+    const int dts = b2s_wthresh(a.drop);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             if (kt >= nkt) continue;
@@ -655,13 +676,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_res_kern
 #pragma unroll
                     for (int r = 0; r < 4; ++r) g += s[kt][t][r] * ga_w(q, kt * 64 + t * 16 + lg * 4 + r, ga_iq, ga_ik, a.ga_inv2s2);
             }
-            if (a.drop.thresh) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        s[kt][t][r] = b2s_keep_w(a.drop, drow, dhk, (uint32_t)(kt * 64 + t * 16 + lg * 4 + r)) ? s[kt][t][r] * a.drop.scale : 0.f;
-            }
+            if (a.drop.thresh) drop_quads(s[kt], dseed, kt * 64, lg, dts, a.drop.scale);
             SP<T, DH, LD>::run(o, sV + kt * 64 * LD, s[kt], li, lg);
         }
         l = group_sum(l);
@@ -731,7 +746,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_res_k
             Dq += gc * a.ga_rows[(long)z * a.Lq + qc];
         }
         if (lg == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;              // the dK/dV kernel reads it
-        const uint32_t drow = (uint32_t)((long)z * a.Lq + qc), dhk = (uint32_t)((a.Lk + 1) >> 1);
+        const uint32_t dseed = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qc));
+    const int dts = b2s_wthresh(a.drop);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             if (kt >= nkt) continue;
@@ -746,13 +762,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_res_k
                     const bool ok = interior || (kt * 64 + t * 16 + lg * 4 + r) < kend;
                     s[t][r] = ok ? fast_exp2(fmaf(s[t][r], sl2, -lse2)) : 0.f;
                 }
-            if (a.drop.thresh) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        dp[t][r] = b2s_keep_w(a.drop, drow, dhk, (uint32_t)(kt * 64 + t * 16 + lg * 4 + r)) ? dp[t][r] * a.drop.scale : 0.f;
-            }
+            if (a.drop.thresh) drop_quads(dp, dseed, kt * 64, lg, dts, a.drop.scale);
             if (__any(gc != 0.f)) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)

@@ -11,7 +11,7 @@
 //                                             first product AS IT LIES: k-slot j of lane half hi <-> streamed row 16 s + 4 hi + (j & 3) + 8 (j >> 2),
 //                                             the transposed reads fetch exactly those rows, so no lane exchange is needed
 // so the softmax is in registers (a row's other half of the keys lives in lane ^ 32: one v_permlane32_swap per reduction), the dropout word of a
-// key PAIR is one hash in the forward / dQ kernels (b2s_common.h: b2s_wword), and 32 rows per wave halve the LDS bytes per FLOP of the 16-row
+// four adjacent keys costs four integer operations in the forward / dQ kernels (b2s_common.h: b2s_keep_w), and 32 rows per wave halve the LDS bytes per FLOP of the 16-row
 // kernels.  LDS tiles are unpadded [64][dh] images with the 16-byte chunk index XORed by row bits (conflict-free for the b128 reads of one tile row
 // per lane AND for the transposed reads of 4 rows x 64 bytes per 32 lanes).
 #include "b2s_common.h"
@@ -38,6 +38,7 @@ __device__ inline float half_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ inline float vmax3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 constexpr float A32_LOG2E = 1.4426950408889634f, A32_LN2 = 0.6931471805599453f;
 constexpr float A32_LAZY = 8.f;                       // running-maximum slack, as attention.hip: B2S_LAZY
 
@@ -144,7 +145,6 @@ template <int DH> __device__ inline void zero_own(bf16_t* dst, int hi) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<uint2*>(dst + dt * 32 + g4 * 8 + hi * 4) = make_uint2(0, 0);
 }
-__device__ inline uint32_t hash_body(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 constexpr uint32_t GOLD = 0x9E3779B1u;
 
 
@@ -176,14 +176,38 @@ __device__ inline void second1(f32x16_t (&acc)[DH / 32], const bf16_t* tile, int
         acc[dt] = mma32(frag_t<DH>(tile, t * 32 + 16, dt * 32, lane), p1, acc[dt]);
     }
 }
-// dropout words of this lane's 16 key pairs of the 64-key tile at k0 (forward / dQ: the lane owns a weight row; xrow includes the lane's 2 hi pair offset)
-__device__ inline void pair_words(uint32_t (&wd)[16], uint32_t xrow, int k0) {
-    const uint32_t xt = xrow + (uint32_t)(k0 >> 1) * GOLD;
+// dropout (b2s_common.h: b2s_keep_w): the two words of each of this lane's 8 key quads of the 64-key tile at k0 -- forward / dQ, where the lane owns a
+// weight row: xrow = seed(row) + hi * GOLD; quad (t, g4) = keys k0 + 32 t + 8 g4 + 4 hi + {0 .. 3} = accumulator registers 4 g4 .. 4 g4 + 3 of half t
+__device__ inline void quad_words(uint32_t (&wd)[16], uint32_t xrow, int k0) {
+    const uint32_t xt = xrow + (uint32_t)(k0 >> 2) * GOLD;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int pr = 0; pr < 8; ++pr)      // pair pr of half t: registers 2 pr, 2 pr + 1 = keys k0 + 32 t + 8 (pr >> 1) + 4 hi + 2 (pr & 1) + {0, 1}
-            wd[t * 8 + pr] = hash_body(xt + (uint32_t)(t * 16 + (pr >> 1) * 4 + (pr & 1)) * GOLD);
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const uint32_t x = xt + (uint32_t)(t * 8 + g4 * 2) * GOLD, y = x ^ (x >> 16);
+            wd[t * 8 + g4 * 2] = y * B2S_WC0; wd[t * 8 + g4 * 2 + 1] = y * B2S_WC1;
+        }
+}
+// 0xffff in every 16-bit field of w that is kept: (int16) field >= ts  <=>  (ts - 1) - field < 0 (saturating, so the sign survives)
+__device__ inline uint32_t keep_mask16(uint32_t w, uint32_t tsm1, uint32_t fifteen) {
+    uint32_t d, m;
+    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(tsm1), "v"(w));
+    asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(m) : "v"(fifteen), "v"(d));
+    return m;
+}
+// B operands of a second product from accumulator registers [8 S8, 8 S8 + 8), with the dropout fields of words wd[4 S8 .. 4 S8 + 3] applied to the bf16 pairs
+template <int S8> __device__ inline bf16x8_t pack8_drop(const f32x16_t& v, const uint32_t* wd, uint32_t tsm1, uint32_t fifteen) {
+    const u32x4_t u = {f2bf2(v[S8 * 8 + 0], v[S8 * 8 + 1]) & keep_mask16(wd[S8 * 4 + 0], tsm1, fifteen), f2bf2(v[S8 * 8 + 2], v[S8 * 8 + 3]) & keep_mask16(wd[S8 * 4 + 1], tsm1, fifteen),
+                       f2bf2(v[S8 * 8 + 4], v[S8 * 8 + 5]) & keep_mask16(wd[S8 * 4 + 2], tsm1, fifteen), f2bf2(v[S8 * 8 + 6], v[S8 * 8 + 7]) & keep_mask16(wd[S8 * 4 + 3], tsm1, fifteen)};
+    return __builtin_bit_cast(bf16x8_t, u);
+}
+template <int DH>
+__device__ inline void second1p(f32x16_t (&acc)[DH / 32], const bf16_t* tile, int t, bf16x8_t p0, bf16x8_t p1, int lane) {
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt) {
+        acc[dt] = mma32(frag_t<DH>(tile, t * 32, dt * 32, lane), p0, acc[dt]);
+        acc[dt] = mma32(frag_t<DH>(tile, t * 32 + 16, dt * 32, lane), p1, acc[dt]);
+    }
 }
 
 // ================================================================================================ forward
@@ -240,16 +264,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
     float ga_iq = 0.f, ga_ik = 0.f;
     if (GA) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
     const float sl2 = a.scale * A32_LOG2E;
-    const uint32_t hk = (uint32_t)((a.Lk + 1) >> 1);
-    const uint32_t xrow = ((uint32_t)((long)z * a.Lq + qc) * hk + (uint32_t)(2 * hi)) * GOLD + a.drop.key;
-    const uint32_t t16 = a.drop.thresh & 0xffff0000u;
+    const uint32_t xrow = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qc)) + (uint32_t)hi * GOLD;
+    const uint32_t tsm1 = ((uint32_t)(b2s_wthresh(a.drop) - 1) & 0xffffu) * 0x10001u, fifteen = 0x000f000fu;
     f32x16_t s0[2], s1[2];
     uint32_t wd[16];
     wait_vm0();
     __syncthreads();
     if (wkt > 0) {
         first2<DH>(s0, sK, qf, l31, hi);
-        if (DROP) pair_words(wd, xrow, 0);
+        if (DROP) quad_words(wd, xrow, 0);
     }
     __syncthreads();                                                // every wave has read K(0): iteration 0 refills its slot
     auto iter = [&](const int kt, f32x16_t (&sc)[2], f32x16_t (&sn)[2]) {
@@ -268,9 +291,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
                         sc[t][r] = (key < kend && (!causal || key <= q)) ? sc[t][r] : -INFINITY;
                     }
             }
-            float mx = fmaxf(sc[0][0], sc[1][0]);
+            float mx = sc[0][0];                                      // (v_max3 by hand: fmaxf on MFMA results costs a canonicalising v_max per operand)
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sc[0][r], sc[1][r]));
+            for (int r = 0; r < 16; ++r) mx = vmax3(mx, sc[0][r], sc[1][r]);
             mx = half_max(mx) * sl2;
             const bool grow = mx > m + A32_LAZY;                     // also true for the first finite maximum (m = -inf)
             if (__any(grow)) {
@@ -300,18 +323,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
                     for (int r = 0; r < 16; ++r) g += sc[t][r] * ga_w(q, k0 + t * 32 + crow(r, hi), ga_iq, ga_ik, a.ga_inv2s2);
             }
             if (DROP) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int pr = 0; pr < 8; ++pr) {
-                        const uint32_t w = wd[t * 8 + pr];
-                        sc[t][2 * pr] = (w << 16) >= t16 ? sc[t][2 * pr] : 0.f;
-                        sc[t][2 * pr + 1] = w >= t16 ? sc[t][2 * pr + 1] : 0.f;
-                    }
+                second1p<DH>(o, sV + cur * TILE, 0, pack8_drop<0>(sc[0], wd, tsm1, fifteen), pack8_drop<1>(sc[0], wd, tsm1, fifteen), lane);
+                second1p<DH>(o, sV + cur * TILE, 1, pack8_drop<0>(sc[1], wd + 8, tsm1, fifteen), pack8_drop<1>(sc[1], wd + 8, tsm1, fifteen), lane);
+            } else {
+                second1<DH>(o, sV + cur * TILE, 0, sc[0], lane);
+                second1<DH>(o, sV + cur * TILE, 1, sc[1], lane);
             }
-            second1<DH>(o, sV + cur * TILE, 0, sc[0], lane);
-            second1<DH>(o, sV + cur * TILE, 1, sc[1], lane);
-            if (DROP) pair_words(wd, xrow, k0 + 64);                  // the next tile's words, beside the P V products
+            if (DROP) quad_words(wd, xrow, k0 + 64);                  // the next tile's words, beside the P V products
         }
         wait_vm0();
         __syncthreads();
@@ -390,9 +408,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
     const float sl2 = a.scale * A32_LOG2E, lse2 = a.lse[(long)z * a.Lq + qc] * A32_LOG2E;
-    const uint32_t hk = (uint32_t)((a.Lk + 1) >> 1);
-    const uint32_t xrow = ((uint32_t)((long)z * a.Lq + qc) * hk + (uint32_t)(2 * hi)) * GOLD + a.drop.key;
-    const uint32_t t16 = a.drop.thresh & 0xffff0000u;
+    const uint32_t xrow = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qc)) + (uint32_t)hi * GOLD;
+    const int ts32 = (int)((uint32_t)b2s_wthresh(a.drop) << 16);        // a field brought to the top 16 bits, compared as a signed word
     const float dscale = a.drop.scale;
     wait_vm0();
     __syncthreads();
@@ -415,7 +432,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
                         s[t][r] = (key < kend && (!causal || key <= q)) ? s[t][r] : -INFINITY;
                     }
             }
-            const uint32_t xt = xrow + (uint32_t)(k0 >> 1) * GOLD;
+            uint32_t wd[16];
+            if (DROP) quad_words(wd, xrow, k0);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -423,9 +441,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
                 if (DROP) {
 #pragma unroll
                     for (int pr = 0; pr < 8; ++pr) {
-                        const uint32_t w = hash_body(xt + (uint32_t)(t * 16 + (pr >> 1) * 4 + (pr & 1)) * GOLD);
-                        dp[t][2 * pr] = (w << 16) >= t16 ? dp[t][2 * pr] * dscale : 0.f;
-                        dp[t][2 * pr + 1] = w >= t16 ? dp[t][2 * pr + 1] * dscale : 0.f;
+                        const uint32_t w = wd[t * 8 + pr];
+                        dp[t][2 * pr] = (int)(w << 16) >= ts32 ? dp[t][2 * pr] * dscale : 0.f;
+                        dp[t][2 * pr + 1] = (int)w >= ts32 ? dp[t][2 * pr + 1] * dscale : 0.f;
                     }
                 }
                 if (GA) {
@@ -450,6 +468,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t sQ[2 * TILE];
     __shared__ __attribute__((aligned(16))) bf16_t sO[2 * TILE];
     __shared__ __attribute__((aligned(16))) float sL[2 * 64], sD[2 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t sS[2 * 64];     // dropout seeds of the tile's query rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     int blk, z;
     a32_block(blk, z);                                               // rank 0 = the first key block (causal: the most query tiles)
@@ -474,11 +493,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
     Dma<DH, NW> dmq, dmo;
     dmq.init(Q, a.ldq, a.Lq, wave, lane); dmo.init(dO, a.ldo, a.Lq, wave, lane);
     float r_l = 0.f, r_d = 0.f;
+    uint32_t r_s = 0;
     if (qt0 < qtiles) {
         dmq.issue(sQ + (qt0 & 1) * TILE, qt0 * 64, wave); dmo.issue(sO + (qt0 & 1) * TILE, qt0 * 64, wave);
         if (tid < 64) {
             const int qq = min(qt0 * 64 + tid, a.Lq - 1);
             sL[(qt0 & 1) * 64 + tid] = a.lse[(long)z * a.Lq + qq] * A32_LOG2E; sD[(qt0 & 1) * 64 + tid] = a.dsum[(long)z * a.Lq + qq];
+            if (DROP) sS[(qt0 & 1) * 64 + tid] = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qq));
         }
     }
     bf16x8_t kf[NKS], vf[NKS];
@@ -498,12 +519,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
     const float sl2 = a.scale * A32_LOG2E, dscale = a.drop.scale;
-    // dropout: word(row = z Lq + qq, pair = key >> 1), half (key & 1); x = (row hk + (key >> 1)) GOLD + dropkey, advanced by hk GOLD per query row
-    const uint32_t hk = (uint32_t)((a.Lk + 1) >> 1);
-    const uint32_t hkg = hk * GOLD, hkg5 = 5u * hkg;
-    const uint32_t xkey = ((uint32_t)z * (uint32_t)a.Lq * hk + (uint32_t)(kc >> 1)) * GOLD + a.drop.key + (uint32_t)(4 * hi) * hkg;
-    const uint32_t hsh = (kc & 1) ? 0u : 16u;                        // shift that brings this key's half to the top
-    const uint32_t t16 = a.drop.thresh & 0xffff0000u;
+    // dropout (b2s_common.h: b2s_keep_w): y = mix(seed(query row) + (key >> 2) GOLD); this key's multiplier and the shift that brings its field to the top
+    const uint32_t xk = (uint32_t)(kc >> 2) * GOLD, wck = (kc & 2) ? B2S_WC1 : B2S_WC0, hsh = (kc & 1) ? 0u : 16u;
+    const int ts32 = (int)((uint32_t)b2s_wthresh(a.drop) << 16);
     wait_vm0();
     __syncthreads();
     for (int qt = qt0; qt < qtiles; ++qt) {
@@ -512,9 +530,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
         const bf16_t* tO = sO + cur * TILE;
         const float* tL = sL + cur * 64;
         const float* tD = sD + cur * 64;
+        const uint32_t* tS = sS + cur * 64;
         if (qt + 1 < qtiles) {
             dmq.issue(sQ + (cur ^ 1) * TILE, q0 + 64, wave); dmo.issue(sO + (cur ^ 1) * TILE, q0 + 64, wave);
-            if (tid < 64) { const int qq = min(q0 + 64 + tid, a.Lq - 1); r_l = a.lse[(long)z * a.Lq + qq] * A32_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq]; }
+            if (tid < 64) {
+                const int qq = min(q0 + 64 + tid, a.Lq - 1);
+                r_l = a.lse[(long)z * a.Lq + qq] * A32_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq];
+                if (DROP) r_s = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qq));
+            }
         }
         if (qt >= wqt0) {
             // all 32 keys of this wave valid and visible to all 64 queries of the tile?  (wave-uniform)
@@ -540,17 +563,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
                     for (int j = 0; j < 4; ++j) s[g4 * 4 + j] = fast_exp2(fmaf(s[g4 * 4 + j], sl2, -lq[j]));
                 }
                 // in place: dp <- dS = P (dropped dP - D) (x a.scale at the end), s <- dropped P (x dscale at the end)
-                uint32_t x = xkey + (uint32_t)(q0 + t * 32) * hkg;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(tD + t * 32 + g4 * 8 + hi * 4);
+                    u32x4_t sd4 = {0, 0, 0, 0};
+                    if (DROP) sd4 = *reinterpret_cast<const u32x4_t*>(tS + t * 32 + g4 * 8 + hi * 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int r = g4 * 4 + j;                     // query row q0 + 32 t + 8 g4 + j (+ 4 hi, in xkey)
+                        const int r = g4 * 4 + j;                     // query row q0 + 32 t + 8 g4 + 4 hi + j
                         bool keep = true;
                         if (DROP) {
-                            if (r) x += j ? hkg : hkg5;
-                            keep = (hash_body(x) << hsh) >= t16;
+                            const uint32_t x = sd4[j] + xk;
+                            keep = (int)(((x ^ (x >> 16)) * wck) << hsh) >= ts32;
                         }
                         float d = keep ? dp[r] * dscale : 0.f;
                         if (GA) { const int qq = q0 + t * 32 + crow(r, hi); d += qq < ga_ql ? gc * ga_w(qq, key, ga_iq, ga_ik, a.ga_inv2s2) : 0.f; }
@@ -565,7 +589,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
                 cfence();
             }
         }
-        if (qt + 1 < qtiles && tid < 64) { sL[(cur ^ 1) * 64 + tid] = r_l; sD[(cur ^ 1) * 64 + tid] = r_d; }
+        if (qt + 1 < qtiles && tid < 64) { sL[(cur ^ 1) * 64 + tid] = r_l; sD[(cur ^ 1) * 64 + tid] = r_d; if (DROP) sS[(cur ^ 1) * 64 + tid] = r_s; }
         wait_vm0();
         __syncthreads();
     }
@@ -587,7 +611,7 @@ int launch32(const AttnArgs& a, int which, hipStream_t st) {
 }
 template <int DH>
 int launch32_dh(const AttnArgs& a, int which, hipStream_t st) {
-    const bool drop = a.drop.thresh != 0, ga = a.ga_rows != nullptr;
+    const bool drop = (a.drop.thresh >> 16) != 0, ga = a.ga_rows != nullptr;     // (rates below 2^-16 drop nothing under the 16-bit field rule)
     if (ga) return drop ? launch32<DH, true, true>(a, which, st) : launch32<DH, false, true>(a, which, st);
     return drop ? launch32<DH, true, false>(a, which, st) : launch32<DH, false, false>(a, which, st);
 }

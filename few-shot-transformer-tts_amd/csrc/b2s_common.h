@@ -71,14 +71,23 @@ struct DropCfg {
 __device__ __host__ inline bool b2s_keep(const DropCfg& d, uint32_t idx) {
     return b2s_hash32(idx * 0x9E3779B1u + d.key) >= d.thresh;
 }
-// attention-weight dropout of the training kernels: ONE hash word per PAIR of adjacent keys of a weight row.  Key k of row r (rows numbered
-// (b H + h) Lq + q, hk = ceil(Lk / 2)) uses the (k & 1)-th 16-bit half of hash32((r hk + (k >> 1)) golden + key) and is dropped when that half
-// is below thresh >> 16 (p = 0.1: 6553 / 65536).  A lane of the 32x32 attention kernels owns adjacent keys of one row: half the hashes.
-__device__ __host__ inline uint32_t b2s_wword(const DropCfg& d, uint32_t row, uint32_t hk, uint32_t kp) {
-    return b2s_hash32((row * hk + kp) * 0x9E3779B1u + d.key);
-}
-__device__ __host__ inline bool b2s_keep_w(const DropCfg& d, uint32_t row, uint32_t hk, uint32_t k) {
-    return ((b2s_wword(d, row, hk, k >> 1) >> ((k & 1u) * 16u)) & 0xffffu) >= (d.thresh >> 16);
+// attention-weight dropout of the training kernels.  A weight row r (rows numbered (b H + h) Lq + q) has a seed, drawn with the full hash once
+// per row; the four keys 4 kq .. 4 kq + 3 of the row share ONE mixing step and take their 16-bit fields from two multiplies of it:
+//      seed(r)     = hash32(r * golden + key)
+//      y(r, kq)    = x ^ (x >> 16),  x = seed(r) + kq * golden
+//      word_j      = y * (j ? 0xC2B2AE35 : 0x85EBCA6B)                  j = (k >> 1) & 1
+//      field(k)    = (k & 1) ? word_j >> 16 : word_j & 0xffff
+//      keep(k)    <=> (int16) field(k) >= (thresh >> 16) - 32768       (the field read as a SIGNED 16-bit number: p = 0.1 drops 6553 of 65536 values)
+// A lane of the attention kernels owns runs of four adjacent keys of one row (32x32 and 16x16 accumulator layouts alike): 4 integer operations per
+// four weights instead of 4 x 8, and the signed compare is one saturating packed subtract + shift on the bf16 pair the weights are packed into.
+// Statistics (keep rate, neighbour / row / diagonal correlations, row and column sums): tests/test_host_logic.py.
+constexpr uint32_t B2S_WC0 = 0x85EBCA6Bu, B2S_WC1 = 0xC2B2AE35u;
+__device__ __host__ inline uint32_t b2s_wseed(const DropCfg& d, uint32_t row) { return b2s_hash32(row * 0x9E3779B1u + d.key); }
+__device__ __host__ inline uint32_t b2s_wmix(uint32_t seed, uint32_t kq) { const uint32_t x = seed + kq * 0x9E3779B1u; return x ^ (x >> 16); }
+__device__ __host__ inline int b2s_wthresh(const DropCfg& d) { return (int)(d.thresh >> 16) - 32768; }
+__device__ __host__ inline bool b2s_keep_w(const DropCfg& d, uint32_t row, uint32_t k) {
+    const uint32_t w = b2s_wmix(b2s_wseed(d, row), k >> 2) * ((k & 2u) ? B2S_WC1 : B2S_WC0);
+    return (int)(int16_t)(uint16_t)(w >> ((k & 1u) * 16u)) >= b2s_wthresh(d);
 }
 inline DropCfg make_drop(float p, uint64_t seed, uint32_t op_id) {
     DropCfg d;

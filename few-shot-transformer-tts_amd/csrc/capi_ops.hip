@@ -152,7 +152,7 @@ extern "C" int b2s_dropout_mask(float p, uint64_t seed, uint32_t op_id, uint8_t*
 
 __global__ void k_dropmask_attn(DropCfg d, uint8_t* out, long rows, int Lk) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < rows * Lk) out[i] = b2s_keep_w(d, (uint32_t)(i / Lk), (uint32_t)((Lk + 1) >> 1), (uint32_t)(i % Lk)) ? 1 : 0;
+    if (i < rows * Lk) out[i] = b2s_keep_w(d, (uint32_t)(i / Lk), (uint32_t)(i % Lk)) ? 1 : 0;
 }
 extern "C" int b2s_dropout_mask_attn(float p, uint64_t seed, uint32_t op_id, uint8_t* out, int64_t rows, int Lk, void* stream) {
     B2S_CHECK(out && rows >= 0 && Lk > 0, "bad argument");

@@ -8,9 +8,10 @@
 //   decode loop:        op id = decode_base + layer, and the key is additionally salted with the frame index t (salt rule below)
 // idx is the flat row-major index of the element in the tensor the site acts on:
 //   B2S_DROP_ROWS  activations [rows, C] (token-major: row = b * L + position; decode loop: row = b):  idx = row * C + column
-//   B2S_DROP_ATTN  softmax weights [B, H, Lq, Lk]:  training: one hash word per PAIR of adjacent keys (b2s_common.h: b2s_wword / b2s_keep_w) --
-//                  word = hash32((((b * H + h) * Lq + q) * ceil(Lk / 2) + (k >> 1)) * 0x9E3779B1 + key), key k uses its (k & 1)-th 16-bit half and
-//                  is dropped when that half < (p * 2^32) >> 16;  decode loop: keep(idx) as above with idx = (b * H + h) * 4096 + k
+//   B2S_DROP_ATTN  softmax weights [B, H, Lq, Lk]:  training: the row-seed / key-quad rule of b2s_common.h (b2s_keep_w) with row = (b * H + h) * Lq + q --
+//                  seed = hash32(row * 0x9E3779B1 + key), y = x ^ (x >> 16) with x = seed + (k >> 2) * 0x9E3779B1, word = y * ((k & 2) ? 0xC2B2AE35 :
+//                  0x85EBCA6B), key k uses the (k & 1)-th 16-bit field of its word and is kept when (int16) field >= ((p * 2^32) >> 16) - 32768;
+//                  decode loop: keep(idx) as above with idx = (b * H + h) * 4096 + k
 // Frame salts of the decode loop (key ^= hash32(...)):
 //   B2S_SALT_ROWS   t * 2246822519 + 3266489917      (prenet, residual and FFN-hidden sites)
 //   B2S_SALT_EMBED  t + 0x9e3779b9                   (the position-encoding dropout)

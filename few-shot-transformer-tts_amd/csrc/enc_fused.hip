@@ -431,15 +431,16 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_fwd(EncfAttnFwd a) {
             for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], sl2, -mref)); lsum += p; s[t][r] = p; }
         lsum = group_sum(lsum);
         if (a.datt.thresh) {
-            const uint32_t drow_ = (uint32_t)((long)z * S + mq), dhk_ = (uint32_t)((S + 1) >> 1);
+            const uint32_t dseed_ = b2s_wseed(a.datt, (uint32_t)((long)z * S + mq));
+            const int dth_ = b2s_wthresh(a.datt);
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {                         // keys (t 16 + lg 4 + r, + 1): one word per pair (b2s_common.h: b2s_wword)
-                    const uint32_t w = b2s_wword(a.datt, drow_, dhk_, (uint32_t)(t * 8 + lg * 2 + (r >> 1)));
-                    s[t][r] = (w & 0xffffu) >= (a.datt.thresh >> 16) ? s[t][r] * a.datt.scale : 0.f;
-                    s[t][r + 1] = (w >> 16) >= (a.datt.thresh >> 16) ? s[t][r + 1] * a.datt.scale : 0.f;
-                }
+            for (int t = 0; t < 8; ++t) {                                // keys t 16 + lg 4 + {0, 1, 2, 3}: one quad of the row (b2s_common.h: b2s_keep_w)
+                const uint32_t y = b2s_wmix(dseed_, (uint32_t)(t * 4 + lg)), w0 = y * B2S_WC0, w1 = y * B2S_WC1;
+                s[t][0] = (int)(int16_t)(uint16_t)w0 >= dth_ ? s[t][0] * a.datt.scale : 0.f;
+                s[t][1] = (int)(int16_t)(uint16_t)(w0 >> 16) >= dth_ ? s[t][1] * a.datt.scale : 0.f;
+                s[t][2] = (int)(int16_t)(uint16_t)w1 >= dth_ ? s[t][2] * a.datt.scale : 0.f;
+                s[t][3] = (int)(int16_t)(uint16_t)(w1 >> 16) >= dth_ ? s[t][3] * a.datt.scale : 0.f;
+            }
         }
         f32x4_t o[4];
 #pragma unroll
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_fwd(EncfAttnFwd a) {
 // dk, dv: per key wave; P recomputed from the saved log-sum-exp)  ->  slab_h = [dq dk dv] Wqkv[head rows] (K = 192, Wqkv^T rows).
 // LDS: q / k / v / dO tiles (72 KB) + lse / D rows (1 KB) + phase-1 ring 3 x 3 granules (72 KB); after the core the [dq dk dv] tile
 // [128][200] takes the tiles' place and the phase-3 ring (3 x 4 granules) follows it.
-constexpr unsigned AB_SQ = 0, AB_SK = AT_TILE, AB_SV = 2 * AT_TILE, AB_SDO = 3 * AT_TILE, AB_SL = 4 * AT_TILE, AB_SD = AB_SL + 512, AB_R1 = AB_SD + 512;
+constexpr unsigned AB_SQ = 0, AB_SK = AT_TILE, AB_SV = 2 * AT_TILE, AB_SDO = 3 * AT_TILE, AB_SL = 4 * AT_TILE, AB_SD = AB_SL + 512, AB_SS = AB_SD + 512, AB_R1 = AB_SS + 512;
 constexpr unsigned AB_XLD = 3 * DH + 8, AB_X = 0, AB_R3 = 128 * AB_XLD * 2, AB_XBLK = 16 * AB_XLD * 2;
 constexpr unsigned AB_SMEM = (AB_R1 + 3 * 3 * GRAN) > (AB_R3 + 3 * 4 * GRAN) ? (AB_R1 + 3 * 3 * GRAN) : (AB_R3 + 3 * 4 * GRAN);
 static_assert(AB_SMEM <= 160 * 1024, "attention backward LDS plan");
@@ -618,6 +619,8 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_bwd(EncfAttnBwd a) {
         for (int ks = 0; ks < 2; ++ks) { qf[ks] = lds_rd128(po, AB_SQ + ks * 64); dof[ks] = lds_rd128(po, AB_SDO + ks * 64); }
         wait_lgkm0(); pin(qf); pin(dof);
         float Dq = group_sum(frag_dot(of[0], dof[0]) + frag_dot(of[1], dof[1]));
+        const uint32_t dseed = b2s_wseed(a.datt, (uint32_t)((long)z * S + mq));        // dropout seed of this lane's weight row (role B reads it from LDS)
+        const int dth = b2s_wthresh(a.datt);
         f32x4_t ds[8];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -634,13 +637,18 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_bwd(EncfAttnBwd a) {
             for (int t = 0; t < 4; ++t) {
                 f32x4_t s = mma(kf[t * 2], qf[0], (f32x4_t){0.f, 0.f, 0.f, 0.f}); s = mma(kf[t * 2 + 1], qf[1], s);
                 f32x4_t dp = mma(vf[t * 2], dof[0], (f32x4_t){0.f, 0.f, 0.f, 0.f}); dp = mma(vf[t * 2 + 1], dof[1], dp);
+                if (a.datt.thresh) {                                     // keys (hf 4 + t) 16 + lg 4 + {0 .. 3}: one quad of this lane's row
+                    const uint32_t y = b2s_wmix(dseed, (uint32_t)((hf * 4 + t) * 4 + lg)), w0 = y * B2S_WC0, w1 = y * B2S_WC1;
+                    dp[0] = (int)(int16_t)(uint16_t)w0 >= dth ? dp[0] * a.datt.scale : 0.f;
+                    dp[1] = (int)(int16_t)(uint16_t)(w0 >> 16) >= dth ? dp[1] * a.datt.scale : 0.f;
+                    dp[2] = (int)(int16_t)(uint16_t)w1 >= dth ? dp[2] * a.datt.scale : 0.f;
+                    dp[3] = (int)(int16_t)(uint16_t)(w1 >> 16) >= dth ? dp[3] * a.datt.scale : 0.f;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = (hf * 4 + t) * 16 + lg * 4 + r;
                     const float p = key < kend ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2)) : 0.f;
-                    float d = dp[r];
-                    if (a.datt.thresh) d = b2s_keep_w(a.datt, (uint32_t)((long)z * S + mq), (uint32_t)((S + 1) >> 1), (uint32_t)key) ? d * a.datt.scale : 0.f;
-                    s[r] = p * (d - Dq) * scale;
+                    s[r] = p * (dp[r] - Dq) * scale;
                 }
                 ds[hf * 4 + t] = s;
             }
@@ -655,7 +663,7 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_bwd(EncfAttnBwd a) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = mma(join8(lo[dt], hi[dt]), bp, dq[dt]);
         }
-        if (lg == 0) { lds_wr32(L0 + AB_SL + mq * 4, lse2); lds_wr32(L0 + AB_SD + mq * 4, Dq); }
+        if (lg == 0) { lds_wr32(L0 + AB_SL + mq * 4, lse2); lds_wr32(L0 + AB_SD + mq * 4, Dq); lds_wr32(L0 + AB_SS + mq * 4, __uint_as_float(dseed)); }
     }
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();                        // lse / D rows of all queries visible
@@ -663,6 +671,9 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_bwd(EncfAttnBwd a) {
     {   // ---- role B: keys kk = wave*16 + li.  s[q][key], dp[q][key]; P^T dO -> dv, dS^T q -> dk
         const int kk = wave * 16 + li;
         const bool key_ok = kk < kend;
+        // dropout (b2s_common.h: b2s_keep_w) with the row seeds role A left in LDS: this key's multiplier, its field brought to the top 16 bits
+        const uint32_t wcB = (kk & 2) ? B2S_WC1 : B2S_WC0, hshB = (kk & 1) ? 0u : 16u;
+        const int dthB = (int)((uint32_t)b2s_wthresh(a.datt) << 16);
         const unsigned ps = L0 + lg * 16;                   // lse / D rows: 4 consecutive queries lg*4 ..
         bf16x8_t kf[2], vf[2];
 #pragma unroll
@@ -672,7 +683,7 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_bwd(EncfAttnBwd a) {
         for (int hf = 0; hf < 2; ++hf) {
             f32x4_t pd[4], dsv[4];
             bf16x8_t qf[8], dof[8];
-            f32x4_t lq[4], dd[4];
+            f32x4_t lq[4], dd[4], sd[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -682,8 +693,9 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_bwd(EncfAttnBwd a) {
                 }
                 lq[t] = lds_rd128f(ps, AB_SL + (hf * 4 + t) * 64);
                 dd[t] = lds_rd128f(ps, AB_SD + (hf * 4 + t) * 64);
+                sd[t] = lds_rd128f(ps, AB_SS + (hf * 4 + t) * 64);
             }
-            wait_lgkm0(); pin(qf); pin(dof); pin(lq); pin(dd);
+            wait_lgkm0(); pin(qf); pin(dof); pin(lq); pin(dd); pin(sd);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 f32x4_t s = mma(qf[t * 2], kf[0], (f32x4_t){0.f, 0.f, 0.f, 0.f}); s = mma(qf[t * 2 + 1], kf[1], s);
@@ -694,7 +706,7 @@ __global__ __launch_bounds__(NTHR, 2) void k_encf_attn_bwd(EncfAttnBwd a) {
                     const float p = (key_ok && qq < S) ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lq[t][r])) : 0.f;
                     float d = dp[r], pp = p;
                     if (a.datt.thresh) {
-                        const bool keep = b2s_keep_w(a.datt, (uint32_t)((long)z * S + qq), (uint32_t)((S + 1) >> 1), (uint32_t)kk);
+                        const bool keep = (int)((b2s_wmix(__float_as_uint(sd[t][r]), (uint32_t)(kk >> 2)) * wcB) << hshB) >= dthB;
                         d = keep ? d * a.datt.scale : 0.f; pp = keep ? p * a.datt.scale : 0.f;
                     }
                     pd[t][r] = pp;

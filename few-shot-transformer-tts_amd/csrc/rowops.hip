@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_softmax_fwd(const float* S, T* P, T* Pd
         TT<T>::st(p + k, v);
         if (pd) {
             float w = v;
-            if (drop.thresh && k < kend) w = b2s_keep_w(drop, (uint32_t)r, (uint32_t)((Lk + 1) >> 1), (uint32_t)k) ? v * drop.scale : 0.f;
+            if (drop.thresh && k < kend) w = b2s_keep_w(drop, (uint32_t)r, (uint32_t)k) ? v * drop.scale : 0.f;
             TT<T>::st(pd + k, w);
         }
     }
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_softmax_bwd(const T* P, const float* dP
     float acc = 0.f;
     for (int k = lane; k < Lk; k += 64) {
         float d = dp[k];
-        if (drop.thresh) d = b2s_keep_w(drop, (uint32_t)r, (uint32_t)((Lk + 1) >> 1), (uint32_t)k) ? d * drop.scale : 0.f;
+        if (drop.thresh) d = b2s_keep_w(drop, (uint32_t)r, (uint32_t)k) ? d * drop.scale : 0.f;
         acc += TT<T>::ld(p + k) * d;
     }
     acc = wave_sum(acc);
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void k_softmax_bwd(const T* P, const float* dP
         float v = 0.f;
         if (k < Lk) {
             float d = dp[k];
-            if (drop.thresh) d = b2s_keep_w(drop, (uint32_t)r, (uint32_t)((Lk + 1) >> 1), (uint32_t)k) ? d * drop.scale : 0.f;
+            if (drop.thresh) d = b2s_keep_w(drop, (uint32_t)r, (uint32_t)k) ? d * drop.scale : 0.f;
             v = TT<T>::ld(p + k) * (d - acc) * scale;
         }
         TT<T>::st(o + k, v);

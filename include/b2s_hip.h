@@ -297,9 +297,11 @@ int b2s_cast(int dtype, const float* in, void* out, int64_t n, void* stream);   
 int b2s_cast_back(int dtype, const void* in, float* out, int64_t n, void* stream); /* compute dtype -> fp32 */
 /* keep-mask of the dropout RNG for element indices [0,n): out[i] = 1 or 0 (statistical tests) */
 int b2s_dropout_mask(float p, uint64_t seed, uint32_t op_id, uint8_t* out, int64_t n, void* stream);
-/* keep-mask of the TRAINING kernels' attention-weight dropout for a [rows, Lk] weight matrix (rows = (b * H + h) * Lq + q): one hash word per pair
- * of adjacent keys, word = lowbias32((row * ceil(Lk / 2) + (k >> 1)) * 0x9E3779B1 + key); key k uses the (k & 1)-th 16-bit half of its word and is
- * dropped when that half < (p * 2^32) >> 16 (a lane of the 32x32x16 attention kernels owns adjacent keys of one row: half the hashes) */
+/* keep-mask of the TRAINING kernels' attention-weight dropout for a [rows, Lk] weight matrix (row = (b * H + h) * Lq + q).  A row has a seed drawn with
+ * the full hash, seed = lowbias32(row * 0x9E3779B1 + key); the four keys 4 kq .. 4 kq + 3 of the row share one mixing step y = x ^ (x >> 16),
+ * x = seed + kq * 0x9E3779B1, and take their 16-bit fields from two multiplies of it: word = y * ((k & 2) ? 0xC2B2AE35 : 0x85EBCA6B), field = the
+ * (k & 1)-th half of word; a key is kept when (int16) field >= ((p * 2^32) >> 16) - 32768 (a lane of the attention kernels owns runs of four adjacent
+ * keys of one row: four integer operations per four weights) */
 int b2s_dropout_mask_attn(float p, uint64_t seed, uint32_t op_id, uint8_t* out, int64_t rows, int Lk, void* stream);
 /* Read-only query of the dropout-site table (csrc/drop_sites.h) -- everything a checker needs to regenerate the mask the model path
  * applied at any of the reference's dropout calls (transformer/modules.py:18,55,64,67,120,132,138,141, attention.py:89, tacotron.py:58,62,89),
@@ -310,7 +312,7 @@ int b2s_dropout_mask_attn(float p, uint64_t seed, uint32_t op_id, uint8_t* out, 
  * (b2s_{encoder,decoder,postnet}_forward, seeded by their `seed` argument); decode = 1: the autoregressive loop (b2s_decode_begin's seed).
  * The mask is keep(idx) = lowbias32(idx * 0x9E3779B1 + key) >= p * 2^32, key = f(seed, *op_id_out) as in b2s_dropout_mask, with
  *   *kind_out = 0: idx = row * C + column of the activation [rows, C] the site acts on (row = b * L + position; decode loop: row = b);
- *   *kind_out = 1: the softmax weights [B, H, Lq, Lk] -- training segments: the key-pair rule of b2s_dropout_mask_attn with rows = (b * H + h) * Lq + q;
+ *   *kind_out = 1: the softmax weights [B, H, Lq, Lk] -- training segments: the row-seed / key-quad rule of b2s_dropout_mask_attn with rows = (b * H + h) * Lq + q;
  *                  decode loop: idx = (b * H + h) * 4096 + k in the element rule above;
  * in the decode loop the key of frame t is additionally XORed with lowbias32(salt(t)): *salt_out = 1: t * 2246822519 + 3266489917,
  * 2: t + 0x9e3779b9, 3: t * 2654435761 + 77 (0: none). */

@@ -41,19 +41,28 @@ def keep_mask(p, seed, op_id, n):
     return rand32(idx, drop_key(seed, op_id)) >= np.uint64(drop_thresh(p))
 
 
-def keep_mask_attn(p, seed, op_id, rows, Lk):
-    """bool[rows, Lk]: the TRAINING kernels' attention-weight masks (csrc/b2s_common.h: b2s_wword / b2s_keep_w, csrc/drop_sites.h:
-    B2S_DROP_ATTN): one hash word per pair of adjacent keys of a weight row, word = rand32(row * ceil(Lk / 2) + (k >> 1)); key k uses the
-    (k & 1)-th 16-bit half and is dropped when that half < (p * 2^32) >> 16."""
+_WC = (np.uint64(0x85EBCA6B), np.uint64(0xC2B2AE35))
+
+
+def keep_mask_attn(p, seed, op_id, rows, Lk, row0=0):
+    """bool[rows, Lk]: the TRAINING kernels' attention-weight masks (csrc/b2s_common.h: b2s_wseed / b2s_wmix / b2s_keep_w, csrc/drop_sites.h:
+    B2S_DROP_ATTN) for weight rows row0 .. row0 + rows - 1: a row has a seed drawn with the full hash, the four keys 4 kq .. 4 kq + 3 share one
+    mixing step and take their 16-bit fields from two multiplies of it; a key is kept when its field, read as a signed 16-bit number, is
+    >= ((p * 2^32) >> 16) - 32768."""
     if p <= 0:
         return np.ones((rows, Lk), dtype=bool)
-    hk = (Lk + 1) // 2
-    assert rows * hk < 2 ** 32, "pair index would wrap"
-    th16 = np.uint64(drop_thresh(p) >> 16)
-    w = rand32(np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(hk) + np.arange(hk, dtype=np.uint64)[None, :], drop_key(seed, op_id))
-    out = np.empty((rows, 2 * hk), dtype=bool)
-    out[:, 0::2] = (w & np.uint64(0xFFFF)) >= th16
-    out[:, 1::2] = (w >> np.uint64(16)) >= th16
+    hq = (Lk + 3) // 4
+    key = drop_key(seed, op_id)
+    ts = (drop_thresh(p) >> 16) - 32768
+    sd = rand32(np.arange(row0, row0 + rows, dtype=np.uint64), key)                       # seed(row) = hash32(row * golden + key)
+    x = _u(sd[:, None] + np.arange(hq, dtype=np.uint64)[None, :] * np.uint64(0x9E3779B1))
+    y = x ^ (x >> np.uint64(16))
+    out = np.empty((rows, 4 * hq), dtype=bool)
+    for j in (0, 1):
+        w = _u(y * _WC[j])
+        for half in (0, 1):
+            f = ((w >> np.uint64(16 * half)) & np.uint64(0xFFFF)).astype(np.int64)
+            out[:, 2 * j + half::4] = np.where(f >= 32768, f - 65536, f) >= ts
     return out[:, :Lk]
 
 
@@ -76,7 +85,7 @@ class DeviceMasks:
     seeds: {"encoder": s, "decoder": s, "postnet": s} -- the `seed` argument of the engine's segment calls (decode loop: the seed
     of b2s_decode_begin under "decoder").  site_info(site, layer, decode) -> (op_id, kind, salt_rule): the library's own table,
     queried by the test through the C ABI (nothing about op ids is restated here).  The index rules (kind: 0 = flat element index,
-    1 = attention weights -- key pairs in the training kernels, keep_mask_attn) and the hash are the documented convention of that query.  decode: the autoregressive loop -- row r of a [B, rows, C] tensor (or query row r of
+    1 = attention weights -- row seeds and key quads in the training kernels, keep_mask_attn) and the hash are the documented convention of that query.  decode: the autoregressive loop -- row r of a [B, rows, C] tensor (or query row r of
     attention weights) was drawn in frame r + frame_offset with a frame-salted key and the per-frame index rules.
     overrides: {(site, layer): op_id} -- deliberately wrong ids, for the test that shows the comparison notices."""
 
@@ -95,7 +104,7 @@ class DeviceMasks:
         n = int(np.prod(shape))
         if not self.decode:
             assert n < 2 ** 32, "element index would wrap"
-            if kind == 1:                           # weights [B, H, Lq, Lk] of the training kernels: one word per key pair
+            if kind == 1:                           # weights [B, H, Lq, Lk] of the training kernels: row seeds + key quads
                 return keep_mask_attn(p, seed, op, int(np.prod(shape[:-1])), shape[-1]).reshape(shape)
             return (rand32(np.arange(n, dtype=np.uint64), key) >= th).reshape(shape)
         out = np.empty(shape, dtype=bool)

@@ -52,7 +52,7 @@ def _mask(lib, L, p, seed, op, n):
 
 
 def _mask_attn(lib, L, p, seed, op, rows, Lk):
-    """attention-weight masks of the training kernels: one hash word per key pair (include/b2s_hip.h: b2s_dropout_mask_attn)"""
+    """attention-weight masks of the training kernels: row seeds + key quads (include/b2s_hip.h: b2s_dropout_mask_attn)"""
     m = torch.empty(rows * Lk, dtype=torch.uint8, device=DEV)
     L.check(lib.b2s_dropout_mask_attn(p, seed, op, m.data_ptr(), rows, Lk, None))
     return m.bool()

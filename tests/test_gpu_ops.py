@@ -301,8 +301,8 @@ def test_dropout_mask_matches_host_restatement():
 
 
 def test_attention_dropout_mask_matches_host_restatement():
-    """The training kernels' attention-weight masks (one hash word per key pair: csrc/b2s_common.h: b2s_keep_w) == oracle/rng.py: keep_mask_attn,
-    bit for bit, for even and odd key counts (an odd Lk leaves the last pair half used)."""
+    """The training kernels' attention-weight masks (row seeds + key quads: csrc/b2s_common.h: b2s_keep_w) == oracle/rng.py: keep_mask_attn,
+    bit for bit, for key counts that are and are not multiples of four."""
     from oracle import rng
     ops, lib = _ops()
     l = lib.load()

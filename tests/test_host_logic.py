@@ -370,8 +370,8 @@ def test_dropout_hash_statistics():
         assert 0.9 < keep.sum(1).var() / (Lk * p * (1 - p)) < 1.1 and 0.85 < keep.sum(0).var() / (rows * p * (1 - p)) < 1.15
         other = rng.keep_mask(p, seed, op + 1, rows * Lk).reshape(rows, Lk)
         assert abs((keep.astype(bool) == other).mean() - ((1 - p) ** 2 + p ** 2)) < 3e-3
-    # the training kernels' attention-weight masks: two keys per hash word (16-bit halves; keep_mask_attn): the same properties, the drop rate
-    # quantised to 1 / 65536, the two halves of a word independent of each other, odd key counts
+    # the training kernels' attention-weight masks (keep_mask_attn: a fully hashed seed per row, ONE mixing step + two multiplies per four keys,
+    # 16-bit fields): the same properties, the drop rate quantised to 1 / 65536, the four fields of a quad independent of each other, odd key counts
     for p, seed, op, Lk in ((0.1, 1234, 8324, 582), (0.1, 77, 8358, 113), (0.5, 99, 77, 582)):
         keep = rng.keep_mask_attn(p, seed, op, rows, Lk).astype(np.float64)
         pq = (rng.drop_thresh(p) >> 16) / 65536.0
@@ -380,15 +380,20 @@ def test_dropout_hash_statistics():
         k = keep - keep.mean()
         var = k.var()
         corr = lambda a, b: abs(float((a * b).mean() / var))
-        ev = Lk & ~1
-        assert corr(k[:, 0:ev:2], k[:, 1:ev:2]) < 4e-3                          # within a word
-        assert corr(k[:, :-1], k[:, 1:]) < 4e-3 and corr(k[:, :-2], k[:, 2:]) < 4e-3
-        assert corr(k[:-1], k[1:]) < 4e-3 and corr(k[:-1, :-1], k[1:, 1:]) < 4e-3
-        assert 0.9 < keep.sum(1).var() / (Lk * p * (1 - p)) < 1.1 and 0.85 < keep.sum(0).var() / (rows * p * (1 - p)) < 1.15
+        ev = Lk & ~3
+        lim = max(4e-3, 4.5 / keep.size ** 0.5)                                       # (4.5 standard errors of an empirical correlation at the short key count)
+        for i in range(4):                                                        # within a quad
+            for j in range(i + 1, 4):
+                assert corr(k[:, i:ev:4], k[:, j:ev:4]) < 2 * lim, (i, j)
+        for d in (1, 2, 3, 4, 8, 16):
+            assert corr(k[:, :-d], k[:, d:]) < lim, d
+        assert corr(k[:-1], k[1:]) < lim and corr(k[:-1, :-1], k[1:, 1:]) < lim and corr(k[:-1, 1:], k[1:, :-1]) < lim
+        assert 0.9 < keep.sum(1).var() / (Lk * p * (1 - p)) < 1.1 and 0.8 < keep.sum(0).var() / (rows * p * (1 - p)) < 1.2
         other = rng.keep_mask_attn(p, seed, op + 1, rows, Lk)
         assert abs((keep.astype(bool) == other).mean() - ((1 - p) ** 2 + p ** 2)) < 3e-3
         flat = rng.keep_mask(p, seed, op, rows * Lk).reshape(rows, Lk)              # and unrelated to the element rule of the same op
         assert abs((keep.astype(bool) == flat).mean() - ((1 - p) ** 2 + p ** 2)) < 3e-3
+        assert np.array_equal(rng.keep_mask_attn(p, seed, op, 7, Lk, row0=100), keep[100:107].astype(bool))
 
 
 def test_persistent_gemm_ticket_register_is_not_touched_between_draw_and_read():
