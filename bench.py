@@ -83,6 +83,22 @@ def cpu_baseline_train(budget_s=25.0):
             "seconds_per_step": round(best, 3)}
 
 
+def load_kernel_stats(suffix="train_bf16_kernel_stats.csv"):
+    """Newest committed rocprofv3 --kernel-trace --stats summary of this command (profiles/rNN_<suffix>, tools/gpu_round_profiles.sh) ->
+    (file name, steps in the profiled run, {kernel name: (launches per step, average ns)}).  The step count is read off a kernel that runs
+    exactly once per step (k_shift_pe_fwd)."""
+    import csv
+    pdir = os.path.join(ROOT, "profiles")
+    names = sorted(n for n in (os.listdir(pdir) if os.path.isdir(pdir) else []) if n.endswith(suffix) and n[0] == "r" and n[1:3].isdigit())
+    if not names:
+        return None, 0, {}
+    rows = list(csv.DictReader(open(os.path.join(pdir, names[-1]))))
+    steps = [int(r["Calls"]) for r in rows if "k_shift_pe_fwd" in r["Name"]]
+    if not steps:
+        return names[-1], 0, {}
+    return names[-1], steps[0], {r["Name"]: (int(r["Calls"]) / steps[0], float(r["AverageNs"])) for r in rows}
+
+
 def _sub_bench(extra, env=None):
     """Run another bench mode in a child process and return the fields of its JSON line that matter on the parent's line."""
     import subprocess
@@ -105,9 +121,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="train", choices=["train", "decode", "finetune"],
+    ap.add_argument("--mode", default="train", choices=["train", "decode", "finetune", "dropin"],
                     help="train: BASELINE configs[1-2]; decode: configs[3]; finetune: configs[4] (frozen encoder, guided "
-                         "attention on, batches of B drawn from a 30-utterance pool)")
+                         "attention on, batches of B drawn from a 30-utterance pool); dropin: the reference's own loop (train.py:171-174,"
+                         "188-190: m(**batch), compute_loss, zero_grad, backward, torch.optim.Adam.step, sched.step) on the drop-in modules")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default=None, choices=["lj", "c3"],
                     help="lj: BASELINE configs[1] (B=14, S=114, T=582, one speaker / language; default at --gpus 1); c3: configs[2], the "
@@ -176,7 +193,28 @@ def main():
     # gradient wire of the data-parallel exchange: the bf16 performance lines send bf16 (167 instead of 334 MB per step over the
     # point-to-point xGMI links; HipTrainer's own default is the reference's fp32 mean) -- stated in config.grad_payload
     payload = os.environ.get("B2S_GRAD_PAYLOAD") or ("bf16" if args.dtype == "bf16" else "fp32")
-    trainer = HipTrainer(model, hp, grad_payload=payload)
+    dropin = args.mode == "dropin"
+    init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if (world > 1 or force_dp) else None
+    if dropin:
+        # the literal reference loop (train.py:130-131,171-174,188-190) around the drop-in modules: autograd functions over the engine's
+        # segments, torch.optim.Adam (foreach), LambdaLR -- what a user gets WITHOUT editing train.py
+        from functools import partial as _partial
+        from transformer.tacotron import compute_loss, learning_rate_schedule
+        optim = torch.optim.Adam(model.parameters(), lr=hp.max_lr, eps=hp.adam_eps)
+        sched = torch.optim.lr_scheduler.LambdaLR(optim, lr_lambda=_partial(learning_rate_schedule, hp=hp))
+        trainer = None
+
+        def train_step(b):
+            outputs = model(**b)
+            losses = compute_loss(model, b["mel_targets"], b["target_lengths"], outputs, hp)
+            optim.zero_grad()
+            losses["loss"].backward()
+            optim.step()
+            sched.step()
+            return [losses["loss"].detach()]
+    else:
+        trainer = HipTrainer(model, hp, grad_payload=payload)
+        train_step = trainer.train_step
     cfg = hp                                           # (synthetic_batch reads vocab_size / num_mels / max_num_* only)
     B, S, T = args.batch, args.S, args.T
     batch = make_batch(cfg, B, S, T, seed=rank, device=device, n_spk=n_spk, n_lang=n_lang)     # same shape on every rank, different data
@@ -194,17 +232,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed(bs, steps, warmup):
+    def timed(bs, steps, warmup, step_fn=None):
         """warmup untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
+        step_fn = step_fn or train_step
         v = None
         for i in range(warmup):
-            v = trainer.train_step(bs[i % len(bs)])
+            v = step_fn(bs[i % len(bs)])
         sync()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
         for i in range(steps):
-            v = trainer.train_step(bs[i % len(bs)])
+            v = step_fn(bs[i % len(bs)])
         e1.record()
         host = time.perf_counter() - t0                # launch loop only: ~= elapsed means the step is host- (launch-) bound
         sync()
@@ -239,7 +278,9 @@ def main():
             enc = 6 * (B * S * (8 * 512 * 512 + 4 * 512 * 2048) + 4 * B * S * S * 512) + 2 * B * (2 * 128 * 128 + 100 * 128)
             step_flops -= 2.0 * enc + 6 * 4 * B * S * 768 * 768
         out = {"metric": "padded mel-frames/sec, " + ("few-shot fine-tune step (frozen encoder, guided attention; fwd+loss+bwd+allreduce+Adam)"
-                                                      if finetune else "full training step (fwd+loss+bwd+allreduce+Adam)"),
+                                                      if finetune else "the reference's own loop on the drop-in modules (train.py:171-174,188-190: m(**batch), compute_loss, "
+                                                      "zero_grad, backward, torch.optim.Adam.step, LambdaLR.step)" if dropin
+                                                      else "full training step (fwd+loss+bwd+allreduce+Adam)"),
                "value": round(world * B * T * args.steps / elapsed, 1), "unit": "mel-frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
@@ -260,13 +301,13 @@ def main():
                                 "frac": round(ach / peak, 4), "flops_per_step": step_flops}
         if extremes:
             out["packer_extremes"] = extremes
-    if rank == 0 and world == 1 and not args.no_roofline_pass:
+    if rank == 0 and world == 1 and not args.no_roofline_pass and not dropin and trainer is not None:
         # dominant kernel (MFMA GEMM): per-launch HIP events on the launch stream, same steps, separate pass
         lib = L.load()
         lib.b2s_prof_enable(1)
         nprof = max(2, min(5, args.steps))
         for _ in range(nprof):
-            trainer.train_step(batch)
+            train_step(batch)
         torch.cuda.synchronize()
         lib.b2s_prof_enable(0)
         res = (C.c_double * 51)()
@@ -292,8 +333,25 @@ def main():
                                  "ms_per_step": round(msv / nprof, 3), "tflops": round(f / (msv * 1e-3) / 1e12, 1)})
                 tot_f += f
                 tot_ms += msv
-        variants.sort(key=lambda d: -d["ms_per_step"])
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_FP32_TFLOPS
+        # The second clock: the committed rocprofv3 --kernel-trace --stats summary of this same command (kernel durations proper; the HIP events
+        # above sit on the launch stream and include the kernel boundary and whatever shares the CUs).  The DOMINANT kernel is the GEMM family with
+        # the most time per step in that summary, and roofline.frac is computed from ITS clock, so that a reader can recompute it from profiles/:
+        #     frac = flops_per_step of the family (counted live, below) / (launches per step x average duration in the csv) / peak
+        ks_file, ks_steps, ks = load_kernel_stats() if (args.dtype == "bf16" and args.mode == "train" and args.workload == "lj" and
+                                                           (B, S, T) == (14, 114, 582)) else (None, 0, {})
+        import re
+        for d in variants:
+            # the csv's names carry the numeric template arguments the variant names abbreviate: NB / MW -> digits, G -> 1 | 2 (conv gather)
+            pats = [re.escape(k).replace("NB", r"\d").replace("MW", r"\d").replace(r",\ G,", r",\ [12],") for k in d["kernel"].split(" + ")]
+            rows = [(n, v) for n, v in ks.items() if any(re.search(pt, n) for pt in pats)]
+            if rows:
+                d["rocprof_launches_per_step"] = round(sum(v[0] for _, v in rows), 2)
+                d["rocprof_ms_per_step"] = round(sum(v[0] * v[1] for _, v in rows) * 1e-6, 4)
+                d["rocprof_avg_us"] = round(d["rocprof_ms_per_step"] * 1e3 / max(d["rocprof_launches_per_step"], 1e-9), 2)
+                d["rocprof_tflops"] = round(d["tflops"] * d["ms_per_step"] / d["rocprof_ms_per_step"], 1)      # same FLOPs, the profiler's clock
+        have_ks = any("rocprof_ms_per_step" in d for d in variants)
+        variants.sort(key=lambda d: -(d.get("rocprof_ms_per_step", 0.0) if have_ks else d["ms_per_step"]))
         dom = variants[0]
         # HBM-side traffic of that kernel from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/gpu_pmc.sh) -- counters cannot be read from inside this process
@@ -346,24 +404,98 @@ def main():
             isolated.append({"shape": "all of the above", "us": round(us_sum, 1), "tflops": round(fl_sum / us_sum / 1e6, 1),
                              "frac_of_peak": round(fl_sum / us_sum / 1e6 / peak, 4)})
             del bufA, bufB, bufC
-        out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM side, PMC)", "traffic_source": traffic_source,
+        ach = dom.get("rocprof_tflops", dom["tflops"])
+        out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (HBM side, PMC)", "traffic_source": traffic_source,
                            "mfma_util": mfma_util,
-                           "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
+                           "clock": ("rocprofv3 kernel durations, profiles/%s (%d profiled steps)" % (ks_file, ks_steps)) if "rocprof_tflops" in dom
+                                    else "HIP events on the launch stream (no committed rocprofv3 summary for this workload)",
+                           "flops_per_step": round(dom["tflops"] * 1e12 * dom["ms_per_step"] * 1e-3),
+                           "avg_launch_us_rocprof": dom.get("rocprof_avg_us"), "avg_launch_us_events": dom["avg_us"],
+                           "achieved_events": dom["tflops"], "frac_events": round(dom["tflops"] / peak, 4),
+                           "launches_per_step": dom["launches_per_step"],
                            "all_gemm": {"tflops": round(tot_f / (tot_ms * 1e-3) / 1e12, 1), "ms_per_step": round(tot_ms / nprof, 3)},
                            "variants": variants, "isolated": isolated,
-                           "note": "algorithmic FLOPs (2MNK per launch) / HIP-event duration on the kernel's launch stream, separate "
+                           "note": "dominant kernel = the GEMM family with the most time per step in the committed rocprofv3 summary; achieved / frac = "
+                                   "algorithmic FLOPs of that family per step (2MNK per launch, counted live) / its duration per step on the profiler's "
+                                   "clock (launches x average ns of the csv); *_events = the same FLOPs / HIP-event durations on the kernel's launch stream, separate "
                                    "instrumented pass of the same steps; the weight-gradient GEMMs (grouped kernel, <true, true, *>) run on a "
                                    "second stream concurrently with the rest of the backward pass, so their event durations -- and those "
                                    "of the main-stream kernels they overlap -- include time spent sharing the CUs; <true, true, *> "
                                    "durations also include the split-K slab reduction that belongs to the launch"}
+    if (world > 1 or force_dp) and args.mode == "train" and not args.no_extras:
+        # One invocation decides the data-parallel defaults: after the headline leg (bucketed all-reduce, the wire named in config.grad_payload) the same
+        # step is timed with the other gradient wire, with the sharded optimizer (reduce-scatter + all-gather of the updated parameters) on both
+        # wires, with the whole exchange path on but the wire removed (every collective completes at once: what the rank pays for hooks, packs,
+        # waits and the tile policy), and with no process group at all (the single-GPU step on this node's GPUs).  Every leg: a fresh model from
+        # the same initial state, the same warm-up and step counts, barrier + synchronize on both sides, MAX over ranks.
+        class _Done(object):
+            def wait(self, *a, **k):
+                return True
+
+        class _NoWire(object):
+            def __init__(self, world_, rank_):
+                self.w, self.r = world_, rank_
+
+            def get_world_size(self, group=None):
+                return self.w
+
+            def get_rank(self, group=None):
+                return self.r
+
+            def broadcast(self, *a, **k):
+                return _Done()
+
+            all_reduce = reduce_scatter_tensor = all_gather_into_tensor = broadcast
+
+        head_ms = elapsed / args.steps * 1e3
+        legs = [{"leg": "headline", "dp_mode": "allreduce", "wire": payload, "ms_per_step": round(head_ms, 3)}]
+        trainer.close()
+        del trainer, train_step
+        torch.cuda.empty_cache()
+        for leg, mode, wire in (("allreduce / fp32 wire", "allreduce", "fp32"), ("allreduce / bf16 wire", "allreduce", "bf16"), ("rs_ag / fp32 wire", "rs_ag", "fp32"),
+                                ("rs_ag / bf16 wire", "rs_ag", "bf16"), ("exchange path on, wire removed", "allreduce", payload), ("no process group (single-GPU step)", None, None)):
+            if (mode, wire) == ("allreduce", payload) and "wire removed" not in leg:
+                continue                                   # = the headline leg
+            m2 = t2 = None
+            try:
+                m2 = Tacotron(hp)
+                m2.load_state_dict(init_state)
+                m2 = m2.to(device).train()
+                if mode is None:
+                    t2 = HipTrainer(m2, hp, dist=False)
+                elif "wire removed" in leg:
+                    t2 = HipTrainer(m2, hp, grad_payload=wire, dp_mode=mode, dist=_NoWire(world, rank))
+                else:
+                    t2 = HipTrainer(m2, hp, grad_payload=wire, dp_mode=mode)
+                v2, el2, _, _ = timed(batches, args.steps, args.warmup, step_fn=t2.train_step)
+                legs.append({"leg": leg, "dp_mode": mode, "wire": wire, "ms_per_step": round(el2 / args.steps * 1e3, 3), "final_loss": round(float(v2[0]), 5)})
+            except Exception as e:                          # a leg that cannot run (e.g. rs_ag at a world size its buckets do not divide) is reported, not fatal
+                legs.append({"leg": leg, "dp_mode": mode, "wire": wire, "error": "%s: %s" % (type(e).__name__, str(e)[:200])})
+                sync()
+            if t2 is not None:
+                t2.close()
+            del t2, m2
+            torch.cuda.empty_cache()
+        if rank == 0:
+            by = {l["leg"]: l.get("ms_per_step") for l in legs}
+            local_ms, nowire_ms = by.get("no process group (single-GPU step)"), by.get("exchange path on, wire removed")
+            out["dp_legs"] = legs
+            out["local_ms_per_step"] = local_ms
+            # weak scaling: value(N) / (N x value(1)) = t(1) / t(N) with t(1) = the no-process-group leg of this same run
+            out["scaling_efficiency"] = round(local_ms / head_ms, 4) if local_ms else None
+            out["exposed_comm_ms"] = round(head_ms - nowire_ms, 3) if nowire_ms else None
+            out["exchange_path_overhead_ms"] = round(nowire_ms - local_ms, 3) if (nowire_ms and local_ms) else None
+            best = min((l for l in legs if l.get("ms_per_step") and l["dp_mode"] and "wire removed" not in l["leg"]), key=lambda l: l["ms_per_step"])
+            out["fastest_dp_leg"] = {"leg": best["leg"], "ms_per_step": best["ms_per_step"]}
+        trainer = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_train()
     if world > 1 or force_dp:
         out_n = torch.distributed.get_world_size()
         if rank == 0:
             out["rccl_ranks"] = out_n                  # what the RCCL group itself reports (== n_gpus)
-    if rank == 0 and world == 1 and args.mode == "train" and args.dtype == "bf16" and args.workload == "lj" and not args.no_extras:
+    if rank == 0 and world == 1 and not force_dp and args.mode == "train" and args.dtype == "bf16" and args.workload == "lj" and not args.no_extras:
         # the other BASELINE.json configs on the same JSON line (each in its own process: the hparams object is global):
         #   decode     configs[3]  64 utterances x 1000 frames, hipGraph-captured KV-cached loop
         #   finetune   configs[4]  frozen encoder + guided-attention loss, batches from a 30-utterance pool
@@ -386,6 +518,9 @@ def main():
         # BASELINE configs[2] on one GPU: the per-rank workload of the N-GPU run (what `--gpus N` times on every rank), exchange path on
         out["c3"] = _sub_bench(["--workload", "c3", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-roofline-pass",
                                 "--no-extras"], env=dp_env)
+        # the reference's own loop (train.py:171-174,188-190) on the drop-in modules, same batch, same timing discipline: what train.py gets UNEDITED
+        out["dropin_loop"] = _sub_bench(["--mode", "dropin", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-roofline-pass",
+                                         "--no-extras"])
     if world > 1 or force_dp:
         torch.distributed.destroy_process_group()
     if rank == 0:

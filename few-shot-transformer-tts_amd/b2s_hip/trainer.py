@@ -84,8 +84,10 @@ class HipTrainer(object):
         self._one = torch.ones(1, dtype=torch.float32, device=g.device)
         self.last_ga_loss = None
         # dist: an object with torch.distributed's interface (get_world_size / broadcast / all_reduce(async_op=True) -> work.wait());
-        # default: torch.distributed when a process group is initialised.  (tests/test_gpu_dp_race.py passes an asynchronous stand-in.)
-        if dist is not None:
+        # default: torch.distributed when a process group is initialised; False: never (bench.py's single-GPU leg inside a multi-rank run).  (tests/test_gpu_dp_race.py passes an asynchronous stand-in.)
+        if dist is False:                                  # explicitly local: no exchange even when a process group is initialised
+            self.dist = None
+        elif dist is not None:
             self.dist = dist
         else:
             self.dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
@@ -144,6 +146,13 @@ class HipTrainer(object):
             if self.tail_adam and not self.freeze_encoder and enc0 is not None and enc0[0] > 0 and self.dp_mode == "allreduce":
                 self.bucketer.split = enc0[0]
             if self.dp_mode == "rs_ag":
+                # every bucket is cut into `world` equal slices of whole 8-element groups; the flat layout's slots are 64-element aligned, so
+                # world sizes 1, 2, 4 and 8 always divide -- anything else is refused here, with the reason, not inside a collective
+                for lo, hi in self.bucketer.plan():
+                    if (hi - lo) % (8 * self.bucketer.world):
+                        raise ValueError("dp_mode='rs_ag' at world size %d: gradient bucket [%d, %d) of %d elements does not split into %d equal "
+                                         "slices of a multiple of 8 elements (parameter slots are 64-element aligned: world sizes 1, 2, 4, 8 "
+                                         "always work); use dp_mode='allreduce'" % (self.bucketer.world, lo, hi, hi - lo, self.bucketer.world))
                 own = self.bucketer.owned_ranges()
                 lo = (C.c_int64 * len(own))(*[a for a, _ in own])
                 hi = (C.c_int64 * len(own))(*[b for _, b in own])
@@ -184,11 +193,32 @@ class HipTrainer(object):
             L.check(self.lib.b2s_gemm_set_tile_policy(0))
             self._set_tile_policy = False
 
+    def gather_optimizer_state(self):
+        """dp_mode='rs_ag': COLLECTIVE -- call on EVERY rank before rank 0 serialises the optimizer (state_dict / utils.checkpoint.save_model).
+        The sharded update advances exp_avg / exp_avg_sq only on the slices a rank owns; this all-gathers both moment buffers in place, bucket by
+        bucket, exactly as all_gather_params does for the parameters, so that every rank holds the whole Adam state of the current step.
+        A no-op in every other mode."""
+        if self.bucketer is None or self.bucketer.mode != "rs_ag":
+            return
+        works = []
+        for buf in (self.exp_avg, self.exp_avg_sq):
+            for lo, hi in self.bucketer.plan():
+                a, b = self.bucketer.shard_of(lo, hi)
+                works.append(self.dist.all_gather_into_tensor(buf[lo:hi], buf[a:b], group=self.bucketer.group, async_op=True))
+        for w in works:
+            w.wait()
+        self._moments_gathered_at = self.global_step
+
     def state_dict(self):
         """Optimizer state in torch.optim.Adam.state_dict() layout (what train.py:130 + checkpoint.py:27 write), so a
         checkpoint written from the fused trainer resumes under the reference loop and vice versa.  Parameters that
         were never updated (no step yet, frozen encoder) have no entry, as in torch."""
         self.sync()
+        if (self.bucketer is not None and self.bucketer.mode == "rs_ag" and self.bucketer.world > 1 and self.global_step > 0 and
+                getattr(self, "_moments_gathered_at", None) != self.global_step):
+            raise L.B2SError("dp_mode='rs_ag': this rank holds the Adam moments of its own 1/%d slices only -- a checkpoint written now would resume "
+                             "with zero moments everywhere else.  Call trainer.gather_optimizer_state() on EVERY rank (it is a collective) after "
+                             "the step, then state_dict() / utils.checkpoint.save_model on the saving rank." % self.bucketer.world)
         names = self._param_names()
         state = {}
         if self.global_step > 0:
@@ -246,17 +276,17 @@ class HipTrainer(object):
         except BaseException as e:          # noqa: B902 (must not propagate into ctypes)
             self._hook_error = e
 
-    def _consume_partial_step(self, step_no, cause):
+    def _consume_partial_step(self, step_no, cause, what=None):
         """A failure AFTER the decoder / postnet update of step `step_no` was issued (a collective of the encoder buckets, the final
         update): those groups are at step_no, the encoder group is not.  The step cannot be retried under the same number (Adam's bias
         correction of the updated groups has advanced; b2s_adam_step_groups refuses a second update of a group in one step), so it is
         marked consumed -- the next train_step runs as step_no + 1 on every group -- and the error says so."""
         self.global_step = step_no
         self.last_step_tail_update = True
-        raise RuntimeError("training step %d failed after its decoder / postnet optimizer update had been issued: a PARTIAL update was "
-                           "applied (encoder parameters keep their step-%d values).  The step counter has advanced to %d so that "
+        what = what or "its decoder / postnet optimizer update had been issued: a PARTIAL update was applied (encoder parameters keep their step-%d values)" % (step_no - 1)
+        raise RuntimeError("training step %d failed after %s.  The step counter has advanced to %d so that "
                            "training can continue; restore a checkpoint if the replicas must stay bit-identical." %
-                           (step_no, step_no - 1, step_no)) from cause
+                           (step_no, what, step_no)) from cause
 
     # ------------------------------------------------------------------ one step
     def train_step(self, batch):
@@ -366,6 +396,7 @@ class HipTrainer(object):
         for c in (c_post, c_dec, c_enc):
             if c is not None:
                 c.free()
+        shard_updated = False
         try:
             if self._hook_error is not None:
                 err, self._hook_error = self._hook_error, None
@@ -378,6 +409,7 @@ class HipTrainer(object):
                 L.check(lib.b2s_adam_step_groups(eng.handle, *adam, 1, 0, L.stream()))
             else:
                 L.check(lib.b2s_adam_step(eng.handle, *adam, L.stream()))
+            shard_updated = self.bucketer is not None and self.bucketer.mode == "rs_ag"     # this rank's slices are at step_no from here on
             if self.bucketer is not None and self.bucketer.mode == "rs_ag":
                 # sharded update: this rank's slices -> parameter wire -> all-gather -> the other ranks' slices into masters / shadows
                 L.check(lib.b2s_param_wire(eng.handle, self.param_wire.data_ptr(), 0, L.stream()))
@@ -389,6 +421,11 @@ class HipTrainer(object):
             eng._needs_zero = True
             if partial:
                 self._consume_partial_step(step_no, e)
+            if shard_updated:
+                # rs_ag: the sharded Adam has run, the parameter exchange behind it has not completed -- a retry under the same step number would
+                # apply Adam to the owned slices a second time while the other ranks' slices never arrived
+                self._consume_partial_step(step_no, e, what="the sharded optimizer update of this rank's slices had been issued but before the "
+                                           "all-gather of the updated parameters completed: masters and shadows of the OTHER ranks' slices are stale")
             raise
         self.global_step = step_no
         self.last_step_tail_update = bool(partial)         # (tests: which optimizer schedule the step took)

@@ -191,3 +191,50 @@ def test_reduce_scatter_all_gather_mode_two_ranks():
     all-gather leaves every rank with every owner's values (train.py:125,188-189: all replicas step to the same parameters)."""
     for payload in ("fp32", "bf16"):
         mp.spawn(_worker_rs_ag, args=(2, _free_port(), payload), nprocs=2, join=True)
+
+
+def _worker_rs_ag_moments(rank, world, port):
+    """HipTrainer.gather_optimizer_state / the state_dict guard, on the trainer's own methods with a CPU stand-in for its device state."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from b2s_hip.dp import GradBucketer
+    from b2s_hip.trainer import HipTrainer
+    from b2s_hip import lib as L
+    n_stages, off, ranges = 7, 0, {}
+    g = torch.Generator().manual_seed(11)
+    for st in range(n_stages):
+        n = 64 * int(torch.randint(1, 30, (1,), generator=g))
+        ranges[st] = (off, off + n)
+        off += n
+    total = off
+    b = GradBucketer(torch.zeros(total), ranges, n_stages, bucket_elems=2000, dist=dist, mode="rs_ag")
+    # what the sharded optimizer leaves behind: true moments on the owned slices, zeros (never updated) everywhere else
+    true_m = torch.randn(total, generator=torch.Generator().manual_seed(1))
+    true_v = torch.rand(total, generator=torch.Generator().manual_seed(2))
+    m, v = torch.zeros(total), torch.zeros(total)
+    for lo, hi in b.owned_ranges():
+        m[lo:hi], v[lo:hi] = true_m[lo:hi], true_v[lo:hi]
+    t = SimpleNamespace(bucketer=b, exp_avg=m, exp_avg_sq=v, dist=dist, global_step=3, sync=lambda: None)
+    try:                                     # a rank-0-only save without the gather would write zero moments for the other rank's half
+        HipTrainer.state_dict(t)
+        raise AssertionError("state_dict under rs_ag must refuse before gather_optimizer_state")
+    except L.B2SError as e:
+        assert "gather_optimizer_state" in str(e)
+    HipTrainer.gather_optimizer_state(t)
+    assert torch.equal(t.exp_avg, true_m) and torch.equal(t.exp_avg_sq, true_v), "every rank holds the whole Adam state after the gather"
+    assert t._moments_gathered_at == 3
+    t.global_step = 4                        # one more step: the gathered copy is stale again
+    try:
+        HipTrainer.state_dict(t)
+        raise AssertionError("a later step invalidates the gathered moments")
+    except L.B2SError:
+        pass
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_state_is_gathered_before_a_checkpoint():
+    """dp_mode = "rs_ag": Adam moments live on the owning rank only; HipTrainer.gather_optimizer_state (a collective) makes every rank's copy whole,
+    and state_dict refuses to serialise a sharded state (utils/checkpoint.py:27 is called on rank 0 only: train.py:183,225)."""
+    mp.spawn(_worker_rs_ag_moments, args=(2, _free_port()), nprocs=2, join=True)

@@ -88,7 +88,7 @@ def _dp_worker(rank, world, port, out_dir):
     torch.manual_seed(0)
     m, cfg, st, hp = _build(TINY, seed=1234 if rank == 0 else 999)      # rank 1 starts different: the trainer must broadcast rank 0's
     m.train()
-    tr = HipTrainer(m, hp, bucket_mb=0.05, grad_payload="fp32")     # exact mean of the rank gradients (the default wire format for world > 1 is bf16)
+    tr = HipTrainer(m, hp, bucket_mb=0.05, grad_payload="fp32")     # exact mean of the rank gradients (HipTrainer's default wire; bench.py selects the bf16 wire for its bf16 lines)
     assert tr.world == 2 and tr.bucketer is not None and tr.bn_broadcast
     for step in range(2):
         nb = synth.synthetic_batch(cfg, B=2, S=9, T=14, seed=100 + 10 * step + rank)
