@@ -885,20 +885,21 @@ bool b2s_flash_supported(int dh) { return dh == 32 || dh == 64 || dh == 96; }
 // bf16, causal (the decoder's self-attention: ~10 key tiles per query block): the 32x32x16 kernels of attention32.hip.  The short-key attention
 // without a causal mask (encoder-decoder attention: 2 .. 4 key tiles) stays on the kernels of this file -- same box, us per launch at (14, 8, 582, 114),
 // dropout on: forward 16.7 (resident keys) against 20.3, dQ 25 against 25, dK / dV 25 against 44 (one 128-key block per head leaves 112
-// workgroups); at 256 keys forward 27.3 / 26.5, backward 71 / 79 (profiles/NOTES_r06.md).  Lab builds: B2S_LAB_ATTN32 = 0 never, 2 always.
+// workgroups); at 256 keys forward 27.3 / 26.5, backward 71 / 79 (profiles/NOTES_r06.md).  Lab builds: B2S_LAB_ATTN32 is a bit mask (1: causal, 2 / 4 / 8: non-causal forward / dQ / dK dV).
 #ifdef B2S_LAB
-static const int g_attn32 = getenv("B2S_LAB_ATTN32") ? atoi(getenv("B2S_LAB_ATTN32")) : 1;
+static const int g_attn32 = getenv("B2S_LAB_ATTN32") ? atoi(getenv("B2S_LAB_ATTN32")) : 1;     // bit 0: causal, bits 1 / 2 / 3: non-causal forward / dQ / dK dV
 #else
 constexpr int g_attn32 = 1;
 #endif
-static inline bool use32(int dtype, const AttnArgs& a, int dh) {
-    return dtype && b2s_flash32_supported(dh) && (g_attn32 == 2 || (g_attn32 == 1 && (a.mask_mode & 2)));
+static inline bool use32(int dtype, const AttnArgs& a, int dh, int which) {
+    if (!dtype || !b2s_flash32_supported(dh) || a.ga_rows) return false;
+    return (a.mask_mode & 2) ? (g_attn32 & 1) != 0 : ((g_attn32 >> (1 + which)) & 1) != 0;
 }
 
 int b2s_flash_fwd(int dtype, const AttnArgs& a, int dh, hipStream_t st) {
     B2S_TRY(check(a, dtype, dh));
     B2S_CHECK(a.out, "attention: null output");
-    if (use32(dtype, a, dh)) return b2s_flash32_launch(a, dh, 0, st);
+    if (use32(dtype, a, dh, 0)) return b2s_flash32_launch(a, dh, 0, st);
     return dtype ? launch_t<bf16_t>(a, dh, 0, st) : launch_t<float>(a, dh, 0, st);
 }
 int b2s_flash_bwd(int dtype, const AttnArgs& a_in, int dh, const void* O, hipStream_t st) {
@@ -907,11 +908,10 @@ int b2s_flash_bwd(int dtype, const AttnArgs& a_in, int dh, const void* O, hipStr
     B2S_CHECK(!a_in.ga_rows || a_in.ga_scale, "attention backward: the guided-attention term needs its scale");
     AttnArgs a = a_in;
     a.oref = O;
-    if (use32(dtype, a, dh)) {
-        B2S_TRY(b2s_flash32_launch(a, dh, 1, st));
-        return b2s_flash32_launch(a, dh, 2, st);
-    }
-    B2S_TRY(dtype ? launch_t<bf16_t>(a, dh, 1, st) : launch_t<float>(a, dh, 1, st));
+    // (both backward kernels write dsum / read it the same way, so the two families mix freely)
+    if (use32(dtype, a, dh, 1)) { B2S_TRY(b2s_flash32_launch(a, dh, 1, st)); }
+    else { B2S_TRY(dtype ? launch_t<bf16_t>(a, dh, 1, st) : launch_t<float>(a, dh, 1, st)); }
+    if (use32(dtype, a, dh, 2)) return b2s_flash32_launch(a, dh, 2, st);
     return dtype ? launch_t<bf16_t>(a, dh, 2, st) : launch_t<float>(a, dh, 2, st);
 }
 int b2s_flash_align(int dtype, const AttnArgs& a, int dh, float* align, hipStream_t st) {

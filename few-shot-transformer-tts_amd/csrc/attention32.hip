@@ -122,10 +122,6 @@ __device__ inline void a32_block(int& rank, int& z) {
         z = wg / nx; rank = wg - z * nx;
     }
 }
-__device__ inline float ga_w(int q, int k, float iq, float ik, float inv2s2) {
-    const float d = (float)k * ik - (float)q * iq;
-    return 1.f - __expf(-d * d * inv2s2);
-}
 // store a transposed [feature][own row] accumulator set as the own row's DH features (4 consecutive features per store)
 template <int DH>
 __device__ inline void store_own(bf16_t* dst, const f32x16_t (&acc)[DH / 32], float mul, int hi) {
@@ -213,7 +209,7 @@ __device__ inline void second1p(f32x16_t (&acc)[DH / 32], const bf16_t* tile, in
 // ================================================================================================ forward
 // Software pipeline inside a wave: the logits of tile t + 1 (MFMA) are issued before the exponentials / row sums / dropout selects / bf16 packs of
 // tile t (VALU), and the dropout words of tile t + 1 are hashed beside the P V products of tile t -- the K ring therefore runs one tile ahead of the V ring.
-template <int DH, int NW, bool DROP, bool GA>
+template <int DH, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
     constexpr int NKS = DH / 16, NDT = DH / 32, TILE = 64 * DH, QB = NW * 32;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2 * TILE];
@@ -231,7 +227,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
     if (!wlive && q < a.Lq) {
         zero_own<DH>(out, hi);
         if (hi == 0 && a.lse) a.lse[(long)z * a.Lq + q] = 0.f;
-        if (hi == 0 && GA) a.ga_rows[(long)z * a.Lq + q] = 0.f;
     }
     if (qb0 >= qlive) return;                                       // nothing live in this workgroup (uniform)
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
@@ -260,9 +255,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float m = -INFINITY, l = 0.f, g = 0.f;
-    float ga_iq = 0.f, ga_ik = 0.f;
-    if (GA) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
+    float m = -INFINITY, l = 0.f;
     const float sl2 = a.scale * A32_LOG2E;
     const uint32_t xrow = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qc)) + (uint32_t)hi * GOLD;
     const uint32_t tsm1 = ((uint32_t)(b2s_wthresh(a.drop) - 1) & 0xffffu) * 0x10001u, fifteen = 0x000f000fu;
@@ -299,7 +292,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
             if (__any(grow)) {
                 const float mn = grow ? mx : m;
                 const float alpha = mn == m ? 1.f : fast_exp2(m - mn);          // m = -inf -> 0
-                m = mn; l *= alpha; g *= alpha;
+                m = mn; l *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -316,12 +309,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
                     l += p;
                     sc[t][r] = p;
                 }
-            if (GA) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) g += sc[t][r] * ga_w(q, k0 + t * 32 + crow(r, hi), ga_iq, ga_ik, a.ga_inv2s2);
-            }
             if (DROP) {
                 second1p<DH>(o, sV + cur * TILE, 0, pack8_drop<0>(sc[0], wd, tsm1, fifteen), pack8_drop<1>(sc[0], wd, tsm1, fifteen), lane);
                 second1p<DH>(o, sV + cur * TILE, 1, pack8_drop<0>(sc[1], wd + 8, tsm1, fifteen), pack8_drop<1>(sc[1], wd + 8, tsm1, fifteen), lane);
@@ -339,17 +326,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
         if (kt + 1 < ktiles) iter(kt + 1, s1, s0);
     }
     l = half_sum(l);
-    if (GA) g = half_sum(g);
     if (wlive && q < a.Lq) {
         const float inv = 1.f / l;
         store_own<DH>(out, o, inv * a.drop.scale, hi);
         if (hi == 0 && a.lse) a.lse[(long)z * a.Lq + q] = (m + __log2f(l)) * A32_LN2;
-        if (hi == 0 && GA) a.ga_rows[(long)z * a.Lq + q] = q < a.qlen[b] ? g * inv : 0.f;
     }
 }
 
 // ================================================================================================ dQ
-template <int DH, int NW, bool DROP, bool GA>
+template <int DH, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
     constexpr int NKS = DH / 16, NDT = DH / 32, TILE = 64 * DH, QB = NW * 32;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2 * TILE];
@@ -394,13 +379,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
         Dq += frag_dot(frag_own(O, a.ldo, qc, ks, hi), dof[ks]);
     }
     Dq = half_sum(Dq);
-    float gc = 0.f, ga_iq = 0.f, ga_ik = 0.f;
-    if (GA) {                                                        // guided attention: dP += c W, D += c rowsum(P W) on valid query rows
-        const int ql = min(a.qlen[b], a.Lq);
-        if (q < ql) gc = *a.ga_scale;
-        ga_iq = 1.f / (float)max(ql, 1); ga_ik = 1.f / (float)max(kend, 1);
-        Dq += gc * a.ga_rows[(long)z * a.Lq + qc];
-    }
     if (wlive && hi == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;   // the dK/dV kernel reads it
     f32x16_t dq[NDT];
 #pragma unroll
@@ -446,10 +424,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
                         dp[t][2 * pr + 1] = (int)w >= ts32 ? dp[t][2 * pr + 1] * dscale : 0.f;
                     }
                 }
-                if (GA) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) dp[t][r] += gc * ga_w(q, k0 + t * 32 + crow(r, hi), ga_iq, ga_ik, a.ga_inv2s2);
-                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[t][r] = s[t][r] * (dp[t][r] - Dq);       // (x a.scale at the end)
                 second1<DH>(dq, tK, t, s[t], lane);
@@ -462,7 +436,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
 }
 
 // ================================================================================================ dK, dV
-template <int DH, int NW, bool DROP, bool GA>
+template <int DH, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
     constexpr int NKS = DH / 16, NDT = DH / 32, TILE = 64 * DH, KB = NW * 32;
     __shared__ __attribute__((aligned(16))) bf16_t sQ[2 * TILE];
@@ -506,13 +480,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) { kf[ks] = frag_own(K, a.ldk, kc, ks, hi); vf[ks] = frag_own(V, a.ldv, kc, ks, hi); }
     const bool key_ok = key < kend;
-    float gc = 0.f, ga_iq = 0.f, ga_ik = 0.f;
-    int ga_ql = 0;
-    if (GA) {
-        ga_ql = min(a.qlen[b], a.Lq);
-        gc = *a.ga_scale;
-        ga_iq = 1.f / (float)max(ga_ql, 1); ga_ik = 1.f / (float)max(kend, 1);
-    }
     f32x16_t dk[NDT], dv[NDT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
@@ -542,8 +509,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
         if (qt >= wqt0) {
             // all 32 keys of this wave valid and visible to all 64 queries of the tile?  (wave-uniform)
             const bool interior = kw0 + 32 <= kend && q0 + 64 <= a.Lq && (!causal || kw0 + 31 <= q0);
-#pragma unroll 1
-            for (int t = 0; t < 2; ++t) {                            // (not unrolled: two halves in flight at once do not fit 256 registers)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
                 f32x16_t s, dp;                                      // s[r] = S[q = q0 + 32 t + crow(r, hi)][key = own]
                 first1<DH>(s, tQ, t, kf, l31, hi);
                 cfence();
@@ -576,8 +543,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
                             const uint32_t x = sd4[j] + xk;
                             keep = (int)(((x ^ (x >> 16)) * wck) << hsh) >= ts32;
                         }
-                        float d = keep ? dp[r] * dscale : 0.f;
-                        if (GA) { const int qq = q0 + t * 32 + crow(r, hi); d += qq < ga_ql ? gc * ga_w(qq, key, ga_iq, ga_ik, a.ga_inv2s2) : 0.f; }
+                        const float d = keep ? dp[r] * dscale : 0.f;
                         dp[r] = s[r] * (d - d4[j]);
                         s[r] = keep ? s[r] : 0.f;
                     }
@@ -596,29 +562,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
     if (wlive && key < a.Lk) { store_own<DH>(dko, dk, a.scale, hi); store_own<DH>(dvo, dv, dscale, hi); }
 }
 
-template <int DH, bool DROP, bool GA>
+template <int DH, bool DROP>
 int launch32(const AttnArgs& a, int which, hipStream_t st) {
     constexpr int NW = 4;
     if (which == 0) {
-        hipLaunchKernelGGL((attn32_fwd_kernel<DH, NW, DROP, GA>), dim3(cdiv(a.Lq, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
+        hipLaunchKernelGGL((attn32_fwd_kernel<DH, NW, DROP>), dim3(cdiv(a.Lq, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
     } else if (which == 1) {
-        hipLaunchKernelGGL((attn32_dq_kernel<DH, NW, DROP, GA>), dim3(cdiv(a.Lq, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
+        hipLaunchKernelGGL((attn32_dq_kernel<DH, NW, DROP>), dim3(cdiv(a.Lq, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
     } else {
-        hipLaunchKernelGGL((attn32_dkv_kernel<DH, NW, DROP, GA>), dim3(cdiv(a.Lk, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
+        hipLaunchKernelGGL((attn32_dkv_kernel<DH, NW, DROP>), dim3(cdiv(a.Lk, NW * 32), a.B * a.H), dim3(NW * 64), 0, st, a);
     }
     B2S_LAUNCH_CHECK();
     return 0;
 }
 template <int DH>
 int launch32_dh(const AttnArgs& a, int which, hipStream_t st) {
-    const bool drop = (a.drop.thresh >> 16) != 0, ga = a.ga_rows != nullptr;     // (rates below 2^-16 drop nothing under the 16-bit field rule)
-    if (ga) return drop ? launch32<DH, true, true>(a, which, st) : launch32<DH, false, true>(a, which, st);
-    return drop ? launch32<DH, true, false>(a, which, st) : launch32<DH, false, false>(a, which, st);
+    // (rates below 2^-16 drop nothing under the 16-bit field rule)
+    return (a.drop.thresh >> 16) != 0 ? launch32<DH, true>(a, which, st) : launch32<DH, false>(a, which, st);
 }
 }  // namespace
 
 bool b2s_flash32_supported(int dh) { return dh == 32 || dh == 64 || dh == 96; }
 int b2s_flash32_launch(const AttnArgs& a, int dh, int which, hipStream_t st) {
+    B2S_CHECK(!a.ga_rows, "the 32x32 attention kernels do not carry the guided-attention term (it belongs to the encoder-decoder attention: attention.hip)");
     switch (dh) {
         case 32: return launch32_dh<32>(a, which, st);
         case 64: return launch32_dh<64>(a, which, st);

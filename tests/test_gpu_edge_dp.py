@@ -153,6 +153,17 @@ def test_rccl_exchange_path_single_rank():
     assert outs[0]["n_gpus"] == 1 and np.isfinite(outs[0]["final_loss"])
     # bf16 + dropout + fp32-atomic conv weight gradients: runs are not bit-reproducible, a few steps differ by ~1e-3
     assert abs(outs[0]["final_loss"] - outs[1]["final_loss"]) < 1e-2 * abs(outs[1]["final_loss"])
+    # the data-parallel line decides the defaults in ONE invocation: every (dp_mode, wire) leg, the exchange path with the wire removed and the
+    # no-process-group step, each timed and finite, plus what the first SCALE run reads off them
+    d = outs[0]
+    assert d["rccl_ranks"] == 1 and "dp_legs" not in outs[1]
+    legs = {l["leg"]: l for l in d["dp_legs"]}
+    assert len(legs) == 6 and all("error" not in l and l["ms_per_step"] > 0 for l in legs.values()), d["dp_legs"]
+    assert {(l["dp_mode"], l["wire"]) for l in legs.values() if l["dp_mode"]} == {("allreduce", "fp32"), ("allreduce", "bf16"), ("rs_ag", "fp32"), ("rs_ag", "bf16")}
+    assert all(np.isfinite(l["final_loss"]) for l in legs.values() if "final_loss" in l)
+    assert d["local_ms_per_step"] == legs["no process group (single-GPU step)"]["ms_per_step"]
+    assert abs(d["scaling_efficiency"] - d["local_ms_per_step"] / d["ms_per_step"]) < 1e-3
+    assert d["exposed_comm_ms"] is not None and d["exchange_path_overhead_ms"] is not None and d["fastest_dp_leg"]["ms_per_step"] > 0
 
 
 def test_ungrouped_weight_gradient_option():
