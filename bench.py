@@ -54,7 +54,11 @@ def fwd_flops(B, S, T, De=512, Fe=2048, Dd=768, Fd=3072, Le=6, Ld=6):
 def make_batch(cfg, B, S, T, seed, device, n_spk=1, n_lang=1):
     from benchdata import synthetic_batch
     nb = synthetic_batch(cfg, B, S, T, seed=seed, n_spk=n_spk, n_lang=n_lang)      # (1, 1) = LJSpeech: one speaker, en-us; (572, 38) = C3
-    return {k: (torch.from_numpy(np.asarray(v)).to(device) if not isinstance(v, list) else v) for k, v in nb.items()}
+    out = {k: (torch.from_numpy(np.asarray(v)).to(device) if not isinstance(v, list) else v) for k, v in nb.items()}
+    # the dataloader's host copy of the lengths travels with the batch (b2s_hip/batching.py: DeviceStager does the same): the fused trainer keeps
+    # the decoder's rows ragged from it -- sum(target_lengths) rows per row-wise kernel instead of B x T -- without a device-to-host read
+    out["target_lengths_host"] = [int(x) for x in np.asarray(nb["target_lengths"])]
+    return out
 
 
 def cpu_baseline_train(budget_s=25.0):
@@ -225,7 +229,9 @@ def main():
         batches = []
         for _ in range(8):
             idx = torch.from_numpy(np.sort(rng.choice(30, B, replace=False))).to(device)
-            batches.append({k: (v.index_select(0, idx) if torch.is_tensor(v) else v) for k, v in pool.items()})
+            bb = {k: (v.index_select(0, idx) if torch.is_tensor(v) else v) for k, v in pool.items()}
+            bb["target_lengths_host"] = [pool["target_lengths_host"][int(i)] for i in idx.cpu()]
+            batches.append(bb)
 
     def sync():
         if world > 1 or force_dp:

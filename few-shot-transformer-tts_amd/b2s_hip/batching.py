@@ -140,6 +140,9 @@ class DeviceStager(object):
                     out[k] = self._pin(k, v, slot).to(self.device, non_blocking=True)
                 else:
                     out[k] = v
+            if isinstance(np_batch.get("target_lengths"), np.ndarray):
+                # the host copy stays with the batch: HipTrainer runs the decoder segment on ragged rows from it (no device-to-host read)
+                out["target_lengths_host"] = [int(x) for x in np_batch["target_lengths"]]
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self._queue.append((out, ev))

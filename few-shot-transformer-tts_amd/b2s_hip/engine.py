@@ -256,13 +256,18 @@ class HipEngine(object):
         self.begin_backward()
         L.check(self.lib.b2s_encoder_backward(self.handle, ctx.handle, L.ptr(dmem.contiguous()), L.stream()))
 
-    def decoder_forward(self, memory, in32, targets, tgt32, train, seed, keep_ctx, memory_ready=None, padded_unobserved=False):
+    def decoder_forward(self, memory, in32, targets, tgt32, train, seed, keep_ctx, memory_ready=None, padded_unobserved=False, target_lengths_host=None):
         """memory_ready: torch.cuda.Event recorded behind the encoder forward on ANOTHER stream; this stream waits for it only when the
         decoder first reads `memory` (b2s_decoder_forward: memory_ready).
         padded_unobserved: the caller will not ask for alignments of query rows >= target length (B2S_DEC_PADDED_UNOBSERVED): the
-        attention kernels skip tiles of padded query rows."""
+        attention kernels skip tiles of padded query rows.
+        target_lengths_host (with padded_unobserved): the HOST copy of target_lengths (sequence of B ints, the values of tgt32) -- the segment then
+        keeps its rows ragged (b2s_decoder_compact_rows: sum(target_lengths) rows per row-wise kernel instead of B x T); B2S_COMPACT=0 ignores it."""
         dev = self.ensure_bound()
         B, T, NM = targets.shape
+        if padded_unobserved and target_lengths_host is not None and os.environ.get("B2S_COMPACT", "1") != "0":
+            lens = (C.c_int32 * B)(*[int(x) for x in target_lengths_host])
+            L.check(self.lib.b2s_decoder_compact_rows(self.handle, lens, B))
         S = memory.shape[1]
         memory = memory.contiguous()
         targets = targets.contiguous()

@@ -117,6 +117,7 @@ _PROTOS = {
     "b2s_adam_step_groups": (C.c_int, [P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, P]),
     "b2s_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "b2s_dropout_mask": (C.c_int, [C.c_float, C.c_uint64, C.c_uint32, P, C.c_int64, P]),
+    "b2s_decoder_compact_rows": (C.c_int, [P, P, C.c_int]),
     "b2s_dropout_mask_attn": (C.c_int, [C.c_float, C.c_uint64, C.c_uint32, P, C.c_int64, C.c_int, P]),
     "b2s_dropout_site": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "b2s_encf_attention_forward": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, P, P, P, P, C.c_int, P]),

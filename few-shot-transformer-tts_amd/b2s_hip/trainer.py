@@ -290,7 +290,10 @@ class HipTrainer(object):
 
     # ------------------------------------------------------------------ one step
     def train_step(self, batch):
-        """batch: the dataloader dict (dataloader.py:498-508) on the device.  Returns the 7 loss values (device)."""
+        """batch: the dataloader dict (dataloader.py:498-508) on the device.  Returns the 7 loss values (device).
+        Optional key "target_lengths_host": the host copy of batch["target_lengths"] (list / CPU tensor; the dataloader has it before the batch
+        is sent to the device, b2s_hip/batching.py keeps it) -- the decoder segment then runs on ragged rows, sum(target_lengths) instead of
+        B x T per row-wise kernel, without a device-to-host read."""
         eng, lib = self.eng, self.lib
         # Re-bind / re-sync on THIS stream before anything forks off it: a full weight sync (parameters loaded or changed behind the
         # optimizer's back: utils.checkpoint.load_model, load_state_dict) re-casts every bf16 shadow, and both the encoder stream and
@@ -315,11 +318,13 @@ class HipTrainer(object):
                                                  True, eng.next_seed("encoder"), not self.freeze_encoder)
                 mem_ready = torch.cuda.Event()
                 mem_ready.record(enc_s)
-            mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed("decoder"), True, memory_ready=mem_ready, padded_unobserved=True)
+            mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed("decoder"), True, memory_ready=mem_ready, padded_unobserved=True,
+                                                    target_lengths_host=batch.get("target_lengths_host"))
         else:
             mem, c_enc = eng.encoder_forward(batch["inputs"], in32, batch.get("input_spk_ids"), batch.get("input_language_vecs"),
                                              True, eng.next_seed("encoder"), not self.freeze_encoder)
-            mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed("decoder"), True, padded_unobserved=True)
+            mels, stop, c_dec = eng.decoder_forward(mem, in32, batch["mel_targets"], tgt32, True, eng.next_seed("decoder"), True, padded_unobserved=True,
+                                                    target_lengths_host=batch.get("target_lengths_host"))
         aft, c_post = eng.postnet_forward(mels, tgt32, mels, True, eng.next_seed("postnet"), True)
         vals, per = eng.loss_forward(mels, aft, stop, batch["mel_targets"], tgt32)
         guided = eng.guided_enabled()

@@ -30,6 +30,10 @@ struct AttnArgs {
     // are written as zeros (lse = dsum = 0) and the dK/dV loop stops before them.  Only for callers whose rows >= qskip[b] are padding
     // that nothing reads and whose upstream gradient is zero (the decoder: its outputs and gradients are masked by target_lengths).
     const int* qskip = nullptr;
+    // ragged rows (the decoder's compact layout, engine.hip): when set, utterance b's rows of the q-side tensors (q, out, dout, oref, dq) are
+    // [qoff[b], qoff[b + 1]) instead of [b Lq, (b + 1) Lq), likewise koff for the k-side tensors (k, v, dk, dv); Lq / Lk stay the padded lengths
+    // (grid size, the [B H, Lq] row indexing of lse / dsum / ga_rows and of the dropout rows).  [B + 1] entries each.
+    const int *qoff = nullptr, *koff = nullptr;
 };
 
 bool b2s_flash_supported(int dh);

@@ -209,50 +209,53 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_fwd_kernel(A
     int tile_, z;
     xcd_block(tile_, z);
     const int b = z / a.H, h = z - b * a.H;
+    // this utterance's rows of the q-side / k-side tensors (AttnArgs::qoff / koff: ragged row offsets; default: the padded [B, L] layout)
+    const int qrow0 = a.qoff ? a.qoff[b] : b * a.Lq, Lq = a.qoff ? a.qoff[b + 1] - qrow0 : a.Lq;
+    const int krow0 = a.koff ? a.koff[b] : b * a.Lk, Lk = a.koff ? a.koff[b + 1] - krow0 : a.Lk;
     const int qb0 = tile_ * 64, q = qb0 + wave * 16 + li;
-    const int qc = min(q, a.Lq - 1);
+    const int qc = min(q, Lq - 1);
     if (a.qskip && qb0 >= a.qskip[b]) {              // a tile of padded query rows (workgroup-uniform)
-        if (q < a.Lq) {
+        if (q < Lq) {
             f32x4_t zero[DH / 16];
 #pragma unroll
             for (int dt = 0; dt < DH / 16; ++dt) zero[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            store_rows<T, DH>(reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q) * a.ldo + h * DH, zero, 1.f, lg);
+            store_rows<T, DH>(reinterpret_cast<T*>(a.out) + ((long)qrow0 + q) * a.ldo + h * DH, zero, 1.f, lg);
             if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = 0.f;
             if (lg == 0 && a.ga_rows) a.ga_rows[(long)z * a.Lq + q] = 0.f;
         }
         return;
     }
-    const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
-    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
-    const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
+    const T* Q = reinterpret_cast<const T*>(a.q) + (long)qrow0 * a.ldq + h * DH;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)krow0 * a.ldk + h * DH;
+    const T* V = reinterpret_cast<const T*>(a.v) + (long)krow0 * a.ldv + h * DH;
     typename AT<T>::frag qf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) qf[ks] = frag_global<T>(Q, a.ldq, qc, ks, lg);
 
-    int kend = a.Lk;
+    int kend = Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     int ktiles = (kend + 63) / 64;
-    if (a.mask_mode & 2) ktiles = min(ktiles, (min(qb0 + 63, a.Lq - 1)) / 64 + 1);
+    if (a.mask_mode & 2) ktiles = min(ktiles, (min(qb0 + 63, Lq - 1)) / 64 + 1);
     f32x4_t o[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;                    // m: reference exponent (log2 domain), l: this lane's part of the row sum
     const bool ga = a.ga_rows != nullptr;
     float g = 0.f, ga_iq = 0.f, ga_ik = 0.f;
-    if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
+    if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
     const float sl2 = a.scale * B2S_LOG2E;
     const int qw0 = qb0 + wave * 16;                 // first query row of this wave
     const uint32_t dseed = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qc));
     const int dts = b2s_wthresh(a.drop);
     TileRegs<T, DH> rk, rv;
-    if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid); }
+    if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, Lk, tid); }
     for (int kt = 0; kt < ktiles; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
         tile_store<T, DH>(sK, rk, tid);
         tile_store<T, DH>(sV, rv, tid);
         __syncthreads();
-        if (kt + 1 < ktiles) { tile_fetch<T, DH>(rk, K, a.ldk, k0 + 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 64, a.Lk, tid); }
+        if (kt + 1 < ktiles) { tile_fetch<T, DH>(rk, K, a.ldk, k0 + 64, Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 64, Lk, tid); }
         f32x4_t s[4];
         first_product<T, DH, LD>(s, sK, qf, li, lg);
         // every key of the tile visible to every row of this wave?  (wave-uniform; the common case skips all mask math)
@@ -301,9 +304,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_fwd_kernel(A
     }
     l = group_sum(l);
     if (ga) g = group_sum(g);
-    if (q < a.Lq) {
+    if (q < Lq) {
         const float inv = 1.f / l;
-        T* out = reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q) * a.ldo + h * DH;
+        T* out = reinterpret_cast<T*>(a.out) + ((long)qrow0 + q) * a.ldo + h * DH;
         store_rows<T, DH>(out, o, inv, lg);
         if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = (m + __log2f(l)) * B2S_LN2;
         if (lg == 0 && ga) a.ga_rows[(long)z * a.Lq + q] = q < a.qlen[b] ? g * inv : 0.f;
@@ -345,22 +348,25 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DQ_WPC : 1) void att
     int tile_, z;
     xcd_block(tile_, z);
     const int b = z / a.H, h = z - b * a.H;
+    // this utterance's rows of the q-side / k-side tensors (AttnArgs::qoff / koff: ragged row offsets; default: the padded [B, L] layout)
+    const int qrow0 = a.qoff ? a.qoff[b] : b * a.Lq, Lq = a.qoff ? a.qoff[b + 1] - qrow0 : a.Lq;
+    const int krow0 = a.koff ? a.koff[b] : b * a.Lk, Lk = a.koff ? a.koff[b + 1] - krow0 : a.Lk;
     const int qb0 = tile_ * 64, q = qb0 + wave * 16 + li;
-    const int qc = min(q, a.Lq - 1);
+    const int qc = min(q, Lq - 1);
     if (a.qskip && qb0 >= a.qskip[b]) {              // padded query rows: d context is zero there, so is dQ (the dK/dV kernel never reads dsum)
-        if (q < a.Lq) {
+        if (q < Lq) {
             f32x4_t zero[DH / 16];
 #pragma unroll
             for (int dt = 0; dt < DH / 16; ++dt) zero[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)b * a.Lq + q) * a.lddq + h * DH, zero, 1.f, lg);
+            store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)qrow0 + q) * a.lddq + h * DH, zero, 1.f, lg);
             if (lg == 0) a.dsum[(long)z * a.Lq + q] = 0.f;
         }
         return;
     }
-    const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
-    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
-    const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
-    const T* dO = reinterpret_cast<const T*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
+    const T* Q = reinterpret_cast<const T*>(a.q) + (long)qrow0 * a.ldq + h * DH;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)krow0 * a.ldk + h * DH;
+    const T* V = reinterpret_cast<const T*>(a.v) + (long)krow0 * a.ldv + h * DH;
+    const T* dO = reinterpret_cast<const T*>(a.dout) + (long)qrow0 * a.ldo + h * DH;
     typename AT<T>::frag qf[NKS], dof[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) { qf[ks] = frag_global<T>(Q, a.ldq, qc, ks, lg); dof[ks] = frag_global<T>(dO, a.ldo, qc, ks, lg); }
@@ -368,24 +374,24 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DQ_WPC : 1) void att
     // D[q] = sum_d dO[q][d] * O[q][d], from the same fragments (each lane holds 1/4 of the row; two shuffles finish it)
     float Dq = 0.f;
     {
-        const T* O = reinterpret_cast<const T*>(a.oref) + (long)b * a.Lq * a.ldo + h * DH;
+        const T* O = reinterpret_cast<const T*>(a.oref) + (long)qrow0 * a.ldo + h * DH;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) Dq += frag_dot(frag_global<T>(O, a.ldo, qc, ks, lg), dof[ks]);
         Dq = group_sum(Dq);
     }
-    int kend = a.Lk;
+    int kend = Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     // guided attention: dP += c W, D += c * rowsum(P W) on valid query rows
     float gc = 0.f, ga_iq = 0.f, ga_ik = 0.f;
     if (a.ga_rows) {
-        const int ql = min(a.qlen[b], a.Lq);
+        const int ql = min(a.qlen[b], Lq);
         if (q < ql) gc = *a.ga_scale;
         ga_iq = 1.f / (float)max(ql, 1); ga_ik = 1.f / (float)max(kend, 1);
         Dq += gc * a.ga_rows[(long)z * a.Lq + qc];
     }
-    if (lg == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;              // the dK/dV kernel reads it
+    if (lg == 0 && q < Lq) a.dsum[(long)z * a.Lq + q] = Dq;              // the dK/dV kernel reads it
     int ktiles = (kend + 63) / 64;
-    if (a.mask_mode & 2) ktiles = min(ktiles, (min(qb0 + 63, a.Lq - 1)) / 64 + 1);
+    if (a.mask_mode & 2) ktiles = min(ktiles, (min(qb0 + 63, Lq - 1)) / 64 + 1);
     f32x4_t dq[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -394,14 +400,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DQ_WPC : 1) void att
     const float sl2 = a.scale * B2S_LOG2E, lse2 = lse * B2S_LOG2E;
     const int qw0 = qb0 + wave * 16;
     TileRegs<T, DH> rk, rv;
-    if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, a.Lk, tid); }
+    if (ktiles > 0) { tile_fetch<T, DH>(rk, K, a.ldk, 0, Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, 0, Lk, tid); }
     for (int kt = 0; kt < ktiles; ++kt) {
         const int k0 = kt * 64;
         __syncthreads();
         tile_store<T, DH>(sK, rk, tid);
         tile_store<T, DH>(sV, rv, tid);
         __syncthreads();
-        if (kt + 1 < ktiles) { tile_fetch<T, DH>(rk, K, a.ldk, k0 + 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 64, a.Lk, tid); }
+        if (kt + 1 < ktiles) { tile_fetch<T, DH>(rk, K, a.ldk, k0 + 64, Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, k0 + 64, Lk, tid); }
         f32x4_t s[4], dp[4];
         first_product<T, DH, LD>(s, sK, qf, li, lg);
         first_product<T, DH, LD>(dp, sV, dof, li, lg);
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DQ_WPC : 1) void att
             for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - Dq) * a.scale;
         SP<T, DH, LD>::run(dq, sK, s, li, lg);
     }
-    if (q < a.Lq) store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)b * a.Lq + q) * a.lddq + h * DH, dq, 1.f, lg);
+    if (q < Lq) store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)qrow0 + q) * a.lddq + h * DH, dq, 1.f, lg);
 }
 
 // dK, dV: per workgroup 64 keys; loops over query tiles
@@ -449,29 +455,32 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DKV_WPC : 1) void at
     int tile_, z;
     xcd_block(tile_, z);
     const int b = z / a.H, h = z - b * a.H;
+    // this utterance's rows of the q-side / k-side tensors (AttnArgs::qoff / koff: ragged row offsets; default: the padded [B, L] layout)
+    const int qrow0 = a.qoff ? a.qoff[b] : b * a.Lq, Lq = a.qoff ? a.qoff[b + 1] - qrow0 : a.Lq;
+    const int krow0 = a.koff ? a.koff[b] : b * a.Lk, Lk = a.koff ? a.koff[b + 1] - krow0 : a.Lk;
     const int kb0 = tile_ * 64, key = kb0 + wave * 16 + li;
-    const int kc = min(key, a.Lk - 1);
-    const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
-    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
-    const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
-    const T* dO = reinterpret_cast<const T*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
+    const int kc = min(key, Lk - 1);
+    const T* Q = reinterpret_cast<const T*>(a.q) + (long)qrow0 * a.ldq + h * DH;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)krow0 * a.ldk + h * DH;
+    const T* V = reinterpret_cast<const T*>(a.v) + (long)krow0 * a.ldv + h * DH;
+    const T* dO = reinterpret_cast<const T*>(a.dout) + (long)qrow0 * a.ldo + h * DH;
     typename AT<T>::frag kf[NKS], vf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) { kf[ks] = frag_global<T>(K, a.ldk, kc, ks, lg); vf[ks] = frag_global<T>(V, a.ldv, kc, ks, lg); }
-    int kend = a.Lk;
+    int kend = Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     const bool key_ok = key < kend;
     float gc = 0.f, ga_iq = 0.f, ga_ik = 0.f;
     int ga_ql = 0;
     if (a.ga_rows) {
-        ga_ql = min(a.qlen[b], a.Lq);
+        ga_ql = min(a.qlen[b], Lq);
         gc = *a.ga_scale;
         ga_iq = 1.f / (float)max(ga_ql, 1); ga_ik = 1.f / (float)max(kend, 1);
     }
     f32x4_t dk[DH / 16], dv[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-    int qtiles = (a.Lq + 63) / 64;
+    int qtiles = (Lq + 63) / 64;
     if (a.qskip) qtiles = min(qtiles, (a.qskip[b] + 63) / 64);             // tiles of padded query rows contribute nothing (d context = 0)
     const int qt0 = (a.mask_mode & 2) ? kb0 / 64 : 0;          // causal: queries before this key tile never see it
     TileRegs<T, DH> rq, ro;
@@ -484,9 +493,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DKV_WPC : 1) void at
     const uint32_t dxk = (uint32_t)(kc >> 2) * 0x9E3779B1u, dwc = (kc & 2) ? B2S_WC1 : B2S_WC0, dsh = (kc & 1) ? 0u : 16u;
     const int dts32 = (int)((uint32_t)b2s_wthresh(a.drop) << 16);
     if (qt0 < qtiles) {
-        tile_fetch<T, DH>(rq, Q, a.ldq, qt0 * 64, a.Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, qt0 * 64, a.Lq, tid);
+        tile_fetch<T, DH>(rq, Q, a.ldq, qt0 * 64, Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, qt0 * 64, Lq, tid);
         if (tid < 64) {
-            const int qq = min(qt0 * 64 + tid, a.Lq - 1);
+            const int qq = min(qt0 * 64 + tid, Lq - 1);
             r_l = a.lse[(long)z * a.Lq + qq] * B2S_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq];
             if (a.drop.thresh) r_s = b2s_wseed(a.drop, zq + (uint32_t)qq);
         }
@@ -499,9 +508,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DKV_WPC : 1) void at
         if (tid < 64) { sL[tid] = r_l; sD[tid] = r_d; sS[tid] = r_s; }
         __syncthreads();
         if (qt + 1 < qtiles) {
-            tile_fetch<T, DH>(rq, Q, a.ldq, q0 + 64, a.Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, q0 + 64, a.Lq, tid);
+            tile_fetch<T, DH>(rq, Q, a.ldq, q0 + 64, Lq, tid); tile_fetch<T, DH>(ro, dO, a.ldo, q0 + 64, Lq, tid);
             if (tid < 64) {
-                const int qq = min(q0 + 64 + tid, a.Lq - 1);
+                const int qq = min(q0 + 64 + tid, Lq - 1);
                 r_l = a.lse[(long)z * a.Lq + qq] * B2S_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq];
                 if (a.drop.thresh) r_s = b2s_wseed(a.drop, zq + (uint32_t)qq);
             }
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DKV_WPC : 1) void at
         first_product<T, DH, LD>(s, sQ, kf, li, lg);          // s[t][r] = S[q = q0 + t*16 + lg*4 + r][key = own]
         first_product<T, DH, LD>(dp, sO, vf, li, lg);
         // all 16 keys of this wave valid and visible to all 64 queries of the tile?  (wave-uniform)
-        const bool interior = kw0 + 16 <= kend && q0 + 64 <= a.Lq && (!(a.mask_mode & 2) || kw0 + 15 <= q0);
+        const bool interior = kw0 + 16 <= kend && q0 + 64 <= Lq && (!(a.mask_mode & 2) || kw0 + 15 <= q0);
         if (interior) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DKV_WPC : 1) void at
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qq = q0 + t * 16 + lg * 4 + r;
-                    const bool ok = key_ok && qq < a.Lq && (!(a.mask_mode & 2) || key <= qq);
+                    const bool ok = key_ok && qq < Lq && (!(a.mask_mode & 2) || key <= qq);
                     s[t][r] = ok ? fast_exp2(fmaf(s[t][r], sl2, -lq[r])) : 0.f;
                 }
             }
@@ -565,9 +574,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? B2S_ATTN_DKV_WPC : 1) void at
         }
         SP<T, DH, LD>::run(dk, sQ, s, li, lg);                 // dK^T[d][key] += sum_q Q[q][d]  * dS[q][key]
     }
-    if (key < a.Lk) {
-        store_rows<T, DH>(reinterpret_cast<T*>(a.dk) + ((long)b * a.Lk + key) * a.lddk + h * DH, dk, 1.f, lg);
-        store_rows<T, DH>(reinterpret_cast<T*>(a.dv) + ((long)b * a.Lk + key) * a.lddv + h * DH, dv, 1.f, lg);
+    if (key < Lk) {
+        store_rows<T, DH>(reinterpret_cast<T*>(a.dk) + ((long)krow0 + key) * a.lddk + h * DH, dk, 1.f, lg);
+        store_rows<T, DH>(reinterpret_cast<T*>(a.dv) + ((long)krow0 + key) * a.lddv + h * DH, dv, 1.f, lg);
     }
 }
 
@@ -584,11 +593,11 @@ constexpr int RES_KEYS = 128;
 
 // K, V rows [0, 128) of one (batch, head) -> LDS images [128][LD] (zero beyond Lk), then one barrier
 template <typename T, int DH>
-__device__ inline void res_load_kv(T* sK, T* sV, const T* K, const T* V, const AttnArgs& a, int nkt, int tid) {
+__device__ inline void res_load_kv(T* sK, T* sV, const T* K, const T* V, const AttnArgs& a, int Lk, int nkt, int tid) {
     constexpr int LD = DH + AT<T>::PAD;
     TileRegs<T, DH> rk, rv;
     for (int kt = 0; kt < nkt; ++kt) {
-        tile_fetch<T, DH>(rk, K, a.ldk, kt * 64, a.Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, kt * 64, a.Lk, tid);
+        tile_fetch<T, DH>(rk, K, a.ldk, kt * 64, Lk, tid); tile_fetch<T, DH>(rv, V, a.ldv, kt * 64, Lk, tid);
         tile_store<T, DH>(sK + kt * 64 * LD, rk, tid); tile_store<T, DH>(sV + kt * 64 * LD, rv, tid);
     }
     __syncthreads();
@@ -604,29 +613,32 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_res_kern
     int chunk, z;
     xcd_block(chunk, z);
     const int b = z / a.H, h = z - b * a.H;
-    const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
-    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
-    const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
-    int kend = a.Lk;
+    // this utterance's rows of the q-side / k-side tensors (AttnArgs::qoff / koff: ragged row offsets; default: the padded [B, L] layout)
+    const int qrow0 = a.qoff ? a.qoff[b] : b * a.Lq, Lq = a.qoff ? a.qoff[b + 1] - qrow0 : a.Lq;
+    const int krow0 = a.koff ? a.koff[b] : b * a.Lk, Lk = a.koff ? a.koff[b + 1] - krow0 : a.Lk;
+    const T* Q = reinterpret_cast<const T*>(a.q) + (long)qrow0 * a.ldq + h * DH;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)krow0 * a.ldk + h * DH;
+    const T* V = reinterpret_cast<const T*>(a.v) + (long)krow0 * a.ldv + h * DH;
+    int kend = Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     const int nkt = (kend + 63) / 64;                              // 0, 1 or 2 key tiles carry valid keys
-    const int ntiles = (a.Lq + 63) / 64;
+    const int ntiles = (Lq + 63) / 64;
     const int t_begin = chunk * tpw, t_end = min(t_begin + tpw, ntiles);
     // tiles of padded query rows need no keys: a chunk that holds nothing else skips the K / V load as well
-    const int q_live = a.qskip ? min(a.qskip[b], a.Lq) : a.Lq;
-    if (t_begin * 64 < q_live) res_load_kv<T, DH>(sK, sV, K, V, a, nkt, tid);
+    const int q_live = a.qskip ? min(a.qskip[b], Lq) : Lq;
+    if (t_begin * 64 < q_live) res_load_kv<T, DH>(sK, sV, K, V, a, Lk, nkt, tid);
     const bool ga = a.ga_rows != nullptr;
     float ga_iq = 0.f, ga_ik = 0.f;
-    if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], a.Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
+    if (ga) { ga_iq = 1.f / (float)max(min(a.qlen[b], Lq), 1); ga_ik = 1.f / (float)max(kend, 1); }
     const float sl2 = a.scale * B2S_LOG2E;
     for (int tile = t_begin; tile < t_end; ++tile) {
-        const int qb0 = tile * 64, q = qb0 + wave * 16 + li, qc = min(q, a.Lq - 1);
+        const int qb0 = tile * 64, q = qb0 + wave * 16 + li, qc = min(q, Lq - 1);
         f32x4_t o[DH / 16];
 #pragma unroll
         for (int dt = 0; dt < DH / 16; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         if (qb0 >= q_live && a.qskip) {                            // a tile of padded query rows (workgroup-uniform)
-            if (q < a.Lq) {
-                store_rows<T, DH>(reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q) * a.ldo + h * DH, o, 1.f, lg);
+            if (q < Lq) {
+                store_rows<T, DH>(reinterpret_cast<T*>(a.out) + ((long)qrow0 + q) * a.ldo + h * DH, o, 1.f, lg);
                 if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = 0.f;
                 if (lg == 0 && ga) a.ga_rows[(long)z * a.Lq + q] = 0.f;
             }
@@ -681,9 +693,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_res_kern
         }
         l = group_sum(l);
         if (ga) g = group_sum(g);
-        if (q < a.Lq) {
+        if (q < Lq) {
             const float inv = 1.f / l;
-            store_rows<T, DH>(reinterpret_cast<T*>(a.out) + ((long)b * a.Lq + q) * a.ldo + h * DH, o, inv, lg);
+            store_rows<T, DH>(reinterpret_cast<T*>(a.out) + ((long)qrow0 + q) * a.ldo + h * DH, o, inv, lg);
             if (lg == 0 && a.lse) a.lse[(long)z * a.Lq + q] = (mref + __log2f(l)) * B2S_LN2;
             if (lg == 0 && ga) a.ga_rows[(long)z * a.Lq + q] = q < a.qlen[b] ? g * inv : 0.f;
         }
@@ -700,34 +712,37 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_res_k
     int chunk, z;
     xcd_block(chunk, z);
     const int b = z / a.H, h = z - b * a.H;
-    const T* Q = reinterpret_cast<const T*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
-    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
-    const T* V = reinterpret_cast<const T*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
-    const T* dO = reinterpret_cast<const T*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
-    const T* O = reinterpret_cast<const T*>(a.oref) + (long)b * a.Lq * a.ldo + h * DH;
-    int kend = a.Lk;
+    // this utterance's rows of the q-side / k-side tensors (AttnArgs::qoff / koff: ragged row offsets; default: the padded [B, L] layout)
+    const int qrow0 = a.qoff ? a.qoff[b] : b * a.Lq, Lq = a.qoff ? a.qoff[b + 1] - qrow0 : a.Lq;
+    const int krow0 = a.koff ? a.koff[b] : b * a.Lk, Lk = a.koff ? a.koff[b + 1] - krow0 : a.Lk;
+    const T* Q = reinterpret_cast<const T*>(a.q) + (long)qrow0 * a.ldq + h * DH;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)krow0 * a.ldk + h * DH;
+    const T* V = reinterpret_cast<const T*>(a.v) + (long)krow0 * a.ldv + h * DH;
+    const T* dO = reinterpret_cast<const T*>(a.dout) + (long)qrow0 * a.ldo + h * DH;
+    const T* O = reinterpret_cast<const T*>(a.oref) + (long)qrow0 * a.ldo + h * DH;
+    int kend = Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     const int nkt = (kend + 63) / 64;
-    const int ntiles = (a.Lq + 63) / 64;
+    const int ntiles = (Lq + 63) / 64;
     const int t_begin = chunk * tpw, t_end = min(t_begin + tpw, ntiles);
-    const int q_live = a.qskip ? min(a.qskip[b], a.Lq) : a.Lq;
-    if (t_begin * 64 < q_live) res_load_kv<T, DH>(sK, sV, K, V, a, nkt, tid);
+    const int q_live = a.qskip ? min(a.qskip[b], Lq) : Lq;
+    if (t_begin * 64 < q_live) res_load_kv<T, DH>(sK, sV, K, V, a, Lk, nkt, tid);
     float gc0 = 0.f, ga_iq = 0.f, ga_ik = 0.f;
     int ga_ql = 0;
     if (a.ga_rows) {
-        ga_ql = min(a.qlen[b], a.Lq);
+        ga_ql = min(a.qlen[b], Lq);
         gc0 = *a.ga_scale;
         ga_iq = 1.f / (float)max(ga_ql, 1); ga_ik = 1.f / (float)max(kend, 1);
     }
     const float sl2 = a.scale * B2S_LOG2E;
     for (int tile = t_begin; tile < t_end; ++tile) {
-        const int qb0 = tile * 64, q = qb0 + wave * 16 + li, qc = min(q, a.Lq - 1);
+        const int qb0 = tile * 64, q = qb0 + wave * 16 + li, qc = min(q, Lq - 1);
         f32x4_t dq[DH / 16];
 #pragma unroll
         for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         if (qb0 >= q_live && a.qskip) {                            // padded query rows: d context is zero there, so is dQ
-            if (q < a.Lq) {
-                store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)b * a.Lq + q) * a.lddq + h * DH, dq, 1.f, lg);
+            if (q < Lq) {
+                store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)qrow0 + q) * a.lddq + h * DH, dq, 1.f, lg);
                 if (lg == 0) a.dsum[(long)z * a.Lq + q] = 0.f;
             }
             continue;
@@ -745,7 +760,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_res_k
             if (q < ga_ql) gc = gc0;
             Dq += gc * a.ga_rows[(long)z * a.Lq + qc];
         }
-        if (lg == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;              // the dK/dV kernel reads it
+        if (lg == 0 && q < Lq) a.dsum[(long)z * a.Lq + q] = Dq;              // the dK/dV kernel reads it
         const uint32_t dseed = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qc));
     const int dts = b2s_wthresh(a.drop);
 #pragma unroll
@@ -775,7 +790,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_res_k
                 for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - Dq) * a.scale;
             SP<T, DH, LD>::run(dq, sK + kt * 64 * LD, s, li, lg);
         }
-        if (q < a.Lq) store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)b * a.Lq + q) * a.lddq + h * DH, dq, 1.f, lg);
+        if (q < Lq) store_rows<T, DH>(reinterpret_cast<T*>(a.dq) + ((long)qrow0 + q) * a.lddq + h * DH, dq, 1.f, lg);
     }
 }
 
@@ -786,9 +801,15 @@ __global__ __launch_bounds__(256) void attn_align_kernel(AttnArgs a, float* alig
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);           // r = z*Lq + q
     if (r >= (long)a.B * a.H * a.Lq) return;
     const int q = (int)(r % a.Lq), z = (int)(r / a.Lq), b = z / a.H, h = z - b * a.H;
-    const T* Q = reinterpret_cast<const T*>(a.q) + ((long)b * a.Lq + q) * a.ldq + h * dh;
-    const T* K = reinterpret_cast<const T*>(a.k) + (long)b * a.Lk * a.ldk + h * dh;
-    int kend = a.Lk;
+    const int qrow0 = a.qoff ? a.qoff[b] : b * a.Lq, Lqb = a.qoff ? a.qoff[b + 1] - qrow0 : a.Lq;
+    const int krow0 = a.koff ? a.koff[b] : b * a.Lk, Lkb = a.koff ? a.koff[b + 1] - krow0 : a.Lk;
+    if (q >= Lqb) {                                    // ragged layout: the row does not exist (the caller declared padded rows unobserved)
+        for (int k = lane; k < a.Lk; k += 64) align[((long)z * a.Lk + k) * a.Lq + q] = 0.f;
+        return;
+    }
+    const T* Q = reinterpret_cast<const T*>(a.q) + ((long)qrow0 + q) * a.ldq + h * dh;
+    const T* K = reinterpret_cast<const T*>(a.k) + (long)krow0 * a.ldk + h * dh;
+    int kend = Lkb;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     if (a.mask_mode & 2) kend = min(kend, q + 1);
     float lse = a.lse[r];

@@ -219,31 +219,34 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
     a32_block(blk, z);
     blk = gridDim.x - 1 - blk;                                      // rank 0 = the last query block (causal: the most key tiles)
     const int b = z / a.H, h = z - b * a.H;
-    const int qb0 = blk * QB, qw0 = qb0 + wave * 32, q = qw0 + l31, qc = min(q, a.Lq - 1);
+    // this utterance's rows of the q-side / k-side tensors (AttnArgs::qoff / koff: ragged row offsets; default: the padded [B, L] layout)
+    const int qrow0 = a.qoff ? a.qoff[b] : b * a.Lq, Lq = a.qoff ? a.qoff[b + 1] - qrow0 : a.Lq;
+    const int krow0 = a.koff ? a.koff[b] : b * a.Lk, Lk = a.koff ? a.koff[b + 1] - krow0 : a.Lk;
+    const int qb0 = blk * QB, qw0 = qb0 + wave * 32, q = qw0 + l31, qc = min(q, Lq - 1);
     // padded query rows (AttnArgs::qskip): 64-row tiles wholly at or beyond qskip[b] are not computed, their rows are written as zeros
-    const int qlive = a.qskip ? min(a.qskip[b], a.Lq) : a.Lq;
-    const bool wlive = (qw0 & ~63) < qlive && qw0 < a.Lq;           // wave-uniform
-    bf16_t* out = reinterpret_cast<bf16_t*>(a.out) + ((long)b * a.Lq + qc) * a.ldo + h * DH;
-    if (!wlive && q < a.Lq) {
+    const int qlive = a.qskip ? min(a.qskip[b], Lq) : Lq;
+    const bool wlive = (qw0 & ~63) < qlive && qw0 < Lq;           // wave-uniform
+    bf16_t* out = reinterpret_cast<bf16_t*>(a.out) + ((long)qrow0 + qc) * a.ldo + h * DH;
+    if (!wlive && q < Lq) {
         zero_own<DH>(out, hi);
         if (hi == 0 && a.lse) a.lse[(long)z * a.Lq + q] = 0.f;
     }
     if (qb0 >= qlive) return;                                       // nothing live in this workgroup (uniform)
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (long)qrow0 * a.ldq + h * DH;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (long)krow0 * a.ldk + h * DH;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (long)krow0 * a.ldv + h * DH;
     const bool causal = a.mask_mode & 2;
-    int kend = a.Lk;
+    int kend = Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     int ktiles = (kend + 63) / 64;
     if (causal) {
-        int qlast = min(qb0 + QB - 1, a.Lq - 1);
+        int qlast = min(qb0 + QB - 1, Lq - 1);
         if (a.qskip) qlast = min(qlast, ((qlive + 63) & ~63) - 1);
         ktiles = min(ktiles, qlast / 64 + 1);
     }
-    const int wkt = !wlive ? 0 : (causal ? min(ktiles, min(qw0 + 31, a.Lq - 1) / 64 + 1) : ktiles);   // key tiles this wave computes
+    const int wkt = !wlive ? 0 : (causal ? min(ktiles, min(qw0 + 31, Lq - 1) / 64 + 1) : ktiles);   // key tiles this wave computes
     Dma<DH, NW> dmk, dmv;
-    dmk.init(K, a.ldk, a.Lk, wave, lane); dmv.init(V, a.ldv, a.Lk, wave, lane);
+    dmk.init(K, a.ldk, Lk, wave, lane); dmv.init(V, a.ldv, Lk, wave, lane);
     if (ktiles > 0) { dmk.issue(sK, 0, wave); dmv.issue(sV, 0, wave); }
     if (ktiles > 1) dmk.issue(sK + TILE, 64, wave);
     bf16x8_t qf[NKS];
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_fwd_kernel(AttnArgs a) {
         if (kt + 1 < ktiles) iter(kt + 1, s1, s0);
     }
     l = half_sum(l);
-    if (wlive && q < a.Lq) {
+    if (wlive && q < Lq) {
         const float inv = 1.f / l;
         store_own<DH>(out, o, inv * a.drop.scale, hi);
         if (hi == 0 && a.lse) a.lse[(long)z * a.Lq + q] = (m + __log2f(l)) * A32_LN2;
@@ -344,32 +347,35 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
     a32_block(blk, z);
     blk = gridDim.x - 1 - blk;
     const int b = z / a.H, h = z - b * a.H;
-    const int qb0 = blk * QB, qw0 = qb0 + wave * 32, q = qw0 + l31, qc = min(q, a.Lq - 1);
-    const int qlive = a.qskip ? min(a.qskip[b], a.Lq) : a.Lq;
-    const bool wlive = (qw0 & ~63) < qlive && qw0 < a.Lq;
-    bf16_t* dqo = reinterpret_cast<bf16_t*>(a.dq) + ((long)b * a.Lq + qc) * a.lddq + h * DH;
-    if (!wlive && q < a.Lq) {                                        // padded query rows: d context is zero there, so is dQ
+    // this utterance's rows of the q-side / k-side tensors (AttnArgs::qoff / koff: ragged row offsets; default: the padded [B, L] layout)
+    const int qrow0 = a.qoff ? a.qoff[b] : b * a.Lq, Lq = a.qoff ? a.qoff[b + 1] - qrow0 : a.Lq;
+    const int krow0 = a.koff ? a.koff[b] : b * a.Lk, Lk = a.koff ? a.koff[b + 1] - krow0 : a.Lk;
+    const int qb0 = blk * QB, qw0 = qb0 + wave * 32, q = qw0 + l31, qc = min(q, Lq - 1);
+    const int qlive = a.qskip ? min(a.qskip[b], Lq) : Lq;
+    const bool wlive = (qw0 & ~63) < qlive && qw0 < Lq;
+    bf16_t* dqo = reinterpret_cast<bf16_t*>(a.dq) + ((long)qrow0 + qc) * a.lddq + h * DH;
+    if (!wlive && q < Lq) {                                        // padded query rows: d context is zero there, so is dQ
         zero_own<DH>(dqo, hi);
         if (hi == 0) a.dsum[(long)z * a.Lq + q] = 0.f;
     }
     if (qb0 >= qlive) return;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
-    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
-    const bf16_t* O = reinterpret_cast<const bf16_t*>(a.oref) + (long)b * a.Lq * a.ldo + h * DH;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (long)qrow0 * a.ldq + h * DH;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (long)krow0 * a.ldk + h * DH;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (long)krow0 * a.ldv + h * DH;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + (long)qrow0 * a.ldo + h * DH;
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(a.oref) + (long)qrow0 * a.ldo + h * DH;
     const bool causal = a.mask_mode & 2;
-    int kend = a.Lk;
+    int kend = Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
     int ktiles = (kend + 63) / 64;
     if (causal) {
-        int qlast = min(qb0 + QB - 1, a.Lq - 1);
+        int qlast = min(qb0 + QB - 1, Lq - 1);
         if (a.qskip) qlast = min(qlast, ((qlive + 63) & ~63) - 1);
         ktiles = min(ktiles, qlast / 64 + 1);
     }
-    const int wkt = !wlive ? 0 : (causal ? min(ktiles, min(qw0 + 31, a.Lq - 1) / 64 + 1) : ktiles);
+    const int wkt = !wlive ? 0 : (causal ? min(ktiles, min(qw0 + 31, Lq - 1) / 64 + 1) : ktiles);
     Dma<DH, NW> dmk, dmv;
-    dmk.init(K, a.ldk, a.Lk, wave, lane); dmv.init(V, a.ldv, a.Lk, wave, lane);
+    dmk.init(K, a.ldk, Lk, wave, lane); dmv.init(V, a.ldv, Lk, wave, lane);
     if (ktiles > 0) { dmk.issue(sK, 0, wave); dmv.issue(sV, 0, wave); }
     bf16x8_t qf[NKS], dof[NKS];
     float Dq = 0.f;                                                  // D[q] = sum_d dO[q][d] O[q][d]: this lane holds half of the row's features
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
         Dq += frag_dot(frag_own(O, a.ldo, qc, ks, hi), dof[ks]);
     }
     Dq = half_sum(Dq);
-    if (wlive && hi == 0 && q < a.Lq) a.dsum[(long)z * a.Lq + q] = Dq;   // the dK/dV kernel reads it
+    if (wlive && hi == 0 && q < Lq) a.dsum[(long)z * a.Lq + q] = Dq;   // the dK/dV kernel reads it
     f32x16_t dq[NDT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dq_kernel(AttnArgs a) {
         wait_vm0();
         __syncthreads();
     }
-    if (wlive && q < a.Lq) store_own<DH>(dqo, dq, a.scale, hi);
+    if (wlive && q < Lq) store_own<DH>(dqo, dq, a.scale, hi);
 }
 
 // ================================================================================================ dK, dV
@@ -447,31 +453,34 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
     int blk, z;
     a32_block(blk, z);                                               // rank 0 = the first key block (causal: the most query tiles)
     const int b = z / a.H, h = z - b * a.H;
-    const int kb0 = blk * KB, kw0 = kb0 + wave * 32, key = kw0 + l31, kc = min(key, a.Lk - 1);
-    int kend = a.Lk;
+    // this utterance's rows of the q-side / k-side tensors (AttnArgs::qoff / koff: ragged row offsets; default: the padded [B, L] layout)
+    const int qrow0 = a.qoff ? a.qoff[b] : b * a.Lq, Lq = a.qoff ? a.qoff[b + 1] - qrow0 : a.Lq;
+    const int krow0 = a.koff ? a.koff[b] : b * a.Lk, Lk = a.koff ? a.koff[b + 1] - krow0 : a.Lk;
+    const int kb0 = blk * KB, kw0 = kb0 + wave * 32, key = kw0 + l31, kc = min(key, Lk - 1);
+    int kend = Lk;
     if (a.mask_mode & 1) kend = min(kend, a.klen[b]);
-    bf16_t* dko = reinterpret_cast<bf16_t*>(a.dk) + ((long)b * a.Lk + kc) * a.lddk + h * DH;
-    bf16_t* dvo = reinterpret_cast<bf16_t*>(a.dv) + ((long)b * a.Lk + kc) * a.lddv + h * DH;
+    bf16_t* dko = reinterpret_cast<bf16_t*>(a.dk) + ((long)krow0 + kc) * a.lddk + h * DH;
+    bf16_t* dvo = reinterpret_cast<bf16_t*>(a.dv) + ((long)krow0 + kc) * a.lddv + h * DH;
     const bool wlive = kw0 < kend;                                   // a wave of masked keys: zero gradients
-    if (!wlive && key < a.Lk) { zero_own<DH>(dko, hi); zero_own<DH>(dvo, hi); }
+    if (!wlive && key < Lk) { zero_own<DH>(dko, hi); zero_own<DH>(dvo, hi); }
     if (kb0 >= kend) return;
     const bool causal = a.mask_mode & 2;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (long)b * a.Lq * a.ldq + h * DH;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (long)b * a.Lk * a.ldk + h * DH;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (long)b * a.Lk * a.ldv + h * DH;
-    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + (long)b * a.Lq * a.ldo + h * DH;
-    int qtiles = (a.Lq + 63) / 64;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (long)qrow0 * a.ldq + h * DH;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (long)krow0 * a.ldk + h * DH;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + (long)krow0 * a.ldv + h * DH;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + (long)qrow0 * a.ldo + h * DH;
+    int qtiles = (Lq + 63) / 64;
     if (a.qskip) qtiles = min(qtiles, (a.qskip[b] + 63) / 64);       // tiles of padded query rows contribute nothing (d context = 0)
     const int qt0 = causal ? kb0 / 64 : 0;                           // queries before this key block never see it
     const int wqt0 = !wlive ? qtiles : (causal ? kw0 / 64 : 0);      // first query tile this wave computes
     Dma<DH, NW> dmq, dmo;
-    dmq.init(Q, a.ldq, a.Lq, wave, lane); dmo.init(dO, a.ldo, a.Lq, wave, lane);
+    dmq.init(Q, a.ldq, Lq, wave, lane); dmo.init(dO, a.ldo, Lq, wave, lane);
     float r_l = 0.f, r_d = 0.f;
     uint32_t r_s = 0;
     if (qt0 < qtiles) {
         dmq.issue(sQ + (qt0 & 1) * TILE, qt0 * 64, wave); dmo.issue(sO + (qt0 & 1) * TILE, qt0 * 64, wave);
         if (tid < 64) {
-            const int qq = min(qt0 * 64 + tid, a.Lq - 1);
+            const int qq = min(qt0 * 64 + tid, Lq - 1);
             sL[(qt0 & 1) * 64 + tid] = a.lse[(long)z * a.Lq + qq] * A32_LOG2E; sD[(qt0 & 1) * 64 + tid] = a.dsum[(long)z * a.Lq + qq];
             if (DROP) sS[(qt0 & 1) * 64 + tid] = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qq));
         }
@@ -501,14 +510,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
         if (qt + 1 < qtiles) {
             dmq.issue(sQ + (cur ^ 1) * TILE, q0 + 64, wave); dmo.issue(sO + (cur ^ 1) * TILE, q0 + 64, wave);
             if (tid < 64) {
-                const int qq = min(q0 + 64 + tid, a.Lq - 1);
+                const int qq = min(q0 + 64 + tid, Lq - 1);
                 r_l = a.lse[(long)z * a.Lq + qq] * A32_LOG2E; r_d = a.dsum[(long)z * a.Lq + qq];
                 if (DROP) r_s = b2s_wseed(a.drop, (uint32_t)((long)z * a.Lq + qq));
             }
         }
         if (qt >= wqt0) {
             // all 32 keys of this wave valid and visible to all 64 queries of the tile?  (wave-uniform)
-            const bool interior = kw0 + 32 <= kend && q0 + 64 <= a.Lq && (!causal || kw0 + 31 <= q0);
+            const bool interior = kw0 + 32 <= kend && q0 + 64 <= Lq && (!causal || kw0 + 31 <= q0);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x16_t s, dp;                                      // s[r] = S[q = q0 + 32 t + crow(r, hi)][key = own]
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int qq = q0 + t * 32 + crow(r, hi);
-                        s[r] = (key_ok && qq < a.Lq && (!causal || key <= qq)) ? s[r] : -INFINITY;
+                        s[r] = (key_ok && qq < Lq && (!causal || key <= qq)) ? s[r] : -INFINITY;
                     }
                 }
 #pragma unroll
@@ -559,7 +568,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn32_dkv_kernel(AttnArgs a) {
         wait_vm0();
         __syncthreads();
     }
-    if (wlive && key < a.Lk) { store_own<DH>(dko, dk, a.scale, hi); store_own<DH>(dvo, dv, dscale, hi); }
+    if (wlive && key < Lk) { store_own<DH>(dko, dk, a.scale, hi); store_own<DH>(dvo, dv, dscale, hi); }
 }
 
 template <int DH, bool DROP>

@@ -48,6 +48,7 @@ struct AttnSave {            // one attention sub-layer
     int Lq = 0, Lk = 0, ldp = 0;
     uint32_t op_attn = 0, op_res = 0;
     const int* qskip = nullptr;   // fused path: per-utterance row count beyond which whole query tiles were skipped (attention.h), or null
+    const int *qoff = nullptr, *koff = nullptr;     // ragged rows of the q-side / k-side tensors (attention.h), or null: the padded layout
 };
 struct FfnSave {
     float* x_in = nullptr;
@@ -83,6 +84,12 @@ struct b2s_ctx {
     void* memT = nullptr;
     void *tgtT = nullptr, *a1 = nullptr, *a2 = nullptr;
     void* outT = nullptr;               // imputed decoder output (T)
+    // ragged rows (b2s_decoder_compact_rows): the segment's token-major tensors hold utterance b's frames t < target_lengths[b] at rows
+    // [rowoff[b], rowoff[b + 1]) -- Mr = sum(target_lengths) rows instead of B x T; padded tensors only at the segment's boundaries
+    bool ragged = false;
+    long Mr = 0;                        // rows the row-wise kernels of this segment process (= B T in the padded layout)
+    int* rowoff = nullptr;              // device [B + 1]
+    float *melc = nullptr, *stopc = nullptr;     // ragged mel / stop outputs before they are scattered into the caller's padded tensors
     float* ga_rows = nullptr;           // guided attention: [Ld][B*H][T] rowsum(P W); ga_small: [0] fwd scale, [1] loss, [2] bwd scale
     float* ga_small = nullptr;
     // postnet
@@ -99,6 +106,7 @@ struct b2s_model {
     std::vector<void*> data, grad, shadow;          // per tensor
     std::vector<void*> exp_avg, exp_avg_sq;
     std::vector<void*> conv_wf, conv_wb;            // per postnet layer (T)
+    std::vector<int> ragged_lens;                   // b2s_decoder_compact_rows: host copy of target_lengths for the NEXT decoder forward
     float *pe_enc = nullptr, *pe_dec = nullptr;
     int pe_len = 0;
     bool bound = false;

@@ -433,14 +433,15 @@ AttnArgs flash_args(const void* q, int ldq, const void* k, int ldk, const void* 
 int attn_core_fwd(int dtype, hipStream_t st, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                   void* ctx, int ldc, int B, int H, int Lq, int Lk, int dh, int mask_mode, const int* klen,
                   const float* bias, long bias_sb, long bias_sq, DropCfg drop, float* S, void* P, void* Pd, float* lse = nullptr,
-                  const GuidedArgs* ga = nullptr, const int* qskip = nullptr) {
+                  const GuidedArgs* ga = nullptr, const int* qskip = nullptr, const int* qoff = nullptr, const int* koff = nullptr) {
     if (lse && !bias && use_flash(dh)) {
         AttnArgs a = flash_args(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, mask_mode, klen, drop, lse);
-        a.out = ctx; a.ldo = ldc; a.qskip = qskip;
+        a.out = ctx; a.ldo = ldc; a.qskip = qskip; a.qoff = qoff; a.koff = koff;
         if (ga) { a.ga_rows = ga->rows; a.qlen = ga->qlen; a.ga_inv2s2 = ga->inv2s2; }
         return b2s_flash_fwd(dtype, a, dh, st);
     }
     B2S_CHECK(!ga, "the guided-attention term needs the fused attention kernels (head size 32 / 64 / 96)");
+    B2S_CHECK(!qoff && !koff, "internal: ragged rows need the fused attention kernels");
     const int ldp = rup8(Lk);
     GemmArgs g;
     g.A.p = q; g.A.ld = ldq; g.A.R = Lq; g.A.C = dh; g.A.bs_o = (long)Lq * ldq; g.A.bs_i = dh;
@@ -462,15 +463,16 @@ int attn_core_bwd(int dtype, hipStream_t st, const void* dctx, int ldc, const vo
                   const void* v, int ldv, const void* P, const void* Pd, void* dq, int lddq, void* dk, int lddk,
                   void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, DropCfg drop, float* dP, void* dS,
                   float* lse = nullptr, const void* O = nullptr, int mask_mode = 0, const int* klen = nullptr,
-                  const GuidedArgs* ga = nullptr, const int* qskip = nullptr) {
+                  const GuidedArgs* ga = nullptr, const int* qskip = nullptr, const int* qoff = nullptr, const int* koff = nullptr) {
     if (lse && use_flash(dh)) {
         AttnArgs a = flash_args(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, mask_mode, klen, drop, lse);
-        a.qskip = qskip;
+        a.qskip = qskip; a.qoff = qoff; a.koff = koff;
         a.dout = dctx; a.ldo = ldc; a.dsum = dP; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
         if (ga) { a.ga_rows = ga->rows; a.qlen = ga->qlen; a.ga_scale = ga->scale; a.ga_inv2s2 = ga->inv2s2; }
         return b2s_flash_bwd(dtype, a, dh, O, st);
     }
     B2S_CHECK(!ga, "the guided-attention term needs the fused attention kernels");
+    B2S_CHECK(!qoff && !koff, "internal: ragged rows need the fused attention kernels");
     const int ldp = rup8(Lk);
     const long ps_o = (long)H * Lq * ldp, ps_i = (long)Lq * ldp;
     const void* Pdrop = drop.thresh ? Pd : P;
@@ -641,6 +643,7 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     c.x_final = xs.back();
     c.mean_f = a.f32(M); c.rstd_f = a.f32(M);
     c.outT = a.T(M * D, esz);
+    c.rowoff = (int*)a.f32(B + 2); c.melc = a.f32(M * cf.num_mels); c.stopc = a.f32(M);
     if (cf.guided_attention_weight > 0.f) { c.ga_rows = a.f32((long)cf.n_decoder_layer * B * H * T); c.ga_small = a.f32(4); }
     const long pn = (long)B * H * T * rup8(std::max(T, S));
     sc.S = a.f32(pn); sc.dP = a.f32(pn); sc.dS = a.T(pn, esz);
@@ -1346,7 +1349,7 @@ int self_attn_bwd(b2s_model* m, hipStream_t st, const AttnSave& s, Scratch& sc, 
     const char* q = (const char*)s.qkv; char* dq = (char*)sc.dqkv;
     B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, q, 3 * D, q + (size_t)D * esz, 3 * D, q + (size_t)2 * D * esz, 3 * D, s.P, s.Pd,
                           dq, 3 * D, dq + (size_t)D * esz, 3 * D, dq + (size_t)2 * D * esz, 3 * D, B, H, L, L, dh, datt, sc.dP, sc.dS,
-                          s.lse, s.ctx, s.mask_mode, klen, nullptr, s.qskip));
+                          s.lse, s.ctx, s.mask_mode, klen, nullptr, s.qskip, s.qoff, s.koff));
     B2S_TRY(linear_dw(m, st, sc.dqkv, 3 * D, s.h, D, (int)M, 3 * D, D, m->G(wq)));
     B2S_TRY(linear_dx(m, st, sc.dqkv, 3 * D, m->W(wq), (int)M, D, 3 * D, sc.dh, 0, D, GemmEpilogue()));
     return ln_bwd_exit(m, st, sc, sc.dh, 0, D, s.x_in, lnp, s.mean, s.rstd, 1, M, D, nullptr, 1, next);
@@ -1497,6 +1500,12 @@ extern "C" int b2s_encoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mem
 }
 
 // ================================================================================================ decoder
+extern "C" int b2s_decoder_compact_rows(b2s_model* m, const int32_t* target_lengths_host, int B) {
+    B2S_CHECK(m && (B == 0 || target_lengths_host) && B >= 0, "bad argument");
+    m->ragged_lens.assign(target_lengths_host, target_lengths_host + B);
+    return 0;
+}
+
 extern "C" size_t b2s_decoder_ws_bytes(const b2s_model* m, int B, int S, int T) {
     if (!m || B <= 0 || S <= 0 || T <= 0) return 0;
     b2s_ctx c; c.B = B; c.S = S; c.T = T; c.train = 1;
@@ -1531,6 +1540,23 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
     const long M = (long)B * T, Mk = (long)B * S;
     const float pt = train ? cf.transformer_dropout_rate : 0.f, pd = train ? cf.decoder_dropout_rate : 0.f;
     const std::string p = "decoder.decoder.";
+    // ragged rows (b2s_decoder_compact_rows handed over the host copy of target_lengths; only for callers that declared padded rows unobserved)
+    std::vector<int> hoff;
+    {
+        std::vector<int> lens;
+        lens.swap(m->ragged_lens);                        // consumed by this call, whatever happens below
+        if (padded_unobserved && (int)lens.size() == B && B <= 64 && use_flash(dh)) {
+            hoff.assign(1, 0);
+            for (int b = 0; b < B; ++b) {
+                if (lens[b] < 1 || lens[b] > T) { delete c; return b2s_fail(__FILE__, __LINE__, "b2s_decoder_compact_rows: target length %d of utterance %d outside [1, %d]", lens[b], b, T); }
+                hoff.push_back(hoff.back() + lens[b]);
+            }
+        }
+    }
+    c->ragged = !hoff.empty();
+    c->Mr = c->ragged ? (long)hoff.back() : M;
+    const long Mr = c->Mr;                                  // rows of every row-wise launch below
+    const int* roff = c->ragged ? c->rowoff : nullptr;
     auto run = [&]() -> int {
         bool have_memory = false;
         auto need_memory = [&]() -> int {          // first use of the encoder output: cast + the memory K/V projection of every layer
@@ -1544,15 +1570,18 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
             return 0;
         };
         if (!memory_ready) B2S_TRY(need_memory());          // (single-stream callers keep the round-2 order)
-        B2S_TRY(ro_cast(dt, targets, c->tgtT, M * NM, st));
+        if (c->ragged) {
+            B2S_TRY(ro_set_rowoff(hoff.data(), B + 1, c->rowoff, st));
+            B2S_TRY(ro_rows_gather(dt, targets, c->tgtT, roff, B, T, NM, st));
+        } else B2S_TRY(ro_cast(dt, targets, c->tgtT, M * NM, st));
         // prenet (tacotron.py:55-65)
         GemmEpilogue e0; e0.bias = m->P("decoder.prenet.dense0.bias"); e0.relu = 1; e0.drop = make_drop(pd, seed, drop_op(DS_DEC_PRENET0, 0));
-        B2S_TRY(linear(m, st, c->tgtT, NM, m->W("decoder.prenet.dense0.weight"), (int)M, HP, NM, c->a1, 0, HP, e0));
+        B2S_TRY(linear(m, st, c->tgtT, NM, m->W("decoder.prenet.dense0.weight"), (int)Mr, HP, NM, c->a1, 0, HP, e0));
         GemmEpilogue e1; e1.bias = m->P("decoder.prenet.dense1.bias"); e1.relu = 1; e1.drop = make_drop(pd, seed, drop_op(DS_DEC_PRENET1, 0));
-        B2S_TRY(linear(m, st, c->a1, HP, m->W("decoder.prenet.dense1.weight"), (int)M, HP, HP, c->a2, 0, HP, e1));
-        B2S_TRY(linear(m, st, c->a2, HP, m->W("decoder.prenet.dense_final.weight"), (int)M, D, HP, sc.a3, 1, D, GemmEpilogue()));
+        B2S_TRY(linear(m, st, c->a1, HP, m->W("decoder.prenet.dense1.weight"), (int)Mr, HP, HP, c->a2, 0, HP, e1));
+        B2S_TRY(linear(m, st, c->a2, HP, m->W("decoder.prenet.dense_final.weight"), (int)Mr, D, HP, sc.a3, 1, D, GemmEpilogue()));
         B2S_TRY(ro_shift_pe_fwd(sc.a3, target_lengths, m->pe_dec, m->P(p + "pe_scale"), xs[0], B, T, D,
-                                make_drop(pt, seed, drop_op(DS_DEC_EMBED, 0)), st));
+                                make_drop(pt, seed, drop_op(DS_DEC_EMBED, 0)), st, roff, (int)Mr));
         const bool guided = cf.guided_attention_weight > 0.f;
         // rows >= target_lengths[b] are padding: the heads mask them (row_len below) and the backward zeroes their gradient, and causal /
         // per-row sub-layers never let a valid row read them -- the attention kernels skip whole 64-row tiles of them (attention.h: qskip)
@@ -1568,22 +1597,22 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
             float* x0 = xs[3 * l]; float* x1 = xs[3 * l + 1]; float* x2 = xs[3 * l + 2]; float* x3 = xs[3 * l + 3];
             // causal self-attention
             const std::string lna = p + "attn_layer_norms." + std::to_string(l);
-            B2S_TRY(ro_layernorm_fwd(dt, x0, m->P(lna + ".weight"), m->P(lna + ".bias"), s.h, D, nullptr, 0, s.mean, s.rstd, (int)M, D,
+            B2S_TRY(ro_layernorm_fwd(dt, x0, m->P(lna + ".weight"), m->P(lna + ".bias"), s.h, D, nullptr, 0, s.mean, s.rstd, (int)Mr, D,
                                      1e-6f, nullptr, 1, st));
-            B2S_TRY(linear(m, st, s.h, D, m->W(nm(p, "self_attentions", l, "qkv_transform.weight")), (int)M, 3 * D, D, s.qkv, 0, 3 * D,
+            B2S_TRY(linear(m, st, s.h, D, m->W(nm(p, "self_attentions", l, "qkv_transform.weight")), (int)Mr, 3 * D, D, s.qkv, 0, 3 * D,
                            GemmEpilogue()));
             s.op_attn = drop_op(DS_DEC_SELF_ATTN, l); s.op_res = drop_op(DS_DEC_SELF_RES, l);
             const char* q = (const char*)s.qkv;
             B2S_TRY(attn_core_fwd(dt, st, q, 3 * D, q + (size_t)D * esz, 3 * D, q + (size_t)2 * D * esz, 3 * D, s.ctx, D, B, H, T, T, dh,
-                                  2, nullptr, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd, s.lse, nullptr, qskip));
-            s.mask_mode = 2; s.qskip = qskip;
+                                  2, nullptr, nullptr, 0, 0, make_drop(pt, seed, s.op_attn), sc.S, s.P, s.Pd, s.lse, nullptr, qskip, roff, roff));
+            s.mask_mode = 2; s.qskip = qskip; s.qoff = s.koff = roff;
             GemmEpilogue ea; ea.drop = make_drop(pt, seed, s.op_res); ea.residual = x0; ea.ldr = D;
-            B2S_TRY(linear(m, st, s.ctx, D, m->W(nm(p, "self_attentions", l, "output_transform.weight")), (int)M, D, D, x1, 1, D, ea));
+            B2S_TRY(linear(m, st, s.ctx, D, m->W(nm(p, "self_attentions", l, "output_transform.weight")), (int)Mr, D, D, x1, 1, D, ea));
             // encoder-decoder attention
             const std::string lnx = p + "encdec_layer_norms." + std::to_string(l);
-            B2S_TRY(ro_layernorm_fwd(dt, x1, m->P(lnx + ".weight"), m->P(lnx + ".bias"), x.h, D, nullptr, 0, x.mean, x.rstd, (int)M, D,
+            B2S_TRY(ro_layernorm_fwd(dt, x1, m->P(lnx + ".weight"), m->P(lnx + ".bias"), x.h, D, nullptr, 0, x.mean, x.rstd, (int)Mr, D,
                                      1e-6f, nullptr, 1, st));
-            B2S_TRY(linear(m, st, x.h, D, m->W(nm(p, "encdec_attentions", l, "q_transform.weight")), (int)M, D, D, x.qkv, 0, D, GemmEpilogue()));
+            B2S_TRY(linear(m, st, x.h, D, m->W(nm(p, "encdec_attentions", l, "q_transform.weight")), (int)Mr, D, D, x.qkv, 0, D, GemmEpilogue()));
             B2S_TRY(need_memory());
             if (!c->kvcat)
                 B2S_TRY(linear(m, st, c->memT, D, m->W(nm(p, "encdec_attentions", l, "kv_transform.weight")), (int)Mk, 2 * D, D, x.kv, 0, 2 * D,
@@ -1596,27 +1625,32 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
                 ga.inv2s2 = 1.f / (2.f * cf.guided_attention_sigma * cf.guided_attention_sigma);
             }
             B2S_TRY(attn_core_fwd(dt, st, x.qkv, D, kv, x.ldkv, kv + (size_t)D * esz, x.ldkv, x.ctx, D, B, H, T, S, dh, 1, input_lengths,
-                                  nullptr, 0, 0, make_drop(pt, seed, x.op_attn), sc.S, x.P, x.Pd, x.lse, guided ? &ga : nullptr, qskip));
-            x.mask_mode = 1; x.qskip = qskip;
+                                  nullptr, 0, 0, make_drop(pt, seed, x.op_attn), sc.S, x.P, x.Pd, x.lse, guided ? &ga : nullptr, qskip, roff, nullptr));
+            x.mask_mode = 1; x.qskip = qskip; x.qoff = roff;
             GemmEpilogue ex; ex.drop = make_drop(pt, seed, x.op_res); ex.residual = x1; ex.ldr = D;
-            B2S_TRY(linear(m, st, x.ctx, D, m->W(nm(p, "encdec_attentions", l, "output_transform.weight")), (int)M, D, D, x2, 1, D, ex));
+            B2S_TRY(linear(m, st, x.ctx, D, m->W(nm(p, "encdec_attentions", l, "output_transform.weight")), (int)Mr, D, D, x2, 1, D, ex));
             // FFN
             const std::string lnf = p + "ffn_layer_norms." + std::to_string(l);
-            B2S_TRY(ro_layernorm_fwd(dt, x2, m->P(lnf + ".weight"), m->P(lnf + ".bias"), f.h, D, nullptr, 0, f.mean, f.rstd, (int)M, D,
+            B2S_TRY(ro_layernorm_fwd(dt, x2, m->P(lnf + ".weight"), m->P(lnf + ".bias"), f.h, D, nullptr, 0, f.mean, f.rstd, (int)Mr, D,
                                      1e-6f, nullptr, 1, st));
             f.op_hid = drop_op(DS_DEC_FFN_HID, l); f.op_res = drop_op(DS_DEC_FFN_RES, l);
             GemmEpilogue f1; f1.relu = 1; f1.drop = make_drop(pt, seed, f.op_hid);
-            B2S_TRY(linear(m, st, f.h, D, m->W(nm(p, "ffn_layers", l, "input_layer.weight")), (int)M, 4 * D, D, f.f, 0, 4 * D, f1));
+            B2S_TRY(linear(m, st, f.h, D, m->W(nm(p, "ffn_layers", l, "input_layer.weight")), (int)Mr, 4 * D, D, f.f, 0, 4 * D, f1));
             GemmEpilogue f2; f2.drop = make_drop(pt, seed, f.op_res); f2.residual = x2; f2.ldr = D;
-            B2S_TRY(linear(m, st, f.f, 4 * D, m->W(nm(p, "ffn_layers", l, "output_layer.weight")), (int)M, D, 4 * D, x3, 1, D, f2));
+            B2S_TRY(linear(m, st, f.f, 4 * D, m->W(nm(p, "ffn_layers", l, "output_layer.weight")), (int)Mr, D, 4 * D, x3, 1, D, f2));
         }
         B2S_TRY(need_memory());                             // (a model without decoder layers still has to order itself behind the event)
         B2S_TRY(ro_layernorm_fwd(dt, c->x_final, m->P(p + "output_layer_norm.weight"), m->P(p + "output_layer_norm.bias"), c->outT, D,
-                                 nullptr, 0, c->mean_f, c->rstd_f, (int)M, D, 1e-6f, target_lengths, T, st));
-        GemmEpilogue em; em.row_len = target_lengths; em.rows_per_batch = T;
-        B2S_TRY(linear(m, st, c->outT, D, m->W("decoder.mel_net.weight"), (int)M, NM, D, mels_out, 1, NM, em));
-        B2S_TRY(ro_rowdot_fwd(dt, c->outT, D, m->P("decoder.stop_net.weight"), m->P("decoder.stop_net.bias"), stop_out, (int)M, D,
-                              target_lengths, T, st));
+                                 nullptr, 0, c->mean_f, c->rstd_f, (int)Mr, D, 1e-6f, c->ragged ? nullptr : target_lengths, T, st));
+        GemmEpilogue em;
+        if (!c->ragged) { em.row_len = target_lengths; em.rows_per_batch = T; }
+        B2S_TRY(linear(m, st, c->outT, D, m->W("decoder.mel_net.weight"), (int)Mr, NM, D, c->ragged ? c->melc : mels_out, 1, NM, em));
+        B2S_TRY(ro_rowdot_fwd(dt, c->outT, D, m->P("decoder.stop_net.weight"), m->P("decoder.stop_net.bias"), c->ragged ? c->stopc : stop_out, (int)Mr, D,
+                              c->ragged ? nullptr : target_lengths, T, st));
+        if (c->ragged) {                                     // the caller's tensors stay padded [B, T, *], zeros beyond target_lengths (tacotron.py:112-115 impute)
+            B2S_TRY(ro_rows_scatter(c->melc, mels_out, roff, B, T, NM, st));
+            B2S_TRY(ro_rows_scatter(c->stopc, stop_out, roff, B, T, 1, st));
+        }
         if (guided) hipLaunchKernelGGL(k_ga_reduce, dim3(1), dim3(1024), 0, st, c->ga_rows, (long)cf.n_decoder_layer * B * H * T, c->ga_small);
         B2S_LAUNCH_CHECK();
         return 0;
@@ -1654,7 +1688,9 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
     hipStream_t st = S_(stream);
     const int B = c->B, S = c->S, T = c->T, D = cf.decoder_hidden, H = cf.n_attention_head, dh = D / H, dt = m->dtype, esz = m->esz;
     const int NM = cf.num_mels, HP = cf.prenet_hidden;
-    const long M = (long)B * T, Mk = (long)B * S;
+    const long Mp = (long)B * T, Mk = (long)B * S;
+    const long M = c->ragged ? c->Mr : Mp;                  // rows of every row-wise launch below (ragged rows: sum(target_lengths))
+    const int* roff = c->ragged ? c->rowoff : nullptr;
     const float pt = c->train ? cf.transformer_dropout_rate : 0.f, pd = c->train ? cf.decoder_dropout_rate : 0.f;
     Arena a; a.base = c->ws; a.cap = c->ws_bytes;
     b2s_ctx tmp; tmp.B = B; tmp.S = S; tmp.T = T; tmp.train = c->train;
@@ -1664,18 +1700,21 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
     const bool guided = c->ga_small != nullptr && d_guided != nullptr;
     if (guided) hipLaunchKernelGGL(k_ga_bscale, dim3(1), dim3(1), 0, st, c->ga_small, d_guided);
     // heads (tacotron.py:112-115)
-    B2S_TRY(ro_cast(dt, d_mels, sc.dmelT, M * NM, st));
+    if (c->ragged) B2S_TRY(ro_rows_gather(dt, d_mels, sc.dmelT, roff, B, T, NM, st));
+    else B2S_TRY(ro_cast(dt, d_mels, sc.dmelT, M * NM, st));
     B2S_TRY(linear_dw(m, st, sc.dmelT, NM, c->outT, D, (int)M, NM, D, m->G("decoder.mel_net.weight")));
-    GemmEpilogue eo; eo.row_len = c->tgt_len; eo.rows_per_batch = T;
+    GemmEpilogue eo;
+    if (!c->ragged) { eo.row_len = c->tgt_len; eo.rows_per_batch = T; }
     B2S_TRY(linear_dx(m, st, sc.dmelT, NM, m->W("decoder.mel_net.weight"), (int)M, D, NM, sc.doutT, 0, D, eo));
     if (d_stop) {
-        hipLaunchKernelGGL(k_rowmask_copy, dim3(cdiv(M, 256)), dim3(256), 0, st, d_stop, sc.dstop_m, c->tgt_len, T, M);
+        if (c->ragged) B2S_TRY(ro_rows_gather(0, d_stop, sc.dstop_m, roff, B, T, 1, st));
+        else hipLaunchKernelGGL(k_rowmask_copy, dim3(cdiv(M, 256)), dim3(256), 0, st, d_stop, sc.dstop_m, c->tgt_len, T, M);
         B2S_TRY(grad_colsum(m, st, dt, c->outT, 0, D, sc.dstop_m, m->G("decoder.stop_net.weight"), 1, (int)M, D));
         B2S_TRY(grad_colsum(m, st, 0, sc.dstop_m, 1, 1, nullptr, m->G("decoder.stop_net.bias"), 1, (int)M, 1));
     }
     DropCfg nd;
     if (cf.n_decoder_layer > 0) nd = make_drop(pt, c->seed, c->ffn[cf.n_decoder_layer - 1].op_res);
-    B2S_TRY(ln_bwd_exit(m, st, sc, sc.doutT, 0, D, c->x_final, p + "output_layer_norm", c->mean_f, c->rstd_f, 0, M, D, c->tgt_len, T,
+    B2S_TRY(ln_bwd_exit(m, st, sc, sc.doutT, 0, D, c->x_final, p + "output_layer_norm", c->mean_f, c->rstd_f, 0, M, D, c->ragged ? nullptr : c->tgt_len, T,
                         cf.n_decoder_layer > 0 ? &nd : nullptr));
     B2S_TRY(end_stage(m, st, 1, false));
     // tail policy (engine.h: dw_hold_from): B2S_DW_TAIL_LAYERS decoder layers' (and the prenet's) weight-gradient groups wait for the end
@@ -1747,7 +1786,7 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
             }
             B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, x.qkv, D, kv, x.ldkv, kv + (size_t)D * esz, x.ldkv, x.P, x.Pd, sc.dqkv, D, dkv, lddkv,
                                   dkv + (size_t)D * esz, lddkv, B, H, T, S, dh, datt, sc.dP, sc.dS, x.lse, x.ctx, x.mask_mode, c->in_len,
-                                  guided ? &ga : nullptr, x.qskip));
+                                  guided ? &ga : nullptr, x.qskip, x.qoff, x.koff));
             B2S_TRY(linear_dw(m, st, sc.dqkv, D, x.h, D, (int)M, D, D, m->G(wq)));
             B2S_TRY(linear_dx(m, st, sc.dqkv, D, m->W(wq), (int)M, D, D, sc.dh, 0, D, GemmEpilogue()));
             B2S_TRY(linear_dw(m, st, sc.dkv, lddkv, c->memT, D, (int)Mk, 2 * D, D, m->G(wkv)));
@@ -1766,7 +1805,8 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
         B2S_TRY(end_stage(m, st, 2 + (cf.n_decoder_layer - 1 - l), false));
     }
     B2S_TRY(finish_dmem());                                  // (no decoder layers)
-    B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, drop_op(DS_DEC_EMBED, 0)), st, m->dx_bf16));
+    B2S_TRY(ro_shift_pe_bwd(dt, sc.dx, c->tgt_len, m->pe_dec, sc.da3, m->G(p + "pe_scale"), B, T, D, make_drop(pt, c->seed, drop_op(DS_DEC_EMBED, 0)), st, m->dx_bf16,
+                            roff, (int)M));
     // prenet backward
     DropCfg d1 = make_drop(pd, c->seed, drop_op(DS_DEC_PRENET0, 0)), d2 = make_drop(pd, c->seed, drop_op(DS_DEC_PRENET1, 0));
     B2S_TRY(linear_dw(m, st, sc.da3, D, c->a2, HP, (int)M, D, HP, m->G("decoder.prenet.dense_final.weight")));
@@ -1804,7 +1844,7 @@ extern "C" int b2s_decoder_alignment(b2s_model* m, b2s_ctx* c, int which, int la
         AttnArgs a;
         if (which) a = flash_args(s.qkv, D, s.kv, s.ldkv, nullptr, 0, c->B, H, s.Lq, s.Lk, dh, 1, c->in_len, DropCfg{0, 0, 1.f}, s.lse);
         else a = flash_args(s.qkv, 3 * D, (const char*)s.qkv + (size_t)D * esz, 3 * D, nullptr, 0, c->B, H, s.Lq, s.Lk, dh, 2, nullptr, DropCfg{0, 0, 1.f}, s.lse);
-        a.qskip = s.qskip;
+        a.qskip = s.qskip; a.qoff = s.qoff; a.koff = s.koff;
         return b2s_flash_align(m->dtype, a, dh, out, S_(stream));
     }
     return ro_align_transpose(m->dtype, s.P, out, c->B * m->cfg.n_attention_head, s.Lq, s.Lk, s.ldp, S_(stream));

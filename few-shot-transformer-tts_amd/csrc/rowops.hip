@@ -468,10 +468,30 @@ __global__ __launch_bounds__(256) void k_cast_back_bf16_v(const bf16_t* __restri
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) out[(n8 << 3) + threadIdx.x] = TT<bf16_t>::ld(in + (n8 << 3) + threadIdx.x);
 }
 
+// ---------------------------------------------------------------------------------- ragged (compact) decoder rows
+// The decoder segment of a training step may keep its token rows RAGGED: utterance b owns rows [off[b], off[b + 1]) = frames t < target_lengths[b]
+// (engine.hip: b2s_decoder_compact_rows), so that every row-wise kernel of the segment runs over sum(target_lengths) rows instead of B x T.
+// These kernels sit at the segment's boundaries: padded [B, T, C] fp32 tensors in, padded out (zeros on padded rows).
+__device__ inline int ragged_batch(const int* __restrict__ off, int B, int row) { int b = 0; while (b + 1 < B && off[b + 1] <= row) ++b; return b; }
+struct RowOff64 { int off[65]; };
+__global__ void k_set_rowoff(RowOff64 h, int* dst, int n) { if ((int)threadIdx.x < n) dst[threadIdx.x] = h.off[threadIdx.x]; }
+template <typename TO>
+__global__ void k_rows_gather(const float* __restrict__ in, TO* __restrict__ out, const int* __restrict__ off, int T, int C) {
+    const int b = blockIdx.y, t = blockIdx.x, r0 = off[b];
+    if (t >= off[b + 1] - r0) return;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) TT<TO>::st(out + (long)(r0 + t) * C + c, in[((long)b * T + t) * C + c]);
+}
+__global__ void k_rows_scatter(const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ off, int T, int C) {
+    const int b = blockIdx.y, t = blockIdx.x, r0 = off[b];
+    const bool live = t < off[b + 1] - r0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[((long)b * T + t) * C + c] = live ? in[(long)(r0 + t) * C + c] : 0.f;
+}
+
 // ---------------------------------------------------------------------------------- decoder input prep
+// (off != nullptr: ragged rows -- `row` is the ragged row index, also the row of the dropout index)
 __global__ void k_shift_pe_fwd(const float* a, const int* lens, const float* pe, const float* pe_scale, float* x,
-                               int T, int D, DropCfg drop) {
-    const int row = blockIdx.x, b = row / T, t = row - b * T;
+                               int T, int D, DropCfg drop, const int* off, int B) {
+    const int row = blockIdx.x, b = off ? ragged_batch(off, B, row) : row / T, t = off ? row - off[b] : row - b * T;
     const bool have = t > 0 && (t - 1) < lens[b];
     const float sc = *pe_scale;
     for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
@@ -483,7 +503,7 @@ __global__ void k_shift_pe_fwd(const float* a, const int* lens, const float* pe,
 }
 template <typename T_, typename TX>
 __global__ __launch_bounds__(512) void k_shift_pe_bwd(const TX* dx, const int* lens, const float* pe, T_* da, float* d_pe_scale, int T,
-                                                      int D, DropCfg drop, int rows) {
+                                                      int D, DropCfg drop, int rows, const int* off, int B) {
     // A wave takes two rows per pass (every load of both issued before the first is used).  At most 256 workgroups: the kernel ends
     // with one float atomic per workgroup on d_pe_scale, and same-address atomics retire at ~7 ns each (2048 workgroups: 35 us of
     // which 15 were the atomics).
@@ -496,9 +516,10 @@ __global__ __launch_bounds__(512) void k_shift_pe_bwd(const TX* dx, const int* l
         for (int q = 0; q < 2; ++q) {
             live[q] = r0 + q * stride < rows;
             row[q] = live[q] ? r0 + q * stride : r0;
-            const int b = row[q] / T;
-            tt[q] = row[q] - b * T;
-            have[q] = (tt[q] + 1) < T && tt[q] < lens[b];            // da[b,t] = g[b,t+1] if t+1 < T and t < len[b]
+            const int b = off ? ragged_batch(off, B, row[q]) : row[q] / T;
+            tt[q] = off ? row[q] - off[b] : row[q] - b * T;
+            // da[b,t] = g[b,t+1] if t+1 < T and t < len[b]  (ragged rows: row t + 1 = len[b] does not exist -- its gradient is zero in the padded layout)
+            have[q] = (tt[q] + 1) < (off ? lens[b] : T) && tt[q] < lens[b];
             nxt[q] = have[q] ? row[q] + 1 : row[q];                   // (the clamped row is loaded and discarded)
         }
 #pragma unroll 3
@@ -1307,17 +1328,34 @@ int ro_cast_back(int dtype, const void* in, float* out, long n, hipStream_t st) 
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_shift_pe_fwd(const float* a, const int* lens, const float* pe, const float* pe_scale, float* x, int B, int T,
-                    int D, DropCfg drop, hipStream_t st) {
+                    int D, DropCfg drop, hipStream_t st, const int* off, int rows) {
     B2S_CHECK(D % 4 == 0, "shift_pe: D=%d must be a multiple of 4", D);
-    hipLaunchKernelGGL(k_shift_pe_fwd, dim3(B * T), dim3(128), 0, st, a, lens, pe, pe_scale, x, T, D, drop);
+    hipLaunchKernelGGL(k_shift_pe_fwd, dim3(off ? rows : B * T), dim3(128), 0, st, a, lens, pe, pe_scale, x, T, D, drop, off, B);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_shift_pe_bwd(int dtype, const float* dx, const int* lens, const float* pe, void* da, float* d_pe_scale, int B,
-                    int T, int D, DropCfg drop, hipStream_t st, int dx_bf16) {
-    if (dx_bf16) RO_DISPATCH(dtype, hipLaunchKernelGGL((k_shift_pe_bwd<TY, bf16_t>), dim3(std::min(cdiv(B * T, 8), 256)), dim3(512), 0, st, (const bf16_t*)dx, lens,
-                                                       pe, (TY*)da, d_pe_scale, T, D, drop, B * T));
-    else RO_DISPATCH(dtype, hipLaunchKernelGGL((k_shift_pe_bwd<TY, float>), dim3(std::min(cdiv(B * T, 8), 256)), dim3(512), 0, st, dx, lens, pe, (TY*)da,
-                                          d_pe_scale, T, D, drop, B * T));
+                    int T, int D, DropCfg drop, hipStream_t st, int dx_bf16, const int* off, int rows) {
+    const int n = off ? rows : B * T;
+    if (dx_bf16) RO_DISPATCH(dtype, hipLaunchKernelGGL((k_shift_pe_bwd<TY, bf16_t>), dim3(std::min(cdiv(n, 8), 256)), dim3(512), 0, st, (const bf16_t*)dx, lens,
+                                                       pe, (TY*)da, d_pe_scale, T, D, drop, n, off, B));
+    else RO_DISPATCH(dtype, hipLaunchKernelGGL((k_shift_pe_bwd<TY, float>), dim3(std::min(cdiv(n, 8), 256)), dim3(512), 0, st, dx, lens, pe, (TY*)da,
+                                          d_pe_scale, T, D, drop, n, off, B));
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_set_rowoff(const int* off_host, int n, int* dst, hipStream_t st) {
+    B2S_CHECK(n >= 2 && n <= 65, "ragged rows: 1 .. 64 utterances (got %d)", n - 1);
+    RowOff64 h;
+    for (int i = 0; i < 65; ++i) h.off[i] = i < n ? off_host[i] : 0;
+    hipLaunchKernelGGL(k_set_rowoff, dim3(1), dim3(128), 0, st, h, dst, n);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_rows_gather(int out_dtype, const float* in, void* out, const int* off, int B, int T, int C, hipStream_t st) {
+    if (out_dtype == 1) hipLaunchKernelGGL((k_rows_gather<bf16_t>), dim3(T, B), dim3(C >= 128 ? 128 : 64), 0, st, in, (bf16_t*)out, off, T, C);
+    else hipLaunchKernelGGL((k_rows_gather<float>), dim3(T, B), dim3(C >= 128 ? 128 : 64), 0, st, in, (float*)out, off, T, C);
+    B2S_LAUNCH_CHECK(); return 0;
+}
+int ro_rows_scatter(const float* in, float* out, const int* off, int B, int T, int C, hipStream_t st) {
+    hipLaunchKernelGGL(k_rows_scatter, dim3(T, B), dim3(C >= 128 ? 128 : 64), 0, st, in, out, off, T, C);
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_spk_embed_fwd(const long* spk_ids, const float* table, const float* W, const float* b, float* e_raw,

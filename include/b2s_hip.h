@@ -74,6 +74,16 @@ int b2s_encoder_forward(b2s_model* m, const int64_t* inputs, const int32_t* inpu
                         float* memory_out, void* stream, b2s_ctx** ctx_out);
 int b2s_encoder_backward(b2s_model* m, b2s_ctx* ctx, const float* d_memory, void* stream);
 
+/* Ragged decoder rows.  HOST copy of target_lengths ([B] int32, 1 <= length <= T, B <= 64) for the NEXT b2s_decoder_forward on this model that is
+ * called with B2S_DEC_PADDED_UNOBSERVED: that segment (forward and its backward) then keeps its token rows ragged -- utterance b owns
+ * sum_{b' < b} length[b'] .. + length[b] of the segment's internal [rows, C] tensors -- so every row-wise kernel (GEMMs, LayerNorms, the weight-gradient
+ * K walks) runs over sum(target_lengths) rows instead of B x T (the reference masks those rows out: transformer/common.py:51-70, modules.py:142-144).
+ * Inputs, outputs and gradients at the boundary stay padded [B, T, *] tensors with zeros on padded rows; results on valid rows are those of the padded
+ * layout (forward outputs and activation gradients bit for bit at dropout 0; weight gradients up to the fp32 summation order of their K walk).
+ * Dropout: the element index of the decoder's row sites (b2s_dropout_site kind 0) counts RAGGED rows, row = offset[b] + t, in such a segment.
+ * The hand-over is consumed by that one forward call (also when it fails or does not qualify); without it the padded layout is used. */
+int b2s_decoder_compact_rows(b2s_model* m, const int32_t* target_lengths_host, int B);
+
 /* ---- Decoder.forward (tacotron.py:107-116; modules.py:108-145) -----------------------------------
  * memory [B,S,Dm], targets [B,T,num_mels] -> mels [B,T,num_mels], stop_logits [B,T]. */
 size_t b2s_decoder_ws_bytes(const b2s_model* m, int B, int S, int T);

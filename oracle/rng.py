@@ -89,8 +89,12 @@ class DeviceMasks:
     attention weights) was drawn in frame r + frame_offset with a frame-salted key and the per-frame index rules.
     overrides: {(site, layer): op_id} -- deliberately wrong ids, for the test that shows the comparison notices."""
 
-    def __init__(self, seeds, site_info, decode=False, overrides=None):
+    def __init__(self, seeds, site_info, decode=False, overrides=None, ragged_lengths=None):
+        """ragged_lengths: {"decoder": target_lengths} when the engine ran that segment on ragged rows (include/b2s_hip.h: b2s_decoder_compact_rows):
+        the element index of its row sites then counts ragged rows -- frame t of utterance b is row sum(lengths[:b]) + t; padded frames
+        (t >= length) do not exist there and keep everything (nothing downstream of the masked heads reads them)."""
         self.seeds, self.site_info, self.decode, self.overrides = seeds, site_info, decode, overrides or {}
+        self.ragged = {k: [int(x) for x in v] for k, v in (ragged_lengths or {}).items()}
         self.calls = []
 
     def keep(self, site, layer, shape, p, frame_offset=0):
@@ -106,6 +110,17 @@ class DeviceMasks:
             assert n < 2 ** 32, "element index would wrap"
             if kind == 1:                           # weights [B, H, Lq, Lk] of the training kernels: row seeds + key quads
                 return keep_mask_attn(p, seed, op, int(np.prod(shape[:-1])), shape[-1]).reshape(shape)
+            lens = self.ragged.get(site.split(".")[0])
+            if lens is not None and len(shape) == 3:            # rows [B, T, C] of a ragged segment: idx = (offset[b] + t) * C + c for t < length[b]
+                B, T, Cc = shape
+                assert len(lens) == B
+                out = np.ones(shape, dtype=bool)
+                off = 0
+                for b, n_b in enumerate(lens):
+                    idx = (np.arange(off, off + n_b, dtype=np.uint64)[:, None] * np.uint64(Cc) + np.arange(Cc, dtype=np.uint64)[None, :])
+                    out[b, :n_b, :] = rand32(idx, key) >= th
+                    off += n_b
+                return out
             return (rand32(np.arange(n, dtype=np.uint64), key) >= th).reshape(shape)
         out = np.empty(shape, dtype=bool)
         if kind == 0:                               # rows [B, R, C]: frame r + offset, idx = b * C + c

@@ -31,7 +31,9 @@ def make_batches(cfg, device, n=8, B=14, S=114, T=582):
     out = []
     for seed in range(n):
         nb = synthetic_batch(cfg, B, S, T, seed=seed, n_spk=1, n_lang=1)
-        out.append({k: (torch.from_numpy(np.asarray(v)).to(device) if not isinstance(v, list) else v) for k, v in nb.items()})
+        d = {k: (torch.from_numpy(np.asarray(v)).to(device) if not isinstance(v, list) else v) for k, v in nb.items()}
+        d["target_lengths_host"] = [int(x) for x in np.asarray(nb["target_lengths"])]        # (ragged decoder rows, as bench.py)
+        out.append(d)
     return out
 
 
