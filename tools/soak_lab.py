@@ -18,6 +18,7 @@ bs = []
 for i, (B, S, T) in enumerate(((14, 114, 582), (9, 158, 808), (32, 50, 250), (14, 114, 582))):
     nb = synthetic_batch(hp, B, S, T, seed=i, n_spk=1, n_lang=1)
     bs.append({k: (torch.from_numpy(np.asarray(v)).cuda() if not isinstance(v, list) else v) for k, v in nb.items()})
+    bs[-1]["target_lengths_host"] = [int(x) for x in np.asarray(nb["target_lengths"])]      # ragged decoder rows, as bench.py
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 for i in range(N):
     v = tr.train_step(bs[i % 4])

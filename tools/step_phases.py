@@ -15,6 +15,7 @@ tr = HipTrainer(m, hp)
 S = int(os.environ.get("LAB_S", "114")); nsl = (572, 38) if S > 128 else (1, 1)
 nb = synthetic_batch(hp, 14, S, 582, seed=0, n_spk=nsl[0], n_lang=nsl[1])
 batch = {k: (torch.from_numpy(np.asarray(v)).cuda() if not isinstance(v, list) else v) for k, v in nb.items()}
+batch["target_lengths_host"] = [int(x) for x in np.asarray(nb["target_lengths"])]      # ragged decoder rows, as bench.py
 eng = tr.eng
 ev = {}
 def mark(name):

@@ -20,6 +20,7 @@ m = Tacotron(hp); initialize_variables(m); m = m.to("cuda").train()
 tr = HipTrainer(m, hp)
 nb = synthetic_batch(hp, 14, 114, 582, seed=0, n_spk=1, n_lang=1)
 batch = {k: (torch.from_numpy(np.asarray(v)).cuda() if not isinstance(v, list) else v) for k, v in nb.items()}
+batch["target_lengths_host"] = [int(x) for x in np.asarray(nb["target_lengths"])]      # ragged decoder rows, as bench.py
 eng = tr.eng
 ev = {}
 def mark(name, stream=None):
