@@ -1589,9 +1589,12 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
         // padded query rows of later layers depend on what earlier layers computed there
         constexpr bool no_qskip = false;
         const int* qskip = (no_qskip || !padded_unobserved) ? nullptr : target_lengths;
-        if (guided)
+        if (guided) {
             hipLaunchKernelGGL(k_ga_scale, dim3(1), dim3(64), 0, st, input_lengths, target_lengths, B, S, T,
                                cf.guided_attention_weight / (float)(cf.n_decoder_layer * H), c->ga_small);
+            // ragged rows: the attention kernels write the [B H, T] row sums of the frames that exist only; the reduction below walks all of them
+            if (c->ragged) B2S_HIP(hipMemsetAsync(c->ga_rows, 0, (size_t)cf.n_decoder_layer * B * H * T * sizeof(float), st));
+        }
         for (int l = 0; l < cf.n_decoder_layer; ++l) {
             AttnSave& s = c->self_attn[l]; AttnSave& x = c->cross_attn[l]; FfnSave& f = c->ffn[l];
             float* x0 = xs[3 * l]; float* x1 = xs[3 * l + 1]; float* x2 = xs[3 * l + 2]; float* x3 = xs[3 * l + 3];

@@ -122,3 +122,34 @@ def test_ragged_dropout_on_matches_oracle_under_device_masks():
         print("ragged step vs oracle with the %s row index: loss rel %.2e, worst gradient %.2e (%s)" % (tag, res[tag][0], e, n))
     assert res["ragged"][0] < 2e-4 and res["ragged"][1] < 1e-3, res["ragged"]
     assert res["padded"][1] > 1e-2, "the padded row index is a different (equally valid) mask: the comparison must notice"
+
+
+def test_ragged_rows_with_guided_attention_and_frozen_encoder():
+    """The few-shot fine-tune configuration (guided-attention loss on the encoder-decoder alignments, frozen encoder: both absent upstream) on ragged
+    rows: the guided loss sums per-frame row sums over [B H, T] -- frames that do not exist in the ragged layout must contribute nothing -- and
+    every loss term and gradient agrees with the padded layout at dropout 0."""
+    over = TINY96 + ",guided_attention_weight=1.0,guided_attention_sigma=0.2,freeze_encoder=true"
+    cfg0 = make_config(TINY96)
+    st = synth.synthetic_state(cfg0, 1234)
+    nb = synth.synthetic_batch(cfg0, B=4, S=19, T=150, seed=5, in_lens=[19, 12, 19, 3], tgt_lens=[150, 70, 128, 2])
+    res = []
+    for ragged in (False, True):
+        from b2s_hip.trainer import HipTrainer
+        m, cfg, _, hp = build(over, compute_dtype="fp32", state_edit=lambda s: s.update(st))
+        m.train()
+        tr = HipTrainer(m, hp, dist=False)
+        b = dev_batch(nb)
+        if ragged:
+            b["target_lengths_host"] = [int(x) for x in nb["target_lengths"]]
+        grads = []
+        tr.grad_probe = lambda flat, wire: grads.append(flat.detach().clone())
+        v = tr.train_step(b).detach().clone()
+        torch.cuda.synchronize()
+        res.append((v, float(tr.last_ga_loss), {n: grads[0][o:o + c].cpu() for n, (o, c) in tr.eng.param_offsets.items() if not n.startswith("encoder.")}))
+    (va, gaa, ga), (vb, gab, gb) = res
+    assert gaa > 0 and abs(gaa - gab) <= 1e-6 * gaa, (gaa, gab)
+    for i in range(va.numel()):
+        assert abs(float(va[i]) - float(vb[i])) <= 1e-6 * abs(float(va[i])) + 1e-9, (i, va, vb)
+    e, n = worst_direction(gb, ga)
+    print("guided attention + frozen encoder: ragged vs padded, guided loss %.6f / %.6f, worst gradient difference %.2e (%s)" % (gaa, gab, e, n))
+    assert e < 2e-5, (e, n)
