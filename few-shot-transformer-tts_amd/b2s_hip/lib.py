@@ -106,6 +106,7 @@ _PROTOS = {
     "b2s_decode_alignment": (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "b2s_decode_end": (None, [P]),
     "b2s_model_second_stream": (C.c_void_p, [P]),
+    "b2s_model_set_side_stream": (C.c_int, [P, P]),
     "b2s_gemm_set_tile_policy": (C.c_int, [C.c_int]),
     "b2s_model_backward_abort": (C.c_int, [P, P]),
     "b2s_model_mark_grads_ready": (C.c_int, [P]),

@@ -43,7 +43,7 @@ class _SchedView(object):
 
 class HipTrainer(object):
     def __init__(self, model, hp, beta1=0.9, beta2=0.999, bucket_mb=32.0, grad_payload=None, dist=None, tail_adam=True, overlap_encoder=True,
-                 dp_mode=None):
+                 dp_mode=None, side_stream=True):
         from transformer.tacotron import learning_rate_schedule
         self.model, self.hp = model, hp
         # tail_adam: with the encoder backward on its own stream, this stream is idle from the end of the decoder backward until the
@@ -57,6 +57,9 @@ class HipTrainer(object):
         # do not read the encoder output), its backward starts as soon as d(memory) is complete, beside the first decoder layer's
         # self-attention backward, the prenet backward and their weight gradients.  False: the single chain.
         self.overlap_encoder = bool(overlap_encoder)
+        # side_stream: during the decoder backward the encoder stream is idle; the dK / dV kernels of the encoder-decoder attentions (224
+        # workgroups, ~30 us each, feeding only memory-side gradients) run there instead of in the decoder's chain (b2s_model_set_side_stream)
+        self.side_stream = bool(side_stream) and os.environ.get("B2S_SIDE_STREAM", "1") != "0"      # (B2S_SIDE_STREAM=0: A/B switch, as B2S_COMPACT)
         self._enc_stream = None
         self.eng = model.engine()
         self.eng.ensure_bound()
@@ -310,6 +313,8 @@ class HipTrainer(object):
         ovl = self.overlap_encoder
         if ovl and self._enc_stream is None:
             self._enc_stream = torch.cuda.Stream(device=eng._gflat.device)
+            # idle during the decoder backward: the memory-side dK / dV kernels of the encoder-decoder attentions run there (include/b2s_hip.h)
+            L.check(lib.b2s_model_set_side_stream(eng.handle, C.c_void_p(self._enc_stream.cuda_stream) if self.side_stream else None))
         enc_s = self._enc_stream if ovl else None
         if enc_s is not None:
             enc_s.wait_stream(cur)                         # (weights synced above; the previous step's optimizer update)

@@ -41,5 +41,6 @@ bool b2s_flash_supported(int dh);
 bool b2s_flash32_supported(int dh);
 int b2s_flash32_launch(const AttnArgs& a, int dh, int which, hipStream_t st);
 int b2s_flash_fwd(int dtype, const AttnArgs& a, int dh, hipStream_t st);
-int b2s_flash_bwd(int dtype, const AttnArgs& a, int dh, const void* O, hipStream_t st);
+// st_dkv (optional): the dK / dV kernel is launched there, behind ev_dq recorded on st after the dQ kernel (which writes the row sums it reads)
+int b2s_flash_bwd(int dtype, const AttnArgs& a, int dh, const void* O, hipStream_t st, hipStream_t st_dkv = nullptr, hipEvent_t ev_dq = nullptr);
 int b2s_flash_align(int dtype, const AttnArgs& a, int dh, float* align, hipStream_t st);

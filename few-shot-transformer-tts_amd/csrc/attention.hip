@@ -923,7 +923,7 @@ int b2s_flash_fwd(int dtype, const AttnArgs& a, int dh, hipStream_t st) {
     if (use32(dtype, a, dh, 0)) return b2s_flash32_launch(a, dh, 0, st);
     return dtype ? launch_t<bf16_t>(a, dh, 0, st) : launch_t<float>(a, dh, 0, st);
 }
-int b2s_flash_bwd(int dtype, const AttnArgs& a_in, int dh, const void* O, hipStream_t st) {
+int b2s_flash_bwd(int dtype, const AttnArgs& a_in, int dh, const void* O, hipStream_t st, hipStream_t st_dkv, hipEvent_t ev_dq) {
     B2S_TRY(check(a_in, dtype, dh));
     B2S_CHECK(a_in.dout && a_in.dq && a_in.dk && a_in.dv && a_in.lse && a_in.dsum && O, "attention backward: null argument");
     B2S_CHECK(!a_in.ga_rows || a_in.ga_scale, "attention backward: the guided-attention term needs its scale");
@@ -932,6 +932,12 @@ int b2s_flash_bwd(int dtype, const AttnArgs& a_in, int dh, const void* O, hipStr
     // (both backward kernels write dsum / read it the same way, so the two families mix freely)
     if (use32(dtype, a, dh, 1)) { B2S_TRY(b2s_flash32_launch(a, dh, 1, st)); }
     else { B2S_TRY(dtype ? launch_t<bf16_t>(a, dh, 1, st) : launch_t<float>(a, dh, 1, st)); }
+    if (st_dkv) {
+        B2S_CHECK(ev_dq, "attention backward: the side stream needs an event");
+        B2S_HIP(hipEventRecord(ev_dq, st));
+        B2S_HIP(hipStreamWaitEvent(st_dkv, ev_dq, 0));
+        st = st_dkv;
+    }
     if (use32(dtype, a, dh, 2)) return b2s_flash32_launch(a, dh, 2, st);
     return dtype ? launch_t<bf16_t>(a, dh, 2, st) : launch_t<float>(a, dh, 2, st);
 }

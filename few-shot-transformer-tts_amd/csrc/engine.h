@@ -134,6 +134,14 @@ struct b2s_model {
     mutable size_t ev_next = 0;
     mutable std::map<const void*, hipEvent_t> aux_readers;     // scratch buffer -> event after its last aux-stream reader
     mutable bool aux_dirty = false;
+    // side stream (b2s_model_set_side_stream: the caller's otherwise idle encoder stream): the decoder backward launches the dK / dV kernel of
+    // every encoder-decoder attention there.  Its results feed only the memory-side gradients (the layer's kv weight gradient on the second
+    // stream, the one d(memory) GEMM at the end of the call), so the main stream's chain never waits for it.  side_ev: event behind the
+    // last kernel launched there (own events: the shared pool wraps around while this one is still referenced)
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t side_ev = nullptr;
+    mutable std::vector<hipEvent_t> side_evs;
+    mutable size_t side_next = 0;
     hipEvent_t next_event() const { hipEvent_t e = ev_pool[ev_next % ev_pool.size()]; ++ev_next; return e; }
     // Weight-gradient GEMMs of one backward stage are deferred and launched as ONE grouped GEMM on the aux stream when the
     // stage ends (bf16 mode with an aux stream): 7 problems of 18..72 tiles each fill the chip together, no split-K slabs.

@@ -264,6 +264,7 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
     hipEvent_t ready = m->next_event();
     B2S_HIP(hipEventRecord(ready, st));
     B2S_HIP(hipStreamWaitEvent(m->aux, ready, 0));
+    if (m->side_ev) B2S_HIP(hipStreamWaitEvent(m->aux, m->side_ev, 0));      // (the kv weight gradients read dK / dV written on the side stream)
     // the stage's LayerNorm parameter-gradient reductions ride along: nothing on the main stream needs them before the join
     if (m->ln_jobs.n > 0) { B2S_TRY(ro_ln_param_reduce_batch(m->ln_jobs, m->aux)); m->ln_jobs.n = 0; }
     B2S_TRY(flush_colsums(m, m->aux));
@@ -463,14 +464,16 @@ int attn_core_bwd(int dtype, hipStream_t st, const void* dctx, int ldc, const vo
                   const void* v, int ldv, const void* P, const void* Pd, void* dq, int lddq, void* dk, int lddk,
                   void* dv, int lddv, int B, int H, int Lq, int Lk, int dh, DropCfg drop, float* dP, void* dS,
                   float* lse = nullptr, const void* O = nullptr, int mask_mode = 0, const int* klen = nullptr,
-                  const GuidedArgs* ga = nullptr, const int* qskip = nullptr, const int* qoff = nullptr, const int* koff = nullptr) {
+                  const GuidedArgs* ga = nullptr, const int* qskip = nullptr, const int* qoff = nullptr, const int* koff = nullptr,
+                  hipStream_t st_dkv = nullptr, hipEvent_t ev_dq = nullptr) {
     if (lse && use_flash(dh)) {
         AttnArgs a = flash_args(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dh, mask_mode, klen, drop, lse);
         a.qskip = qskip; a.qoff = qoff; a.koff = koff;
         a.dout = dctx; a.ldo = ldc; a.dsum = dP; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
         if (ga) { a.ga_rows = ga->rows; a.qlen = ga->qlen; a.ga_scale = ga->scale; a.ga_inv2s2 = ga->inv2s2; }
-        return b2s_flash_bwd(dtype, a, dh, O, st);
+        return b2s_flash_bwd(dtype, a, dh, O, st, st_dkv, ev_dq);
     }
+    B2S_CHECK(!st_dkv, "internal: the side stream needs the fused attention kernels");
     B2S_CHECK(!ga, "the guided-attention term needs the fused attention kernels");
     B2S_CHECK(!qoff && !koff, "internal: ragged rows need the fused attention kernels");
     const int ldp = rup8(Lk);
@@ -530,6 +533,7 @@ struct Scratch {
     int i_lnws = 0;
     void *dmelT = nullptr, *doutT = nullptr, *da3 = nullptr, *dz1 = nullptr, *dz2 = nullptr;
     void* dkvcat = nullptr;          // [Mk][L*2D]: dK / dV of every decoder layer (models with a kv_cat weight slab)
+    void* dctx_x = nullptr; float* dsum_x = nullptr;     // encoder-decoder attention backward with its dK / dV kernel on the side stream: own d ctx / row-sum buffers (the self-attention that follows on the main stream rewrites dctx / dP at once)
     void* slabs = nullptr;           // fused encoder: [16][M][512] partial sublayer outputs (enc_fused.h)
 };
 
@@ -660,6 +664,7 @@ void plan_decoder(const b2s_model* m, b2s_ctx& c, Arena& a, Scratch& sc, std::ve
     if (m->kv_cat) sc.dkvcat = a.T(Mk * cf.n_decoder_layer * 2 * D, esz);
     sc.lnws = a.f32((long)RO_LN_WS_ROWS * 2 * D);
     for (int i = 0; i < (m->dw_group ? 3 * cf.n_decoder_layer + 2 : RO_LN_BATCH); ++i) sc.r_lnws.push_back(a.f32((long)RO_LN_WS_ROWS * 2 * D));
+    if (m->kv_cat) { sc.dctx_x = a.T(M * D, esz); sc.dsum_x = a.f32((long)B * H * T); }
 }
 
 struct PostScratch { std::vector<void*> du, dy; float* stat; int stat_stride; void* col = nullptr; };       // stat: [n layers][2 maxc] column sums (zeroed once per forward)
@@ -749,6 +754,7 @@ extern "C" void b2s_model_destroy(b2s_model* m) {
     (void)hipDeviceSynchronize();                 // nothing of this model is in flight any more
     if (m->aux) (void)hipStreamDestroy(m->aux);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : m->side_evs) (void)hipEventDestroy(e);
     if (m->enc_wT_ev) (void)hipEventDestroy(m->enc_wT_ev);
     for (void* p : m->owned) (void)hipFree(p);
     delete m;
@@ -1075,6 +1081,12 @@ extern "C" int b2s_dropout_site(const char* site, int layer, int decode, uint32_
     return b2s_fail(__FILE__, __LINE__, "unknown dropout site %s", site);
 }
 extern "C" void* b2s_model_second_stream(b2s_model* m) { return (m && m->bound) ? (void*)m->aux : nullptr; }
+extern "C" int b2s_model_set_side_stream(b2s_model* m, void* stream) {
+    B2S_CHECK(m, "null model");
+    B2S_CHECK(!stream || S_(stream) != m->aux, "b2s_model_set_side_stream: the library's own second stream cannot be the side stream");
+    m->side = S_(stream);
+    return 0;
+}
 extern "C" int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int, void*), void* user, void* stream) {
     B2S_CHECK(m, "null model");
     m->stage_hook = hook; m->stage_user = user; m->hook_stream = hook ? (hipStream_t)stream : nullptr;
@@ -1739,9 +1751,19 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
         m->dw_tail_cap = tail_cap;
     }
     bool first_mem = true, dmem_finished = false;
+    // side stream (engine.h): the dK / dV kernels of the encoder-decoder attentions leave this stream
+    m->side_ev = nullptr;
+    struct SideReset { b2s_model* m; ~SideReset() { m->side_ev = nullptr; } } side_reset{m};
+    const bool side = m->side && m->side != st && sc.dkvcat && sc.dctx_x && dt == 1 && use_flash(dh);
+    if (side && m->side_evs.empty()) {
+        m->side_evs.resize(16);
+        for (auto& e : m->side_evs) B2S_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     auto finish_dmem = [&]() -> int {
         if (dmem_finished) return 0;
         dmem_finished = true;
+        // every layer's dK / dV; from here on this stream's events cover the side stream's work
+        if (m->side_ev) { B2S_HIP(hipStreamWaitEvent(st, m->side_ev, 0)); m->side_ev = nullptr; }
         if (want_dmem && sc.dkvcat && cf.n_decoder_layer > 0) {
             // d(memory) = [dKV_0 .. dKV_{L-1}] [Mk, L*2D] x Wcat [L*2D, D]: one GEMM with K = L*2D instead of L accumulating launches.
             // 56 output tiles only -> K split over 4 workgroups each (slab workspace; free here: with grouped weight gradients
@@ -1775,7 +1797,10 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
             const void* dy;
             B2S_TRY(take_dy(m, st, sc, M, D, dres, &dy));
             B2S_TRY(linear_dw(m, st, dy, D, x.ctx, D, (int)M, D, D, m->G(wo)));
-            B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, sc.dctx, 0, D, GemmEpilogue()));
+            void* const dctx = side ? sc.dctx_x : sc.dctx;
+            float* const dsum = side ? sc.dsum_x : sc.dP;
+            if (side && m->side_ev) B2S_HIP(hipStreamWaitEvent(st, m->side_ev, 0));      // the layer above has read dctx_x / dsum_x (long done: it ran a whole layer ago)
+            B2S_TRY(linear_dx(m, st, dy, D, m->W(wo), (int)M, D, D, dctx, 0, D, GemmEpilogue()));
             sc.dqkv = Scratch::rot(sc.r_dqkv, sc.i_dqkv);
             B2S_TRY(guard_write(m, sc.dqkv, st));
             int lddkv = 2 * D;
@@ -1787,9 +1812,14 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
                 ga.rows = c->ga_rows + (long)l * B * H * T; ga.qlen = c->tgt_len; ga.scale = c->ga_small + 2;
                 ga.inv2s2 = 1.f / (2.f * cf.guided_attention_sigma * cf.guided_attention_sigma);
             }
-            B2S_TRY(attn_core_bwd(dt, st, sc.dctx, D, x.qkv, D, kv, x.ldkv, kv + (size_t)D * esz, x.ldkv, x.P, x.Pd, sc.dqkv, D, dkv, lddkv,
-                                  dkv + (size_t)D * esz, lddkv, B, H, T, S, dh, datt, sc.dP, sc.dS, x.lse, x.ctx, x.mask_mode, c->in_len,
-                                  guided ? &ga : nullptr, x.qskip, x.qoff, x.koff));
+            B2S_TRY(attn_core_bwd(dt, st, dctx, D, x.qkv, D, kv, x.ldkv, kv + (size_t)D * esz, x.ldkv, x.P, x.Pd, sc.dqkv, D, dkv, lddkv,
+                                  dkv + (size_t)D * esz, lddkv, B, H, T, S, dh, datt, dsum, sc.dS, x.lse, x.ctx, x.mask_mode, c->in_len,
+                                  guided ? &ga : nullptr, x.qskip, x.qoff, x.koff, side ? m->side : nullptr, side ? m->next_event() : nullptr));
+            if (side) {
+                hipEvent_t e = m->side_evs[m->side_next++ % m->side_evs.size()];
+                B2S_HIP(hipEventRecord(e, m->side));
+                m->side_ev = e;
+            }
             B2S_TRY(linear_dw(m, st, sc.dqkv, D, x.h, D, (int)M, D, D, m->G(wq)));
             B2S_TRY(linear_dx(m, st, sc.dqkv, D, m->W(wq), (int)M, D, D, sc.dh, 0, D, GemmEpilogue()));
             B2S_TRY(linear_dw(m, st, sc.dkv, lddkv, c->memT, D, (int)Mk, 2 * D, D, m->G(wkv)));
@@ -2192,6 +2222,7 @@ extern "C" int b2s_model_backward_abort(b2s_model* m, void* stream) {
     m->pending_ev = nullptr;
     m->dw_hold_from = -1; m->dw_tail_cap = 0; m->dw_flush_capped = false;      // (a decoder backward that failed mid-call leaves its tail policy set)
     m->grads_marked = false;
+    if (m->side_ev) { B2S_HIP(hipStreamWaitEvent(S_(stream), m->side_ev, 0)); m->side_ev = nullptr; }
     if (m->aux) { m->aux_dirty = true; B2S_TRY(join_aux(m, S_(stream))); }
     return 0;
 }

@@ -152,6 +152,13 @@ int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int stage, void* user), 
  * stream that completes the gradients instead of a fifth stream: more than four concurrently ACTIVE HIP streams (main, second, encoder,
  * exchange, RCCL's own) were measured at 12.6 ms per step against 7.9 with four (MI355X, profiles/NOTES_r04.md). */
 void* b2s_model_second_stream(b2s_model* m);
+/* Side stream (hipStream_t, or NULL to clear): a stream of the caller that is idle while b2s_decoder_backward runs -- HipTrainer passes the
+ * stream its encoder forward / backward run on.  The decoder backward then launches the dK / dV kernel of every encoder-decoder attention
+ * (transformer/attention.py:72-92 under autograd: the gradient of the memory-side K / V) there: its results feed only the layer's kv weight
+ * gradient and the single d(memory) GEMM at the end of the call, so the query-side chain on the call's stream does not wait for it.  The
+ * call's stream has joined the side stream's work when b2s_decoder_backward returns (and where it records dmem_done).  Results are
+ * identical with and without a side stream (same kernels, same order of every reduction).  No further stream is created. */
+int b2s_model_set_side_stream(b2s_model* m, void* stream);
 /* Give up a backward pass between its entry points (after a failed call, or when the caller will not make the joining call that
  * B2S_POST_BWD_DEFER_JOIN / B2S_DEC_BWD_DEFER_JOIN promised): queued weight-gradient work, reductions and stage hooks are dropped
  * unlaunched / unfired, `stream` waits for what the second stream is already running.  Call before freeing the contexts.  The gradient
