@@ -58,6 +58,8 @@ def make_batch(cfg, B, S, T, seed, device, n_spk=1, n_lang=1):
     # the dataloader's host copy of the lengths travels with the batch (b2s_hip/batching.py: DeviceStager does the same): the fused trainer keeps
     # the decoder's rows ragged from it -- sum(target_lengths) rows per row-wise kernel instead of B x T -- without a device-to-host read
     out["target_lengths_host"] = [int(x) for x in np.asarray(nb["target_lengths"])]
+    for k in ("input_lengths", "target_lengths"):          # (and int32 device copies of the lengths, as DeviceStager.put)
+        out[k + "_i32"] = torch.from_numpy(np.asarray(nb[k]).astype(np.int32)).to(device)
     return out
 
 

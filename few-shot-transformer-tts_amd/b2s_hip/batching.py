@@ -140,6 +140,11 @@ class DeviceStager(object):
                     out[k] = self._pin(k, v, slot).to(self.device, non_blocking=True)
                 else:
                     out[k] = v
+            for k in ("input_lengths", "target_lengths"):
+                # int32 device copies of the lengths (what the kernels read): cast on the host, staged with the rest -- HipTrainer then starts
+                # the step without two device-side cast kernels
+                if isinstance(np_batch.get(k), np.ndarray):
+                    out[k + "_i32"] = self._pin(k + "_i32", np_batch[k].astype(np.int32), slot).to(self.device, non_blocking=True)
             if isinstance(np_batch.get("target_lengths"), np.ndarray):
                 # the host copy stays with the batch: HipTrainer runs the decoder segment on ragged rows from it (no device-to-host read)
                 out["target_lengths_host"] = [int(x) for x in np_batch["target_lengths"]]

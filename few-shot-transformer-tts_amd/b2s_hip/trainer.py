@@ -308,7 +308,9 @@ class HipTrainer(object):
             broadcast_buffers(self._bn_buffers, self.dist, 0)
         # the fused Adam kernel rewrote the fp32 masters AND their bf16 shadows; only conv re-layouts remain
         L.check(lib.b2s_model_sync_weights(eng.handle, L.stream(), int(self.global_step > 0)))
-        in32, tgt32 = _i32(batch["input_lengths"]), _i32(batch["target_lengths"])
+        # (the stager's int32 device copies when the batch carries them: two cast kernels less at the head of the step's critical path)
+        in32 = batch["input_lengths_i32"] if "input_lengths_i32" in batch else _i32(batch["input_lengths"])
+        tgt32 = batch["target_lengths_i32"] if "target_lengths_i32" in batch else _i32(batch["target_lengths"])
         cur = torch.cuda.current_stream()
         ovl = self.overlap_encoder
         if ovl and self._enc_stream is None:

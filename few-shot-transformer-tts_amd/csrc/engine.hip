@@ -296,7 +296,12 @@ int flush_dw(const b2s_model* m, hipStream_t st) {
         constexpr int round_env = 256;       // (0: never)
         const int round_tiles = m->dw_flush_exposed ? round_env : 0;
         const bool capped = m->dw_flush_capped && m->dw_tail_cap > 0;
-        const long cap = capped ? m->dw_tail_cap : (round_tiles > 0 ? round_tiles : (1L << 30));
+#ifdef B2S_LAB
+        static const long lab_cap = getenv("B2S_LAB_DW_CAP") ? atol(getenv("B2S_LAB_DW_CAP")) : 0;      // (lab: every hand-over in launches of at most this many tiles)
+#else
+        constexpr long lab_cap = 0;
+#endif
+        const long cap = capped ? m->dw_tail_cap : (round_tiles > 0 ? round_tiles : (lab_cap > 0 ? lab_cap : (1L << 30)));
         size_t i = 0;
         while (i < q.size()) {
             size_t ce = i + 1;
