@@ -1665,12 +1665,10 @@ extern "C" int b2s_decoder_forward(b2s_model* m, const float* memory, const int3
         GemmEpilogue em;
         if (!c->ragged) { em.row_len = target_lengths; em.rows_per_batch = T; }
         B2S_TRY(linear(m, st, c->outT, D, m->W("decoder.mel_net.weight"), (int)Mr, NM, D, c->ragged ? c->melc : mels_out, 1, NM, em));
-        B2S_TRY(ro_rowdot_fwd(dt, c->outT, D, m->P("decoder.stop_net.weight"), m->P("decoder.stop_net.bias"), c->ragged ? c->stopc : stop_out, (int)Mr, D,
-                              c->ragged ? nullptr : target_lengths, T, st));
-        if (c->ragged) {                                     // the caller's tensors stay padded [B, T, *], zeros beyond target_lengths (tacotron.py:112-115 impute)
-            B2S_TRY(ro_rows_scatter(c->melc, mels_out, roff, B, T, NM, st));
-            B2S_TRY(ro_rows_scatter(c->stopc, stop_out, roff, B, T, 1, st));
-        }
+        if (c->ragged)      // the caller's tensors stay padded [B, T, *], zeros beyond target_lengths (tacotron.py:112-115 impute): stop projection + both scatters in one launch
+            B2S_TRY(ro_heads_scatter(dt, c->outT, D, m->P("decoder.stop_net.weight"), m->P("decoder.stop_net.bias"), c->melc, mels_out, stop_out, roff, B, T, NM, D, st));
+        else
+            B2S_TRY(ro_rowdot_fwd(dt, c->outT, D, m->P("decoder.stop_net.weight"), m->P("decoder.stop_net.bias"), stop_out, (int)Mr, D, target_lengths, T, st));
         if (guided) hipLaunchKernelGGL(k_ga_reduce, dim3(1), dim3(1024), 0, st, c->ga_rows, (long)cf.n_decoder_layer * B * H * T, c->ga_small);
         B2S_LAUNCH_CHECK();
         return 0;
@@ -1720,15 +1718,14 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
     const bool guided = c->ga_small != nullptr && d_guided != nullptr;
     if (guided) hipLaunchKernelGGL(k_ga_bscale, dim3(1), dim3(1), 0, st, c->ga_small, d_guided);
     // heads (tacotron.py:112-115)
-    if (c->ragged) B2S_TRY(ro_rows_gather(dt, d_mels, sc.dmelT, roff, B, T, NM, st));
+    if (c->ragged) B2S_TRY(ro_rows_gather(dt, d_mels, sc.dmelT, roff, B, T, NM, st, d_stop, sc.dstop_m, 1));      // (d_stop rides along: one launch)
     else B2S_TRY(ro_cast(dt, d_mels, sc.dmelT, M * NM, st));
     B2S_TRY(linear_dw(m, st, sc.dmelT, NM, c->outT, D, (int)M, NM, D, m->G("decoder.mel_net.weight")));
     GemmEpilogue eo;
     if (!c->ragged) { eo.row_len = c->tgt_len; eo.rows_per_batch = T; }
     B2S_TRY(linear_dx(m, st, sc.dmelT, NM, m->W("decoder.mel_net.weight"), (int)M, D, NM, sc.doutT, 0, D, eo));
     if (d_stop) {
-        if (c->ragged) B2S_TRY(ro_rows_gather(0, d_stop, sc.dstop_m, roff, B, T, 1, st));
-        else hipLaunchKernelGGL(k_rowmask_copy, dim3(cdiv(M, 256)), dim3(256), 0, st, d_stop, sc.dstop_m, c->tgt_len, T, M);
+        if (!c->ragged) hipLaunchKernelGGL(k_rowmask_copy, dim3(cdiv(M, 256)), dim3(256), 0, st, d_stop, sc.dstop_m, c->tgt_len, T, M);
         B2S_TRY(grad_colsum(m, st, dt, c->outT, 0, D, sc.dstop_m, m->G("decoder.stop_net.weight"), 1, (int)M, D));
         B2S_TRY(grad_colsum(m, st, 0, sc.dstop_m, 1, 1, nullptr, m->G("decoder.stop_net.bias"), 1, (int)M, 1));
     }

@@ -55,8 +55,9 @@ int ro_shift_pe_fwd(const float* a, const int* lens, const float* pe, const floa
 int ro_shift_pe_bwd(int dtype, const float* dx, const int* lens, const float* pe, void* da, float* d_pe_scale, int B,
                     int T, int D, DropCfg drop, hipStream_t st, int dx_bf16 = 0, const int* off = nullptr, int rows = 0);
 int ro_set_rowoff(const int* off_host, int n, int* dst, hipStream_t st);                       // n = B + 1 <= 65 offsets through the kernel arguments
-int ro_rows_gather(int out_dtype, const float* in, void* out, const int* off, int B, int T, int C, hipStream_t st);     // padded [B, T, C] fp32 -> ragged rows
-int ro_rows_scatter(const float* in, float* out, const int* off, int B, int T, int C, hipStream_t st);                  // ragged rows -> padded fp32, zeros on padded rows
+int ro_rows_gather(int out_dtype, const float* in, void* out, const int* off, int B, int T, int C, hipStream_t st, const float* in2 = nullptr, float* out2 = nullptr, int C2 = 0);     // padded [B, T, C] fp32 -> ragged rows
+int ro_heads_scatter(int dtype, const void* x, int ldx, const float* w, const float* bias, const float* mel_in, float* mel_out, float* stop_out,
+                     const int* off, int B, int T, int C, int D, hipStream_t st);
 
 // speaker / language embeddings (tacotron.py:21-31), written into memory[:, :, col0 : col0+E] for all S
 int ro_spk_embed_fwd(const long* spk_ids, const float* table, const float* W, const float* b, float* e_raw,

@@ -475,16 +475,34 @@ __global__ __launch_bounds__(256) void k_cast_back_bf16_v(const bf16_t* __restri
 __device__ inline int ragged_batch(const int* __restrict__ off, int B, int row) { int b = 0; while (b + 1 < B && off[b + 1] <= row) ++b; return b; }
 struct RowOff64 { int off[65]; };
 __global__ void k_set_rowoff(RowOff64 h, int* dst, int n) { if ((int)threadIdx.x < n) dst[threadIdx.x] = h.off[threadIdx.x]; }
+// (in2 / out2, optional: a second fp32 tensor [B, T, C2] gathered by the same launch -- the decoder backward's d_stop beside d_mels)
 template <typename TO>
-__global__ void k_rows_gather(const float* __restrict__ in, TO* __restrict__ out, const int* __restrict__ off, int T, int C) {
+__global__ void k_rows_gather(const float* __restrict__ in, TO* __restrict__ out, const int* __restrict__ off, int T, int C,
+                              const float* __restrict__ in2, float* __restrict__ out2, int C2) {
     const int b = blockIdx.y, t = blockIdx.x, r0 = off[b];
     if (t >= off[b + 1] - r0) return;
     for (int c = threadIdx.x; c < C; c += blockDim.x) TT<TO>::st(out + (long)(r0 + t) * C + c, in[((long)b * T + t) * C + c]);
+    if (in2) for (int c = threadIdx.x; c < C2; c += blockDim.x) out2[(long)(r0 + t) * C2 + c] = in2[((long)b * T + t) * C2 + c];
 }
-__global__ void k_rows_scatter(const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ off, int T, int C) {
-    const int b = blockIdx.y, t = blockIdx.x, r0 = off[b];
+// decoder heads on ragged rows, one launch: the stop projection of a frame (k_rowdot's arithmetic, term for term) + the scatter of its mel row and its
+// stop logit into the caller's padded [B, T, *] tensors (zeros where the frame does not exist) -- instead of k_rowdot + two k_rows_scatter
+template <typename TX>
+__global__ __launch_bounds__(64) void k_heads_scatter(const TX* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const float* __restrict__ mel_in, float* __restrict__ mel_out, float* __restrict__ stop_out,
+                                                      const int* __restrict__ off, int T, int C, int D) {
+    const int b = blockIdx.y, t = blockIdx.x, r0 = off[b], lane = threadIdx.x;
     const bool live = t < off[b + 1] - r0;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) out[((long)b * T + t) * C + c] = live ? in[(long)(r0 + t) * C + c] : 0.f;
+    const long row = r0 + t, prow = (long)b * T + t;
+    for (int c = lane; c < C; c += 64) mel_out[prow * C + c] = live ? mel_in[row * C + c] : 0.f;
+    float acc = 0.f;
+    if (live) {
+        for (int c = lane * 4; c < D; c += 256) {
+            float4 v = ld4(x + row * ldx + c), ww = ld4(w + c);
+            acc += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+        }
+        acc = wave_sum(acc);
+    }
+    if (lane == 0) stop_out[prow] = live ? acc + bias[0] : 0.f;
 }
 
 // ---------------------------------------------------------------------------------- decoder input prep
@@ -1349,13 +1367,15 @@ int ro_set_rowoff(const int* off_host, int n, int* dst, hipStream_t st) {
     hipLaunchKernelGGL(k_set_rowoff, dim3(1), dim3(128), 0, st, h, dst, n);
     B2S_LAUNCH_CHECK(); return 0;
 }
-int ro_rows_gather(int out_dtype, const float* in, void* out, const int* off, int B, int T, int C, hipStream_t st) {
-    if (out_dtype == 1) hipLaunchKernelGGL((k_rows_gather<bf16_t>), dim3(T, B), dim3(C >= 128 ? 128 : 64), 0, st, in, (bf16_t*)out, off, T, C);
-    else hipLaunchKernelGGL((k_rows_gather<float>), dim3(T, B), dim3(C >= 128 ? 128 : 64), 0, st, in, (float*)out, off, T, C);
+int ro_rows_gather(int out_dtype, const float* in, void* out, const int* off, int B, int T, int C, hipStream_t st, const float* in2, float* out2, int C2) {
+    if (out_dtype == 1) hipLaunchKernelGGL((k_rows_gather<bf16_t>), dim3(T, B), dim3(C >= 128 ? 128 : 64), 0, st, in, (bf16_t*)out, off, T, C, in2, out2, C2);
+    else hipLaunchKernelGGL((k_rows_gather<float>), dim3(T, B), dim3(C >= 128 ? 128 : 64), 0, st, in, (float*)out, off, T, C, in2, out2, C2);
     B2S_LAUNCH_CHECK(); return 0;
 }
-int ro_rows_scatter(const float* in, float* out, const int* off, int B, int T, int C, hipStream_t st) {
-    hipLaunchKernelGGL(k_rows_scatter, dim3(T, B), dim3(C >= 128 ? 128 : 64), 0, st, in, out, off, T, C);
+int ro_heads_scatter(int dtype, const void* x, int ldx, const float* w, const float* bias, const float* mel_in, float* mel_out, float* stop_out,
+                     const int* off, int B, int T, int C, int D, hipStream_t st) {
+    B2S_CHECK(D % 4 == 0, "heads: D=%d must be a multiple of 4", D);
+    RO_DISPATCH(dtype, hipLaunchKernelGGL((k_heads_scatter<TY>), dim3(T, B), dim3(64), 0, st, (const TY*)x, ldx, w, bias, mel_in, mel_out, stop_out, off, T, C, D));
     B2S_LAUNCH_CHECK(); return 0;
 }
 int ro_spk_embed_fwd(const long* spk_ids, const float* table, const float* W, const float* b, float* e_raw,
