@@ -138,6 +138,9 @@ struct b2s_model {
     // every encoder-decoder attention there.  Its results feed only the memory-side gradients (the layer's kv weight gradient on the second
     // stream, the one d(memory) GEMM at the end of the call), so the main stream's chain never waits for it.  side_ev: event behind the
     // last kernel launched there (own events: the shared pool wraps around while this one is still referenced)
+#ifdef B2S_LAB
+    mutable bool lab_early_marked = false;
+#endif
     mutable hipStream_t side = nullptr;
     mutable hipEvent_t side_ev = nullptr;
     mutable std::vector<hipEvent_t> side_evs;

@@ -1857,6 +1857,15 @@ extern "C" int b2s_decoder_backward(b2s_model* m, b2s_ctx* c, const float* d_mel
     // (deferred join: the caller's next call is b2s_encoder_backward on this stream, whose last stage joins the second stream and fires
     // this stage's hook -- the main stream does not idle here until the prenet's weight-gradient group has finished, ~0.12 ms)
     if (flags & B2S_DEC_BWD_FLUSH_TAIL) {
+#ifdef B2S_LAB
+        // (timing lab, tools/early_adam_lab.py: the mark in front of the held groups -- the update of the held layer then races with its gradients)
+        static const bool lab_early_mark = getenv("B2S_LAB_EARLY_MARK") != nullptr;
+        if (lab_early_mark && m->aux) {
+            if (!m->grads_mark_ev) B2S_HIP(hipEventCreateWithFlags(&m->grads_mark_ev, hipEventDisableTiming));
+            B2S_HIP(hipEventRecord(m->grads_mark_ev, m->aux));
+            m->lab_early_marked = true;
+        }
+#endif
         // hand everything that is still queued to the second stream behind an event of THIS stream (the operands were produced here), but
         // leave the join to the caller's next entry point -- which may run on another stream and must not be the one that orders them
         m->dw_flush_capped = m->dw_hold_from >= 0;
@@ -2207,6 +2216,9 @@ extern "C" int b2s_model_mark_grads_ready(b2s_model* m) {
     B2S_CHECK(m->dw_pending.empty() && m->aux_jobs.empty() && m->ln_jobs.n == 0 && m->dw_stages_pending == 0,
               "b2s_model_mark_grads_ready: gradient work is still queued on the host side (call the backward entry point with B2S_DEC_BWD_FLUSH_TAIL)");
     if (!m->grads_mark_ev) B2S_HIP(hipEventCreateWithFlags(&m->grads_mark_ev, hipEventDisableTiming));
+#ifdef B2S_LAB
+    if (m->lab_early_marked) { m->lab_early_marked = false; m->grads_marked = true; return 0; }
+#endif
     B2S_HIP(hipEventRecord(m->grads_mark_ev, m->aux));
     m->grads_marked = true;
     return 0;
