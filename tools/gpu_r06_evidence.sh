@@ -1,3 +1,5 @@
+#!/bin/bash
+# Round-6 evidence files (profiles/r06_attn32_lab.txt, r06_attn32_pmc.txt, r06_valu_lab.txt, r06_*_ab.txt) in one gpurun call; see tools/README.md
 out=gpurun_out
 tools/bin/attn32_lab > $out/r06_attn32_lab.txt 2>&1; tail -3 $out/r06_attn32_lab.txt
 tools/bin/valu_lab > $out/r06_valu_lab.txt 2>&1; tail -3 $out/r06_valu_lab.txt
