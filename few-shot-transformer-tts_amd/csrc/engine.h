@@ -1,6 +1,7 @@
 // Internal model / context structures of libb2s_hip (see engine.hip).
 #pragma once
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <functional>

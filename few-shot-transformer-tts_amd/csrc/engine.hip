@@ -176,6 +176,26 @@ int linear_dx(const b2s_model* m, hipStream_t st, const void* dY, int lddy, cons
     g.M = M; g.N = Nin; g.K = Kout; g.C = out; g.c_fp32 = out_fp32; g.ldc = ldo; g.epi = e;
     return b2s_gemm_launch(g, m->dtype, false, true, st);
 }
+// The second stream is ONE stream per device and process, shared by every model bound there and never destroyed.  HIP maps a stream onto one of a few
+// hardware queues (4 by default) when it is created -- the least-loaded one at that moment -- and two streams of one queue do not run beside each
+// other: with a fresh second stream per model (and a fresh encoder stream per trainer) the third model of a process landed on the main stream's
+// queue and ran the step in 13.3 instead of 6.5 ms (tools/leg_order_lab.py; bench.py --gpus N builds one trainer per leg).  Models of one process
+// do not run concurrently in any flow of this package; if they did, the shared stream would order their weight-gradient work, not break it.
+int aux_stream_of(hipStream_t* out) {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> per_device;
+    int dev = 0;
+    B2S_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = per_device.find(dev);
+    if (it == per_device.end()) {
+        hipStream_t s = nullptr;
+        B2S_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        it = per_device.emplace(dev, s).first;
+    }
+    *out = it->second;
+    return 0;
+}
 // ---- aux-stream plumbing (see b2s_model::aux)
 int guard_write(const b2s_model* m, const void* buf, hipStream_t st) {       // main stream is about to overwrite `buf`
     auto it = m->aux_readers.find(buf);
@@ -757,7 +777,7 @@ extern "C" int b2s_model_create(const b2s_config* cfg, b2s_model** out) {
 extern "C" void b2s_model_destroy(b2s_model* m) {
     if (!m) return;
     (void)hipDeviceSynchronize();                 // nothing of this model is in flight any more
-    if (m->aux) (void)hipStreamDestroy(m->aux);
+    // (m->aux is the process-wide second stream of its device: aux_stream_of() -- never destroyed)
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->side_evs) (void)hipEventDestroy(e);
     if (m->enc_wT_ev) (void)hipEventDestroy(m->enc_wT_ev);
@@ -1034,7 +1054,7 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
     if (!m->aux && true) {
         // (a lowest-priority second stream was measured: no change -- a weight-gradient workgroup holds its CU for ~110 us once it
         // has started, whatever the queue priorities say)
-        B2S_HIP(hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking));
+        B2S_TRY(aux_stream_of(&m->aux));
         m->ev_pool.resize(256);
         for (auto& ev : m->ev_pool) B2S_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }

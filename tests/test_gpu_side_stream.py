@@ -82,3 +82,25 @@ def test_side_stream_trainer_step_within_run_to_run_bars(monkeypatch):
     e, n = worst_direction(ga, gb)
     print("worst per-tensor gradient difference side stream on vs off %.2e (%s)" % (e, n))
     assert e < 1e-2, (e, n)
+
+
+def test_streams_are_shared_by_every_trainer_of_a_process():
+    """HIP assigns a stream its hardware queue when the stream is created; a fresh second stream per model and a fresh encoder stream per trainer put the
+    third trainer of one process on the main stream's queue (13.3 instead of 6.5 ms per step, tools/leg_order_lab.py -- bench.py --gpus N builds one
+    trainer per leg).  Both are process-wide per device now: every model / trainer sees the streams of the first."""
+    from b2s_hip.trainer import HipTrainer
+    over = TINY96
+    cfg0 = make_config(over)
+    st = synth.synthetic_state(cfg0, 1234)
+    nb = synth.synthetic_batch(cfg0, B=3, S=11, T=23, seed=7, in_lens=[11, 7, 4], tgt_lens=[23, 15, 9])
+    seen = []
+    for _ in range(3):
+        m, cfg, _, hp = build(over, compute_dtype="bf16", state_edit=lambda s: s.update(st))
+        m.train()
+        tr = HipTrainer(m, hp, dist=False)
+        v = tr.train_step(dev_batch(nb))
+        torch.cuda.synchronize()
+        assert np.isfinite(float(v[0]))
+        seen.append((tr._enc_stream.cuda_stream, tr.lib.b2s_model_second_stream(tr.eng.handle)))
+        tr.close()
+    assert seen[0][0] and seen[0][1] and seen[0] == seen[1] == seen[2], seen
