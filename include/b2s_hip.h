@@ -148,7 +148,8 @@ void b2s_ctx_free(b2s_ctx* ctx);
  * wait for the collectives as before).  hook = NULL removes the hook. */
 int b2s_model_set_stage_hook(b2s_model* m, void (*hook)(int stage, void* user), void* user, void* stream);
 /* The engine's second stream (hipStream_t; NULL before b2s_model_bind or when the model runs single-stream): the stream its weight-gradient
- * work runs on.  A data-parallel caller passes it to b2s_model_set_stage_hook, so that the gradient exchange is launched from the
+ * work runs on -- ONE stream per device and process, shared by every model bound there and never destroyed (HIP assigns hardware queues when a
+ * stream is created; a fresh stream per model eventually lands on the caller's queue and serialises the step, profiles/NOTES_r06.md section 8).  A data-parallel caller passes it to b2s_model_set_stage_hook, so that the gradient exchange is launched from the
  * stream that completes the gradients instead of a fifth stream: more than four concurrently ACTIVE HIP streams (main, second, encoder,
  * exchange, RCCL's own) were measured at 12.6 ms per step against 7.9 with four (MI355X, profiles/NOTES_r04.md). */
 void* b2s_model_second_stream(b2s_model* m);
