@@ -347,6 +347,7 @@ class HipTrainer(object):
         if guided:
             self.last_ga_loss = eng.guided_loss(c_dec, add_to=vals)       # vals[0] (total loss) += weight * guided loss
         # (1 = B2S_ZERO_GRADS_OVERWRITE_DW: this step runs every backward segment exactly once)
+        eng._reclaim_lent()                                  # (a .grad the autograd path lent out of the flat buffer gets its own copy first)
         L.check(lib.b2s_zero_grads(eng.handle, L.stream(), 1))
         eng._needs_zero = False
         if self.bucketer is not None:

@@ -115,6 +115,8 @@ struct b2s_model {
     // multi-tensor chunk tables (device)
     MtChunk *l2_chunks = nullptr, *adam_chunks = nullptr;
     int n_l2_chunks = 0, n_adam_chunks = 0;
+    MtChunk* cast_chunks = nullptr;                 // (a = fp32 master, s = bf16 shadow) of every GEMM weight: one cast launch (b2s_model_sync_weights)
+    int n_cast_chunks = 0;
     float* small = nullptr;                         // device scratch: [0..15] misc scalars
     // per-chunk sum of squares of the L2 members, written by the fused Adam step for the parameters it just produced:
     // the next loss evaluation reads the regulariser from here instead of re-reading 83 M parameters.  l2_fresh is

@@ -1066,6 +1066,32 @@ extern "C" int b2s_model_bind(b2s_model* m, void* const* data_host, void* const*
     B2S_TRY(ensure_pe(m, 2048));
     m->l2_fresh = false;
     B2S_TRY(build_chunks(m, true, false, &m->l2_chunks, &m->n_l2_chunks));
+    if (m->dtype == 1) {                                   // cast table of the bf16 shadows
+        std::vector<MtChunk> h;
+        const int CH = 16384;
+        for (size_t i = 0; i < m->tinfo.size(); ++i) {
+            const TensorInfo& t = m->tinfo[i];
+            if (!t.gemm_weight || !m->shadow[i] || m->shadow[i] == m->data[i]) continue;
+            for (long o = 0; o < t.numel; o += CH) {
+                MtChunk c;
+                c.a = (float*)m->data[i] + o; c.b = nullptr; c.c = nullptr; c.d = nullptr; c.s = (bf16_t*)m->shadow[i] + o;
+                c.n = (int)std::min<long>(CH, t.numel - o); c.pad = 0; c.s2 = nullptr; c.cin = 0; c.cout = 0; c.off = o;
+                h.push_back(c);
+            }
+        }
+        if (m->cast_chunks) {
+            auto it = std::find(m->owned.begin(), m->owned.end(), (void*)m->cast_chunks);
+            if (it != m->owned.end()) m->owned.erase(it);
+            (void)hipFree(m->cast_chunks);
+            m->cast_chunks = nullptr;
+        }
+        m->n_cast_chunks = (int)h.size();
+        if (!h.empty()) {
+            B2S_HIP(hipMalloc(&m->cast_chunks, h.size() * sizeof(MtChunk)));
+            B2S_HIP(hipMemcpy(m->cast_chunks, h.data(), h.size() * sizeof(MtChunk), hipMemcpyHostToDevice));
+            m->owned.push_back(m->cast_chunks);
+        }
+    }
     B2S_TRY(build_zero_table(m));
     m->bound = true;
     // A fused optimizer bound earlier (b2s_adam_bind) holds the OLD parameter / gradient pointers in its chunk table: rebuild
@@ -1079,9 +1105,7 @@ extern "C" int b2s_model_sync_weights(b2s_model* m, void* stream, int shadows_fr
     B2S_TRY(check_bound(m));
     hipStream_t st = S_(stream);
     if (!shadows_fresh) m->l2_fresh = false;
-    if (m->dtype && !shadows_fresh)
-        for (size_t i = 0; i < m->tinfo.size(); ++i)
-            if (m->tinfo[i].gemm_weight) B2S_TRY(ro_cast(1, (const float*)m->data[i], m->shadow[i], m->tinfo[i].numel, st));
+    if (m->dtype && !shadows_fresh) B2S_TRY(ro_mt_cast(m->cast_chunks, m->n_cast_chunks, st));      // every GEMM weight's bf16 shadow, one launch
     // (bf16 mode after a fused optimizer step: the Adam kernel has written both conv weight images itself)
     // (after a fused optimizer step the conv images are current: bf16 -- the Adam kernel writes them itself; fp32 -- the step
     // re-lays them out behind the update, b2s_adam_step_ex)

@@ -115,6 +115,7 @@ struct MtChunk {            // pad: 1 = member of the L2 set; s: bf16 shadow (or
 };
 int ro_mt_sumsq(const MtChunk* chunks, int nchunks, float* out, float scale, hipStream_t st);
 int ro_mt_param_wire(const MtChunk* chunks, int nchunks, float* wire, const float* gbase, bool scatter, hipStream_t st);      // sharded optimizer: pack / scatter
+int ro_mt_cast(const MtChunk* chunks, int nchunks, hipStream_t st);                                        // s[0..n) = bf16(a[0..n)) for every chunk
 int ro_mt_zero(const MtChunk* chunks, int nchunks, hipStream_t st);                                        // a[0..n) = 0 for every chunk         // out += scale*sum a^2
 int ro_mt_axpy(const MtChunk* chunks, int nchunks, float alpha, const float* gscale, hipStream_t st);  // b += alpha*gscale*a
 // Adam: a=param b=grad c=m d=v ; lr and step read from device (hp[0]=lr, hp[1]=bias_corr1, hp[2]=bias_corr2)

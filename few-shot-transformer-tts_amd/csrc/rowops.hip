@@ -1589,6 +1589,27 @@ int ro_add(const float* a, const float* b, float* out, long n, hipStream_t st) {
     hipLaunchKernelGGL(k_add, dim3(ew_grid(n)), dim3(256), 0, st, a, b, out, n);
     B2S_LAUNCH_CHECK(); return 0;
 }
+// s[0..n) = bf16(a[0..n)) for every chunk of a table: the bf16 shadows of all GEMM weights in ONE launch (b2s_model_sync_weights after the parameters
+// changed behind the optimizer's back -- every step of the reference's own loop, where torch.optim.Adam owns the update: 74 cast launches before)
+__global__ __launch_bounds__(256) void k_mt_cast(const MtChunk* __restrict__ ch) {
+    const MtChunk c = ch[blockIdx.x];
+    int i0 = 0;
+    if (((((size_t)c.a) & 15) == 0) && ((((size_t)c.s) & 7) == 0)) {
+        const float4* P = reinterpret_cast<const float4*>(c.a);
+        uint2* S = reinterpret_cast<uint2*>(c.s);
+        for (int i = threadIdx.x; i < (c.n >> 2); i += 256) {
+            const float4 v = P[i];
+            uint2 u; u.x = f2bf2(v.x, v.y); u.y = f2bf2(v.z, v.w);
+            S[i] = u;
+        }
+        i0 = (c.n >> 2) << 2;
+    }
+    for (int i = i0 + threadIdx.x; i < c.n; i += 256) c.s[i] = f2bf(c.a[i]);
+}
+int ro_mt_cast(const MtChunk* chunks, int nchunks, hipStream_t st) {
+    if (nchunks > 0) hipLaunchKernelGGL(k_mt_cast, dim3(nchunks), dim3(256), 0, st, chunks);
+    B2S_LAUNCH_CHECK(); return 0;
+}
 // out-of-line: zero the `a` ranges of a chunk table (a, n) in one launch (the gradient ranges that still accumulate: a memset per range would
 // be ~40 fill kernels of 3-5 us)
 __global__ __launch_bounds__(256) void k_mt_zero(const MtChunk* __restrict__ ch) {
