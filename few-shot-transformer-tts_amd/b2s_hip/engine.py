@@ -448,6 +448,79 @@ class DecoderFn(torch.autograd.Function):
         return (None, None, None, dmem if ctx.mem_req else None, None, None, None, None, None) + grads
 
 
+_ENC_STREAMS = {}          # device index -> the process-wide encoder stream (HIP assigns a stream its hardware queue at creation: one per process, see trainer.py)
+
+
+def encoder_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _ENC_STREAMS:
+        _ENC_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _ENC_STREAMS[key]
+
+
+class EncDecFn(torch.autograd.Function):
+    """Encoder + decoder of one Tacotron.forward as ONE autograd node (tacotron.py:126-129), so that the encoder can run BESIDE the decoder the way it
+    does under HipTrainer -- inside the node, invisible to autograd: the forward runs the encoder on the process-wide encoder stream while this stream
+    runs the decoder's prenet and first self-attention (which do not read the encoder output; b2s_decoder_forward waits for `memory_ready` where it first
+    needs it); the backward starts the encoder backward there as soon as d(memory) is complete (`dmem_done`), beside the first decoder layer's
+    self-attention backward, the prenet backward and the last weight-gradient groups.  Both streams are joined before either method returns: nothing a
+    caller can see is ever pending on the other stream.  Same kernels, same seeds, same results as EncoderFn + DecoderFn (which stay for the modules
+    used on their own); the reference's loop went from 9.0 to 8.x ms per step (profiles/NOTES_r06.md section 9)."""
+
+    @staticmethod
+    def forward(ctx, eng, n_enc, enc_names, dec_names, inputs, in32, spk, lang, targets, tgt32, train, holder, *params):
+        need_enc = any(ctx.needs_input_grad[12:12 + n_enc])          # (grad mode is off inside forward(); this reflects the caller's mode)
+        cur = torch.cuda.current_stream()
+        enc_s = encoder_stream(inputs.device)
+        L.check(eng.lib.b2s_model_set_side_stream(eng.handle, C.c_void_p(enc_s.cuda_stream)))
+        eng.ensure_bound()                               # (on THIS stream, before anything forks off it: shadows / re-layouts)
+        enc_s.wait_stream(cur)
+        with torch.cuda.stream(enc_s):
+            mem, c_enc = eng.encoder_forward(inputs, in32, spk, lang, train, eng.next_seed("encoder"), need_enc)
+            mem_ready = torch.cuda.Event()
+            mem_ready.record(enc_s)
+        mels, stop, c_dec = eng.decoder_forward(mem, in32, targets, tgt32, train, eng.next_seed("decoder"), True, memory_ready=mem_ready)
+        cur.wait_stream(enc_s)                           # join (the decoder already waited for mem_ready; this covers everything else of that stream)
+        mem.record_stream(cur)
+        holder.append(c_dec)
+        holder.append(mem.shape)
+        ctx.eng, ctx.c_enc, ctx.c_dec, ctx.n_enc = eng, c_enc, c_dec, n_enc
+        ctx.enc_names, ctx.dec_names = enc_names, dec_names
+        ctx.req = [p.requires_grad for p in params]
+        ctx.params = params
+        ctx.mem_shape = mem.shape
+        ctx.need_enc = need_enc
+        guided = eng.guided_loss(c_dec).reshape(()) if eng.guided_enabled() else None
+        return mels, stop, guided
+
+    @staticmethod
+    def backward(ctx, dmels, dstop, dguided):
+        eng = ctx.eng
+        eng.begin_backward()
+        eng._claim_backward("decoder")
+        if dmels is None:
+            dmels = torch.zeros(ctx.mem_shape[0], ctx.c_dec.keep[3].shape[1], ctx.c_dec.keep[3].shape[2], device=ctx.c_dec.keep[0].device)
+        dg = dguided.reshape(1) if dguided is not None else None
+        if ctx.need_enc:
+            eng._claim_backward("encoder")
+            cur = torch.cuda.current_stream()
+            enc_s = encoder_stream(dmels.device)
+            dmem_done = torch.cuda.Event()
+            dmem_done.record(cur)                        # (torch creates the HIP event at its first record: the library re-records this handle)
+            dmem = eng.decoder_backward(ctx.c_dec, dmels, dstop, ctx.mem_shape, dg, True, defer_join=True, dmem_done=dmem_done)
+            enc_s.wait_event(dmem_done)                  # d(memory) only: the rest of the decoder backward runs beside the encoder's
+            with torch.cuda.stream(enc_s):
+                eng.encoder_backward(ctx.c_enc, dmem)    # (its last stage joins the engine's second stream)
+            cur.wait_stream(enc_s)
+        else:
+            eng.decoder_backward(ctx.c_dec, dmels, dstop, ctx.mem_shape, dg, False)
+        if ctx.c_enc is not None:
+            ctx.c_enc.free()
+        names = ["encoder." + n for n in ctx.enc_names] + ["decoder." + n for n in ctx.dec_names]
+        grads = tuple(eng.grad_out(n, p) if r else None for n, r, p in zip(names, ctx.req, ctx.params))
+        return (None,) * 12 + grads
+
+
 class PostnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, prefix, names, inputs, len32, fuse_add, train, *params):

@@ -15,7 +15,7 @@ import weakref
 import torch
 
 from . import lib as L
-from .engine import _i32
+from .engine import _i32, encoder_stream
 from .dp import GradBucketer
 
 _HOOK_T = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
@@ -39,9 +39,6 @@ class _SchedView(object):
 
     def load_state_dict(self, sd):
         self._t.global_step = int(sd["last_epoch"])
-
-
-_ENC_STREAMS = {}          # device index -> the process-wide encoder stream (see HipTrainer.train_step)
 
 
 class HipTrainer(object):
@@ -319,11 +316,7 @@ class HipTrainer(object):
         if ovl and self._enc_stream is None:
             # ONE encoder stream per device and process (as the library's second stream, engine.hip: aux_stream_of): HIP assigns a stream its hardware
             # queue at creation, and a fresh stream per trainer put the third trainer of a process on the main stream's queue (13.3 instead of 6.5 ms)
-            dev = eng._gflat.device
-            key = dev.index if dev.index is not None else torch.cuda.current_device()
-            if key not in _ENC_STREAMS:
-                _ENC_STREAMS[key] = torch.cuda.Stream(device=dev)
-            self._enc_stream = _ENC_STREAMS[key]
+            self._enc_stream = encoder_stream(eng._gflat.device)
             # idle during the decoder backward: the memory-side dK / dV kernels of the encoder-decoder attentions run there (include/b2s_hip.h)
             L.check(lib.b2s_model_set_side_stream(eng.handle, C.c_void_p(self._enc_stream.cuda_stream) if self.side_stream else None))
         enc_s = self._enc_stream if ovl else None

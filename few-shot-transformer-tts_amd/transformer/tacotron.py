@@ -1,12 +1,13 @@
 """Tacotron wrapper (encoder / decoder / postnet), loss, init and LR schedule with the reference's API
 (transformer/tacotron.py:1-179).  forward/backward of every segment run in libb2s_hip (hand-written HIP for
 gfx950); this file only holds parameters under the reference's state_dict names and wires autograd."""
+import os
 import weakref
 
 import torch
 from torch import nn
 
-from b2s_hip.engine import HipEngine, EncoderFn, DecoderFn, PostnetFn, LossFn, _i32, DTYPES
+from b2s_hip.engine import HipEngine, EncoderFn, DecoderFn, EncDecFn, PostnetFn, LossFn, _i32, DTYPES
 from b2s_hip import ops
 from transformer.attention import HipLinear
 from transformer.modules import TransformerEncoder, TransformerDecoder
@@ -198,8 +199,20 @@ class Tacotron(nn.Module):
             raise B2SError("nn.DataParallel over more than one device is not supported by the HIP engine (it is bound to one device); run one "
                            "process per GPU -- torch.distributed.run + DistributedDataParallel (train.py --ddp) or b2s_hip.trainer.HipTrainer -- "
                            "or restrict the wrapper: nn.DataParallel(m, device_ids=[0])")
-        enc_outputs = self.encoder(inputs, input_lengths, input_spk_ids, input_language_vecs)
-        mel_bef, stop_logits, alignments = self.decoder(enc_outputs, input_lengths, mel_targets, target_lengths)
+        if inputs.is_cuda and os.environ.get("B2S_DROPIN_OVERLAP", "1") != "0":
+            # encoder + decoder as ONE autograd node: the encoder runs beside the decoder's first kernels (forward) and beside the end of the decoder
+            # backward, as under HipTrainer; both streams are joined inside the node (b2s_hip/engine.py: EncDecFn).  B2S_DROPIN_OVERLAP=0: two nodes
+            eng = self.engine()
+            en, ep = self.encoder._params()
+            dn, dp = self.decoder._params()
+            holder = []
+            mel_bef, stop_logits, guided = EncDecFn.apply(eng, len(ep), en, dn, inputs, _i32(input_lengths), input_spk_ids, input_language_vecs,
+                                                          mel_targets, _i32(target_lengths), self.training, holder, *(ep + dp))
+            alignments = LazyAlignments(eng, holder[0], self.decoder._n_layers, mel_targets.shape[0], self.decoder._heads, mel_targets.shape[1], holder[1][1])
+            alignments.guided_loss = guided
+        else:
+            enc_outputs = self.encoder(inputs, input_lengths, input_spk_ids, input_language_vecs)
+            mel_bef, stop_logits, alignments = self.decoder(enc_outputs, input_lengths, mel_targets, target_lengths)
         mel_aft = self.postnet(mel_bef, target_lengths, _fuse_add=True)          # mel_bef + postnet(mel_bef), fused
         outputs = {'mel_bef': mel_bef, 'mel_aft': mel_aft, 'stop_logits': stop_logits, 'alignments': alignments}
         if getattr(alignments, "guided_loss", None) is not None:

@@ -164,7 +164,7 @@ def test_product_library_has_no_lab_switches():
         for f in fs:
             if f.endswith(".py"):
                 py |= set(re.findall(r"environ[^\n]*?[\"'](B2S_[A-Z0-9_]+)[\"']", open(os.path.join(d, f)).read()))
-    assert py <= {"B2S_LIB_PATH", "B2S_FORCE_DP", "B2S_GRAD_PAYLOAD", "B2S_BN_BROADCAST", "B2S_DECODE_LANES", "B2S_DP_MODE", "B2S_COMPACT", "B2S_SIDE_STREAM"}, sorted(py)
+    assert py <= {"B2S_LIB_PATH", "B2S_FORCE_DP", "B2S_GRAD_PAYLOAD", "B2S_BN_BROADCAST", "B2S_DECODE_LANES", "B2S_DP_MODE", "B2S_COMPACT", "B2S_SIDE_STREAM", "B2S_DROPIN_OVERLAP"}, sorted(py)
 
 
 def test_c_abi_layout_queries_and_errors():
